@@ -1,0 +1,262 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (PyTorch-CPU, fp32, the reference's own NCHW op sequence) of the
+RandLA-Net hot path of /root/reference/randlanet/utils/modules.py, written as pure
+functions over a reference-layout state_dict.  It is the checker for the HIP path
+(tests/, __graft_entry__.smoke()) and the timed CPU baseline of bench.py
+(cpu_baseline.kind = "port"); the product path under 3d_recognizer_amd/ never imports it.
+
+Each function cites the reference lines it restates.  Pinned against the real reference
+(imported here, in this container, by tests/golden/make_golden.py) through the committed
+fixtures tests/golden/net_*.npz, mod_*.npz and train_*.npz -- see tests/test_oracle_net.py.
+
+Differences from the reference, all deliberate and recorded in DESIGN.md:
+  * KNN is exact everywhere.  The reference's decoder always calls faiss IVF
+    (modules.py:358 -> knn.py:87-96, un-vendored faiss-cpu==1.7.2, approximate); the
+    oracle uses the exact search that IVF approximates, via oracle/knn_oracle.c
+    (restating the reference's own C++ knn, knn.cpp:43-61).
+  * The numpy permutation (modules.py:571) is an explicit argument; callers that want
+    the reference's behaviour pass np.random.permutation(N) drawn from the global RNG.
+"""
+import ctypes
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+BN_EPS = 1e-6       # modules.py:87, :497
+BN_MOMENTUM = 0.99  # modules.py:87, :497
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libknn_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing - run `make -C oracle` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        for name in ("knn_oracle_brute", "knn_oracle_grid"):
+            fn = getattr(lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _LIB = lib
+    return _LIB
+
+
+def knn(support: torch.Tensor, query: torch.Tensor, k: int, method: str = "grid"
+        ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """knn_tpk.knn(support, querry, k) (bindings.cpp:5-7, knn.cpp:43-61):
+    (B,Ns,3),(B,Nq,3) fp32 CPU contiguous -> idx int64 (B,Nq,k), d2 fp32 (B,Nq,k) ascending."""
+    if support.is_cuda or query.is_cuda:
+        raise RuntimeError("support/query must be a CPU tensor")          # knn.cpp:47-48
+    if not (support.is_contiguous() and query.is_contiguous()):
+        raise RuntimeError("support/query must be a contiguous tensor")   # knn.cpp:45-46
+    support = support.float()
+    query = query.float()
+    B, Ns, _ = support.shape
+    Nq = query.shape[1]
+    if Ns < k:
+        raise RuntimeError(f"Not enough points in support to find {k} neighboors")  # knn.cpp:15-17
+    idx = torch.empty((B, Nq, k), dtype=torch.int64)
+    d2 = torch.empty((B, Nq, k), dtype=torch.float32)
+    fn = _lib().knn_oracle_grid if method == "grid" else _lib().knn_oracle_brute
+    rc = fn(support.data_ptr(), query.data_ptr(), B, Ns, Nq, k, idx.data_ptr(), d2.data_ptr())
+    if rc != 0:
+        raise RuntimeError(f"knn oracle failed with code {rc}")
+    return idx, d2
+
+
+# ----------------------------------------------------------------------------------------------
+# building blocks
+
+
+def shared_mlp(P: Dict[str, torch.Tensor], name: str, x: torch.Tensor, *, transpose: bool = False,
+               bn: bool = True, act: Optional[str] = None, slope: float = 0.01,
+               training: bool = False, buffers: Optional[Dict[str, torch.Tensor]] = None
+               ) -> torch.Tensor:
+    """SharedMLP.forward (modules.py:93-104): 1x1 (transposed) conv -> BN(eps 1e-6,
+    momentum 0.99) -> activation, on (B,C,N,K|1)."""
+    w, b = P[f"{name}.conv.weight"], P[f"{name}.conv.bias"]
+    y = F.conv_transpose2d(x, w, b) if transpose else F.conv2d(x, w, b)
+    if bn:
+        y = batch_norm(P, f"{name}.batch_norm", y, training, buffers)
+    return activation(y, act, slope)
+
+
+def batch_norm(P, name, y, training, buffers):
+    rm, rv = P[f"{name}.running_mean"], P[f"{name}.running_var"]
+    if training and buffers is not None:
+        # functional update: the new running stats land in `buffers`, P is left untouched
+        rm, rv = rm.clone(), rv.clone()
+        buffers[f"{name}.running_mean"], buffers[f"{name}.running_var"] = rm, rv
+    elif training:
+        rm = rv = None
+    return F.batch_norm(y, rm, rv, P[f"{name}.weight"], P[f"{name}.bias"], training,
+                        BN_MOMENTUM, BN_EPS)
+
+
+def activation(y, act, slope=0.01):
+    if act is None:
+        return y
+    if act == "relu":
+        return F.relu(y)
+    if act == "lrelu":
+        return F.leaky_relu(y, slope)
+    raise ValueError(act)
+
+
+def relative_position_encoding(xyz, idx, dist):
+    """RelativePositionEncoding.forward (modules.py:156-186) -> (B,10,N,K):
+    [xyz_i, xyz_j, xyz_i - xyz_j, dist]."""
+    B, N, K = idx.shape
+    center = xyz.transpose(-2, -1).unsqueeze(-1).expand(B, 3, N, K)
+    neigh = torch.gather(center, 2, idx.unsqueeze(1).expand(B, 3, N, K))
+    return torch.cat((center, neigh, center - neigh, dist.unsqueeze(-3)), dim=-3)
+
+
+def point_feature_augmentation(rpe, feats, idx):
+    """PointFeatureAugmentation.forward (modules.py:194-221): cat[rpe, feats[:, :, idx]]."""
+    B, N, K = idx.shape
+    C = feats.size(1)
+    neigh = torch.gather(feats.expand(B, -1, N, K), 2, idx.unsqueeze(1).expand(B, C, N, K))
+    return torch.cat((rpe, neigh), dim=-3)
+
+
+def attentive_pooling(P, name, x, training=False, buffers=None):
+    """AttentivePooling.forward (modules.py:239-253): softmax over K of x.W^T (no bias),
+    weighted sum over K, then SharedMLP(BN, ReLU)."""
+    W = P[f"{name}.score_fn.0.weight"]
+    scores = F.softmax(F.linear(x.permute(0, 2, 3, 1), W), dim=-2).permute(0, 3, 1, 2).contiguous()
+    pooled = torch.sum(scores * x, dim=-1, keepdim=True)
+    return shared_mlp(P, f"{name}.mlp", pooled, act="relu", training=training, buffers=buffers)
+
+
+def local_feature_aggregation(P, name, xyz, x, k, training=False, buffers=None, knn_fn=knn):
+    """LocalFeatureAggregation.forward (modules.py:298-325)."""
+    idx, d2 = knn_fn(xyz.contiguous(), xyz.contiguous(), k)
+    dist = torch.sqrt(d2)                                               # modules.py:149
+    kw = dict(training=training, buffers=buffers)
+    f = shared_mlp(P, f"{name}.mlp1", x, act="lrelu", slope=0.2, **kw)
+    r = shared_mlp(P, f"{name}.mlp_rpe1", relative_position_encoding(xyz, idx, dist), act="relu", **kw)
+    f = attentive_pooling(P, f"{name}.pool1", point_feature_augmentation(r, f, idx), **kw)
+    r = shared_mlp(P, f"{name}.mlp_rpe2", r, act="relu", **kw)
+    f = attentive_pooling(P, f"{name}.pool2", point_feature_augmentation(r, f, idx), **kw)
+    out = shared_mlp(P, f"{name}.mlp2", f, **kw) + shared_mlp(P, f"{name}.shortcut", x, **kw)
+    return F.leaky_relu(out, 0.01)                                      # modules.py:294,325
+
+
+def upsample(features, xyz, xyz_up, approach="nni", knn_fn=knn):
+    """UpSampler.forward (modules.py:416-456).  'nna' dispatches with the default
+    inverse_distance_weighting=True (modules.py:434-437), i.e. nna == idw."""
+    if approach == "none":
+        return features
+    if approach == "nni":
+        idx, _ = knn_fn(xyz.contiguous(), xyz_up.contiguous(), 1)
+        return torch.gather(features, -2, idx.unsqueeze(1).expand(-1, features.size(1), -1, 1))
+    if approach in ("nna", "idw", "isdw"):
+        power = 2.0 if approach == "isdw" else 1.0
+        k = 8
+        idx, d2 = knn_fn(xyz.contiguous(), xyz_up.contiguous(), k)
+        dist = torch.sqrt(d2)
+        C = features.size(1)
+        neigh = torch.gather(features.expand(-1, -1, -1, k), 2, idx.unsqueeze(1).expand(-1, C, -1, k))
+        eps = 1e-7
+        w = (1.0 + eps) / (dist ** power + eps)                          # modules.py:399-400
+        w = w / torch.sum(w, dim=-1, keepdim=True)
+        return torch.sum(w.unsqueeze(1).expand(-1, C, -1, k) * neigh, dim=-1, keepdim=True)
+    raise ValueError(f"Upsampling approach {approach} not understood!")
+
+
+def min_points(layer_sizes: Sequence[int], k: int, decimation: int = 4) -> int:
+    L = len(layer_sizes)
+    return max(k * decimation ** (L - 1), 2 * decimation ** L)          # modules.py:488-491
+
+
+def forward(P: Dict[str, torch.Tensor], inp: torch.Tensor, permutation: np.ndarray, *,
+            layer_sizes: Sequence[int], n_neighbors: int, decimation: int = 4,
+            training: bool = False, dropout_p: float = 0.5,
+            buffers: Optional[Dict[str, torch.Tensor]] = None, knn_fn=knn) -> torch.Tensor:
+    """RandLANet.forward (modules.py:542-611): (B,N,3+F) -> logits (B,C,N)."""
+    B, N, _ = inp.shape
+    assert N >= min_points(layer_sizes, n_neighbors, decimation)
+    kw = dict(training=training, buffers=buffers)
+    xyz = inp[..., :3].float()
+    x = F.linear(inp, P["fc_start.weight"], P["fc_start.bias"]).transpose(-2, -1).unsqueeze(-1)
+    x = F.leaky_relu(batch_norm(P, "bn_start.0", x, training, buffers), 0.2)
+    perm = torch.from_numpy(np.asarray(permutation))
+    xyz = xyz[:, perm]
+    x = x[:, :, perm]
+    ratio, stack = 1, []
+    xyz_l, x_l = xyz, x
+    for l in range(len(layer_sizes)):
+        x = local_feature_aggregation(P, f"encoder.{l}", xyz_l, x_l, n_neighbors, knn_fn=knn_fn, **kw)
+        stack.append(x)
+        ratio *= decimation
+        xyz_l, x_l = xyz[:, : N // ratio], x[:, :, : N // ratio]
+    x = shared_mlp(P, "mlp", x_l, act="relu", **kw)
+    for j in range(len(layer_sizes)):
+        up = upsample(x, xyz[:, : N // ratio], xyz[:, : decimation * N // ratio], "nni", knn_fn)
+        x = shared_mlp(P, f"decoder.{j}", torch.cat((up, stack.pop()), dim=1), transpose=True,
+                       act="relu", **kw)
+        ratio //= decimation
+    x = x[:, :, torch.argsort(perm)]
+    x = shared_mlp(P, "fc_end.0", x, act="relu", **kw)
+    x = shared_mlp(P, "fc_end.1", x, act="relu", **kw)
+    x = F.dropout(x, dropout_p, training)                               # modules.py:528
+    x = shared_mlp(P, "fc_end.3", x, bn=False, **kw)
+    return x.squeeze(-1)
+
+
+# ----------------------------------------------------------------------------------------------
+# state_dict layout (modules.py:494-530), used by tests to build parameters without the reference
+
+
+def state_dict_layout(n_classes: int, n_features: int, layer_sizes: Sequence[int]
+                      ) -> List[Tuple[str, Tuple[int, ...]]]:
+    items: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def bn(name, c):
+        items.extend([(f"{name}.weight", (c,)), (f"{name}.bias", (c,)),
+                      (f"{name}.running_mean", (c,)), (f"{name}.running_var", (c,)),
+                      (f"{name}.num_batches_tracked", ())])
+
+    def mlp(name, cin, cout, transpose=False, with_bn=True):
+        items.append((f"{name}.conv.weight", (cin, cout, 1, 1) if transpose else (cout, cin, 1, 1)))
+        items.append((f"{name}.conv.bias", (cout,)))
+        if with_bn:
+            bn(f"{name}.batch_norm", cout)
+
+    items.append(("fc_start.weight", (8, 3 + n_features)))
+    items.append(("fc_start.bias", (8,)))
+    bn("bn_start.0", 8)
+    cin = 8
+    for l, d in enumerate(layer_sizes):
+        e = f"encoder.{l}"
+        mlp(f"{e}.mlp1", cin, d // 2)
+        mlp(f"{e}.mlp2", d, 2 * d)
+        mlp(f"{e}.shortcut", cin, 2 * d)
+        mlp(f"{e}.mlp_rpe1", 10, d // 2)
+        mlp(f"{e}.mlp_rpe2", d // 2, d // 2)
+        items.append((f"{e}.pool1.score_fn.0.weight", (d, d)))
+        mlp(f"{e}.pool1.mlp", d, d // 2)
+        items.append((f"{e}.pool2.score_fn.0.weight", (d, d)))
+        mlp(f"{e}.pool2.mlp", d, d)
+        cin = 2 * d
+    mlp("mlp", cin, cin)
+    cin *= 2
+    j = 0
+    for d in list(layer_sizes)[::-1][1:]:
+        mlp(f"decoder.{j}", cin, 2 * d, transpose=True)
+        cin = 4 * d
+        j += 1
+    mlp(f"decoder.{j}", cin, 8, transpose=True)
+    mlp("fc_end.0", 8, 64)
+    mlp("fc_end.1", 64, 32)
+    mlp("fc_end.3", 32, n_classes, with_bn=False)
+    return items

@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and oracle/_ref/knn_tpk.so, the
+reference's own C++ KNN built by oracle/build_ref.sh).  Fixtures are data only - inputs and
+the reference's outputs; no reference source is stored.  Weights come from
+oracle/init_formula.py, so they are not stored either.
+
+How the reference is run ("PyTorch-CPU + C++ KNN"):
+  * `import randlanet` from /root/reference needs two packages this image lacks; both get
+    inert placeholders in sys.modules: `faiss` (knn.py:3; never called here) and
+    `torch.utils.tensorboard` (trainer.py:11; SummaryWriter is never constructed here).
+  * settings.knn = "approximate" and randlanet.utils.modules.knn_approximate is replaced by
+    the reference's own compiled knn_tpk.knn - the contract of KNN.forward
+    (modules.py:139-144) and the intent of its commented-out kdtree branch (modules.py:135-138).
+    So every neighbour index / distance in the fixtures is produced by reference code.
+
+Usage:  python tests/golden/make_golden.py            (writes *.npz / *.json next to itself)
+"""
+import json
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("REF_ROOT", "/root/reference")
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(REPO, "oracle", "_ref"))
+sys.path.insert(0, REPO)
+import knn_tpk  # noqa: E402  (the reference's C++ KNN, compiled from /root/reference)
+
+from oracle.init_formula import formula_state_dict  # noqa: E402
+
+
+def _import_reference():
+    faiss = types.ModuleType("faiss")  # inert: knn_approximate is replaced below
+    sys.modules.setdefault("faiss", faiss)
+    tb = types.ModuleType("torch.utils.tensorboard")
+
+    class SummaryWriter:  # never constructed by this script
+        def __init__(self, *a, **k):
+            raise RuntimeError("tensorboard placeholder")
+
+    tb.SummaryWriter = SummaryWriter
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    sys.path.insert(0, REF)
+    import randlanet  # noqa: F401
+    from randlanet.utils import modules as M
+
+    def knn_cpp(xyz, xyz_query, k):
+        return knn_tpk.knn(xyz.contiguous().float().cpu(), xyz_query.contiguous().float().cpu(), k)
+
+    M.knn_approximate = knn_cpp
+    return M
+
+
+M = _import_reference()
+from randlanet.utils import losses as RL  # noqa: E402
+from randlanet.utils import metrics as RM  # noqa: E402
+from randlanet.utils.trainer import Trainer  # noqa: E402
+
+torch.manual_seed(0)
+DEV = torch.device("cpu")
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def mock_cloud(n, seed=0):
+    files = sorted(f for f in os.listdir(os.path.join(REF, "data", "mock")) if f.endswith("_data.npy"))
+    xyz = np.load(os.path.join(REF, "data", "mock", files[-1])).astype(np.float32)
+    sel = np.random.RandomState(seed).choice(xyz.shape[0], n, replace=False)
+    return np.ascontiguousarray(xyz[sel])
+
+
+# --------------------------------------------------------------------------------- G1: KNN
+def g1_knn():
+    cases = {}
+
+    def add(tag, support, query, k, data_tag=None):
+        """data_tag: cases sharing one point set store it once under <data_tag>/support."""
+        s = torch.from_numpy(support[None]).contiguous()
+        q = torch.from_numpy(query[None]).contiguous()
+        idx, d2 = knn_tpk.knn(s, q, k)
+        data_tag = data_tag or tag
+        cases[f"{data_tag}/support"] = support
+        if query is not support:
+            cases[f"{data_tag}/query"] = query
+        cases[f"{tag}/data"] = np.array(data_tag)
+        cases[f"{tag}/idx"] = idx[0].numpy().astype(np.int32)
+        cases[f"{tag}/d2"] = d2[0].numpy()
+        cases[f"{tag}/k"] = np.int32(k)
+
+    rs = np.random.RandomState(0)
+    for n in (64, 1000, 4096):
+        pts = rs.uniform(0, 1, (n, 3)).astype(np.float32)
+        for k in (1, 16, 32):
+            add(f"uniform_n{n}_k{k}", pts, pts, k, f"uniform_n{n}")
+    sup = rs.uniform(0, 1, (1024, 3)).astype(np.float32)
+    qry = np.concatenate([sup, rs.uniform(0, 1, (3072, 3)).astype(np.float32)])
+    add("cross_1nn", sup, qry, 1, "cross")
+    add("cross_8nn", sup, qry, 8, "cross")
+    mock = mock_cloud(4096)
+    add("mock_k16", mock, mock, 16)
+    # predict.py:23 warm-up shape: 30 base points sampled up to 2500 with duplicates
+    base = rs.uniform(0, 1, (30, 3)).astype(np.float32)
+    dup = base[np.r_[np.arange(30), rs.randint(0, 30, 2470)]]
+    add("duplicates_k32", dup, dup, 32)
+    g = np.arange(16, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    add("lattice_k16", lattice, lattice, 16)
+    save("knn_cases.npz", **cases)
+
+
+# ----------------------------------------------------------------------- helpers for models
+def build_ref_net(n_classes, n_points, k, layer_sizes, n_features=0):
+    s = M.RandLANetSettings(n_classes=n_classes, n_points=n_points, n_features=n_features,
+                            n_neighbors=k, layer_sizes=list(layer_sizes), knn="approximate")
+    net = M.RandLANet(s, DEV)
+    sd = net.state_dict()
+    net.load_state_dict(formula_state_dict([(k_, tuple(v.shape)) for k_, v in sd.items()]))
+    return net
+
+
+def dump_layout(tag, net):
+    layout = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    with open(os.path.join(HERE, f"state_dict_{tag}.json"), "w") as f:
+        json.dump(layout, f)
+    n_param = sum(p.numel() for p in net.parameters())
+    print(f"state_dict_{tag}.json: {len(layout)} entries, {n_param} parameters")
+
+
+CONFIGS = {
+    # tag: (n_classes, N, K, layer_sizes, B)
+    "a4": (2, 2048, 16, [16, 64, 128, 256], 2),      # config A architecture, reduced N
+    "s5": (13, 4096, 16, [8, 16, 32, 64, 128], 1),    # 5 encoder layers, 13 classes
+    "p32": (2, 2500, 32, [16, 64, 128, 256], 1),     # train.py:50-51 settings
+}
+
+
+def make_input(tag, B, N, seed):
+    rs = np.random.RandomState(seed)
+    if tag == "p32":
+        return mock_cloud(N, seed)[None].repeat(B, 0)
+    return rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
+
+
+# ------------------------------------------------------------------ G2: eval-mode forward
+def g2_net_eval():
+    for tag, (C, N, K, layers, B) in CONFIGS.items():
+        net = build_ref_net(C, N, K, layers).eval()
+        dump_layout(tag, net)
+        x = make_input(tag, B, N, 7)
+        np.random.seed(0)
+        perm = np.random.permutation(N)
+        np.random.seed(0)
+        with torch.no_grad():
+            logits = net(torch.from_numpy(x))
+        save(f"net_eval_{tag}.npz", input=x, permutation=perm.astype(np.int64),
+             logits=logits.numpy(), meta=np.array([C, N, K, B] + list(layers), dtype=np.int64))
+
+
+def g2_modules():
+    """Single-module outputs (eval mode) for pinning the oracle restatement block by block."""
+    out = {}
+    rs = np.random.RandomState(3)
+    B, N, K, d_in, d = 2, 256, 16, 8, 16
+    xyz = rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    feats = rs.uniform(-1, 1, (B, d_in, N, 1)).astype(np.float32)
+    lfa = M.LocalFeatureAggregation(d_in, d, K, DEV)
+    sd = lfa.state_dict()
+    lfa.load_state_dict(formula_state_dict([(k_, tuple(v.shape)) for k_, v in sd.items()], seed=77))
+    lfa.eval()
+    with torch.no_grad():
+        y = lfa(torch.from_numpy(xyz), torch.from_numpy(feats), "approximate")
+        idx, dist = lfa.knn(torch.from_numpy(xyz), torch.from_numpy(xyz), K, "approximate")
+        rpe = lfa.rpe(torch.from_numpy(xyz), idx, dist)
+        pool_in = torch.from_numpy(rs.uniform(-1, 1, (B, d, N, K)).astype(np.float32))
+        pooled = lfa.pool1(pool_in)
+    out.update(lfa_xyz=xyz, lfa_feats=feats, lfa_out=y.numpy(), rpe=rpe.numpy(),
+               pool_in=pool_in.numpy(), pool_out=pooled.numpy(),
+               lfa_layout=np.array(json.dumps([[k_, list(v.shape)] for k_, v in sd.items()])))
+    # UpSampler variants (modules.py:416-456)
+    f = torch.from_numpy(rs.uniform(-1, 1, (B, 5, 64, 1)).astype(np.float32))
+    xyz_c, xyz_f = torch.from_numpy(xyz[:, :64].copy()), torch.from_numpy(xyz)
+    for approach in ("nni", "nna", "idw", "isdw"):
+        up = M.UpSampler(approach, DEV)
+        with torch.no_grad():
+            out[f"up_{approach}"] = up(f, xyz_c, xyz_f).numpy()
+    out["up_feats"] = f.numpy()
+    save("mod_blocks.npz", **out)
+
+
+# ------------------------------------------------------------- G3: train mode, grads, Adam
+def g3_train():
+    C, N, K, layers, B = 3, 512, 8, [8, 16, 32, 32], 2
+    net = build_ref_net(C, N, K, layers)
+    dump_layout("t4", net)
+    net.fc_end[2].p = 0.0          # neutralise Dropout (torch RNG is not part of the contract)
+    net.train()
+    rs = np.random.RandomState(11)
+    x = rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    labels = (np.floor(x[..., 2] * C).clip(0, C - 1)).astype(np.int64)
+    np.random.seed(5)
+    perm = np.random.permutation(N)
+    np.random.seed(5)
+    crit = Trainer._get_loss("dice")
+    logits = net(torch.from_numpy(x))
+    loss = crit(logits, torch.from_numpy(labels))
+    net.zero_grad()
+    loss.backward()
+    out = dict(input=x, labels=labels, permutation=perm.astype(np.int64), logits=logits.detach().numpy(),
+               loss=np.float32(loss.item()), meta=np.array([C, N, K, B] + layers, dtype=np.int64))
+    for name, p in net.named_parameters():
+        out[f"grad/{name}"] = p.grad.numpy().copy()
+    for name, b in net.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            out[f"buf/{name}"] = b.numpy().copy()
+    # five Adam steps (trainer.py:78, 114-119), same batch, fresh permutation each forward
+    net2 = build_ref_net(C, N, K, layers)
+    net2.fc_end[2].p = 0.0
+    net2.train()
+    opt = torch.optim.Adam(net2.parameters(), lr=1e-2)
+    np.random.seed(9)
+    traj = []
+    for _ in range(5):
+        lg = net2(torch.from_numpy(x))
+        ls = crit(lg, torch.from_numpy(labels))
+        opt.zero_grad()
+        ls.backward()
+        opt.step()
+        traj.append(ls.item())
+    out["adam_losses"] = np.array(traj, dtype=np.float32)
+    out["adam_final_fc_end3_w"] = net2.state_dict()["fc_end.3.conv.weight"].numpy().copy()
+    save("train_t4.npz", **out)
+
+
+# ------------------------------------------------------------------ G4: losses and metrics
+def g4_loss_metrics():
+    rs = np.random.RandomState(21)
+    out = {}
+    for tag, (B, C, N) in {"c2": (2, 2, 300), "c5": (3, 5, 200)}.items():
+        logits = rs.normal(0, 2, (B, C, N)).astype(np.float32)
+        labels = rs.randint(0, C, (B, N)).astype(np.int64)
+        if tag == "c5":
+            labels[labels == 3] = 1      # class 3 absent from labels
+            logits[:, 4] = -50.0         # class 4 never predicted
+        out[f"{tag}/logits"], out[f"{tag}/labels"] = logits, labels
+        lt, yt = torch.from_numpy(logits).requires_grad_(True), torch.from_numpy(labels)
+        for name in ("cross_entropy", "focal", "dice", "tversky", "focal_tversky"):
+            crit = Trainer._get_loss(name)
+            l = crit(lt, yt)
+            (g,) = torch.autograd.grad(l, lt)
+            out[f"{tag}/{name}"] = np.float32(l.item())
+            out[f"{tag}/{name}_grad"] = g.numpy()
+        oa, pca = RM.accuracy(lt.detach(), yt)
+        miou, pci = RM.iou(lt.detach(), yt)
+        out[f"{tag}/oa"], out[f"{tag}/pca"] = np.float64(oa), np.array(pca)
+        out[f"{tag}/miou"], out[f"{tag}/pci"] = np.float64(miou), np.array(pci)
+    save("loss_metrics.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g2m", "g3", "g4"]
+    if "g1" in which:
+        g1_knn()
+    if "g2" in which:
+        g2_net_eval()
+    if "g2m" in which:
+        g2_modules()
+    if "g3" in which:
+        g3_train()
+    if "g4" in which:
+        g4_loss_metrics()
