@@ -1,0 +1,234 @@
+// BatchNorm2d(eps 1e-6, momentum 0.99) of the reference's SharedMLP / bn_start
+// (randlanet/utils/modules.py:85-89, 496-499) folded into per-channel (scale, shift) that the
+// consumers apply while loading ("lazy" operands), and its backward.
+//
+// Forward: producers leave one partial (sum, sum of squares) per workgroup and channel, in
+// double; rl_bn_finalize sums them in slot order (deterministic), forms mean / biased variance,
+// updates the running statistics the way torch does and emits scale = gamma*invstd,
+// shift = beta - mean*scale.
+// Backward: G holds d(loss)/d(activated output).  With g = G*act'(z) and xhat = (Y-mean)*invstd,
+//   dbeta = sum g, dgamma = sum g*xhat, dY = scale*(g - mean(g) - xhat*mean(g*xhat)).
+#include "rl_common.h"
+
+namespace {
+
+// one wavefront per channel
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const double* __restrict__ stats, int nslots, double count, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+    int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        double s = 0.0, q = 0.0;
+        for (int i = lane; i < nslots; i += 64) {
+            s += stats[((long)i * 2 + 0) * C + c];
+            q += stats[((long)i * 2 + 1) * C + c];
+        }
+        s = rl_wave_sum(s);
+        q = rl_wave_sum(q);
+        mean = s / count;
+        var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = (double)rmean[c];
+        var = (double)rvar[c];
+    }
+    if (lane != 0) return;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    if (training && rmean && rvar) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        if (c == 0 && nbt) nbt[0] += 1;
+    }
+}
+
+struct BwdParams {
+    float* G;
+    const float* Y;
+    long ld, bstride;
+    int n, C;
+    long M;
+    int contig;
+    int act;
+    float slope;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+    double* stats;
+    const float* coef;
+};
+
+__device__ __forceinline__ long row_off(const BwdParams& p, long R) {
+    if (p.contig) return R * p.ld;
+    const int b = (int)(R / p.n);
+    const int i = (int)(R - (long)b * p.n);
+    return ((long)b * p.bstride + i) * p.ld;
+}
+
+constexpr int BN_ROWS = 256;  // rows per tile (rl_row_blocks(M, 256) partial slots)
+
+// thread layout shared by reduce and apply: tpr threads sweep one row, 256/tpr rows in flight
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
+    __shared__ float red[2][256];
+    const int C = p.C;
+    const int tpr = C < 256 ? C : 256;
+    const int rpar = 256 / tpr;
+    const int col = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const bool active = rsub < rpar;
+    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const long rend = min(p.M, (tile + 1) * BN_ROWS);
+            for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+                const long off = row_off(p, R);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int c = col + it * 256;
+                    if (c < C) {
+                        const float y = p.Y[off + c];
+                        const float sc = p.scale ? p.scale[c] : 1.f, sh = p.shift ? p.shift[c] : 0.f;
+                        const float g = p.G[off + c] * rl_act_grad(y * sc + sh, p.act, p.slope);
+                        const float xh = (y - p.mean[c]) * p.invstd[c];
+                        sg[it] += g;
+                        sx[it] += g * xh;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (it * 256 >= C) break;
+        __syncthreads();
+        red[0][threadIdx.x] = active ? sg[it] : 0.f;
+        red[1][threadIdx.x] = active ? sx[it] : 0.f;
+        __syncthreads();
+        if (threadIdx.x < tpr) {
+            const int c = threadIdx.x + it * 256;
+            if (c < C) {
+                double s = 0.0, q = 0.0;
+                for (int j = 0; j < rpar; ++j) {
+                    s += (double)red[0][j * tpr + threadIdx.x];
+                    q += (double)red[1][j * tpr + threadIdx.x];
+                }
+                p.stats[((long)blockIdx.x * 2 + 0) * C + c] = s;
+                p.stats[((long)blockIdx.x * 2 + 1) * C + c] = q;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nslots,
+                                                              double count, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < nslots; i += 64) {
+        s += stats[((long)i * 2 + 0) * C + c];
+        q += stats[((long)i * 2 + 1) * C + c];
+    }
+    s = rl_wave_sum(s);
+    q = rl_wave_sum(q);
+    if (lane != 0) return;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    coef[c] = (float)(s / count);
+    coef[C + c] = (float)(q / count);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
+    const int C = p.C;
+    const int tpr = C < 256 ? C : 256;
+    const int rpar = 256 / tpr;
+    const int col = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    if (rsub >= rpar) return;
+    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long rend = min(p.M, (tile + 1) * BN_ROWS);
+        for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+            const long off = row_off(p, R);
+            for (int c = col; c < C; c += 256) {
+                const float y = p.Y[off + c];
+                const float sc = p.scale ? p.scale[c] : 1.f, sh = p.shift ? p.shift[c] : 0.f;
+                float g = p.G[off + c] * rl_act_grad(y * sc + sh, p.act, p.slope);
+                if (p.coef) {
+                    const float xh = (y - p.mean[c]) * p.invstd[c];
+                    g = g - p.coef[c] - xh * p.coef[C + c];
+                }
+                p.G[off + c] = sc * g;
+            }
+        }
+    }
+}
+
+int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
+    RL_REQUIRE(d && d->G && d->Y && d->B > 0 && d->n > 0 && d->C > 0 && d->C <= 1024, RL_ERR_ARGS, "%s: bad descriptor", who);
+    RL_REQUIRE(d->ld >= d->C && d->bstride >= d->n, RL_ERR_ARGS, "%s: bad strides", who);
+    p->G = d->G; p->Y = d->Y; p->ld = d->ld; p->bstride = d->bstride; p->n = d->n; p->C = d->C;
+    p->M = (long)d->B * d->n; p->contig = d->bstride == d->n;
+    p->act = d->act; p->slope = d->slope; p->scale = d->scale; p->shift = d->shift;
+    p->mean = d->mean; p->invstd = d->invstd; p->stats = d->stats; p->coef = d->coef;
+    return RL_OK;
+}
+
+}  // namespace
+
+extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, int64_t* nbt,
+                              float momentum, float eps, int training, float* scale, float* shift,
+                              float* save_mean, float* save_invstd, void* stream) {
+    RL_REQUIRE(C > 0 && scale && shift, RL_ERR_ARGS, "rl_bn_finalize: bad arguments");
+    if (training) RL_REQUIRE(stats && nslots > 0 && count > 0, RL_ERR_ARGS, "rl_bn_finalize: training needs partial statistics");
+    else RL_REQUIRE(running_mean && running_var, RL_ERR_ARGS, "rl_bn_finalize: eval needs running statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rl_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, stats, nslots,
+                       (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, training,
+                       scale, shift, save_mean, save_invstd);
+    RL_LAUNCH_CHECK("rl_bn_finalize");
+    return RL_OK;
+}
+
+extern "C" int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream) {
+    BwdParams p;
+    int rc = fill(&p, d, "rl_bn_bwd_reduce");
+    if (rc) return rc;
+    RL_REQUIRE(p.stats && p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_reduce: needs stats/mean/invstd");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    RL_LAUNCH_CHECK("rl_bn_bwd_reduce");
+    return RL_OK;
+}
+
+extern "C" int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, float* dgamma,
+                                  float* dbeta, float* coef, void* stream) {
+    RL_REQUIRE(stats && nslots > 0 && count > 0 && C > 0 && coef, RL_ERR_ARGS, "rl_bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rl_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, stats,
+                       nslots, (double)count, C, dgamma, dbeta, coef);
+    RL_LAUNCH_CHECK("rl_bn_bwd_finalize");
+    return RL_OK;
+}
+
+extern "C" int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream) {
+    BwdParams p;
+    int rc = fill(&p, d, "rl_bn_bwd_apply");
+    if (rc) return rc;
+    if (p.coef) RL_REQUIRE(p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_apply: coef needs mean/invstd");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    RL_LAUNCH_CHECK("rl_bn_bwd_apply");
+    return RL_OK;
+}

@@ -1,0 +1,17 @@
+// Error text, version and small host helpers of the C ABI (include/rl_randlanet.h).
+#include "rl_common.h"
+
+static thread_local char g_err[512] = "";
+
+void rl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* rl_last_error(void) { return g_err; }
+extern "C" int rl_version(void) { return RL_VERSION; }
+extern "C" int rl_row_blocks(int64_t rows, int rows_per_tile) {
+    return rl_row_blocks_host(rows, rows_per_tile);
+}

@@ -1,0 +1,78 @@
+// Shared host/device helpers for the gfx950 kernels behind include/rl_randlanet.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/rl_randlanet.h"
+
+// ---- error plumbing ---------------------------------------------------------------------
+void rl_set_error(const char* fmt, ...);
+
+#define RL_REQUIRE(cond, code, ...)      \
+    do {                                 \
+        if (!(cond)) {                   \
+            rl_set_error(__VA_ARGS__);   \
+            return (code);               \
+        }                                \
+    } while (0)
+
+#define RL_LAUNCH_CHECK(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            rl_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return RL_ERR_LAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+
+static inline int rl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Number of row blocks a row-streaming kernel uses for M rows (one partial-statistics slot per
+// block); shared by the producers (gemm / reduce kernels) and the finalize kernels.
+static inline int rl_row_blocks_host(long rows, int rows_per_tile) {
+    long tiles = (rows + rows_per_tile - 1) / rows_per_tile;
+    if (tiles < 1) tiles = 1;
+    return (int)(tiles < RL_MAX_SLOTS ? tiles : RL_MAX_SLOTS);
+}
+
+// ---- device helpers ---------------------------------------------------------------------
+#define RL_ACT_NONE 0
+#define RL_ACT_RELU 1
+#define RL_ACT_LRELU 2
+
+__device__ __forceinline__ float rl_act(float z, int act, float slope) {
+    if (act == RL_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == RL_ACT_LRELU) return z > 0.f ? z : z * slope;
+    return z;
+}
+// derivative of the activation w.r.t. its input z (torch: relu/leaky_relu backward use z > 0)
+__device__ __forceinline__ float rl_act_grad(float z, int act, float slope) {
+    if (act == RL_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == RL_ACT_LRELU) return z > 0.f ? 1.f : slope;
+    return 1.f;
+}
+
+// lazily-normalised operand: value = act(raw * scale[c] + shift[c]); scale == nullptr -> raw
+struct RlLazy {
+    const float* scale;
+    const float* shift;
+    int act;
+    float slope;
+};
+__device__ __forceinline__ float rl_lazy(const RlLazy& t, float raw, int c) {
+    if (t.scale == nullptr) return raw;
+    return rl_act(raw * t.scale[c] + t.shift[c], t.act, t.slope);
+}
+
+__device__ __forceinline__ double rl_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float rl_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

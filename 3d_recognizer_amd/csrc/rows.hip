@@ -1,0 +1,277 @@
+// Row movement and the neighbourhood-pooling element-wise kernels of the RandLA-Net path:
+//   rl_copy_rows / rl_scatter_add_rows : permutation + prefix slicing (reference
+//       randlanet/utils/modules.py:571-573, 608), PointFeatureAugmentation gather + concat
+//       (modules.py:213-221), nearest-neighbour interpolation gather + skip concat
+//       (modules.py:359-364, 600-602), and the transposed (gradient) movements
+//   rl_attpool_fwd / _bwd : softmax over the K neighbours + weighted sum (modules.py:246-253)
+//   rl_add_act_fwd / _bwd : residual sum of two BatchNorm outputs + LeakyReLU (modules.py:325)
+//   rl_scale_mask : Dropout(0.5) of fc_end (modules.py:528) with a caller-drawn keep mask
+//   rl_logits_unpermute / rl_logits_permute_grad : inverse permutation + (B,C,N) layout
+//       (modules.py:608-611)
+// All are HBM-bound: channel-last rows make every access a contiguous C-float segment.
+#include "rl_common.h"
+
+namespace {
+
+struct RowsParams {
+    const float* src;
+    long lds, src_bstride;
+    float* dst;
+    long ldd;
+    long rows, rows_per_batch;
+    int C;
+    const int32_t* i32;
+    const int64_t* i64;
+    int shared;
+    int accumulate;
+    RlLazy lazy;
+};
+
+__device__ __forceinline__ long src_row(const RowsParams& p, long r) {
+    const long b = r / p.rows_per_batch;
+    const long i = r - b * p.rows_per_batch;
+    long j = i;
+    if (p.i32) j = p.shared ? p.i32[i] : p.i32[r];
+    else if (p.i64) j = p.shared ? p.i64[i] : p.i64[r];
+    return b * p.src_bstride + j;
+}
+
+// one thread per (row, channel quad) when C % 4 == 0 and pointers allow, else per element
+template <int VEC>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
+    const int cpr = p.C / VEC;  // chunks per row
+    const long total = p.rows * cpr;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / cpr;
+        const int c = (int)(e - r * cpr) * VEC;
+        const long so = src_row(p, r) * p.lds + c;
+        const long dofs = r * p.ldd + c;
+        if (VEC == 4) {
+            float4 v = *reinterpret_cast<const float4*>(p.src + so);
+            if (p.lazy.scale) {
+                v.x = rl_lazy(p.lazy, v.x, c + 0);
+                v.y = rl_lazy(p.lazy, v.y, c + 1);
+                v.z = rl_lazy(p.lazy, v.z, c + 2);
+                v.w = rl_lazy(p.lazy, v.w, c + 3);
+            }
+            float4* d = reinterpret_cast<float4*>(p.dst + dofs);
+            if (p.accumulate) {
+                const float4 o = *d;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *d = v;
+        } else {
+            float v = rl_lazy(p.lazy, p.src[so], c);
+            if (p.accumulate) v += p.dst[dofs];
+            p.dst[dofs] = v;
+        }
+    }
+}
+
+// dst[(b*dst_bstride + index[r])*ldd + c] += src[r*lds + c]
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const RowsParams p) {
+    const long total = p.rows * p.C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / p.C;
+        const int c = (int)(e - r * p.C);
+        const long drow = src_row(p, r);  // the index addresses the destination here
+        atomicAdd(p.dst + drow * p.ldd + c, p.src[r * p.lds + c]);
+    }
+}
+
+int fill(RowsParams* p, const rl_rows_desc* d, const char* who) {
+    RL_REQUIRE(d && d->src && d->dst && d->rows >= 0 && d->rows_per_batch > 0 && d->C > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
+    RL_REQUIRE(!(d->index32 && d->index64), RL_ERR_ARGS, "%s: give index32 or index64, not both", who);
+    RL_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), RL_ERR_ARGS, "%s: scale/shift must come together", who);
+    p->src = d->src; p->lds = d->lds; p->src_bstride = d->src_bstride; p->dst = d->dst; p->ldd = d->ldd;
+    p->rows = d->rows; p->rows_per_batch = d->rows_per_batch; p->C = d->C; p->i32 = d->index32;
+    p->i64 = d->index64; p->shared = d->index_shared; p->accumulate = d->accumulate;
+    p->lazy.scale = d->scale; p->lazy.shift = d->shift; p->lazy.act = d->act; p->lazy.slope = d->slope;
+    return RL_OK;
+}
+
+int grid_for(long work) {
+    long g = (work + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g < 4096 ? g : 4096);
+}
+
+// ---------------------------------------------------------------------- attentive pooling
+// thread = (point, channel); the K rows of a point are K*C floats apart by C
+__global__ __launch_bounds__(256) void attpool_fwd_kernel(const float* __restrict__ X, const float* __restrict__ S,
+                                                          long P, int K, int C, float* __restrict__ Pout) {
+    const long total = P * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long pt = e / C;
+        const int c = (int)(e - pt * C);
+        const float* s = S + pt * K * C + c;
+        const float* x = X + pt * K * C + c;
+        float m = s[0];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, s[(long)k * C]);
+        float den = 0.f, num = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float w = expf(s[(long)k * C] - m);
+            den += w;
+            num += w * x[(long)k * C];
+        }
+        Pout[e] = num / den;
+    }
+}
+
+__global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ S,
+                                                          const float* __restrict__ Pout, const float* __restrict__ dP,
+                                                          long P, int K, int C, float* __restrict__ dS,
+                                                          float* __restrict__ dXa) {
+    const long total = P * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long pt = e / C;
+        const int c = (int)(e - pt * C);
+        const long base = pt * K * C + c;
+        float m = S[base];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, S[base + (long)k * C]);
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) den += expf(S[base + (long)k * C] - m);
+        const float inv = 1.f / den, g = dP[e], po = Pout[e];
+        for (int k = 0; k < K; ++k) {
+            const long o = base + (long)k * C;
+            const float a = expf(S[o] - m) * inv;
+            dXa[o] = g * a;
+            dS[o] = a * g * (X[o] - po);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_act_fwd_kernel(const float* __restrict__ Y1, const float* __restrict__ s1,
+                                                          const float* __restrict__ b1, const float* __restrict__ Y2,
+                                                          const float* __restrict__ s2, const float* __restrict__ b2,
+                                                          long total, int C, float slope, float* __restrict__ O) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float z = (Y1[e] * s1[c] + b1[c]) + (Y2[e] * s2[c] + b2[c]);
+        O[e] = z > 0.f ? z : z * slope;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_act_bwd_kernel(float* __restrict__ G, const float* __restrict__ O, long total,
+                                                          float slope) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256)
+        G[e] = O[e] > 0.f ? G[e] : G[e] * slope;
+}
+
+__global__ __launch_bounds__(256) void scale_mask_kernel(float* __restrict__ x, const uint8_t* __restrict__ mask, float scale,
+                                                         long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256)
+        x[e] = mask[e] ? x[e] * scale : 0.f;
+}
+
+// out[b][c][perm[i]] = in[b][i][c]
+__global__ __launch_bounds__(256) void logits_unpermute_kernel(const float* __restrict__ in, const int64_t* __restrict__ perm,
+                                                               int B, int N, int C, float* __restrict__ out) {
+    const long total = (long)B * N;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / N;
+        const long i = e - b * N;
+        const long j = perm[i];
+        for (int c = 0; c < C; ++c) out[(b * C + c) * N + j] = in[e * C + c];
+    }
+}
+__global__ __launch_bounds__(256) void logits_permute_grad_kernel(const float* __restrict__ dout, const int64_t* __restrict__ perm,
+                                                                  int B, int N, int C, float* __restrict__ din) {
+    const long total = (long)B * N;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / N;
+        const long i = e - b * N;
+        const long j = perm[i];
+        for (int c = 0; c < C; ++c) din[e * C + c] = dout[(b * C + c) * N + j];
+    }
+}
+
+}  // namespace
+
+extern "C" int rl_copy_rows(const rl_rows_desc* d, void* stream) {
+    RowsParams p;
+    int rc = fill(&p, d, "rl_copy_rows");
+    if (rc) return rc;
+    if (p.rows == 0) return RL_OK;
+    const bool v4 = (p.C % 4 == 0) && (p.lds % 4 == 0) && (p.ldd % 4 == 0) &&
+                    (((uintptr_t)p.src & 15) == 0) && (((uintptr_t)p.dst & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (v4) hipLaunchKernelGGL((copy_rows_kernel<4>), dim3(grid_for(p.rows * (p.C / 4))), dim3(256), 0, st, p);
+    else    hipLaunchKernelGGL((copy_rows_kernel<1>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
+    RL_LAUNCH_CHECK("rl_copy_rows");
+    return RL_OK;
+}
+
+extern "C" int rl_scatter_add_rows(const rl_rows_desc* d, void* stream) {
+    RowsParams p;
+    int rc = fill(&p, d, "rl_scatter_add_rows");
+    if (rc) return rc;
+    RL_REQUIRE(p.i32 || p.i64, RL_ERR_ARGS, "rl_scatter_add_rows: needs an index");
+    RL_REQUIRE(p.lazy.scale == nullptr, RL_ERR_ARGS, "rl_scatter_add_rows: no lazy transform here");
+    if (p.rows == 0) return RL_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(p.rows * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    RL_LAUNCH_CHECK("rl_scatter_add_rows");
+    return RL_OK;
+}
+
+extern "C" int rl_attpool_fwd(const float* X, const float* S, int64_t P, int K, int C, float* Pout, void* stream) {
+    RL_REQUIRE(X && S && Pout && P >= 0 && K > 0 && C > 0, RL_ERR_ARGS, "rl_attpool_fwd: bad arguments");
+    if (P == 0) return RL_OK;
+    hipLaunchKernelGGL(attpool_fwd_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, (long)P, K, C, Pout);
+    RL_LAUNCH_CHECK("rl_attpool_fwd");
+    return RL_OK;
+}
+
+extern "C" int rl_attpool_bwd(const float* X, const float* S, const float* Pout, const float* dP, int64_t P, int K,
+                              int C, float* dS, float* dXa, void* stream) {
+    RL_REQUIRE(X && S && Pout && dP && dS && dXa && P >= 0 && K > 0 && C > 0, RL_ERR_ARGS, "rl_attpool_bwd: bad arguments");
+    if (P == 0) return RL_OK;
+    hipLaunchKernelGGL(attpool_bwd_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, Pout, dP,
+                       (long)P, K, C, dS, dXa);
+    RL_LAUNCH_CHECK("rl_attpool_bwd");
+    return RL_OK;
+}
+
+extern "C" int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1, const float* Y2, const float* s2,
+                              const float* b2, int64_t rows, int C, float slope, float* O, void* stream) {
+    RL_REQUIRE(Y1 && s1 && b1 && Y2 && s2 && b2 && O && rows >= 0 && C > 0, RL_ERR_ARGS, "rl_add_act_fwd: bad arguments");
+    if (rows == 0) return RL_OK;
+    hipLaunchKernelGGL(add_act_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
+                       s2, b2, (long)rows * C, C, slope, O);
+    RL_LAUNCH_CHECK("rl_add_act_fwd");
+    return RL_OK;
+}
+
+extern "C" int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, void* stream) {
+    RL_REQUIRE(G && O && rows >= 0 && C > 0, RL_ERR_ARGS, "rl_add_act_bwd: bad arguments");
+    if (rows == 0) return RL_OK;
+    hipLaunchKernelGGL(add_act_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, G, O,
+                       (long)rows * C, slope);
+    RL_LAUNCH_CHECK("rl_add_act_bwd");
+    return RL_OK;
+}
+
+extern "C" int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t count, void* stream) {
+    RL_REQUIRE(x && mask && count >= 0, RL_ERR_ARGS, "rl_scale_mask: bad arguments");
+    if (count == 0) return RL_OK;
+    hipLaunchKernelGGL(scale_mask_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, (long)count);
+    RL_LAUNCH_CHECK("rl_scale_mask");
+    return RL_OK;
+}
+
+extern "C" int rl_logits_unpermute(const float* in, const int64_t* perm, int B, int N, int C, float* out, void* stream) {
+    RL_REQUIRE(in && perm && out && B > 0 && N > 0 && C > 0, RL_ERR_ARGS, "rl_logits_unpermute: bad arguments");
+    hipLaunchKernelGGL(logits_unpermute_kernel, dim3(grid_for((long)B * N)), dim3(256), 0, (hipStream_t)stream, in, perm,
+                       B, N, C, out);
+    RL_LAUNCH_CHECK("rl_logits_unpermute");
+    return RL_OK;
+}
+
+extern "C" int rl_logits_permute_grad(const float* dout, const int64_t* perm, int B, int N, int C, float* din,
+                                      void* stream) {
+    RL_REQUIRE(dout && perm && din && B > 0 && N > 0 && C > 0, RL_ERR_ARGS, "rl_logits_permute_grad: bad arguments");
+    hipLaunchKernelGGL(logits_permute_grad_kernel, dim3(grid_for((long)B * N)), dim3(256), 0, (hipStream_t)stream, dout,
+                       perm, B, N, C, din);
+    RL_LAUNCH_CHECK("rl_logits_permute_grad");
+    return RL_OK;
+}

@@ -1,0 +1,4 @@
+"""MI355X-native drop-in for the `randlanet` package of matthiasverstraete/3d_recognizer
+(reference randlanet/__init__.py:1-11).  Put the directory that contains this package
+(3d_recognizer_amd/) on PYTHONPATH and the reference's train.py / predict.py import it unchanged.
+"""

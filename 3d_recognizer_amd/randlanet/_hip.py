@@ -1,0 +1,151 @@
+"""ctypes binding of librandla_hip.so (C ABI: include/rl_randlanet.h).
+
+Nothing here touches HIP at import time (train.py spawns its worker with
+multiprocessing 'spawn', reference train.py:108-115, so importing the package must not create
+a GPU context).  The library is loaded on first use; if it is missing the product path fails
+loudly - there is no CPU or PyTorch fallback for the kernels.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_LIB: Optional[C.CDLL] = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc",
+                         "librandla_hip.so")
+
+MAX_SLOTS = 1024
+KNN_MAX_K = 64
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+ERR_ARGS, ERR_FEW_SUPPORT, ERR_LAUNCH, ERR_UNSUPPORTED = -1, -2, -3, -4
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_bstride", C.c_int64),
+        ("a_mode", C.c_int32), ("in_act", C.c_int32), ("in_slope", C.c_float),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+        ("xyz", C.c_void_p), ("xyz_bstride", C.c_int64),
+        ("nbr_idx", C.c_void_p), ("nbr_d2", C.c_void_p), ("nbr_k", C.c_int32),
+        ("B", C.c_int32), ("n", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("W", C.c_void_p), ("w_ks", C.c_int64), ("w_ns", C.c_int64),
+        ("bias", C.c_void_p),
+        ("Y", C.c_void_p), ("ldy", C.c_int64), ("y_bstride", C.c_int64),
+        ("accumulate", C.c_int32),
+        ("stats", C.c_void_p),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_bstride", C.c_int64),
+        ("a_mode", C.c_int32), ("in_act", C.c_int32), ("in_slope", C.c_float),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+        ("xyz", C.c_void_p), ("xyz_bstride", C.c_int64),
+        ("nbr_idx", C.c_void_p), ("nbr_d2", C.c_void_p), ("nbr_k", C.c_int32),
+        ("B", C.c_int32), ("n", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("dY", C.c_void_p), ("lddy", C.c_int64), ("dy_bstride", C.c_int64),
+        ("dW", C.c_void_p), ("w_ks", C.c_int64), ("w_ns", C.c_int64),
+        ("dbias", C.c_void_p),
+        ("slab", C.c_void_p), ("slab_floats", C.c_int64),
+    ]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [
+        ("G", C.c_void_p), ("Y", C.c_void_p), ("ld", C.c_int64), ("bstride", C.c_int64),
+        ("B", C.c_int32), ("n", C.c_int32), ("C", C.c_int32), ("act", C.c_int32),
+        ("slope", C.c_float),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+        ("stats", C.c_void_p), ("coef", C.c_void_p),
+    ]
+
+
+class RowsDesc(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("lds", C.c_int64), ("src_bstride", C.c_int64),
+        ("dst", C.c_void_p), ("ldd", C.c_int64),
+        ("rows", C.c_int64), ("rows_per_batch", C.c_int64),
+        ("C", C.c_int32),
+        ("index32", C.c_void_p), ("index64", C.c_void_p),
+        ("index_shared", C.c_int32), ("accumulate", C.c_int32), ("act", C.c_int32),
+        ("slope", C.c_float),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+    ]
+
+
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGNATURES = {
+    "rl_last_error": (C.c_char_p, []),
+    "rl_version": (_i, []),
+    "rl_row_blocks": (_i, [_l, _i]),
+    "rl_knn_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
+    "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
+    "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),
+    "rl_bn_bwd_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp]),
+    "rl_bn_bwd_apply": (_i, [C.POINTER(BnBwdDesc), _vp]),
+    "rl_copy_rows": (_i, [C.POINTER(RowsDesc), _vp]),
+    "rl_scatter_add_rows": (_i, [C.POINTER(RowsDesc), _vp]),
+    "rl_attpool_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
+    "rl_attpool_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp]),
+    "rl_add_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp, _vp]),
+    "rl_add_act_bwd": (_i, [_vp, _vp, _l, _i, _f, _vp]),
+    "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
+    "rl_logits_unpermute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rl_logits_permute_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rl_loss_work_doubles": (_l, [_l, _i]),
+    "rl_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "rl_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _f, _vp, _vp]),
+    "rl_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load librandla_hip.so (once).  Raises if it was not built - never falls back."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise HipKernelError(
+                f"{_LIB_PATH} not found: build it with `make -C 3d_recognizer_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback path for the HIP kernels")
+        handle = C.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().rl_last_error().decode("utf-8", "replace")
+        raise HipKernelError(f"{what or 'librandla_hip'} failed ({rc}): {msg}")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def row_blocks(rows: int, rows_per_tile: int) -> int:
+    tiles = max(1, -(-rows // rows_per_tile))
+    return min(tiles, MAX_SLOTS)

@@ -1,0 +1,389 @@
+"""Tensor-level wrappers over the C ABI (include/rl_randlanet.h).  PyTorch is used for device
+memory and streams only; all arithmetic happens in librandla_hip.so.  Every wrapper checks
+shapes on the host before launching (a faulting kernel can reset the GPU) and raises
+HipKernelError on failure - there is no fallback implementation.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _hip as H
+
+F32 = torch.float32
+
+
+@dataclass
+class Lazy:
+    """A (rows, C) fp32 tensor whose value is act(raw*scale + shift) - the output of a
+    SharedMLP before its BatchNorm+activation is applied (reference modules.py:93-104)."""
+    raw: torch.Tensor                      # storage; logical rows are (B, n) with batch stride
+    B: int
+    n: int
+    bstride: int                           # rows between clouds in `raw`
+    C: int
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    act: int = H.ACT_NONE
+    slope: float = 0.0
+    mean: Optional[torch.Tensor] = None    # saved batch statistics (training)
+    invstd: Optional[torch.Tensor] = None
+    bn: Optional[str] = None               # parameter prefix of its BatchNorm, if any
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.n
+
+    def prefix(self, n: int) -> "Lazy":
+        """First n rows of every cloud (the reference's random-sampling prefix slice)."""
+        assert n <= self.n
+        return Lazy(self.raw, self.B, n, self.bstride, self.C, self.scale, self.shift, self.act,
+                    self.slope, self.mean, self.invstd, self.bn)
+
+
+def plain(t: torch.Tensor, B: int, n: int) -> Lazy:
+    assert t.dim() == 2 and t.shape[0] == B * n and t.is_contiguous()
+    return Lazy(t, B, n, n, t.shape[1])
+
+
+def _dev_check(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise H.HipKernelError("HIP kernels need device tensors")
+        if not t.is_contiguous():
+            raise H.HipKernelError("HIP kernels need contiguous tensors")
+
+
+def _st():
+    return H.stream_ptr()
+
+
+# ------------------------------------------------------------------------------------- knn
+def knn_i32(support: torch.Tensor, query: torch.Tensor, Ns: int, Nq: int, k: int
+            ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """support (B, >=Ns, 3), query (B, >=Nq, 3): searches the first Ns / Nq points of each cloud."""
+    _dev_check(support, query)
+    assert support.dtype == F32 and query.dtype == F32 and support.shape[-1] == 3 and query.shape[-1] == 3
+    B = support.shape[0]
+    assert query.shape[0] == B and support.shape[1] >= Ns and query.shape[1] >= Nq
+    idx = torch.empty((B, Nq, k), dtype=torch.int32, device=support.device)
+    d2 = torch.empty((B, Nq, k), dtype=F32, device=support.device)
+    H.check(H.lib().rl_knn_i32(support.data_ptr(), support.shape[1], query.data_ptr(), query.shape[1],
+                               B, Ns, Nq, k, idx.data_ptr(), d2.data_ptr(), _st()), "rl_knn_i32")
+    return idx, d2
+
+
+def knn_f32(support: torch.Tensor, query: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    _dev_check(support, query)
+    B, Ns, _ = support.shape
+    Nq = query.shape[1]
+    idx = torch.empty((B, Nq, k), dtype=torch.int64, device=support.device)
+    d2 = torch.empty((B, Nq, k), dtype=F32, device=support.device)
+    H.check(H.lib().rl_knn_f32(support.data_ptr(), query.data_ptr(), B, Ns, Nq, k, idx.data_ptr(),
+                               d2.data_ptr(), _st()), "rl_knn_f32")
+    return idx, d2
+
+
+# ------------------------------------------------------------------------------------ gemm
+@dataclass
+class Rpe:
+    """Relative-position-encoding A operand (reference modules.py:173-186), never materialised."""
+    xyz: torch.Tensor      # (B, n_parent, 3)
+    idx: torch.Tensor      # (B, n, K) int32
+    d2: torch.Tensor       # (B, n, K) fp32
+    B: int
+    n: int
+    K: int
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.n * self.K
+
+
+def _fill_a(d, a):
+    if isinstance(a, Rpe):
+        _dev_check(a.xyz, a.idx, a.d2)
+        assert a.idx.dtype == torch.int32 and a.idx.shape == (a.B, a.n, a.K) and a.d2.shape == a.idx.shape
+        assert a.xyz.shape[0] == a.B and a.xyz.shape[1] >= a.n and a.xyz.shape[2] == 3
+        d.a_mode = 1
+        d.xyz, d.xyz_bstride = a.xyz.data_ptr(), a.xyz.shape[1]
+        d.nbr_idx, d.nbr_d2, d.nbr_k = a.idx.data_ptr(), a.d2.data_ptr(), a.K
+        d.B, d.n, d.K = a.B, a.n, 10
+        return a.rows, 10
+    _dev_check(a.raw, a.scale, a.shift)
+    assert a.raw.dtype == F32 and a.raw.dim() == 2 and a.raw.shape[1] >= a.C
+    assert a.raw.shape[0] >= (a.B - 1) * a.bstride + a.n, "A operand rows out of range"
+    d.a_mode = 0
+    d.A, d.lda, d.a_bstride = a.raw.data_ptr(), a.raw.shape[1], a.bstride
+    if a.scale is not None:
+        assert a.scale.numel() == a.C and a.shift.numel() == a.C
+        d.in_scale, d.in_shift, d.in_act, d.in_slope = a.scale.data_ptr(), a.shift.data_ptr(), a.act, a.slope
+    d.B, d.n, d.K = a.B, a.n, a.C
+    return a.rows, a.C
+
+
+def weight_strides(W: torch.Tensor, transposed: bool, K: int, N: int) -> Tuple[int, int]:
+    """(w_ks, w_ns) for a reference-layout weight: Conv2d/Linear (N,K[,1,1]) or
+    ConvTranspose2d (K,N,1,1)."""
+    if transposed:
+        assert W.shape[0] == K and W.shape[1] == N, (tuple(W.shape), K, N)
+        return N, 1
+    assert W.shape[0] == N and W.shape[1] == K, (tuple(W.shape), K, N)
+    return 1, K
+
+
+def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.Tensor] = None, *,
+         out: Optional[torch.Tensor] = None, out_bstride: Optional[int] = None,
+         accumulate: bool = False, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d = H.GemmDesc()
+    M, K = _fill_a(d, a)
+    rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
+    _dev_check(W, bias, out, stats)
+    assert W.dtype == F32 and W.numel() == K * N
+    if out is None:
+        out = torch.empty((M, N), dtype=F32, device=W.device)
+        out_bstride = rows_per_batch
+    else:
+        assert out.dtype == F32 and out.dim() == 2 and out.shape[1] >= N
+        out_bstride = rows_per_batch if out_bstride is None else out_bstride
+        assert out.shape[0] >= (d.B - 1) * out_bstride + rows_per_batch, "Y rows out of range"
+    if bias is not None:
+        assert bias.numel() == N
+    if stats is not None:
+        assert stats.dtype == torch.float64 and stats.numel() >= H.row_blocks(M, 128) * 2 * N
+    d.N, d.W, d.w_ks, d.w_ns, d.bias = N, W.data_ptr(), w_ks, w_ns, H.ptr(bias)
+    d.Y, d.ldy, d.y_bstride, d.accumulate = out.data_ptr(), out.shape[1], out_bstride, int(accumulate)
+    d.stats = H.ptr(stats)
+    H.check(H.lib().rl_gemm(C.byref(d), _st()), "rl_gemm")
+    return out
+
+
+_SLAB = {}
+
+
+def _slab(device, floats: int) -> torch.Tensor:
+    """Scratch for rl_wgrad partial slabs: one growing buffer per device (stream-ordered reuse)."""
+    buf = _SLAB.get(device)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(max(floats, 1 << 20), dtype=F32, device=device)
+        _SLAB[device] = buf
+    return buf
+
+
+def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: int, w_ns: int,
+          dbias: Optional[torch.Tensor] = None) -> None:
+    d = H.WgradDesc()
+    M, K = _fill_a(d, a)
+    rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
+    _dev_check(dY, dW, dbias)
+    assert dY.dtype == F32 and dY.dim() == 2 and dY.shape[1] >= N
+    assert dY.shape[0] >= (d.B - 1) * dy_bstride + rows_per_batch
+    assert dW.numel() == K * N and (dbias is None or dbias.numel() == N)
+    floats = H.lib().rl_wgrad_slab_floats(M, N, K)
+    slab = _slab(dY.device, floats)
+    d.N, d.dY, d.lddy, d.dy_bstride = N, dY.data_ptr(), dY.shape[1], dy_bstride
+    d.dW, d.w_ks, d.w_ns, d.dbias = dW.data_ptr(), w_ks, w_ns, H.ptr(dbias)
+    d.slab, d.slab_floats = slab.data_ptr(), slab.numel()
+    H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
+
+
+# -------------------------------------------------------------------------------------- bn
+def new_stats(device, C: int) -> torch.Tensor:
+    return torch.empty((H.MAX_SLOTS, 2, C), dtype=torch.float64, device=device)
+
+
+def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, nbt, momentum: float,
+                eps: float, training: bool):
+    dev = gamma.device
+    scale = torch.empty(C, dtype=F32, device=dev)
+    shift = torch.empty(C, dtype=F32, device=dev)
+    mean = torch.empty(C, dtype=F32, device=dev) if training else None
+    invstd = torch.empty(C, dtype=F32, device=dev) if training else None
+    _dev_check(stats, gamma, beta, rmean, rvar, nbt)
+    H.check(H.lib().rl_bn_finalize(H.ptr(stats), H.row_blocks(rows, tile), rows, C, H.ptr(gamma), H.ptr(beta),
+                                   H.ptr(rmean), H.ptr(rvar), H.ptr(nbt), momentum, eps, int(training),
+                                   scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), _st()),
+            "rl_bn_finalize")
+    return scale, shift, mean, invstd
+
+
+def _bn_bwd_desc(G: torch.Tensor, g_bstride: int, y: Lazy) -> H.BnBwdDesc:
+    _dev_check(G, y.raw)
+    assert G.dim() == 2 and G.shape[1] == y.raw.shape[1] and g_bstride == y.bstride, \
+        "gradient must share the layout of the tensor it belongs to"
+    assert G.shape[0] >= (y.B - 1) * y.bstride + y.n
+    d = H.BnBwdDesc()
+    d.G, d.Y, d.ld, d.bstride = G.data_ptr(), y.raw.data_ptr(), y.raw.shape[1], y.bstride
+    d.B, d.n, d.C, d.act, d.slope = y.B, y.n, y.C, y.act, y.slope
+    d.scale, d.shift, d.mean, d.invstd = H.ptr(y.scale), H.ptr(y.shift), H.ptr(y.mean), H.ptr(y.invstd)
+    return d
+
+
+def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
+                training: bool) -> None:
+    """In place: G (gradient w.r.t. the activated value of `y`) becomes the gradient w.r.t. y.raw."""
+    d = _bn_bwd_desc(G, y.bstride, y)
+    if training and y.mean is not None:
+        stats = new_stats(G.device, y.C)
+        coef = torch.empty(2 * y.C, dtype=F32, device=G.device)
+        d.stats = stats.data_ptr()
+        H.check(H.lib().rl_bn_bwd_reduce(C.byref(d), _st()), "rl_bn_bwd_reduce")
+        H.check(H.lib().rl_bn_bwd_finalize(stats.data_ptr(), H.row_blocks(y.rows, 256), y.rows, y.C,
+                                           H.ptr(dgamma), H.ptr(dbeta), coef.data_ptr(), _st()),
+                "rl_bn_bwd_finalize")
+        d.coef = coef.data_ptr()
+    H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
+
+
+# ------------------------------------------------------------------------------------ rows
+def copy_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, dst: torch.Tensor,
+              dst_cols: Tuple[int, int], rows: int, rows_per_batch: int, *, index=None,
+              index_shared: bool = False, accumulate: bool = False, lazy: Optional[Lazy] = None) -> None:
+    """dst[r, dst_cols] (=|+=) f(src[b*src_bstride + idx, src_cols]); column ranges are (start, count)."""
+    _dev_check(src, dst, index)
+    d = H.RowsDesc()
+    es = src.element_size()
+    assert src.dtype == F32 and dst.dtype == F32 and src.dim() == 2 and dst.dim() == 2
+    c0s, cn = src_cols
+    c0d, cn2 = dst_cols
+    assert cn == cn2 and c0s + cn <= src.shape[1] and c0d + cn <= dst.shape[1] and dst.shape[0] >= rows
+    d.src, d.lds, d.src_bstride = src.data_ptr() + c0s * es, src.shape[1], src_bstride
+    d.dst, d.ldd = dst.data_ptr() + c0d * es, dst.shape[1]
+    d.rows, d.rows_per_batch, d.C = rows, rows_per_batch, cn
+    if index is not None:
+        if index.dtype == torch.int32:
+            d.index32 = index.data_ptr()
+        else:
+            assert index.dtype == torch.int64
+            d.index64 = index.data_ptr()
+        assert index.numel() >= (rows_per_batch if index_shared else rows)
+    d.index_shared, d.accumulate = int(index_shared), int(accumulate)
+    if lazy is not None and lazy.scale is not None:
+        assert c0s == 0 and cn == lazy.C
+        d.scale, d.shift, d.act, d.slope = lazy.scale.data_ptr(), lazy.shift.data_ptr(), lazy.act, lazy.slope
+    H.check(H.lib().rl_copy_rows(C.byref(d), _st()), "rl_copy_rows")
+
+
+def scatter_add_rows(src: torch.Tensor, src_cols: Tuple[int, int], dst: torch.Tensor, dst_bstride: int,
+                     rows: int, rows_per_batch: int, index: torch.Tensor, index_shared: bool = False) -> None:
+    """dst[b*dst_bstride + index[r], :] += src[r, src_cols] (fp32 atomics; dst zeroed by the caller)."""
+    _dev_check(src, dst, index)
+    d = H.RowsDesc()
+    c0s, cn = src_cols
+    assert cn == dst.shape[1] and c0s + cn <= src.shape[1] and src.shape[0] >= rows
+    d.src, d.lds, d.src_bstride = src.data_ptr() + c0s * 4, src.shape[1], dst_bstride
+    d.dst, d.ldd = dst.data_ptr(), dst.shape[1]
+    d.rows, d.rows_per_batch, d.C = rows, rows_per_batch, cn
+    if index.dtype == torch.int32:
+        d.index32 = index.data_ptr()
+    else:
+        d.index64 = index.data_ptr()
+    d.index_shared = int(index_shared)
+    H.check(H.lib().rl_scatter_add_rows(C.byref(d), _st()), "rl_scatter_add_rows")
+
+
+# ------------------------------------------------------------------------- pooling, residual
+def attpool_fwd(X: torch.Tensor, S: torch.Tensor, P: int, K: int) -> torch.Tensor:
+    _dev_check(X, S)
+    Cc = X.shape[1]
+    assert X.shape == S.shape == (P * K, Cc)
+    out = torch.empty((P, Cc), dtype=F32, device=X.device)
+    H.check(H.lib().rl_attpool_fwd(X.data_ptr(), S.data_ptr(), P, K, Cc, out.data_ptr(), _st()), "rl_attpool_fwd")
+    return out
+
+
+def attpool_bwd(X, S, Pout, dP, P: int, K: int):
+    _dev_check(X, S, Pout, dP)
+    Cc = X.shape[1]
+    assert X.shape == S.shape == (P * K, Cc) and Pout.shape == dP.shape == (P, Cc)
+    dS = torch.empty_like(S)
+    dXa = torch.empty_like(X)
+    H.check(H.lib().rl_attpool_bwd(X.data_ptr(), S.data_ptr(), Pout.data_ptr(), dP.data_ptr(), P, K, Cc,
+                                   dS.data_ptr(), dXa.data_ptr(), _st()), "rl_attpool_bwd")
+    return dS, dXa
+
+
+def add_act_fwd(y1: Lazy, y2: Lazy, slope: float) -> torch.Tensor:
+    assert y1.rows == y2.rows and y1.C == y2.C and y1.bstride == y1.n and y2.bstride == y2.n
+    out = torch.empty((y1.rows, y1.C), dtype=F32, device=y1.raw.device)
+    H.check(H.lib().rl_add_act_fwd(y1.raw.data_ptr(), y1.scale.data_ptr(), y1.shift.data_ptr(), y2.raw.data_ptr(),
+                                   y2.scale.data_ptr(), y2.shift.data_ptr(), y1.rows, y1.C, slope, out.data_ptr(),
+                                   _st()), "rl_add_act_fwd")
+    return out
+
+
+def add_act_bwd(G: torch.Tensor, O: torch.Tensor, slope: float) -> None:
+    assert G.shape == O.shape and G.is_contiguous() and O.is_contiguous()
+    H.check(H.lib().rl_add_act_bwd(G.data_ptr(), O.data_ptr(), G.shape[0], G.shape[1], slope, _st()), "rl_add_act_bwd")
+
+
+def scale_mask(x: torch.Tensor, mask: torch.Tensor, scale: float) -> None:
+    _dev_check(x, mask)
+    assert mask.dtype == torch.uint8 and mask.numel() == x.numel() and x.dtype == F32
+    H.check(H.lib().rl_scale_mask(x.data_ptr(), mask.data_ptr(), scale, x.numel(), _st()), "rl_scale_mask")
+
+
+def logits_unpermute(lp: torch.Tensor, perm: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    Cc = lp.shape[1]
+    assert lp.shape == (B * N, Cc) and perm.dtype == torch.int64 and perm.numel() == N
+    out = torch.empty((B, Cc, N), dtype=F32, device=lp.device)
+    H.check(H.lib().rl_logits_unpermute(lp.data_ptr(), perm.data_ptr(), B, N, Cc, out.data_ptr(), _st()),
+            "rl_logits_unpermute")
+    return out
+
+
+def logits_permute_grad(dlogits: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    B, Cc, N = dlogits.shape
+    _dev_check(dlogits, perm)
+    out = torch.empty((B * N, Cc), dtype=F32, device=dlogits.device)
+    H.check(H.lib().rl_logits_permute_grad(dlogits.data_ptr(), perm.data_ptr(), B, N, Cc, out.data_ptr(), _st()),
+            "rl_logits_permute_grad")
+    return out
+
+
+# ------------------------------------------------------------------------------ loss, adam
+LOSS_KINDS = {  # reference trainer.py:244-269
+    "cross_entropy": (0, 0.0, 0.0),
+    "focal": (1, 0.0, 2.0),
+    "dice": (2, 0.5, 1.0),
+    "tversky": (2, 0.7, 1.0),
+    "focal_tversky": (2, 0.7, 4.0 / 3.0),
+}
+
+
+def loss_forward(logits: torch.Tensor, labels: torch.Tensor, kind: int, alpha: float, gamma: float,
+                 neglect_background: bool = True):
+    """Returns (out, work): out[0] = loss, out[1:] metric counts (doubles, on device)."""
+    _dev_check(logits, labels)
+    B, Cc, N = logits.shape
+    assert labels.shape == (B, N) and labels.dtype == torch.int64 and logits.dtype == F32
+    work = torch.empty(H.lib().rl_loss_work_doubles(B * N, Cc), dtype=torch.float64, device=logits.device)
+    out = torch.empty(1 + 4 * Cc, dtype=torch.float64, device=logits.device)
+    H.check(H.lib().rl_loss_forward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
+                                    int(neglect_background), work.data_ptr(), out.data_ptr(), _st()),
+            "rl_loss_forward")
+    return out, work
+
+
+def loss_backward(logits, labels, kind: int, alpha: float, gamma: float, neglect_background: bool, work,
+                  grad_scale: float = 1.0) -> torch.Tensor:
+    B, Cc, N = logits.shape
+    dlogits = torch.empty_like(logits)
+    H.check(H.lib().rl_loss_backward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
+                                     int(neglect_background), work.data_ptr(), grad_scale, dlogits.data_ptr(),
+                                     _st()), "rl_loss_backward")
+    return dlogits
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr: torch.Tensor, step: torch.Tensor, beta1=0.9, beta2=0.999,
+              eps=1e-8, grad_scale=1.0) -> None:
+    _dev_check(param, grad, exp_avg, exp_avg_sq, lr, step)
+    n = param.numel()
+    assert grad.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n
+    assert lr.dtype == F32 and step.dtype == torch.int64
+    H.check(H.lib().rl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                                 lr.data_ptr(), beta1, beta2, eps, grad_scale, step.data_ptr(), _st()),
+            "rl_adam_step")

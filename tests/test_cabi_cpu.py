@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI boundary: the library loads without a GPU, exports every symbol
+include/rl_randlanet.h declares, and the ctypes table binds exactly that set."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "rl_randlanet.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from randlanet import _hip
+    if not os.path.exists(_hip.library_path()):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "3d_recognizer_amd", "csrc"), "-j4"])
+    return ctypes.CDLL(_hip.library_path())
+
+
+def test_header_symbols_are_exported(lib):
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/rl_randlanet.h but not exported"
+
+
+def test_ctypes_table_matches_header():
+    from randlanet import _hip
+    assert sorted(_hip.EXPORTS) == _declared()
+
+
+def test_host_only_entry_points(lib):
+    from randlanet import _hip
+    L = _hip.lib()
+    assert L.rl_version() == 100
+    assert L.rl_row_blocks(1, 128) == 1 and L.rl_row_blocks(128 * 5000, 128) == 1024
+    assert L.rl_row_blocks(129, 128) == 2
+    assert L.rl_wgrad_slab_floats(1000, 16, 16) > 0
+    assert L.rl_loss_work_doubles(10, 2) == 1025 * 11
+    # argument validation happens on the host, before any launch
+    assert L.rl_knn_f32(None, None, 1, 3, 3, 4, None, None, None) == _hip.ERR_FEW_SUPPORT
+    assert b"Not enough points" in L.rl_last_error()
+    assert L.rl_knn_f32(None, None, 1, 100, 3, 65, None, None, None) == _hip.ERR_UNSUPPORTED
+    assert L.rl_gemm(None, None) == _hip.ERR_ARGS
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from randlanet import _hip
+    monkeypatch.setattr(_hip, "_LIB", None)
+    monkeypatch.setattr(_hip, "_LIB_PATH", "/nonexistent/librandla_hip.so")
+    with pytest.raises(_hip.HipKernelError, match="no fallback"):
+        _hip.lib()

@@ -1,0 +1,378 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point against the oracle (KNN, losses)
+or a plain PyTorch fp32 statement of the same op.  Tolerances are written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from knn_parity import check_knn  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from randlanet import _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def H():
+    from randlanet import _hip
+    return _hip
+
+
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+# ------------------------------------------------------------------------------------ KNN
+def _golden_cases(golden_dir):
+    z = np.load(f"{golden_dir}/knn_cases.npz")
+    for t in sorted({k.split("/")[0] for k in z.files if k.endswith("/idx")}):
+        data = str(z[f"{t}/data"])
+        sup = z[f"{data}/support"]
+        qry = z[f"{data}/query"] if f"{data}/query" in z.files else sup
+        yield t, sup, qry, int(z[f"{t}/k"]), z[f"{t}/idx"], z[f"{t}/d2"]
+
+
+def test_knn_golden_reference_vectors(ops, golden_dir):
+    """HIP KNN vs outputs of the reference's own knn_tpk.knn: d2 bit-exact, idx tie-aware."""
+    for tag, sup, qry, k, ref_idx, ref_d2 in _golden_cases(golden_dir):
+        idx, d2 = ops.knn_f32(_t(sup[None]), _t(qry[None]), k)
+        frac = check_knn(idx[0].cpu().numpy(), d2[0].cpu().numpy(), ref_idx, ref_d2, sup, qry,
+                         expect_lowest_index=True)
+        if tag.startswith(("uniform", "cross")):
+            assert frac == 1.0, tag
+
+
+@pytest.mark.parametrize("B,Ns,Nq,k", [(2, 5000, 3000, 16), (1, 2049, 1025, 32), (3, 700, 700, 1),
+                                        (1, 64, 10, 64), (2, 1500, 1500, 5)])
+def test_knn_matches_oracle_bitwise(ops, B, Ns, Nq, k):
+    from oracle import randlanet_oracle as O
+    rs = np.random.RandomState(Ns + k)
+    s = rs.normal(0, 1, (B, Ns, 3)).astype(np.float32)
+    q = rs.normal(0, 1, (B, Nq, 3)).astype(np.float32)
+    ri, rd = O.knn(torch.from_numpy(s), torch.from_numpy(q), k, "grid")
+    idx, d2 = ops.knn_f32(_t(s), _t(q), k)
+    assert torch.equal(idx.cpu(), ri) and torch.equal(d2.cpu().view(torch.int32), rd.view(torch.int32))
+    i32, d2b = ops.knn_i32(_t(s), _t(q), Ns, Nq, k)
+    assert torch.equal(i32.cpu().long(), ri) and torch.equal(d2b.cpu(), rd)
+
+
+def test_knn_prefix_strides_and_errors(ops, H):
+    from oracle import randlanet_oracle as O
+    rs = np.random.RandomState(1)
+    xyz = rs.uniform(0, 1, (2, 4096, 3)).astype(np.float32)
+    # the network searches prefixes of the permuted cloud in place (modules.py:587-598)
+    i32, d2 = ops.knn_i32(_t(xyz), _t(xyz), 1024, 4096, 1)
+    ri, rd = O.knn(torch.from_numpy(xyz[:, :1024].copy()), torch.from_numpy(xyz), 1)
+    assert torch.equal(i32.cpu().long(), ri) and torch.equal(d2.cpu(), rd)
+    assert torch.equal(i32[:, :1024, 0].cpu(), torch.arange(1024, dtype=torch.int32).expand(2, -1))
+    with pytest.raises(H.HipKernelError, match="Not enough points"):
+        ops.knn_f32(_t(xyz[:, :3]), _t(xyz[:, :3]), 4)
+    with pytest.raises(H.HipKernelError, match="RL_KNN_MAX_K"):
+        ops.knn_f32(_t(xyz), _t(xyz), 65)
+    idx, d2 = ops.knn_f32(_t(xyz), _t(xyz[:, :0]), 3)       # empty query set
+    assert idx.shape == (2, 0, 3)
+
+
+def test_knn_full_size_properties(ops):
+    """Config A size (N=40960, K=16): properties that need no oracle run."""
+    rs = np.random.RandomState(2)
+    xyz = _t(rs.uniform(0, 1, (2, 40960, 3)).astype(np.float32))
+    idx, d2 = ops.knn_i32(xyz, xyz, 40960, 40960, 16)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 40960
+    assert bool((d2[..., 1:] >= d2[..., :-1]).all())
+    assert torch.equal(idx[..., 0], torch.arange(40960, device=DEV, dtype=torch.int32).expand(2, -1))
+    assert float(d2[..., 0].abs().max()) == 0.0
+    g = torch.gather(xyz, 1, idx.long().reshape(2, -1, 1).expand(-1, -1, 3)).reshape(2, 40960, 16, 3)
+    diff = xyz[:, :, None, :] - g
+    chk = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert torch.equal(chk, d2)
+    # a 2048-query sample against the oracle
+    from oracle import randlanet_oracle as O
+    ri, rd = O.knn(xyz[:1].cpu(), xyz[:1, :2048].cpu().contiguous(), 16)
+    assert torch.equal(idx[0, :2048].cpu().long(), ri[0]) and torch.equal(d2[0, :2048].cpu(), rd[0])
+
+
+# ----------------------------------------------------------------------------------- GEMM
+def _act(z, act, slope):
+    if act == 1:
+        return torch.relu(z)
+    if act == 2:
+        return torch.nn.functional.leaky_relu(z, slope)
+    return z
+
+
+@pytest.mark.parametrize("B,n,K,N,transposed,lazy,bias", [
+    (2, 1000, 3, 8, False, False, True),       # fc_start shape (K not a multiple of 4)
+    (2, 3000, 8, 16, False, True, True),
+    (1, 517, 16, 16, False, False, False),     # score Linear, no bias
+    (2, 777, 64, 32, False, True, True),
+    (3, 130, 128, 256, False, True, True),
+    (2, 160, 512, 512, False, True, True),     # bottleneck
+    (2, 640, 1024, 256, True, False, True),    # decoder.0 ConvTranspose2d
+    (2, 999, 64, 8, True, True, True),
+    (1, 300, 32, 2, False, True, True),        # fc_end.3
+    (1, 300, 32, 13, False, False, True),
+])
+def test_gemm_forward(ops, B, n, K, N, transposed, lazy, bias):
+    torch.manual_seed(K * N + n)
+    A = torch.randn(B * n, K, device=DEV)
+    W = torch.randn((K, N) if transposed else (N, K), device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV) if bias else None
+    a = ops.plain(A, B, n)
+    ref_in = A
+    if lazy:
+        a.scale, a.shift = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.3
+        a.act, a.slope = 2, 0.2
+        ref_in = _act(A * a.scale + a.shift, 2, 0.2)
+    ks, ns = ops.weight_strides(W, transposed, K, N)
+    stats = ops.new_stats(DEV, N)
+    Y = ops.gemm(a, W, ks, ns, N, b, stats=stats)
+    Wm = W if transposed else W.t()
+    ref = ref_in.double() @ Wm.double() + (b.double() if bias else 0)
+    tol = 2e-6 * K ** 0.5 * float(ref.abs().max()) + 1e-6   # exact-fp32 FMA chain vs fp64
+    assert float((Y.double() - ref).abs().max()) <= tol
+    nslots = min(-(-B * n // 128), 1024)
+    s = stats[:nslots]
+    np.testing.assert_allclose(s[:, 0].sum(0).cpu().numpy(), Y.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(s[:, 1].sum(0).cpu().numpy(), (Y.double() ** 2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric W catches a transposed C/D fragment map."""
+    n = 128
+    A = torch.eye(n, device=DEV)
+    W = (torch.arange(n * 48, device=DEV, dtype=torch.float32).reshape(48, n) % 97) - 11.0   # (N,K)
+    Y = ops.gemm(ops.plain(A, 1, n), W, 1, n, 48)
+    assert torch.equal(Y, W.t().contiguous())
+
+
+def test_gemm_batch_strided_accumulate(ops):
+    torch.manual_seed(0)
+    B, n_parent, n, K, N = 3, 400, 100, 32, 16
+    A = torch.randn(B * n_parent, K, device=DEV)
+    W = torch.randn(N, K, device=DEV)
+    a = ops.Lazy(A, B, n, n_parent, K)
+    out = torch.randn(B * n_parent, N, device=DEV)
+    before = out.clone()
+    ops.gemm(a, W, 1, K, N, None, out=out, out_bstride=n_parent, accumulate=True)
+    Av = A.view(B, n_parent, K)[:, :n]
+    ref = before.view(B, n_parent, N).clone()
+    ref[:, :n] += Av @ W.t()
+    assert float((out.view(B, n_parent, N) - ref).abs().max()) < 1e-4
+    assert torch.equal(out.view(B, n_parent, N)[:, n:], before.view(B, n_parent, N)[:, n:])
+
+
+def _rpe_ref(xyz, idx, d2):
+    B, n, K = idx.shape
+    xi = xyz[:, :n, None, :].expand(B, n, K, 3)
+    xj = torch.gather(xyz, 1, idx.long().reshape(B, n * K, 1).expand(-1, -1, 3)).reshape(B, n, K, 3)
+    return torch.cat([xi, xj, xi - xj, torch.sqrt(d2)[..., None]], -1).reshape(B * n * K, 10)
+
+
+def test_gemm_rpe_source_and_wgrad(ops):
+    torch.manual_seed(3)
+    B, n_parent, n, K, N = 2, 600, 300, 16, 8
+    xyz = torch.rand(B, n_parent, 3, device=DEV)
+    idx, d2 = ops.knn_i32(xyz, xyz, n, n, K)
+    W = torch.randn(N, 10, device=DEV)
+    b = torch.randn(N, device=DEV)
+    rpe = ops.Rpe(xyz, idx, d2, B, n, K)
+    Y = ops.gemm(rpe, W, 1, 10, N, b)
+    R = _rpe_ref(xyz, idx, d2)
+    ref = R @ W.t() + b
+    assert float((Y - ref).abs().max()) < 1e-5
+    dY = torch.randn_like(Y)
+    dW, db = torch.empty_like(W), torch.empty_like(b)
+    ops.wgrad(rpe, dY, n * K, N, dW, 1, 10, db)
+    assert float((dW - dY.t() @ R).abs().max()) < 2e-4 * float((dY.t() @ R).abs().max())
+    assert float((db - dY.sum(0)).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("B,n,K,N,transposed,lazy", [
+    (2, 5000, 8, 16, False, True), (1, 333, 16, 16, False, False), (2, 700, 64, 128, False, True),
+    (2, 640, 1024, 256, True, False), (3, 257, 256, 512, False, True), (1, 4096, 32, 2, False, True),
+    (2, 100, 3, 8, False, False),
+])
+def test_wgrad(ops, B, n, K, N, transposed, lazy):
+    torch.manual_seed(n + K)
+    A = torch.randn(B * n, K, device=DEV)
+    dY = torch.randn(B * n, N, device=DEV)
+    a = ops.plain(A, B, n)
+    ref_in = A
+    if lazy:
+        a.scale, a.shift, a.act, a.slope = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV), 1, 0.0
+        ref_in = torch.relu(A * a.scale + a.shift)
+    dW = torch.full((K, N) if transposed else (N, K), 7.0, device=DEV)
+    db = torch.empty(N, device=DEV)
+    ks, ns = ops.weight_strides(dW, transposed, K, N)
+    ops.wgrad(a, dY, n, N, dW, ks, ns, db)
+    ref = (ref_in.double().t() @ dY.double())           # (K,N)
+    ref = ref if transposed else ref.t()
+    tol = 3e-6 * (B * n) ** 0.5 * float(ref.abs().max()) + 1e-5
+    assert float((dW.double() - ref).abs().max()) <= tol
+    assert float((db.double() - dY.double().sum(0)).abs().max()) <= 1e-5 * B * n
+
+
+# ------------------------------------------------------------------------------ BatchNorm
+@pytest.mark.parametrize("C,rows", [(8, 5000), (64, 999), (512, 300), (1024, 257)])
+def test_bn_forward_backward(ops, C, rows):
+    torch.manual_seed(C)
+    Y = (torch.randn(rows, C, device=DEV) * 2 + 1).requires_grad_(True)
+    gamma = (torch.rand(C, device=DEV) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, device=DEV).requires_grad_(True)
+    rm, rv = torch.randn(C, device=DEV), torch.rand(C, device=DEV) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    # batch statistics come from a GEMM epilogue: run Y through an identity layer
+    stats = ops.new_stats(DEV, C)
+    eye = torch.eye(C, device=DEV)
+    Yc = ops.gemm(ops.plain(Y.detach().contiguous(), 1, rows), eye, 1, C, C, None, stats=stats)
+    assert torch.equal(Yc, Y.detach())
+    scale, shift, mean, invstd = ops.bn_finalize(stats, rows, 128, C, gamma.detach(), beta.detach(), rm, rv, nbt,
+                                                 0.99, 1e-6, True)
+    ref = torch.nn.functional.batch_norm(Y.t()[None], rm_ref, rv_ref, gamma, beta, True, 0.99, 1e-6)[0].t()
+    out = Y.detach() * scale + shift
+    assert float((out - ref.detach()).abs().max()) < 2e-5 * max(1.0, float(ref.detach().abs().max()))
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv_ref.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert int(nbt) == 1
+    # backward through leaky_relu(bn(Y))
+    act = torch.nn.functional.leaky_relu(ref, 0.2)
+    G = torch.randn(rows, C, device=DEV)
+    act.backward(G)
+    lz = ops.Lazy(Y.detach().contiguous(), 1, rows, rows, C, scale, shift, 2, 0.2, mean, invstd)
+    g = G.clone()
+    dgamma, dbeta = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_backward(g, lz, dgamma, dbeta, True)
+    sc = float(Y.grad.abs().max())
+    assert float((g - Y.grad).abs().max()) < 1e-4 * sc + 1e-6
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gamma.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), beta.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    # eval mode: scale/shift from running statistics
+    s2, b2, _, _ = ops.bn_finalize(None, rows, 128, C, gamma.detach(), beta.detach(), rm, rv, None, 0.99, 1e-6, False)
+    ref2 = torch.nn.functional.batch_norm(Y.detach().t()[None], rm, rv, gamma.detach(), beta.detach(), False, 0.99,
+                                          1e-6)[0].t()
+    assert float((Y.detach() * s2 + b2 - ref2).abs().max()) < 1e-5 * max(1.0, float(ref2.abs().max()))
+
+
+# ----------------------------------------------------------------------------- rows, pool
+def test_copy_rows_gather_concat_scatter(ops):
+    torch.manual_seed(5)
+    B, n_src, n, K, Cc = 2, 500, 200, 16, 8
+    src = torch.randn(B * n_src, Cc, device=DEV)
+    idx = torch.randint(0, n, (B, n, K), device=DEV, dtype=torch.int32)
+    lz = ops.Lazy(src, B, n, n_src, Cc, torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV), 2, 0.2)
+    U = torch.randn(B * n * K, Cc, device=DEV)
+    X = torch.empty(B * n * K, 2 * Cc, device=DEV)
+    ops.copy_rows(U, (0, Cc), n * K, X, (0, Cc), B * n * K, n * K)
+    ops.copy_rows(src, (0, Cc), n_src, X, (Cc, Cc), B * n * K, n * K, index=idx, lazy=lz)
+    act = torch.nn.functional.leaky_relu(src * lz.scale + lz.shift, 0.2).view(B, n_src, Cc)
+    g = torch.gather(act, 1, idx.long().reshape(B, n * K, 1).expand(-1, -1, Cc)).reshape(B * n * K, Cc)
+    assert torch.equal(X[:, :Cc], U) and float((X[:, Cc:] - g).abs().max()) < 1e-6
+    # shared permutation index (int64), as for the input permutation (modules.py:571-573)
+    perm = torch.randperm(n_src, device=DEV)
+    out = torch.empty(B * n_src, Cc, device=DEV)
+    ops.copy_rows(src, (0, Cc), n_src, out, (0, Cc), B * n_src, n_src, index=perm, index_shared=True)
+    assert torch.equal(out.view(B, n_src, Cc), src.view(B, n_src, Cc)[:, perm])
+    # 3-channel rows (scalar path): the xyz permutation
+    xyz = torch.randn(B * n_src, 3, device=DEV)
+    out3 = torch.empty_like(xyz)
+    ops.copy_rows(xyz, (0, 3), n_src, out3, (0, 3), B * n_src, n_src, index=perm, index_shared=True)
+    assert torch.equal(out3.view(B, n_src, 3), xyz.view(B, n_src, 3)[:, perm])
+    # transposed movement: gradient of the gather
+    dX = torch.randn(B * n * K, 2 * Cc, device=DEV)
+    dG = torch.zeros(B * n_src, Cc, device=DEV)
+    ops.scatter_add_rows(dX, (Cc, Cc), dG, n_src, B * n * K, n * K, idx)
+    ref = torch.zeros(B, n_src, Cc, device=DEV)
+    ref.scatter_add_(1, idx.long().reshape(B, n * K, 1).expand(-1, -1, Cc), dX[:, Cc:].reshape(B, n * K, Cc))
+    assert float((dG.view(B, n_src, Cc) - ref).abs().max()) < 1e-4
+    # accumulate into a column range
+    acc = torch.ones(B * n * K, Cc, device=DEV)
+    ops.copy_rows(dX, (0, Cc), n * K, acc, (0, Cc), B * n * K, n * K, accumulate=True)
+    assert torch.equal(acc, 1 + dX[:, :Cc])
+
+
+@pytest.mark.parametrize("P,K,Cc", [(1000, 16, 16), (300, 32, 64), (77, 16, 256), (50, 5, 10)])
+def test_attpool(ops, P, K, Cc):
+    torch.manual_seed(P)
+    X = torch.randn(P * K, Cc, device=DEV, requires_grad=True)
+    S = (torch.randn(P * K, Cc, device=DEV) * 2).requires_grad_(True)
+    out = ops.attpool_fwd(X.detach(), S.detach(), P, K)
+    A = torch.softmax(S.view(P, K, Cc), dim=1)
+    ref = (A * X.view(P, K, Cc)).sum(1)
+    assert float((out - ref).abs().max()) < 1e-5
+    dP = torch.randn(P, Cc, device=DEV)
+    ref.backward(dP)
+    dS, dXa = ops.attpool_bwd(X.detach(), S.detach(), out, dP, P, K)
+    assert float((dS - S.grad).abs().max()) < 1e-5 and float((dXa - X.grad).abs().max()) < 1e-5
+
+
+def test_add_act_and_logits_layout(ops):
+    torch.manual_seed(9)
+    rows, Cc = 1234, 32
+    y1, y2 = torch.randn(rows, Cc, device=DEV), torch.randn(rows, Cc, device=DEV)
+    l1 = ops.Lazy(y1, 1, rows, rows, Cc, torch.rand(Cc, device=DEV) + .5, torch.randn(Cc, device=DEV))
+    l2 = ops.Lazy(y2, 1, rows, rows, Cc, torch.rand(Cc, device=DEV) + .5, torch.randn(Cc, device=DEV))
+    O = ops.add_act_fwd(l1, l2, 0.01)
+    ref = torch.nn.functional.leaky_relu((y1 * l1.scale + l1.shift) + (y2 * l2.scale + l2.shift), 0.01)
+    assert float((O - ref).abs().max()) < 1e-6
+    G = torch.randn_like(O)
+    g = G.clone()
+    ops.add_act_bwd(g, O, 0.01)
+    assert torch.equal(g, torch.where(O > 0, G, G * 0.01))
+    B, N, C = 2, 500, 3
+    lp = torch.randn(B * N, C, device=DEV)
+    perm = torch.randperm(N, device=DEV)
+    logits = ops.logits_unpermute(lp, perm, B, N)
+    ref = torch.empty(B, N, C, device=DEV)
+    ref[:, perm] = lp.view(B, N, C)
+    assert torch.equal(logits, ref.permute(0, 2, 1).contiguous())
+    assert torch.equal(ops.logits_permute_grad(logits, perm), lp)
+
+
+# ----------------------------------------------------------------------------- loss, adam
+def test_loss_metrics_against_golden_and_oracle(ops, golden_dir):
+    from oracle import loss_metrics_oracle as LM
+    z = np.load(f"{golden_dir}/loss_metrics.npz")
+    for tag in ("c2", "c5"):
+        logits, labels = _t(z[f"{tag}/logits"]), _t(z[f"{tag}/labels"])
+        C = logits.shape[1]
+        for name, (kind, alpha, gamma) in ops.LOSS_KINDS.items():
+            out, work = ops.loss_forward(logits, labels, kind, alpha, gamma, True)
+            assert abs(float(out[0]) - float(z[f"{tag}/{name}"])) < 2e-6, (tag, name)     # vs the reference
+            g = ops.loss_backward(logits, labels, kind, alpha, gamma, True, work)
+            ref = z[f"{tag}/{name}_grad"]
+            assert np.abs(g.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max() + 1e-9, (tag, name)
+        cnt = out[1:].cpu().numpy().reshape(4, C)
+        inter, lab, pred = cnt[0], cnt[1], cnt[2]
+        oa, pca = LM.accuracy(z[f"{tag}/logits"], z[f"{tag}/labels"])
+        miou, pci = LM.iou(z[f"{tag}/logits"], z[f"{tag}/labels"])
+        assert abs(inter.sum() / lab.sum() - oa) < 1e-7
+        for c in range(C):
+            union = lab[c] + pred[c] - inter[c]
+            assert abs((1.0 if union == 0 else inter[c] / union) - pci[c]) < 1e-7
+            assert abs((1.0 if lab[c] == 0 else inter[c] / lab[c]) - pca[c]) < 1e-7
+
+
+def test_adam_matches_torch(ops):
+    torch.manual_seed(1)
+    n = 100003
+    p = torch.randn(n, device=DEV)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    lr = torch.tensor([1e-2], device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for it in range(4):
+        g = torch.randn(n, device=DEV)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g, m, v, lr, step)
+    assert int(step) == 4
+    assert float((p - ref.detach()).abs().max()) < 1e-6
