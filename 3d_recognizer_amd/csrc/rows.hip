@@ -164,6 +164,42 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(float* __restrict__ x, 
         x[e] = mask[e] ? x[e] * scale : 0.f;
 }
 
+// UpSampler (modules.py:343-414) on channel-first features: out[b][f][q] = sum_j w_j feat[b][f][idx[b][q][j]],
+// w_j = (1+eps)/(dist_j^power + eps) normalised over j (power 0 -> plain nearest-neighbour copy of j = 0)
+__global__ __launch_bounds__(256) void upsample_cf_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ d2, int B, int F, int N1, int N2, int k,
+                                                          int power, float* __restrict__ out) {
+    const long total = (long)B * N2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / N2;
+        const long q = e - b * N2;
+        const int32_t* id = idx + e * k;
+        const float* fb = feat + b * (long)F * N1;
+        float* ob = out + b * (long)F * N2 + q;
+        if (power == 0) {
+            const int j = id[0];
+            for (int f = 0; f < F; ++f) ob[(long)f * N2] = fb[(long)f * N1 + j];
+            continue;
+        }
+        float wsum = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const float dist = __fsqrt_rn(d2[e * k + j]);
+            const float dp = power == 2 ? dist * dist : dist;
+            wsum += (1.0f + 1e-7f) / (dp + 1e-7f);
+        }
+        for (int f = 0; f < F; ++f) {
+            float acc = 0.f;
+            for (int j = 0; j < k; ++j) {
+                const float dist = __fsqrt_rn(d2[e * k + j]);
+                const float dp = power == 2 ? dist * dist : dist;
+                const float w = ((1.0f + 1e-7f) / (dp + 1e-7f)) / wsum;
+                acc += w * fb[(long)f * N1 + id[j]];
+            }
+            ob[(long)f * N2] = acc;
+        }
+    }
+}
+
 // out[b][c][perm[i]] = in[b][i][c]
 __global__ __launch_bounds__(256) void logits_unpermute_kernel(const float* __restrict__ in, const int64_t* __restrict__ perm,
                                                                int B, int N, int C, float* __restrict__ out) {
@@ -256,6 +292,17 @@ extern "C" int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t
     if (count == 0) return RL_OK;
     hipLaunchKernelGGL(scale_mask_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, (long)count);
     RL_LAUNCH_CHECK("rl_scale_mask");
+    return RL_OK;
+}
+
+extern "C" int rl_upsample_cf(const float* feat, const int32_t* idx, const float* d2, int B, int F, int N1, int N2, int k,
+                              int power, float* out, void* stream) {
+    RL_REQUIRE(feat && idx && out && B > 0 && F > 0 && N1 > 0 && N2 >= 0 && k > 0, RL_ERR_ARGS, "rl_upsample_cf: bad arguments");
+    RL_REQUIRE(power >= 0 && power <= 2 && (power == 0 || d2), RL_ERR_ARGS, "rl_upsample_cf: power must be 0, 1 or 2");
+    if (N2 == 0) return RL_OK;
+    hipLaunchKernelGGL(upsample_cf_kernel, dim3(grid_for((long)B * N2)), dim3(256), 0, (hipStream_t)stream, feat, idx, d2, B,
+                       F, N1, N2, k, power, out);
+    RL_LAUNCH_CHECK("rl_upsample_cf");
     return RL_OK;
 }
 

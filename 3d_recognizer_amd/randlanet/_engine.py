@@ -1,0 +1,285 @@
+"""Forward / backward schedule of the RandLA-Net hot path over the HIP kernels.
+
+This is the host side of RandLANet.forward (reference randlanet/utils/modules.py:542-611) and
+of its autograd backward, written as an explicit launch schedule: every step below is one call
+into librandla_hip.so (include/rl_randlanet.h) on the current HIP stream, with no host
+synchronisation, so a whole training step can be captured into one hipGraph (see bench.py).
+
+Layout: activations are point-major / channel-last (B*n rows of C floats) instead of the
+reference's (B,C,N,K); parameters stay in the reference's state_dict layout and are read in
+place through strides, so nothing is converted at the boundary except the logits
+((B,C,N), original point order).
+
+Representation: the output of a SharedMLP is kept RAW (pre-BatchNorm) together with the
+per-channel (scale, shift) of its BatchNorm and its activation (`_ops.Lazy`); consumers apply
+them while loading.  BatchNorm therefore costs one tiny finalize kernel, not a pass over memory.
+
+Random sampling: the permutation (modules.py:571-573) is applied once to the input rows; all
+levels are prefixes of the permuted order (modules.py:587-598), read through batch strides;
+fc_end runs in permuted order (it is per-point, and BatchNorm statistics are order-invariant)
+and only the logits are un-permuted (modules.py:608).
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _hip as H
+from . import _ops as ops
+from ._ops import Lazy, Rpe
+
+BN_EPS = 1e-6       # modules.py:87, :497
+BN_MOMENTUM = 0.99
+
+
+class Context:
+    """What one forward leaves behind for its backward."""
+
+    def __init__(self):
+        self.tape: List[tuple] = []
+        self.grads: Dict[int, list] = {}     # id(raw tensor) -> [gradient tensor, initialised]
+        self.keep: List[torch.Tensor] = []
+        self.training = False
+        self.B = self.N = 0
+        self.perm: Optional[torch.Tensor] = None
+        self.logits_perm: Optional[Lazy] = None
+
+
+class Engine:
+    def __init__(self, layer_sizes, n_neighbors: int, decimation: int, n_classes: int, n_features: int,
+                 params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor]):
+        self.layers = list(layer_sizes)
+        self.K = int(n_neighbors)
+        self.dec = int(decimation)
+        self.C = int(n_classes)
+        self.F = int(n_features)
+        self.P = params      # reference state_dict names -> tensors (parameters)
+        self.Bf = buffers    # running_mean / running_var / num_batches_tracked
+
+    # ------------------------------------------------------------------------ forward pieces
+    def _w2(self, name: str) -> torch.Tensor:
+        w = self.P[name]
+        return w.view(w.shape[0], w.shape[1])
+
+    def _bn(self, ctx: Context, out: Lazy, stats, bn_name: str, act: int, slope: float):
+        nbt = self.Bf.get(f"{bn_name}.num_batches_tracked")
+        scale, shift, mean, invstd = ops.bn_finalize(
+            stats, out.rows, 128, out.C, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
+            self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
+            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training)
+        out.scale, out.shift, out.mean, out.invstd = scale, shift, mean, invstd
+        out.act, out.slope, out.bn = act, slope, bn_name
+
+    def _linear(self, ctx: Context, a, wname: str, bname: Optional[str], n_out: int, *, transposed=False,
+                bn: Optional[str] = None, act: int = H.ACT_NONE, slope: float = 0.0, a_grad: bool = True) -> Lazy:
+        """Y = A'.W + b  (+ lazy BatchNorm/activation).  Records the layer for backward."""
+        W = self._w2(wname)
+        K = 10 if isinstance(a, Rpe) else a.C
+        ks, ns = ops.weight_strides(W, transposed, K, n_out)
+        stats = ops.new_stats(W.device, n_out) if (bn and ctx.training) else None
+        Y = ops.gemm(a, W, ks, ns, n_out, self.P[bname] if bname else None, stats=stats)
+        rpb = a.n * a.K if isinstance(a, Rpe) else a.n
+        out = Lazy(Y, a.B, rpb, rpb, n_out)
+        if bn:
+            self._bn(ctx, out, stats, bn, act, slope)
+        else:
+            assert act == H.ACT_NONE
+        ctx.tape.append(("linear", a, out, wname, bname, ks, ns, a_grad))
+        return out
+
+    def _mlp(self, ctx, a, name: str, n_out: int, act: int = H.ACT_NONE, slope: float = 0.0, *, transposed=False,
+             bn=True, a_grad=True) -> Lazy:
+        """SharedMLP (modules.py:60-104)."""
+        return self._linear(ctx, a, f"{name}.conv.weight", f"{name}.conv.bias", n_out, transposed=transposed,
+                            bn=f"{name}.batch_norm" if bn else None, act=act, slope=slope, a_grad=a_grad)
+
+    def _pool(self, ctx, name: str, u: Lazy, g: Lazy, idx: torch.Tensor, n: int, d: int, n_out: int) -> Lazy:
+        """PointFeatureAugmentation + AttentivePooling (modules.py:213-221, 246-253)."""
+        B, K, h = u.B, self.K, d // 2
+        rows = B * n * K
+        X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
+        ops.copy_rows(u.raw, (0, h), n * K, X, (0, h), rows, n * K, lazy=u)
+        ops.copy_rows(g.raw, (0, h), g.bstride, X, (h, h), rows, n * K, index=idx, lazy=g)
+        Ws = self.P[f"{name}.score_fn.0.weight"]
+        S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None)
+        Pt = ops.attpool_fwd(X, S, B * n, K)
+        pooled = ops.plain(Pt, B, n)
+        ctx.tape.append(("pool", name, u, g, idx, X, S, pooled, n, d))
+        return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
+
+    def _lfa(self, ctx, l: int, xin: Lazy, xyz: torch.Tensor, n: int, d: int) -> Lazy:
+        """LocalFeatureAggregation (modules.py:298-325)."""
+        e = f"encoder.{l}"
+        B, K, h = xin.B, self.K, d // 2
+        idx, d2 = ops.knn_i32(xyz, xyz, n, n, K)
+        ctx.keep += [idx, d2]
+        f0 = self._mlp(ctx, xin, f"{e}.mlp1", h, H.ACT_LRELU, 0.2)
+        sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
+        rpe = Rpe(xyz, idx, d2, B, n, K)
+        u1 = self._mlp(ctx, rpe, f"{e}.mlp_rpe1", h, H.ACT_RELU, a_grad=False)
+        q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, n, d, h)
+        u2 = self._mlp(ctx, u1, f"{e}.mlp_rpe2", h, H.ACT_RELU)
+        q2 = self._pool(ctx, f"{e}.pool2", u2, q1, idx, n, d, d)
+        m2 = self._mlp(ctx, q2, f"{e}.mlp2", 2 * d)
+        O = ops.plain(ops.add_act_fwd(m2, sc, 0.01), B, n)
+        ctx.tape.append(("add_act", m2, sc, O))
+        return O
+
+    # ------------------------------------------------------------------------------ forward
+    def min_points(self) -> int:
+        L = len(self.layers)
+        return max(self.K * self.dec ** (L - 1), 2 * self.dec ** L)       # modules.py:488-491
+
+    def forward(self, inp: torch.Tensor, perm: torch.Tensor, training: bool, dropout_p: float = 0.5,
+                keep_mask: Optional[torch.Tensor] = None):
+        """inp (B,N,3+F) fp32 on the device, perm (N,) int64 on the device -> logits (B,C,N), ctx."""
+        B, N, cin = inp.shape
+        assert cin == 3 + self.F and inp.dtype == torch.float32 and inp.is_cuda and inp.is_contiguous()
+        assert perm.dtype == torch.int64 and perm.numel() == N and perm.is_cuda
+        assert N >= self.min_points()
+        dev = inp.device
+        ctx = Context()
+        ctx.training, ctx.B, ctx.N, ctx.perm = training, B, N, perm
+        L, dec = len(self.layers), self.dec
+
+        # random permutation of the rows (modules.py:571-573), once, on the input
+        inp_p = torch.empty((B * N, cin), dtype=torch.float32, device=dev)
+        ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=perm, index_shared=True)
+        if cin == 3:
+            xyz = inp_p.view(B, N, 3)
+        else:
+            xyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+            ops.copy_rows(inp_p, (0, 3), N, xyz.view(B * N, 3), (0, 3), B * N, N)
+        ctx.keep += [inp_p, xyz]
+
+        # fc_start + bn_start (modules.py:565-566)
+        x = self._linear(ctx, ops.plain(inp_p, B, N), "fc_start.weight", "fc_start.bias", 8, bn="bn_start.0",
+                         act=H.ACT_LRELU, slope=0.2, a_grad=False)
+        # encoder (modules.py:582-589)
+        skips: List[Lazy] = []
+        ratio = 1
+        for l, d in enumerate(self.layers):
+            n_l = N // ratio
+            x = self._lfa(ctx, l, x.prefix(n_l), xyz, n_l, d)
+            skips.append(x)
+            ratio *= dec
+        x = self._mlp(ctx, x.prefix(N // ratio), "mlp", x.C, H.ACT_RELU)        # modules.py:591
+        # decoder (modules.py:594-605)
+        for j in range(L):
+            n_c, n_f = N // ratio, dec * N // ratio
+            nn, _ = ops.knn_i32(xyz, xyz, n_c, n_f, 1)
+            skip = skips.pop()
+            assert skip.n == n_f and x.n == n_c
+            cat = torch.empty((B * n_f, x.C + skip.C), dtype=torch.float32, device=dev)
+            ops.copy_rows(x.raw, (0, x.C), x.bstride, cat, (0, x.C), B * n_f, n_f, index=nn, lazy=x)
+            ops.copy_rows(skip.raw, (0, skip.C), skip.bstride, cat, (x.C, skip.C), B * n_f, n_f)
+            catl = ops.plain(cat, B, n_f)
+            ctx.tape.append(("interp_concat", x, skip, nn, catl))
+            n_out = 8 if j == L - 1 else 2 * self.layers[L - 2 - j]
+            x = self._mlp(ctx, catl, f"decoder.{j}", n_out, H.ACT_RELU, transposed=True)
+            ratio //= dec
+        # fc_end in permuted order; the logits are un-permuted at the very end (modules.py:608-611)
+        x = self._mlp(ctx, x, "fc_end.0", 64, H.ACT_RELU)
+        x = self._mlp(ctx, x, "fc_end.1", 32, H.ACT_RELU)
+        if training and dropout_p > 0.0:
+            if keep_mask is None:
+                keep_mask = (torch.rand((B * N, 32), device=dev) >= dropout_p).to(torch.uint8)
+            t = torch.empty((B * N, 32), dtype=torch.float32, device=dev)
+            ops.copy_rows(x.raw, (0, 32), N, t, (0, 32), B * N, N, lazy=x)
+            ops.scale_mask(t, keep_mask, 1.0 / (1.0 - dropout_p))
+            dropped = ops.plain(t, B, N)
+            ctx.tape.append(("dropout", x, dropped, keep_mask, 1.0 / (1.0 - dropout_p)))
+            x = dropped
+        lp = self._mlp(ctx, x, "fc_end.3", self.C, bn=False)
+        ctx.logits_perm = lp
+        logits = ops.logits_unpermute(lp.raw, perm, B, N)
+        return logits, ctx
+
+    # ----------------------------------------------------------------------------- backward
+    @staticmethod
+    def _gbuf(ctx: Context, lz: Lazy):
+        ent = ctx.grads.get(id(lz.raw))
+        if ent is None:
+            ent = [torch.empty_like(lz.raw), False]
+            ctx.grads[id(lz.raw)] = ent
+        return ent
+
+    def backward(self, ctx: Context, dlogits: torch.Tensor, grads: Dict[str, torch.Tensor]) -> None:
+        """dlogits (B,C,N) -> fills grads[name] for every parameter (reference names/layouts)."""
+        if not ctx.training:
+            raise H.HipKernelError("backward is implemented for training-mode forwards (batch statistics)")
+        B, N = ctx.B, ctx.N
+        assert dlogits.shape == (B, self.C, N) and dlogits.is_cuda
+        dlogits = dlogits.contiguous().float()
+        ctx.grads[id(ctx.logits_perm.raw)] = [ops.logits_permute_grad(dlogits, ctx.perm), True]
+        for rec in reversed(ctx.tape):
+            kind = rec[0]
+            if kind == "linear":
+                self._bwd_linear(ctx, grads, *rec[1:])
+            elif kind == "pool":
+                self._bwd_pool(ctx, grads, *rec[1:])
+            elif kind == "add_act":
+                _, m2, sc, O = rec
+                G, init = self._gbuf(ctx, O)
+                assert init
+                ops.add_act_bwd(G, O.raw, 0.01)
+                g2 = torch.empty_like(G)
+                ops.copy_rows(G, (0, O.C), O.n, g2, (0, O.C), O.rows, O.n)
+                ctx.grads[id(m2.raw)] = [G, True]
+                ctx.grads[id(sc.raw)] = [g2, True]
+            elif kind == "interp_concat":
+                _, prev, skip, nn, catl = rec
+                G, init = self._gbuf(ctx, catl)
+                assert init
+                gp = self._gbuf(ctx, prev)
+                if not gp[1]:
+                    gp[0].zero_()
+                    gp[1] = True
+                ops.scatter_add_rows(G, (0, prev.C), gp[0], prev.bstride, catl.rows, catl.n, nn)
+                gs = self._gbuf(ctx, skip)
+                ops.copy_rows(G, (prev.C, skip.C), catl.n, gs[0], (0, skip.C), catl.rows, catl.n, accumulate=gs[1])
+                gs[1] = True
+            elif kind == "dropout":
+                _, src, dropped, mask, scale = rec
+                G, init = self._gbuf(ctx, dropped)
+                assert init
+                ops.scale_mask(G, mask, scale)
+                ctx.grads[id(src.raw)] = [G, True]
+            else:
+                raise AssertionError(kind)
+        ctx.tape.clear()
+        ctx.grads.clear()
+        ctx.keep.clear()
+
+    def _bwd_linear(self, ctx, grads, a, out: Lazy, wname, bname, ks, ns, a_grad):
+        G, init = self._gbuf(ctx, out)
+        assert init, f"no gradient reached {wname}"
+        if out.scale is not None:
+            ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True)
+        n_out = out.C
+        ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns, grads[bname] if bname else None)
+        if a_grad and isinstance(a, Lazy):
+            ga = self._gbuf(ctx, a)
+            if not ga[1]:
+                assert a.n == a.bstride and a.raw.shape[0] == a.B * a.n, "first writer must cover the tensor"
+            gl = Lazy(G, out.B, out.n, out.bstride, n_out)
+            # dA = dY . W^T : the same kernel with the weight strides swapped
+            ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=ga[0], out_bstride=a.bstride, accumulate=ga[1])
+            ga[1] = True
+
+    def _bwd_pool(self, ctx, grads, name, u: Lazy, g: Lazy, idx, X, S, pooled: Lazy, n, d):
+        B, K, h = u.B, self.K, d // 2
+        rows = B * n * K
+        GP, init = self._gbuf(ctx, pooled)
+        assert init
+        dS, dX = ops.attpool_bwd(X, S, pooled.raw, GP, B * n, K)
+        Ws = self.P[f"{name}.score_fn.0.weight"]
+        ops.wgrad(ops.plain(X, B, n * K), dS, n * K, d, grads[f"{name}.score_fn.0.weight"], 1, d, None)
+        ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
+        gu = self._gbuf(ctx, u)
+        ops.copy_rows(dX, (0, h), n * K, gu[0], (0, h), rows, n * K, accumulate=gu[1])
+        gu[1] = True
+        gg = self._gbuf(ctx, g)
+        if not gg[1]:
+            gg[0].zero_()
+            gg[1] = True
+        ops.scatter_add_rows(dX, (h, h), gg[0], g.bstride, rows, n * K, idx)

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "rl_add_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp, _vp]),
     "rl_add_act_bwd": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
+    "rl_upsample_cf": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rl_logits_unpermute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_logits_permute_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_loss_work_doubles": (_l, [_l, _i]),

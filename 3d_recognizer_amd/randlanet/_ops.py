@@ -326,6 +326,18 @@ def scale_mask(x: torch.Tensor, mask: torch.Tensor, scale: float) -> None:
     H.check(H.lib().rl_scale_mask(x.data_ptr(), mask.data_ptr(), scale, x.numel(), _st()), "rl_scale_mask")
 
 
+def upsample_cf(feat: torch.Tensor, idx: torch.Tensor, d2: Optional[torch.Tensor], power: int) -> torch.Tensor:
+    """feat (B,F,N1) channel-first, idx/d2 (B,N2,k) -> (B,F,N2)."""
+    _dev_check(feat, idx, d2)
+    B, Fc, N1 = feat.shape
+    _, N2, k = idx.shape
+    assert idx.dtype == torch.int32 and feat.dtype == F32 and idx.shape[0] == B
+    out = torch.empty((B, Fc, N2), dtype=F32, device=feat.device)
+    H.check(H.lib().rl_upsample_cf(feat.data_ptr(), idx.data_ptr(), H.ptr(d2), B, Fc, N1, N2, k, power,
+                                   out.data_ptr(), _st()), "rl_upsample_cf")
+    return out
+
+
 def logits_unpermute(lp: torch.Tensor, perm: torch.Tensor, B: int, N: int) -> torch.Tensor:
     Cc = lp.shape[1]
     assert lp.shape == (B * N, Cc) and perm.dtype == torch.int64 and perm.numel() == N

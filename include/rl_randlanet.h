@@ -32,6 +32,7 @@
  *   rl_attpool_*          AttentivePooling softmax over K + weighted sum (modules.py:246-253)
  *   rl_add_act_*          LocalFeatureAggregation residual + LeakyReLU (modules.py:325)
  *   rl_scale_mask         Dropout of fc_end (modules.py:528)
+ *   rl_upsample_cf        UpSampler nni / nna / idw / isdw (modules.py:343-456)
  *   rl_logits_*           un-permute + (B,C,N) layout of the logits (modules.py:608-611)
  *   rl_loss_*             FocalTverskyLoss / FocalLoss / cross entropy (utils/losses.py:17-87,
  *                         trainer.py:244-269) and accuracy / iou (utils/metrics.py:8-59)
@@ -236,6 +237,13 @@ int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, v
 /* Dropout (fc_end, modules.py:528) with a keep-mask drawn by the caller (uint8, 1 = keep):
  * x[i] = mask[i] ? x[i]*scale : 0, in place; the same call is its own backward.             */
 int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t count, void* stream);
+
+/* UpSampler (modules.py:343-456) on channel-first features feat (B,F,N1) with neighbours
+ * idx/d2 (B,N2,k) from rl_knn_i32: power 0 = nearest-neighbour interpolation (k = 1),
+ * power 1 / 2 = inverse (squared) distance weighting, w = (1+1e-7)/(dist^power + 1e-7)
+ * normalised over the k neighbours.  out (B,F,N2).                                          */
+int rl_upsample_cf(const float* feat, const int32_t* idx, const float* d2, int B, int F, int N1,
+                   int N2, int k, int power, float* out, void* stream);
 
 /* logits (B,N,C) channel-last in permuted order  <->  (B,C,N) in original order
  * (modules.py:608-611): out[b][c][perm[i]] = in[b][i][c]; backward is the gather.           */
