@@ -61,6 +61,48 @@ def _st():
     return H.stream_ptr()
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    Each record: (category, shape key, algorithmic bytes, flops, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for cat, key, nbytes, flops, e0, e1 in self.records:
+            a = agg.setdefault((cat, key), dict(category=cat, shape=key, launches=0, ms=0.0, bytes=0, flops=0))
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["bytes"] += nbytes
+            a["flops"] += flops
+        return sorted(agg.values(), key=lambda a: -a["ms"])
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+class _rec:
+    """with _rec(category, key, bytes, flops): <one launch>  - free unless TIMER is set."""
+    __slots__ = ("args", "e0")
+
+    def __init__(self, cat, key, nbytes, flops=0):
+        self.args = (cat, key, nbytes, flops)
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if TIMER is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            TIMER.records.append(self.args + (self.e0, e1))
+        return False
+
+
 # ------------------------------------------------------------------------------------- knn
 def knn_i32(support: torch.Tensor, query: torch.Tensor, Ns: int, Nq: int, k: int
             ) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -71,8 +113,9 @@ def knn_i32(support: torch.Tensor, query: torch.Tensor, Ns: int, Nq: int, k: int
     assert query.shape[0] == B and support.shape[1] >= Ns and query.shape[1] >= Nq
     idx = torch.empty((B, Nq, k), dtype=torch.int32, device=support.device)
     d2 = torch.empty((B, Nq, k), dtype=F32, device=support.device)
-    H.check(H.lib().rl_knn_i32(support.data_ptr(), support.shape[1], query.data_ptr(), query.shape[1],
-                               B, Ns, Nq, k, idx.data_ptr(), d2.data_ptr(), _st()), "rl_knn_i32")
+    with _rec("knn", (B, Ns, Nq, k), B * (12 * (Ns + Nq) + 8 * Nq * k), 8 * B * Ns * Nq):
+        H.check(H.lib().rl_knn_i32(support.data_ptr(), support.shape[1], query.data_ptr(), query.shape[1],
+                                   B, Ns, Nq, k, idx.data_ptr(), d2.data_ptr(), _st()), "rl_knn_i32")
     return idx, d2
 
 
@@ -82,8 +125,9 @@ def knn_f32(support: torch.Tensor, query: torch.Tensor, k: int) -> Tuple[torch.T
     Nq = query.shape[1]
     idx = torch.empty((B, Nq, k), dtype=torch.int64, device=support.device)
     d2 = torch.empty((B, Nq, k), dtype=F32, device=support.device)
-    H.check(H.lib().rl_knn_f32(support.data_ptr(), query.data_ptr(), B, Ns, Nq, k, idx.data_ptr(),
-                               d2.data_ptr(), _st()), "rl_knn_f32")
+    with _rec("knn", (B, Ns, Nq, k), B * (12 * (Ns + Nq) + 12 * Nq * k), 8 * B * Ns * Nq):
+        H.check(H.lib().rl_knn_f32(support.data_ptr(), query.data_ptr(), B, Ns, Nq, k, idx.data_ptr(),
+                                   d2.data_ptr(), _st()), "rl_knn_f32")
     return idx, d2
 
 
@@ -157,7 +201,8 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     d.N, d.W, d.w_ks, d.w_ns, d.bias = N, W.data_ptr(), w_ks, w_ns, H.ptr(bias)
     d.Y, d.ldy, d.y_bstride, d.accumulate = out.data_ptr(), out.shape[1], out_bstride, int(accumulate)
     d.stats = H.ptr(stats)
-    H.check(H.lib().rl_gemm(C.byref(d), _st()), "rl_gemm")
+    with _rec("gemm_rpe" if isinstance(a, Rpe) else "gemm", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N * (2 if accumulate else 1) + K * N), 2 * M * K * N):
+        H.check(H.lib().rl_gemm(C.byref(d), _st()), "rl_gemm")
     return out
 
 
@@ -187,7 +232,8 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     d.N, d.dY, d.lddy, d.dy_bstride = N, dY.data_ptr(), dY.shape[1], dy_bstride
     d.dW, d.w_ks, d.w_ns, d.dbias = dW.data_ptr(), w_ks, w_ns, H.ptr(dbias)
     d.slab, d.slab_floats = slab.data_ptr(), slab.numel()
-    H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
+    with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N + K * N), 2 * M * K * N):
+        H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
 
 
 # -------------------------------------------------------------------------------------- bn
@@ -230,12 +276,14 @@ def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta:
         stats = new_stats(G.device, y.C)
         coef = torch.empty(2 * y.C, dtype=F32, device=G.device)
         d.stats = stats.data_ptr()
-        H.check(H.lib().rl_bn_bwd_reduce(C.byref(d), _st()), "rl_bn_bwd_reduce")
+        with _rec("bn_bwd_reduce", (y.rows, y.C), 8 * y.rows * y.C, 0):
+            H.check(H.lib().rl_bn_bwd_reduce(C.byref(d), _st()), "rl_bn_bwd_reduce")
         H.check(H.lib().rl_bn_bwd_finalize(stats.data_ptr(), H.row_blocks(y.rows, 256), y.rows, y.C,
                                            H.ptr(dgamma), H.ptr(dbeta), coef.data_ptr(), _st()),
                 "rl_bn_bwd_finalize")
         d.coef = coef.data_ptr()
-    H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
+    with _rec("bn_bwd_apply", (y.rows, y.C), 12 * y.rows * y.C, 0):
+        H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
 
 
 # ------------------------------------------------------------------------------------ rows
@@ -264,7 +312,8 @@ def copy_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, ds
     if lazy is not None and lazy.scale is not None:
         assert c0s == 0 and cn == lazy.C
         d.scale, d.shift, d.act, d.slope = lazy.scale.data_ptr(), lazy.shift.data_ptr(), lazy.act, lazy.slope
-    H.check(H.lib().rl_copy_rows(C.byref(d), _st()), "rl_copy_rows")
+    with _rec("copy_rows", (rows, cn, index is not None), (8 + 4 * int(accumulate)) * rows * cn, 0):
+        H.check(H.lib().rl_copy_rows(C.byref(d), _st()), "rl_copy_rows")
 
 
 def scatter_add_rows(src: torch.Tensor, src_cols: Tuple[int, int], dst: torch.Tensor, dst_bstride: int,
@@ -282,7 +331,8 @@ def scatter_add_rows(src: torch.Tensor, src_cols: Tuple[int, int], dst: torch.Te
     else:
         d.index64 = index.data_ptr()
     d.index_shared = int(index_shared)
-    H.check(H.lib().rl_scatter_add_rows(C.byref(d), _st()), "rl_scatter_add_rows")
+    with _rec("scatter_add", (rows, cn), 12 * rows * cn, 0):
+        H.check(H.lib().rl_scatter_add_rows(C.byref(d), _st()), "rl_scatter_add_rows")
 
 
 # ------------------------------------------------------------------------- pooling, residual
@@ -291,7 +341,8 @@ def attpool_fwd(X: torch.Tensor, S: torch.Tensor, P: int, K: int) -> torch.Tenso
     Cc = X.shape[1]
     assert X.shape == S.shape == (P * K, Cc)
     out = torch.empty((P, Cc), dtype=F32, device=X.device)
-    H.check(H.lib().rl_attpool_fwd(X.data_ptr(), S.data_ptr(), P, K, Cc, out.data_ptr(), _st()), "rl_attpool_fwd")
+    with _rec("attpool_fwd", (P, K, Cc), 4 * (2 * P * K * Cc + P * Cc), 0):
+        H.check(H.lib().rl_attpool_fwd(X.data_ptr(), S.data_ptr(), P, K, Cc, out.data_ptr(), _st()), "rl_attpool_fwd")
     return out
 
 
@@ -301,23 +352,26 @@ def attpool_bwd(X, S, Pout, dP, P: int, K: int):
     assert X.shape == S.shape == (P * K, Cc) and Pout.shape == dP.shape == (P, Cc)
     dS = torch.empty_like(S)
     dXa = torch.empty_like(X)
-    H.check(H.lib().rl_attpool_bwd(X.data_ptr(), S.data_ptr(), Pout.data_ptr(), dP.data_ptr(), P, K, Cc,
-                                   dS.data_ptr(), dXa.data_ptr(), _st()), "rl_attpool_bwd")
+    with _rec("attpool_bwd", (P, K, Cc), 4 * (4 * P * K * Cc + 2 * P * Cc), 0):
+        H.check(H.lib().rl_attpool_bwd(X.data_ptr(), S.data_ptr(), Pout.data_ptr(), dP.data_ptr(), P, K, Cc,
+                                       dS.data_ptr(), dXa.data_ptr(), _st()), "rl_attpool_bwd")
     return dS, dXa
 
 
 def add_act_fwd(y1: Lazy, y2: Lazy, slope: float) -> torch.Tensor:
     assert y1.rows == y2.rows and y1.C == y2.C and y1.bstride == y1.n and y2.bstride == y2.n
     out = torch.empty((y1.rows, y1.C), dtype=F32, device=y1.raw.device)
-    H.check(H.lib().rl_add_act_fwd(y1.raw.data_ptr(), y1.scale.data_ptr(), y1.shift.data_ptr(), y2.raw.data_ptr(),
-                                   y2.scale.data_ptr(), y2.shift.data_ptr(), y1.rows, y1.C, slope, out.data_ptr(),
-                                   _st()), "rl_add_act_fwd")
+    with _rec("add_act", (y1.rows, y1.C), 12 * y1.rows * y1.C, 0):
+        H.check(H.lib().rl_add_act_fwd(y1.raw.data_ptr(), y1.scale.data_ptr(), y1.shift.data_ptr(), y2.raw.data_ptr(),
+                                       y2.scale.data_ptr(), y2.shift.data_ptr(), y1.rows, y1.C, slope, out.data_ptr(),
+                                       _st()), "rl_add_act_fwd")
     return out
 
 
 def add_act_bwd(G: torch.Tensor, O: torch.Tensor, slope: float) -> None:
     assert G.shape == O.shape and G.is_contiguous() and O.is_contiguous()
-    H.check(H.lib().rl_add_act_bwd(G.data_ptr(), O.data_ptr(), G.shape[0], G.shape[1], slope, _st()), "rl_add_act_bwd")
+    with _rec("add_act", (G.shape[0], G.shape[1]), 12 * G.numel(), 0):
+        H.check(H.lib().rl_add_act_bwd(G.data_ptr(), O.data_ptr(), G.shape[0], G.shape[1], slope, _st()), "rl_add_act_bwd")
 
 
 def scale_mask(x: torch.Tensor, mask: torch.Tensor, scale: float) -> None:
@@ -374,9 +428,10 @@ def loss_forward(logits: torch.Tensor, labels: torch.Tensor, kind: int, alpha: f
     assert labels.shape == (B, N) and labels.dtype == torch.int64 and logits.dtype == F32
     work = torch.empty(H.lib().rl_loss_work_doubles(B * N, Cc), dtype=torch.float64, device=logits.device)
     out = torch.empty(1 + 4 * Cc, dtype=torch.float64, device=logits.device)
-    H.check(H.lib().rl_loss_forward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
-                                    int(neglect_background), work.data_ptr(), out.data_ptr(), _st()),
-            "rl_loss_forward")
+    with _rec("loss", (B, Cc, N), 4 * B * Cc * N + 8 * B * N, 0):
+        H.check(H.lib().rl_loss_forward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
+                                        int(neglect_background), work.data_ptr(), out.data_ptr(), _st()),
+                "rl_loss_forward")
     return out, work
 
 
@@ -384,9 +439,10 @@ def loss_backward(logits, labels, kind: int, alpha: float, gamma: float, neglect
                   grad_scale: float = 1.0) -> torch.Tensor:
     B, Cc, N = logits.shape
     dlogits = torch.empty_like(logits)
-    H.check(H.lib().rl_loss_backward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
-                                     int(neglect_background), work.data_ptr(), grad_scale, dlogits.data_ptr(),
-                                     _st()), "rl_loss_backward")
+    with _rec("loss", (B, Cc, N), 8 * B * Cc * N + 8 * B * N, 0):
+        H.check(H.lib().rl_loss_backward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
+                                         int(neglect_background), work.data_ptr(), grad_scale, dlogits.data_ptr(),
+                                         _st()), "rl_loss_backward")
     return dlogits
 
 
@@ -396,6 +452,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr: torch.Tensor, step: torch.Te
     n = param.numel()
     assert grad.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n
     assert lr.dtype == F32 and step.dtype == torch.int64
-    H.check(H.lib().rl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
-                                 lr.data_ptr(), beta1, beta2, eps, grad_scale, step.data_ptr(), _st()),
-            "rl_adam_step")
+    with _rec("adam", (n,), 28 * n, 0):
+        H.check(H.lib().rl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n,
+                                     lr.data_ptr(), beta1, beta2, eps, grad_scale, step.data_ptr(), _st()),
+                "rl_adam_step")

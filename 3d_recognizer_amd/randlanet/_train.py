@@ -1,0 +1,151 @@
+"""Fused training step of the hot path: forward + loss/metrics + backward + gradient all-reduce +
+Adam as one launch schedule on one HIP stream, optionally captured into a hipGraph.
+
+This is the inner loop of Trainer.train (reference randlanet/utils/trainer.py:107-131) with the
+host out of the way: parameters, gradients and both Adam moments live in four flat fp32
+buffers (the module's nn.Parameters are views into them, so state_dict()/optimisers/checkpoints
+keep working); the loss and the metric counts come back as ONE packed record per step
+(the reference does 2C+2 `.item()` round trips); with world_size > 1 the flat gradient buffer is
+all-reduced once per step over RCCL and divided by the world size inside the Adam kernel.
+"""
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _hip as H
+from . import _ops as ops
+
+
+class FlatParameters:
+    """Re-homes a module's parameters into one flat fp32 buffer (plus a matching gradient buffer)."""
+
+    def __init__(self, module: torch.nn.Module):
+        named = list(module.named_parameters())
+        dev = named[0][1].device
+        total = sum(p.numel() for _, p in named)
+        self.param = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads: Dict[str, torch.Tensor] = {}
+        o = 0
+        for name, p in named:
+            n = p.numel()
+            self.param[o:o + n].copy_(p.detach().reshape(-1))
+            p.data = self.param[o:o + n].view(p.shape)
+            g = self.grad[o:o + n].view(p.shape)
+            p.grad = g
+            self.grads[name] = g
+            o += n
+        self.total = total
+
+
+class TrainStep:
+    """One data-parallel training step on the HIP kernels.
+
+    step(perm) consumes a host permutation (np.random.permutation(N), drawn by the caller from
+    the global numpy RNG like the reference, modules.py:571), runs the schedule and leaves the
+    packed loss/metric record in `self.out` (device) / `self.out_host` (pinned, asynchronous)."""
+
+    def __init__(self, module, B: int, N: int, loss: str = "dice", lr: float = 1e-2, use_graph: bool = True,
+                 process_group=None, world_size: int = 1):
+        self.module = module
+        self.dev = module.device
+        if self.dev.type != "cuda":
+            raise H.HipKernelError("TrainStep needs an MI355X (HIP) device")
+        s = module.settings
+        self.B, self.N, self.C = B, N, s.n_classes
+        self.kind, self.alpha, self.gamma = ops.LOSS_KINDS[loss]
+        self.flat = FlatParameters(module)
+        self.engine = module.engine()
+        self.p_drop = float(module.fc_end[2].p)
+        self.world, self.pg = world_size, process_group
+        self.exp_avg = torch.zeros_like(self.flat.param)
+        self.exp_avg_sq = torch.zeros_like(self.flat.param)
+        self.lr = torch.tensor([lr], dtype=torch.float32, device=self.dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        # static buffers; all start VALID (the capture pass launches kernels that index with them)
+        self.inp = torch.rand((B, N, 3 + s.n_features), dtype=torch.float32, device=self.dev)
+        self.labels = torch.zeros((B, N), dtype=torch.int64, device=self.dev)
+        self.perm = torch.arange(N, dtype=torch.int64, device=self.dev)
+        self.perm_host = torch.empty(N, dtype=torch.int64).pin_memory()
+        self.out = torch.zeros(1 + 4 * self.C, dtype=torch.float64, device=self.dev)
+        self.out_host = torch.zeros(1 + 4 * self.C, dtype=torch.float64).pin_memory()
+        self.use_graph = use_graph
+        self._g_main: Optional[torch.cuda.CUDAGraph] = None
+        self._g_adam: Optional[torch.cuda.CUDAGraph] = None
+
+    # -- the schedule ------------------------------------------------------------------------
+    def _fwd_bwd(self):
+        logits, ctx = self.engine.forward(self.inp, self.perm, True, self.p_drop)
+        out, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True)
+        dlogits = ops.loss_backward(logits, self.labels, self.kind, self.alpha, self.gamma, True, work)
+        self.engine.backward(ctx, dlogits, self.flat.grads)
+        self.out.copy_(out)
+
+    def _adam(self):
+        ops.adam_step(self.flat.param, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
+                      grad_scale=1.0 / self.world)
+
+    def _allreduce(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def capture(self, warmup: int = 2) -> None:
+        """Run a few eager steps on a side stream (allocator warm-up), then capture."""
+        self.module.train()
+        if not self.use_graph:
+            return
+        snap = (self.flat.param.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.step_count.clone())
+        bufs = {k: v.clone() for k, v in self.module.named_buffers()}
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._fwd_bwd()
+                self._adam()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self._g_main = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_main):
+            self._fwd_bwd()
+            if self.world == 1:
+                self._adam()
+        if self.world > 1:
+            self._g_adam = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_adam):
+                self._adam()
+        # the warm-up and capture passes must not count as training: restore the state
+        self.flat.param.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
+        self.step_count.copy_(snap[3])
+        for k, v in self.module.named_buffers():
+            v.copy_(bufs[k])
+        torch.cuda.synchronize(self.dev)
+
+    def set_batch(self, inp: torch.Tensor, labels: torch.Tensor) -> None:
+        self.inp.copy_(inp, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+
+    def step(self, perm: np.ndarray) -> None:
+        self.perm_host.copy_(torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int64)))
+        self.perm.copy_(self.perm_host, non_blocking=True)
+        if self._g_main is not None:
+            self._g_main.replay()
+            if self.world > 1:
+                self._allreduce()
+                self._g_adam.replay()
+        else:
+            self._fwd_bwd()
+            self._allreduce()
+            self._adam()
+        self.out_host.copy_(self.out, non_blocking=True)
+
+    def last_metrics(self) -> Dict[str, float]:
+        """Synchronises and unpacks the record of the last step (reference metrics.py:8-59)."""
+        from .utils.metrics import accuracy_from_counts, iou_from_counts
+        torch.cuda.current_stream(self.dev).synchronize()
+        rec = self.out_host.numpy().copy()
+        cnt = rec[1:1 + 3 * self.C].reshape(3, self.C)
+        oa, pca = accuracy_from_counts(cnt)
+        miou, pci = iou_from_counts(cnt)
+        return dict(loss=float(rec[0]), OA=oa, mAcc=float(np.mean(pca)), mIoU=miou, per_class_iou=pci)

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RandLA-Net training clouds/sec on MI355X (BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config A of BASELINE.json / SURVEY.md 8d): N=40960 points per cloud, 2 classes,
+k=16, encoder layers [16,64,128,256], 4 clouds per GPU, synthetic clouds xyz ~ U[0,1)^3 from
+RandomState(1234+rank), labels = sphere rule, random-init weights.  One step = per-forward
+numpy permutation -> forward -> dice loss + metric counts -> backward -> (RCCL all-reduce of
+the flat gradient when N>1) -> Adam, all on hand-written HIP kernels (librandla_hip.so),
+replayed as a hipGraph.  Inputs are resident in HBM before the timed region.  Weak scaling:
+per-GPU batch is fixed, clouds are sharded over ranks, the only collective is one all-reduce.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     - the kernel with the largest share of the step (measured with HIP events around
+                 every launch of an instrumented eager pass on the launch stream): algorithmic
+                 bytes per launch / mean launch duration vs the 8 TB/s HBM peak.
+  cpu_baseline - the same training step on the host cores: oracle/ restatement of the
+                 reference's PyTorch-CPU graph + single-threaded exact C KNN ("port"), on a
+                 bounded sample (B=2 clouds, 1 warm-up + 2 timed steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "3d_recognizer_amd"))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+CFG = dict(n_points=40960, n_classes=2, n_neighbors=16, layer_sizes=[16, 64, 128, 256], per_gpu_batch=4)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def synthetic_batch(B, N, C, seed):
+    """xyz ~ U[0,1)^3; class = 1 + floor((C-1) z) clipped inside a sphere of radius
+    0.25 around the centre, else 0."""
+    rs = np.random.RandomState(seed)
+    xyz = rs.uniform(0.0, 1.0, (B, N, 3)).astype(np.float32)
+    inside = np.linalg.norm(xyz - 0.5, axis=-1) < 0.25
+    cls = np.clip(1 + np.floor((C - 1) * xyz[..., 2]).astype(np.int64), 1, C - 1)
+    return xyz, np.where(inside, cls, 0).astype(np.int64)
+
+
+def build_model(device, seed=0):
+    from randlanet.utils.modules import RandLANet, RandLANetSettings
+    torch.manual_seed(seed)
+    s = RandLANetSettings(n_classes=CFG["n_classes"], n_points=CFG["n_points"], n_neighbors=CFG["n_neighbors"],
+                          layer_sizes=list(CFG["layer_sizes"]), knn="kdtree")
+    return RandLANet(s, device)
+
+
+def host_cores():
+    """Cores this process may use: the scheduler affinity, capped at the 16-core CPU share a
+    one-GPU box grants (oversubscribing the 256 visible cores made torch-CPU ~30x slower)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("RL_CPU_BASELINE_CORES", "16"))))
+
+
+def cpu_baseline(steps=2, B=2):
+    """The reference's training step on the host: PyTorch-CPU NCHW graph + exact C KNN (oracle/)."""
+    from oracle import randlanet_oracle as O
+    from oracle.loss_metrics_oracle import loss_by_name
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    net = build_model(torch.device("cpu"))
+    P = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    params = [v.requires_grad_(True) for k, v in P.items() if v.is_floating_point() and "running" not in k]
+    opt = torch.optim.Adam(params, lr=1e-2)
+    xyz, labels = synthetic_batch(B, CFG["n_points"], CFG["n_classes"], 1234)
+    x, y = torch.from_numpy(xyz), torch.from_numpy(labels)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        perm = np.random.permutation(CFG["n_points"])
+        buffers = {}
+        logits = O.forward(P, x, perm, layer_sizes=CFG["layer_sizes"], n_neighbors=CFG["n_neighbors"],
+                           training=True, buffers=buffers)
+        loss = loss_by_name("dice", logits, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for k, v in buffers.items():
+            P[k] = v
+        times.append(time.perf_counter() - t0)
+    t = float(np.mean(times[1:]))
+    return dict(value=round(B / t, 4), unit="clouds/s", cores=cores, kind="port",
+                sample=f"{steps} timed steps (+1 warm-up) of the same train step at B={B} clouds of "
+                       f"{CFG['n_points']} points; PyTorch-CPU NCHW restatement (oracle/randlanet_oracle.py) "
+                       "+ single-threaded exact C KNN (oracle/knn_oracle.c)")
+
+
+def roofline_pass(stepper, eager_steps=2):
+    """Instrumented eager steps: HIP events around every launch, on the launch stream."""
+    from randlanet import _ops as ops
+    ops.TIMER = ops.KernelTimer()
+    g_main, g_adam = stepper._g_main, stepper._g_adam
+    stepper._g_main = stepper._g_adam = None
+    try:
+        for _ in range(eager_steps):
+            stepper.step(np.random.permutation(stepper.N))
+        rows = ops.TIMER.summary()
+    finally:
+        ops.TIMER = None
+        stepper._g_main, stepper._g_adam = g_main, g_adam
+    total_ms = sum(r["ms"] for r in rows)
+    by_cat = {}
+    for r in rows:
+        c = by_cat.setdefault(r["category"], dict(ms=0.0, launches=0, bytes=0, flops=0))
+        c["ms"] += r["ms"]; c["launches"] += r["launches"]; c["bytes"] += r["bytes"]; c["flops"] += r["flops"]
+    top = rows[0]
+    per_launch_ms = top["ms"] / top["launches"]
+    per_launch_bytes = top["bytes"] / top["launches"]
+    achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+    roof = dict(bound="hbm", kernel=f"{top['category']}{list(top['shape'])}", achieved=round(achieved, 2),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                bytes_per_launch=int(per_launch_bytes), ms_per_launch=round(per_launch_ms, 4),
+                share_of_step=round(top["ms"] / total_ms, 3))
+    pmc = os.path.join(REPO, "profiles", "r01_pmc_dominant.json")
+    if os.path.exists(pmc):
+        try:
+            roof["traffic"] = json.load(open(pmc)).get(top["category"])
+        except Exception:
+            pass
+    breakdown = dict(step_kernel_ms=round(total_ms / eager_steps, 3),
+                     categories={k: dict(ms_per_step=round(v["ms"] / eager_steps, 3),
+                                         launches_per_step=v["launches"] // eager_steps,
+                                         GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                         TFLOPs=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2))
+                                 for k, v in sorted(by_cat.items(), key=lambda kv: -kv[1]["ms"])},
+                     top_shapes=[dict(kernel=f"{r['category']}{list(r['shape'])}",
+                                      ms_per_step=round(r["ms"] / eager_steps, 3),
+                                      launches_per_step=r["launches"] // eager_steps,
+                                      GBps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)) for r in rows[:12]])
+    return roof, breakdown
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--batch", type=int, default=CFG["per_gpu_batch"], help="clouds per GPU")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from randlanet._train import TrainStep
+    B, N, C = args.batch, CFG["n_points"], CFG["n_classes"]
+    model = build_model(dev, seed=0)          # identical replicas: same seed on every rank
+    model.train()
+    stepper = TrainStep(model, B, N, loss="dice", lr=1e-2, use_graph=not args.no_graph, world_size=world)
+    xyz, labels = synthetic_batch(B, N, C, 1234 + rank)
+    stepper.set_batch(torch.from_numpy(xyz).to(dev), torch.from_numpy(labels).to(dev))
+    np.random.seed(1234 + rank)                # rank-distinct permutation streams
+    if world > 1:                              # replicas must start identical
+        dist.broadcast(stepper.flat.param, 0)
+    stepper.capture()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        stepper.step(np.random.permutation(N))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step(np.random.permutation(N))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    metrics = stepper.last_metrics()
+
+    roof = breakdown = cpu = None
+    if rank == 0 and not args.no_roofline:
+        roof, breakdown = roofline_pass(stepper)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        line = {
+            "metric": "training clouds/sec, N=40960 pts",
+            "value": round(B * world * args.steps / elapsed, 3),
+            "unit": "clouds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "RandLA-Net train step: 40960 pts/cloud, 2 classes, k=16, 4 encoder layers "
+                                   "[16,64,128,256], dice loss + Adam", "per_gpu_batch": B,
+                       "global_batch": B * world, "parallelism": f"dp{world}", "graph": not args.no_graph},
+            "final_loss": round(metrics["loss"], 5),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        if breakdown is not None:
+            os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(REPO, "gpurun_out", f"bench_breakdown_n{world}.json"), "w") as f:
+                json.dump(breakdown, f, indent=1)
+            print(json.dumps(breakdown), file=sys.stderr)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
