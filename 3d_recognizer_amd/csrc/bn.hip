@@ -176,6 +176,105 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
     }
 }
 
+// ---- float4 variants: C % 4 == 0, C/4 a power of two <= 256, 16-byte aligned rows ----------
+// tpr = min(C/4, 256) lanes sweep one row (16 B each), 256/tpr rows in flight per workgroup
+__device__ __forceinline__ void bn_row_math(const BwdParams& p, const float4 y, const float4 gin, int c,
+                                            float4* g, float4* xh) {
+    const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    g->x = gin.x * rl_act_grad(y.x * sc.x + sh.x, p.act, p.slope);
+    g->y = gin.y * rl_act_grad(y.y * sc.y + sh.y, p.act, p.slope);
+    g->z = gin.z * rl_act_grad(y.z * sc.z + sh.z, p.act, p.slope);
+    g->w = gin.w * rl_act_grad(y.w * sc.w + sh.w, p.act, p.slope);
+    if (xh) {
+        const float4 mu = *reinterpret_cast<const float4*>(p.mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(p.invstd + c);
+        xh->x = (y.x - mu.x) * is.x; xh->y = (y.y - mu.y) * is.y;
+        xh->z = (y.z - mu.z) * is.z; xh->w = (y.w - mu.w) * is.w;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BwdParams p) {
+    __shared__ float red[256][9];
+    const int C = p.C, c4 = C >> 2;
+    const int tpr = c4 < 256 ? c4 : 256;
+    const int rpar = 256 / tpr;
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int c = q * 4;
+    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long rend = min(p.M, (tile + 1) * BN_ROWS);
+        for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+            const long off = row_off(p, R) + c;
+            const float4 y = *reinterpret_cast<const float4*>(p.Y + off);
+            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
+            float4 g, xh;
+            bn_row_math(p, y, gi, c, &g, &xh);
+            acc[0] += g.x; acc[1] += g.y; acc[2] += g.z; acc[3] += g.w;
+            acc[4] += g.x * xh.x; acc[5] += g.y * xh.y; acc[6] += g.z * xh.z; acc[7] += g.w * xh.w;
+        }
+    }
+    // lanes of one wavefront that share a channel quad (tpr < 64) combine by butterfly
+    for (int o = 32; o >= tpr && o >= 1; o >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        // remaining copies of this quad: one per wavefront (tpr < 64) or one per row lane (tpr >= 64)
+        const int step = tpr < 64 ? 64 : tpr;
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = threadIdx.x; t < 256; t += step)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += (double)red[t][j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p.stats[((long)blockIdx.x * 2 + 0) * C + c + j] = s[j];
+            p.stats[((long)blockIdx.x * 2 + 1) * C + c + j] = s[4 + j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BwdParams p) {
+    const int C = p.C, c4 = C >> 2;
+    const int tpr = c4 < 256 ? c4 : 256;
+    const int rpar = 256 / tpr;
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int c = q * 4;
+    const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0;
+    if (p.coef) {
+        k0 = *reinterpret_cast<const float4*>(p.coef + c);
+        k1 = *reinterpret_cast<const float4*>(p.coef + C + c);
+    }
+    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long rend = min(p.M, (tile + 1) * BN_ROWS);
+        for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+            const long off = row_off(p, R) + c;
+            const float4 y = *reinterpret_cast<const float4*>(p.Y + off);
+            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
+            float4 g, xh;
+            bn_row_math(p, y, gi, c, &g, p.coef ? &xh : nullptr);
+            if (p.coef) {
+                g.x = g.x - k0.x - xh.x * k1.x; g.y = g.y - k0.y - xh.y * k1.y;
+                g.z = g.z - k0.z - xh.z * k1.z; g.w = g.w - k0.w - xh.w * k1.w;
+            }
+            g.x *= sc.x; g.y *= sc.y; g.z *= sc.z; g.w *= sc.w;
+            *reinterpret_cast<float4*>(p.G + off) = g;
+        }
+    }
+}
+
+bool vec_ok(const BwdParams& p) {
+    const int c4 = p.C >> 2;
+    return (p.C % 4 == 0) && c4 <= 256 && (c4 & (c4 - 1)) == 0 && (p.ld % 4 == 0) &&
+           (((uintptr_t)p.G & 15) == 0) && (((uintptr_t)p.Y & 15) == 0);
+}
+
 int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
     RL_REQUIRE(d && d->G && d->Y && d->B > 0 && d->n > 0 && d->C > 0 && d->C <= 1024, RL_ERR_ARGS, "%s: bad descriptor", who);
     RL_REQUIRE(d->ld >= d->C && d->bstride >= d->n, RL_ERR_ARGS, "%s: bad strides", who);
@@ -207,8 +306,12 @@ extern "C" int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream) {
     int rc = fill(&p, d, "rl_bn_bwd_reduce");
     if (rc) return rc;
     RL_REQUIRE(p.stats && p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_reduce: needs stats/mean/invstd");
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    if (vec_ok(p))
+        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+                           (hipStream_t)stream, p);
     RL_LAUNCH_CHECK("rl_bn_bwd_reduce");
     return RL_OK;
 }
@@ -227,8 +330,12 @@ extern "C" int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream) {
     int rc = fill(&p, d, "rl_bn_bwd_apply");
     if (rc) return rc;
     if (p.coef) RL_REQUIRE(p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_apply: coef needs mean/invstd");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    if (vec_ok(p))
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+                           (hipStream_t)stream, p);
     RL_LAUNCH_CHECK("rl_bn_bwd_apply");
     return RL_OK;
 }

@@ -322,20 +322,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
 }
 
+// 16 consecutive output elements x 16 slab lanes per workgroup: fixed summation order
+// (lane-strided partial sums, then a fixed LDS tree), so the gradient is deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit,
                                                            int N, int K, float* __restrict__ dW,
                                                            long w_ks, long w_ns,
                                                            float* __restrict__ dbias) {
+    __shared__ float red[16][17];
     const long per = (long)N * K + N;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= per) return;
+    const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
+    const long e = (long)blockIdx.x * 16 + ex;
     float s = 0.f;
-    for (int i = 0; i < nsplit; ++i) s += slab[(long)i * per + e];
-    if (e < (long)N * K) {
-        const int n = (int)(e / K), k = (int)(e - (long)n * K);
-        dW[(long)k * w_ks + (long)n * w_ns] = s;
-    } else if (dbias) {
-        dbias[e - (long)N * K] = s;
+    if (e < per)
+        for (int i = sy; i < nsplit; i += 16) s += slab[(long)i * per + e];
+    red[sy][ex] = s;
+    __syncthreads();
+    if (sy == 0 && e < per) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][ex];
+        if (e < (long)N * K) {
+            const int n = (int)(e / K), k = (int)(e - (long)n * K);
+            dW[(long)k * w_ks + (long)n * w_ns] = t;
+        } else if (dbias) {
+            dbias[e - (long)N * K] = t;
+        }
     }
 }
 
@@ -435,7 +446,7 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
     hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
     RL_LAUNCH_CHECK("rl_wgrad");
     const long per = (long)d->N * d->K + d->N;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rl_cdiv(per, 256)), dim3(256), 0, st, d->slab, nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rl_cdiv(per, 16)), dim3(256), 0, st, d->slab, nsplit,
                        d->N, d->K, d->dW, (long)d->w_ks, (long)d->w_ns, d->dbias);
     RL_LAUNCH_CHECK("rl_wgrad_reduce");
     return RL_OK;

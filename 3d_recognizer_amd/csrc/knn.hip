@@ -7,6 +7,9 @@
 // Rows ascend by the 64-bit key (bits(d2) << 32 | index): d2 >= +0 so its bit pattern is
 // monotone, and exact-distance ties resolve to the lowest index, independent of scan order.
 //
+// Two searches with identical results: the tiled scan below (small supports, or no workspace) and
+// the uniform-grid search of knn_grid.hip (supports >= 1024 points when a workspace is given).
+//
 // Tiled brute-force search: a workgroup owns 256 queries (one per lane, 4 wavefronts); support
 // points stream through LDS in tiles of 1024 (x,y,z,pad) read back as wave-wide broadcasts
 // (one ds_read_b128, conflict-free); each lane keeps its K best keys sorted in registers and
@@ -89,8 +92,18 @@ int launch(const float* S, long s_bs, const float* Q, long q_bs, int B, int Ns, 
     return RL_OK;
 }
 
+}  // namespace
+
+int64_t rl_knn_grid_workspace_bytes(int B, int Ns, int k);
+int rl_knn_grid_run(const float* S, long s_bs, const float* Q, long q_bs, int B, int Ns, int Nq, int k, int32_t* i32,
+                    int64_t* i64, float* d2, void* workspace, int64_t workspace_bytes, hipStream_t st);
+
+namespace {
+
+constexpr int KNN_GRID_MIN_SUPPORT = 1024;  // below this the tiled scan is cheaper than building a grid
+
 int knn_dispatch(const float* S, long s_bs, const float* Q, long q_bs, int B, int Ns, int Nq, int k,
-                 int32_t* i32, int64_t* i64, float* d2, void* stream) {
+                 int32_t* i32, int64_t* i64, float* d2, void* workspace, int64_t workspace_bytes, void* stream) {
     RL_REQUIRE(B >= 0 && Ns >= 0 && Nq >= 0 && k > 0, RL_ERR_ARGS, "rl_knn: bad sizes B=%d Ns=%d Nq=%d k=%d", B, Ns, Nq, k);
     RL_REQUIRE(Ns >= k, RL_ERR_FEW_SUPPORT, "Not enough points in support to find %d neighboors", k);
     RL_REQUIRE(k <= RL_KNN_MAX_K, RL_ERR_UNSUPPORTED, "rl_knn: k=%d exceeds RL_KNN_MAX_K=%d", k, RL_KNN_MAX_K);
@@ -98,6 +111,8 @@ int knn_dispatch(const float* S, long s_bs, const float* Q, long q_bs, int B, in
     RL_REQUIRE(S && Q && d2 && (i32 || i64), RL_ERR_ARGS, "rl_knn: null pointer");
     RL_REQUIRE(B <= 65535, RL_ERR_ARGS, "rl_knn: B=%d too large", B);
     hipStream_t st = (hipStream_t)stream;
+    if (workspace != nullptr && Ns >= KNN_GRID_MIN_SUPPORT)
+        return rl_knn_grid_run(S, s_bs, Q, q_bs, B, Ns, Nq, k, i32, i64, d2, workspace, workspace_bytes, st);
     if (k == 1) return launch<1>(S, s_bs, Q, q_bs, B, Ns, Nq, k, i32, i64, d2, st);
     if (k <= 4) return launch<4>(S, s_bs, Q, q_bs, B, Ns, Nq, k, i32, i64, d2, st);
     if (k <= 8) return launch<8>(S, s_bs, Q, q_bs, B, Ns, Nq, k, i32, i64, d2, st);
@@ -108,14 +123,21 @@ int knn_dispatch(const float* S, long s_bs, const float* Q, long q_bs, int B, in
 
 }  // namespace
 
+extern "C" int64_t rl_knn_workspace_bytes(int B, int Ns, int Nq, int k) {
+    (void)Nq;
+    if (B <= 0 || Ns < KNN_GRID_MIN_SUPPORT || k <= 0) return 0;
+    return rl_knn_grid_workspace_bytes(B, Ns, k);
+}
+
 extern "C" int rl_knn_f32(const float* support, const float* query, int B, int Ns, int Nq, int k,
-                          int64_t* idx_out, float* d2_out, void* stream) {
-    return knn_dispatch(support, Ns, query, Nq, B, Ns, Nq, k, nullptr, idx_out, d2_out, stream);
+                          int64_t* idx_out, float* d2_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    return knn_dispatch(support, Ns, query, Nq, B, Ns, Nq, k, nullptr, idx_out, d2_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int rl_knn_i32(const float* support, int64_t support_bstride, const float* query,
                           int64_t query_bstride, int B, int Ns, int Nq, int k, int32_t* idx_out,
-                          float* d2_out, void* stream) {
+                          float* d2_out, void* workspace, int64_t workspace_bytes, void* stream) {
     RL_REQUIRE(support_bstride >= Ns && query_bstride >= Nq, RL_ERR_ARGS, "rl_knn_i32: batch stride smaller than the cloud");
-    return knn_dispatch(support, support_bstride, query, query_bstride, B, Ns, Nq, k, idx_out, nullptr, d2_out, stream);
+    return knn_dispatch(support, support_bstride, query, query_bstride, B, Ns, Nq, k, idx_out, nullptr, d2_out, workspace,
+                        workspace_bytes, stream);
 }

@@ -1,0 +1,357 @@
+// Exact K nearest neighbours through a uniform grid - the large-cloud path of rl_knn_*.
+//
+// Same contract as the brute-force kernel in knn.hip (reference knn_tpk.knn, knn.cpp:43-61):
+// d2 = ((dx*dx)+(dy*dy))+(dz*dz) in un-fused fp32, rows ascending by (d2, index).  The result is
+// defined by the 64-bit key (bits(d2) << 32 | index), so it does not depend on the order in which
+// candidates are visited: the grid only prunes, it never approximates.
+//
+// Per call and cloud:  bounding box -> grid geometry (~max(2, k/2) points per cell) -> counting
+// sort of the support points by cell (histogram, scan, scatter into (x,y,z,index) records of
+// 16 B, read back with one dwordx4 load per candidate) -> one lane per query walks the cells in
+// Chebyshev rings around its own cell, keeping its K best keys in registers, and stops when the
+// K-th distance lies strictly inside the nearest face of the visited block that still has
+// unvisited cells behind it (ties beyond that face could carry a lower index, so the test is
+// strict and carries a rounding slack).  For a self-search the lanes walk the queries in cell
+// order, so a wavefront's lanes share cells and cache lines.
+#include "rl_common.h"
+
+namespace {
+
+struct GridGeom {
+    float lo[3];
+    float inv[3];
+    float h[3];
+    int n[3];
+    int ncell;
+    float slack;
+};
+
+__device__ __forceinline__ unsigned enc(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void grid_init_kernel(unsigned* bbox, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * 6) bbox[i] = (i % 6 < 3) ? 0xffffffffu : 0u;
+}
+
+__global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict__ S, long s_bs, int Ns,
+                                                        unsigned* __restrict__ bbox) {
+    const int b = blockIdx.y;
+    const float* Sb = S + (size_t)b * s_bs * 3;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < Ns; j += gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = Sb[(size_t)j * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bbox[b * 6 + a], enc(mn[a]));
+            atomicMax(&bbox[b * 6 + 3 + a], enc(mx[a]));
+        }
+    }
+}
+
+__global__ void grid_geom_kernel(const unsigned* __restrict__ bbox, GridGeom* __restrict__ geom, int B, int Ns,
+                                 float per_cell, int maxcells) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    GridGeom g;
+    float ext[3];
+    double vol = 1.0;
+    int flat = 0;
+    float extent = 0.f;
+    for (int a = 0; a < 3; ++a) {
+        g.lo[a] = dec(bbox[b * 6 + a]);
+        const float hi = dec(bbox[b * 6 + 3 + a]);
+        ext[a] = hi - g.lo[a];
+        if (!(ext[a] > 0.f)) { ext[a] = 0.f; flat++; } else vol *= (double)ext[a];
+        extent = fmaxf(extent, ext[a]);
+    }
+    double want = (double)Ns / (double)per_cell;
+    if (want < 1.0) want = 1.0;
+    const double side = (flat == 3) ? 1.0 : pow(vol / want, 1.0 / (double)(3 - flat));
+    long total = 1;
+    for (int a = 0; a < 3; ++a) {
+        int n = (ext[a] > 0.f && side > 0.0) ? (int)ceil((double)ext[a] / side) : 1;
+        if (n < 1) n = 1;
+        if (n > 1024) n = 1024;
+        g.n[a] = n;
+        total *= n;
+    }
+    while (total > maxcells) {  // ceil() overshoot on thin clouds: halve the longest axis
+        int a = 0;
+        if (g.n[1] > g.n[a]) a = 1;
+        if (g.n[2] > g.n[a]) a = 2;
+        g.n[a] = (g.n[a] + 1) / 2;
+        total = (long)g.n[0] * g.n[1] * g.n[2];
+    }
+    for (int a = 0; a < 3; ++a) {
+        g.h[a] = (ext[a] > 0.f) ? ext[a] / (float)g.n[a] : 1.f;
+        g.inv[a] = 1.f / g.h[a];
+    }
+    g.ncell = (int)total;
+    g.slack = 1e-5f * extent + 1e-30f;
+    geom[b] = g;
+}
+
+__device__ __forceinline__ void cell_coords(const GridGeom& g, float x, float y, float z, int c[3]) {
+    const float p[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int ci = (int)floorf((p[a] - g.lo[a]) * g.inv[a]);
+        ci = ci < 0 ? 0 : ci;
+        ci = ci >= g.n[a] ? g.n[a] - 1 : ci;
+        c[a] = ci;
+    }
+}
+__device__ __forceinline__ int cell_id(const GridGeom& g, const int c[3]) {
+    return (c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ S, long s_bs, int Ns,
+                                                         const GridGeom* __restrict__ geom,
+                                                         int* __restrict__ count, int cstride) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Ns) return;
+    const GridGeom g = geom[b];
+    const float* p = S + ((size_t)b * s_bs + j) * 3;
+    int c[3];
+    cell_coords(g, p[0], p[1], p[2], c);
+    atomicAdd(&count[(size_t)b * cstride + cell_id(g, c)], 1);
+}
+
+// exclusive scan of count[0..ncell) -> start[0..ncell], cursor copy; one workgroup per cloud
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridGeom* __restrict__ geom, const int* __restrict__ count,
+                                                         int* __restrict__ start, int* __restrict__ cursor, int cstride) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int ncell = geom[b].ncell;
+    const int* cnt = count + (size_t)b * cstride;
+    int* st = start + (size_t)b * cstride;
+    int* cu = cursor + (size_t)b * cstride;
+    const int chunk = (ncell + 1023) / 1024;
+    const int lo = t * chunk, hi = min(ncell, lo + chunk);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;  // exclusive prefix of this chunk
+    for (int i = lo; i < hi; ++i) {
+        st[i] = run;
+        cu[i] = run;
+        run += cnt[i];
+    }
+    if (t == 1023) st[ncell] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ S, long s_bs, int Ns,
+                                                           const GridGeom* __restrict__ geom, int* __restrict__ cursor,
+                                                           int cstride, float4* __restrict__ sorted) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Ns) return;
+    const GridGeom g = geom[b];
+    const float* p = S + ((size_t)b * s_bs + j) * 3;
+    int c[3];
+    cell_coords(g, p[0], p[1], p[2], c);
+    const int pos = atomicAdd(&cursor[(size_t)b * cstride + cell_id(g, c)], 1);
+    sorted[(size_t)b * Ns + pos] = make_float4(p[0], p[1], p[2], __int_as_float(j));
+}
+
+template <int KMAX>
+__device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int begin, int end, float qx, float qy,
+                                           float qz, unsigned long long (&best)[KMAX]) {
+    for (int t = begin; t < end; ++t) {
+        const float4 c = pts[t];
+        const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
+        if (key < best[KMAX - 1]) {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const bool lt = key < best[s];
+                const unsigned long long lo = lt ? key : best[s];
+                const unsigned long long hi = lt ? best[s] : key;
+                best[s] = lo;
+                key = hi;
+            }
+        }
+    }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ Q, long q_bs, int Nq, int Ns, int k,
+                                                         int self_mode, const GridGeom* __restrict__ geom,
+                                                         const int* __restrict__ start, int cstride,
+                                                         const float4* __restrict__ sorted, int32_t* __restrict__ idx32,
+                                                         int64_t* __restrict__ idx64, float* __restrict__ d2out) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Nq) return;
+    const GridGeom g = geom[b];
+    const float4* pts = sorted + (size_t)b * Ns;
+    const int* st = start + (size_t)b * cstride;
+    float qx, qy, qz;
+    int qi;
+    if (self_mode) {  // queries are the support points themselves: walk them in cell order
+        const float4 me = pts[t];
+        qx = me.x; qy = me.y; qz = me.z;
+        qi = __float_as_int(me.w);
+    } else {
+        const float* p = Q + ((size_t)b * q_bs + t) * 3;
+        qx = p[0]; qy = p[1]; qz = p[2];
+        qi = t;
+    }
+    int c[3];
+    cell_coords(g, qx, qy, qz, c);
+    unsigned long long best[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
+
+    for (int r = 0;; ++r) {
+        const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.n[2] - 1);
+        const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
+        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.n[0] - 1);
+        for (int z = z0; z <= z1; ++z) {
+            const bool zedge = (z == c[2] - r) || (z == c[2] + r);
+            for (int y = y0; y <= y1; ++y) {
+                const int row = (z * g.n[1] + y) * g.n[0];
+                if (zedge || y == c[1] - r || y == c[1] + r) {
+                    // the whole x-run of this row lies on the ring: one contiguous candidate range
+                    scan_range<KMAX>(pts, st[row + x0], st[row + x1 + 1], qx, qy, qz, best);
+                } else {
+                    if (c[0] - r >= 0) scan_range<KMAX>(pts, st[row + c[0] - r], st[row + c[0] - r + 1], qx, qy, qz, best);
+                    if (c[0] + r < g.n[0]) scan_range<KMAX>(pts, st[row + c[0] + r], st[row + c[0] + r + 1], qx, qy, qz, best);
+                }
+            }
+        }
+        const bool covers = (c[0] - r <= 0) && (c[0] + r >= g.n[0] - 1) && (c[1] - r <= 0) && (c[1] + r >= g.n[1] - 1) &&
+                            (c[2] - r <= 0) && (c[2] + r >= g.n[2] - 1);
+        if (covers) break;
+        unsigned long long kth = best[KMAX - 1];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (s == k - 1) kth = best[s];
+        if (kth != ~0ull) {
+            float bound = INFINITY;
+            const float q[3] = {qx, qy, qz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (c[a] - r > 0) bound = fminf(bound, q[a] - (g.lo[a] + (float)(c[a] - r) * g.h[a]));
+                if (c[a] + r < g.n[a] - 1) bound = fminf(bound, (g.lo[a] + (float)(c[a] + r + 1) * g.h[a]) - q[a]);
+            }
+            bound -= g.slack;
+            const float kd = __uint_as_float((unsigned)(kth >> 32));
+            if (bound > 0.f && kd < bound * bound * 0.999999f) break;
+        }
+    }
+    const size_t o = ((size_t)b * Nq + qi) * k;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        if (s < k) {
+            const unsigned id = (unsigned)(best[s] & 0xffffffffull);
+            if (idx32) idx32[o + s] = (int32_t)id;
+            if (idx64) idx64[o + s] = (int64_t)id;
+            d2out[o + s] = __uint_as_float((unsigned)(best[s] >> 32));
+        }
+    }
+}
+
+struct Plan {
+    int maxcells, cstride;
+    float per_cell;
+    size_t off_geom, off_bbox, off_count, off_start, off_cursor, off_sorted, bytes;
+};
+
+Plan make_plan(int B, int Ns, int k) {
+    Plan p;
+    p.per_cell = fmaxf(2.f, 0.5f * (float)k);
+    const long want = (long)((double)Ns / p.per_cell) + 1;
+    p.maxcells = (int)(4 * want + 64);
+    p.cstride = p.maxcells + 1;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 255) & ~(size_t)255; return at; };
+    p.off_geom = take(sizeof(GridGeom) * B);
+    p.off_bbox = take(sizeof(unsigned) * 6 * B);
+    p.off_count = take(sizeof(int) * (size_t)p.cstride * B);
+    p.off_start = take(sizeof(int) * (size_t)p.cstride * B);
+    p.off_cursor = take(sizeof(int) * (size_t)p.cstride * B);
+    p.off_sorted = take(sizeof(float4) * (size_t)Ns * B);
+    p.bytes = o;
+    return p;
+}
+
+template <int KMAX>
+void launch_query(dim3 grid, hipStream_t st, const float* Q, long q_bs, int Nq, int Ns, int k, int self_mode,
+                  const GridGeom* geom, const int* start, int cstride, const float4* sorted, int32_t* i32, int64_t* i64,
+                  float* d2) {
+    hipLaunchKernelGGL((grid_query_kernel<KMAX>), grid, dim3(256), 0, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start,
+                       cstride, sorted, i32, i64, d2);
+}
+
+}  // namespace
+
+int64_t rl_knn_grid_workspace_bytes(int B, int Ns, int k) { return (int64_t)make_plan(B, Ns, k).bytes; }
+
+// Called by knn.hip's dispatcher once sizes were validated.
+int rl_knn_grid_run(const float* S, long s_bs, const float* Q, long q_bs, int B, int Ns, int Nq, int k, int32_t* i32,
+                    int64_t* i64, float* d2, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    const Plan p = make_plan(B, Ns, k);
+    RL_REQUIRE(workspace && workspace_bytes >= (int64_t)p.bytes, RL_ERR_ARGS, "rl_knn: workspace too small (%ld < %ld bytes)",
+               (long)workspace_bytes, (long)p.bytes);
+    RL_REQUIRE(((uintptr_t)workspace & 255) == 0, RL_ERR_ARGS, "rl_knn: workspace must be 256-byte aligned");
+    char* w = (char*)workspace;
+    GridGeom* geom = (GridGeom*)(w + p.off_geom);
+    unsigned* bbox = (unsigned*)(w + p.off_bbox);
+    int* count = (int*)(w + p.off_count);
+    int* start = (int*)(w + p.off_start);
+    int* cursor = (int*)(w + p.off_cursor);
+    float4* sorted = (float4*)(w + p.off_sorted);
+
+    hipLaunchKernelGGL(grid_init_kernel, dim3(rl_cdiv(B * 6, 64)), dim3(64), 0, st, bbox, B);
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int) * (size_t)p.cstride * B, st);
+    RL_REQUIRE(e == hipSuccess, RL_ERR_LAUNCH, "rl_knn: memset failed: %s", hipGetErrorString(e));
+    int gb = rl_cdiv(Ns, 256);
+    if (gb > 256) gb = 256;
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(gb, B), dim3(256), 0, st, S, s_bs, Ns, bbox);
+    hipLaunchKernelGGL(grid_geom_kernel, dim3(rl_cdiv(B, 64)), dim3(64), 0, st, bbox, geom, B, Ns, p.per_cell, p.maxcells);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(rl_cdiv(Ns, 256), B), dim3(256), 0, st, S, s_bs, Ns, geom, count, p.cstride);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(B), dim3(1024), 0, st, geom, count, start, cursor, p.cstride);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(rl_cdiv(Ns, 256), B), dim3(256), 0, st, S, s_bs, Ns, geom, cursor,
+                       p.cstride, sorted);
+    const int self_mode = (S == Q && s_bs == q_bs && Ns == Nq) ? 1 : 0;
+    dim3 grid(rl_cdiv(Nq, 256), B);
+    if (k == 1) launch_query<1>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
+    else if (k <= 4) launch_query<4>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
+    else if (k <= 8) launch_query<8>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
+    else if (k <= 16) launch_query<16>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
+    else if (k <= 32) launch_query<32>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
+    else launch_query<64>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
+    RL_LAUNCH_CHECK("rl_knn(grid)");
+    return RL_OK;
+}

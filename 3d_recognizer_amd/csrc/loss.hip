@@ -86,11 +86,16 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(double* __restrict__
                                                             double* __restrict__ out) {
     __shared__ double tot[5 * LS_MAXC + 1];
     const int rs = rec_size(C);
-    for (int e = threadIdx.x; e < rs; e += 256) {
+    // one wavefront per record entry, lanes stride over the slots (fixed order -> deterministic)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = wave; e < rs; e += 4) {
         double s = 0.0;
-        for (int i = 0; i < nslots; ++i) s += work[(long)i * rs + e];
-        tot[e] = s;
-        work[(long)RL_MAX_SLOTS * rs + e] = s;  // totals record, read by the backward kernel
+        for (int i = lane; i < nslots; i += 64) s += work[(long)i * rs + e];
+        s = rl_wave_sum(s);
+        if (lane == 0) {
+            tot[e] = s;
+            work[(long)RL_MAX_SLOTS * rs + e] = s;  // totals record, read by the backward kernel
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -85,8 +85,9 @@ _SIGNATURES = {
     "rl_last_error": (C.c_char_p, []),
     "rl_version": (_i, []),
     "rl_row_blocks": (_i, [_l, _i]),
-    "rl_knn_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rl_knn_workspace_bytes": (_l, [_i, _i, _i, _i]),
+    "rl_knn_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
+    "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),

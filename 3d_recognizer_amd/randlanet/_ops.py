@@ -104,7 +104,17 @@ class _rec:
 
 
 # ------------------------------------------------------------------------------------- knn
-def knn_i32(support: torch.Tensor, query: torch.Tensor, Ns: int, Nq: int, k: int
+def _knn_workspace(device, B: int, Ns: int, Nq: int, k: int, brute: bool):
+    """Scratch for the grid search (None -> tiled brute force inside the library)."""
+    if brute or k > H.KNN_MAX_K or Ns < k:
+        return None, 0
+    nbytes = H.lib().rl_knn_workspace_bytes(B, Ns, Nq, k)
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def knn_i32(support: torch.Tensor, query: torch.Tensor, Ns: int, Nq: int, k: int, brute: bool = False
             ) -> Tuple[torch.Tensor, torch.Tensor]:
     """support (B, >=Ns, 3), query (B, >=Nq, 3): searches the first Ns / Nq points of each cloud."""
     _dev_check(support, query)
@@ -113,21 +123,25 @@ def knn_i32(support: torch.Tensor, query: torch.Tensor, Ns: int, Nq: int, k: int
     assert query.shape[0] == B and support.shape[1] >= Ns and query.shape[1] >= Nq
     idx = torch.empty((B, Nq, k), dtype=torch.int32, device=support.device)
     d2 = torch.empty((B, Nq, k), dtype=F32, device=support.device)
+    ws, nbytes = _knn_workspace(support.device, B, Ns, Nq, k, brute)
     with _rec("knn", (B, Ns, Nq, k), B * (12 * (Ns + Nq) + 8 * Nq * k), 8 * B * Ns * Nq):
         H.check(H.lib().rl_knn_i32(support.data_ptr(), support.shape[1], query.data_ptr(), query.shape[1],
-                                   B, Ns, Nq, k, idx.data_ptr(), d2.data_ptr(), _st()), "rl_knn_i32")
+                                   B, Ns, Nq, k, idx.data_ptr(), d2.data_ptr(), H.ptr(ws), nbytes, _st()),
+                "rl_knn_i32")
     return idx, d2
 
 
-def knn_f32(support: torch.Tensor, query: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def knn_f32(support: torch.Tensor, query: torch.Tensor, k: int, brute: bool = False
+            ) -> Tuple[torch.Tensor, torch.Tensor]:
     _dev_check(support, query)
     B, Ns, _ = support.shape
     Nq = query.shape[1]
     idx = torch.empty((B, Nq, k), dtype=torch.int64, device=support.device)
     d2 = torch.empty((B, Nq, k), dtype=F32, device=support.device)
+    ws, nbytes = _knn_workspace(support.device, B, Ns, Nq, k, brute)
     with _rec("knn", (B, Ns, Nq, k), B * (12 * (Ns + Nq) + 12 * Nq * k), 8 * B * Ns * Nq):
         H.check(H.lib().rl_knn_f32(support.data_ptr(), query.data_ptr(), B, Ns, Nq, k, idx.data_ptr(),
-                                   d2.data_ptr(), _st()), "rl_knn_f32")
+                                   d2.data_ptr(), H.ptr(ws), nbytes, _st()), "rl_knn_f32")
     return idx, d2
 
 

@@ -69,15 +69,20 @@ int rl_row_blocks(int64_t rows, int rows_per_tile);
  * Exact K nearest neighbours.  d2 = ((dx*dx)+(dy*dy))+(dz*dz) in IEEE fp32 without FMA
  * (nanoflann.hpp:488-497), rows ascending by (d2, index).  support (B,Ns,3), query (B,Nq,3)
  * contiguous fp32; idx_out (B,Nq,k) int64, d2_out (B,Nq,k) fp32.  k <= RL_KNN_MAX_K.
- * Replaces knn_tpk.knn (bindings.cpp:5-7).                                                 */
+ * Replaces knn_tpk.knn (bindings.cpp:5-7).
+ * workspace: device scratch of rl_knn_workspace_bytes(B,Ns,Nq,k) bytes, 256-byte aligned; with it
+ * supports of >= 1024 points are searched through a uniform grid (same answer, ~100x fewer
+ * distance evaluations); NULL selects the tiled brute-force scan.                           */
+int64_t rl_knn_workspace_bytes(int B, int Ns, int Nq, int k);
 int rl_knn_f32(const float* support, const float* query, int B, int Ns, int Nq, int k,
-               int64_t* idx_out, float* d2_out, void* stream);
+               int64_t* idx_out, float* d2_out, void* workspace, int64_t workspace_bytes,
+               void* stream);
 
 /* Same search with int32 indices and batch strides (in points), used inside the network:
  * cloud b of the support starts at support + b*support_bstride*3.                          */
 int rl_knn_i32(const float* support, int64_t support_bstride, const float* query,
                int64_t query_bstride, int B, int Ns, int Nq, int k, int32_t* idx_out,
-               float* d2_out, void* stream);
+               float* d2_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-point linear layer (1x1 conv / conv-transpose / Linear):   Y = A' . W (+ bias)

@@ -46,9 +46,10 @@ def test_host_only_entry_points(lib):
     assert L.rl_wgrad_slab_floats(1000, 16, 16) > 0
     assert L.rl_loss_work_doubles(10, 2) == 1025 * 11
     # argument validation happens on the host, before any launch
-    assert L.rl_knn_f32(None, None, 1, 3, 3, 4, None, None, None) == _hip.ERR_FEW_SUPPORT
+    assert L.rl_knn_f32(None, None, 1, 3, 3, 4, None, None, None, 0, None) == _hip.ERR_FEW_SUPPORT
     assert b"Not enough points" in L.rl_last_error()
-    assert L.rl_knn_f32(None, None, 1, 100, 3, 65, None, None, None) == _hip.ERR_UNSUPPORTED
+    assert L.rl_knn_f32(None, None, 1, 100, 3, 65, None, None, None, 0, None) == _hip.ERR_UNSUPPORTED
+    assert L.rl_knn_workspace_bytes(4, 40960, 40960, 16) > 4 * 40960 * 16 and L.rl_knn_workspace_bytes(1, 100, 100, 4) == 0
     assert L.rl_gemm(None, None) == _hip.ERR_ARGS
 
 

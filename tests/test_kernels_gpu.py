@@ -62,6 +62,38 @@ def test_knn_matches_oracle_bitwise(ops, B, Ns, Nq, k):
     assert torch.equal(i32.cpu().long(), ri) and torch.equal(d2b.cpu(), rd)
 
 
+def _clouds():
+    rs = np.random.RandomState(7)
+    yield "uniform", rs.uniform(0, 1, (2, 3000, 3)).astype(np.float32)
+    yield "clustered", (rs.normal(0, 1, (2, 3000, 3)) ** 3).astype(np.float32)
+    yield "planar", np.concatenate([rs.uniform(0, 1, (1, 2500, 2)), np.full((1, 2500, 1), 0.25)], -1).astype(np.float32)
+    line = np.zeros((1, 2048, 3), np.float32)
+    line[0, :, 1] = rs.uniform(-5, 5, 2048)
+    yield "collinear", line
+    yield "identical", np.full((1, 1500, 3), 0.75, np.float32)
+    g = np.arange(12, dtype=np.float32)
+    yield "lattice", np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(1, -1, 3)
+    dup = rs.uniform(0, 1, (1, 40, 3)).astype(np.float32)[:, rs.randint(0, 40, 2500)]
+    yield "duplicates", dup
+
+
+@pytest.mark.parametrize("k", [1, 16, 32])
+def test_knn_grid_equals_brute_force_on_hard_clouds(ops, k):
+    """The uniform-grid search (supports >= 1024 points) and the tiled scan give the same bits,
+    in self-search mode (queries walked in cell order) and for foreign queries, including
+    queries far outside the support's bounding box."""
+    for name, pts in _clouds():
+        x = _t(pts)
+        bi, bd = ops.knn_i32(x, x, pts.shape[1], pts.shape[1], k, brute=True)
+        gi, gd = ops.knn_i32(x, x, pts.shape[1], pts.shape[1], k)                 # self mode
+        assert torch.equal(bi, gi) and torch.equal(bd, gd), (name, "self")
+        rs = np.random.RandomState(3)
+        q = _t((pts[:, :777] + rs.normal(0, 0.3, pts[:, :777].shape)).astype(np.float32) * 1.7 - 0.4)
+        bi, bd = ops.knn_i32(x, q, pts.shape[1], 777, k, brute=True)
+        gi, gd = ops.knn_i32(x, q, pts.shape[1], 777, k)
+        assert torch.equal(bi, gi) and torch.equal(bd, gd), (name, "cross")
+
+
 def test_knn_prefix_strides_and_errors(ops, H):
     from oracle import randlanet_oracle as O
     rs = np.random.RandomState(1)
