@@ -391,6 +391,301 @@ int fill_a(AOperand* a, const char* who, const float* A, long lda, long a_bstrid
     return RL_OK;
 }
 
+
+// ===========================================================================================
+// Streaming variants for the narrow layers (K <= 64 and N <= 64: levels 0/1 of the encoder,
+// the decoder tail and fc_end), where a layer is pure HBM traffic: no LDS, no barriers.
+//
+// Forward: a wavefront owns 16-row blocks.  Lane (i = l&15, j = l>>4) loads 16 B of row i at
+// column 16c + 4j (one dwordx4 per 16-column chunk c; the wavefront reads 16 rows x 64 B, fully
+// coalesced when rows are contiguous).  MFMA step (c, s) uses component s of that load, i.e.
+// k = 16c + 4j + s: any k order is valid as long as A and B fragments agree, and the weight
+// fragments - which live in registers for the whole kernel - are loaded in exactly that order.
+//
+// Weight gradient: lane (c = l&15, r = l>>4) loads dY[row0 + r][16nb + c] and A'[row0 + r][16kb + c]
+// (4 rows x 64 B per load instruction); these are the MFMA operands as they stand, with the row
+// as the reduction index.  The four wavefronts of a workgroup take interleaved row groups and
+// are combined through LDS in a fixed order; every workgroup leaves one partial slab.
+// ===========================================================================================
+
+template <int KC, int NT>
+__global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
+    __shared__ double red[4][2][16 * NT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    const int K = p.a.K, N = p.N;
+    const long M = p.a.M;
+
+    float wf[KC][4][NT];
+    float sc[KC][4], sh[KC][4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * c + 4 * lj + s;
+            sc[c][s] = (p.a.lazy.scale && k < K) ? p.a.lazy.scale[k] : 1.f;
+            sh[c][s] = (p.a.lazy.scale && k < K) ? p.a.lazy.shift[k] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                const int n = nb * 16 + li;
+                wf[c][s][nb] = (k < K && n < N) ? p.W[(long)k * p.w_ks + (long)n * p.w_ns] : 0.f;
+            }
+        }
+    float bias[NT], ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        const int n = nb * 16 + li;
+        bias[nb] = (p.bias && n < N) ? p.bias[n] : 0.f;
+        ssum[nb] = ssq[nb] = 0.f;
+    }
+    const bool lazy = p.a.lazy.scale != nullptr;
+    const int act = p.a.lazy.act;
+    const float slope = p.a.lazy.slope;
+
+    const long nblk = (M + 15) >> 4;
+    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+        const long row = blk * 16 + li;
+        float4 a[KC];
+        const bool rvalid = row < M;
+        const long aoff = rvalid ? a_row_offset(p.a, row) : 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rvalid && 16 * c + 4 * lj < K) a[c] = *reinterpret_cast<const float4*>(p.a.A + aoff + 16 * c + 4 * lj);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float v = av[s];
+                if (lazy) v = rl_act(v * sc[c][s] + sh[c][s], act, slope);
+                if (!rvalid || 16 * c + 4 * lj + s >= K) v = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wf[c][s][nb], acc[nb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long R = blk * 16 + lj * 4 + r;
+            if (R < M) {
+                long yoff;
+                if (p.y_contig) yoff = R * p.ldy;
+                else {
+                    const int b = (int)(R / p.rows_per_batch);
+                    const int i = (int)(R - (long)b * p.rows_per_batch);
+                    yoff = ((long)b * p.y_bstride + i) * p.ldy;
+                }
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) {
+                    const int n = nb * 16 + li;
+                    if (n < N) {
+                        float v = acc[nb][r] + bias[nb];
+                        if (p.accumulate) v += p.Y[yoff + n];
+                        p.Y[yoff + n] = v;
+                        ssum[nb] += v;
+                        ssq[nb] += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            float s = ssum[nb], q = ssq[nb];
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (lane < 16) {
+                red[wave][0][nb * 16 + lane] = (double)s;
+                red[wave][1][nb * 16 + lane] = (double)q;
+            }
+        }
+        __syncthreads();
+        if (tid < 16 * NT && tid < N) {
+            p.stats[((long)blockIdx.x * 2 + 0) * N + tid] = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+            p.stats[((long)blockIdx.x * 2 + 1) * N + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+        }
+    }
+}
+
+constexpr int SW_U = 4;  // row groups (of 4 rows) in flight per wavefront
+
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
+    __shared__ float red[KT * NT * 4 * 64 + NT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lr = lane >> 4;
+    const int N = p.N, K = p.a.K;
+    const AOperand& a = p.a;
+    const long r_begin = (long)blockIdx.x * p.rows_per_block;
+    const long r_end = min(a.M, r_begin + p.rows_per_block);
+
+    float sc[KT], sh[KT];
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb) {
+        const int k = kb * 16 + lc;
+        sc[kb] = (a.lazy.scale && k < K) ? a.lazy.scale[k] : 1.f;
+        sh[kb] = (a.lazy.scale && k < K) ? a.lazy.shift[k] : 0.f;
+    }
+    const bool lazy = a.lazy.scale != nullptr;
+    f32x4 acc[NT][KT];
+    float bsum[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        bsum[nb] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KT; ++kb) acc[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (long base = r_begin + (long)wave * 4 * SW_U; base < r_end; base += 16 * SW_U) {
+        float dy[SW_U][NT], av[SW_U][KT];
+#pragma unroll
+        for (int u = 0; u < SW_U; ++u) {
+            const long R = base + u * 4 + lr;
+            const bool valid = R < r_end;
+            long doff = 0;
+            if (valid) {
+                if (p.dy_contig) doff = R * p.lddy;
+                else {
+                    const int b = (int)(R / p.rows_per_batch);
+                    const int i = (int)(R - (long)b * p.rows_per_batch);
+                    doff = ((long)b * p.dy_bstride + i) * p.lddy;
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                const int n = nb * 16 + lc;
+                dy[u][nb] = (valid && n < N) ? p.dY[doff + n] : 0.f;
+            }
+            if (a.a_mode == 1) {
+                // relative position encoding, channel lc of row R (modules.py:173-186)
+                float v = 0.f;
+                if (valid && lc < 10) {
+                    if (lc == 9) v = __fsqrt_rn(a.nbr_d2[R]);
+                    else {
+                        const long pt = R / a.nbr_k;
+                        const int b = (int)(pt / a.n);
+                        const int i = (int)(pt - (long)b * a.n);
+                        const int ax = lc % 3;
+                        const float* xb = a.xyz + (long)b * a.xyz_bstride * 3;
+                        const float xi = xb[(long)i * 3 + ax];
+                        if (lc < 3) v = xi;
+                        else {
+                            const float xj = xb[(long)a.nbr_idx[R] * 3 + ax];
+                            v = lc < 6 ? xj : xi - xj;
+                        }
+                    }
+                }
+                av[u][0] = v;
+#pragma unroll
+                for (int kb = 1; kb < KT; ++kb) av[u][kb] = 0.f;
+            } else {
+                const long aoff = valid ? a_row_offset(a, R) : 0;
+#pragma unroll
+                for (int kb = 0; kb < KT; ++kb) {
+                    const int k = kb * 16 + lc;
+                    float v = 0.f;
+                    if (valid && k < K) {
+                        v = a.A[aoff + k];
+                        if (lazy) v = rl_act(v * sc[kb] + sh[kb], a.lazy.act, a.lazy.slope);
+                    }
+                    av[u][kb] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SW_U; ++u)
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                bsum[nb] += dy[u][nb];
+#pragma unroll
+                for (int kb = 0; kb < KT; ++kb)
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[u][nb], av[u][kb], acc[nb][kb], 0, 0, 0);
+            }
+    }
+    // bias partials: lanes sharing a column (same lc) combine first
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        bsum[nb] += __shfl_xor(bsum[nb], 16, 64);
+        bsum[nb] += __shfl_xor(bsum[nb], 32, 64);
+    }
+    // wavefronts 1..3 hand their tiles to wavefront 0 through LDS, in order
+    float* rb = red + KT * NT * 4 * 64;
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+#pragma unroll
+                for (int kb = 0; kb < KT; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((nb * KT + kb) * 4 + r) * 64 + lane] = acc[nb][kb][r];
+                rb[nb * 64 + lane] = bsum[nb];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+#pragma unroll
+                for (int kb = 0; kb < KT; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[nb][kb][r] += red[((nb * KT + kb) * 4 + r) * 64 + lane];
+                bsum[nb] += rb[nb * 64 + lane];
+            }
+        }
+    }
+    if (wave == 0) {
+        float* out = p.slab + (long)blockIdx.x * ((long)N * K + N);
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+#pragma unroll
+            for (int kb = 0; kb < KT; ++kb) {
+                const int k = kb * 16 + lc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb * 16 + lr * 4 + r;
+                    if (n < N && k < K) out[(long)n * K + k] = acc[nb][kb][r];
+                }
+            }
+            const int n = nb * 16 + lc;
+            if (p.has_bias && lr == 0 && n < N) out[(long)N * K + n] = bsum[nb];
+        }
+    }
+}
+
+// slab split for the streaming wgrad: one slab per workgroup
+void swgrad_split(long M, int* nsplit, long* rows_per_block) {
+    long want = (M + 511) / 512;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    long rpb = (M + want - 1) / want;
+    rpb = ((rpb + 63) / 64) * 64;
+    *rows_per_block = rpb;
+    *nsplit = (int)((M + rpb - 1) / rpb);
+    if (*nsplit < 1) *nsplit = 1;
+}
+
+inline bool stream_wgrad_ok(int N, int K) { return N <= 64 && K <= 64; }
+
+template <int KC>
+void launch_sgemm(int N, int gx, hipStream_t st, const GemmParams& p) {
+    if (N <= 16)      hipLaunchKernelGGL((sgemm_kernel<KC, 1>), dim3(gx), dim3(256), 0, st, p);
+    else if (N <= 32) hipLaunchKernelGGL((sgemm_kernel<KC, 2>), dim3(gx), dim3(256), 0, st, p);
+    else              hipLaunchKernelGGL((sgemm_kernel<KC, 4>), dim3(gx), dim3(256), 0, st, p);
+}
+template <int KT>
+void launch_swgrad(int N, dim3 grid, hipStream_t st, const WgradParams& p) {
+    if (N <= 16)      hipLaunchKernelGGL((swgrad_kernel<KT, 1>), grid, dim3(256), 0, st, p);
+    else if (N <= 32) hipLaunchKernelGGL((swgrad_kernel<KT, 2>), grid, dim3(256), 0, st, p);
+    else              hipLaunchKernelGGL((swgrad_kernel<KT, 4>), grid, dim3(256), 0, st, p);
+}
+
 }  // namespace
 
 extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
@@ -409,6 +704,13 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     p.accumulate = d->accumulate; p.stats = d->stats;
     const int gx = rl_row_blocks_host(p.a.M, GM_BM);
     hipStream_t st = (hipStream_t)stream;
+    if (d->a_mode == 0 && p.a.vec4 && d->K <= 64 && d->N <= 64) {
+        if (d->K <= 16)      launch_sgemm<1>(d->N, gx, st, p);
+        else if (d->K <= 32) launch_sgemm<2>(d->N, gx, st, p);
+        else                 launch_sgemm<4>(d->N, gx, st, p);
+        RL_LAUNCH_CHECK("rl_gemm(stream)");
+        return RL_OK;
+    }
     if (d->N <= 16)      hipLaunchKernelGGL((gemm_kernel<1>), dim3(gx, 1), dim3(256), 0, st, p);
     else if (d->N <= 32) hipLaunchKernelGGL((gemm_kernel<2>), dim3(gx, 1), dim3(256), 0, st, p);
     else if (d->N <= 64) hipLaunchKernelGGL((gemm_kernel<4>), dim3(gx, 1), dim3(256), 0, st, p);
@@ -419,7 +721,8 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
 
 extern "C" int64_t rl_wgrad_slab_floats(int64_t M, int N, int K) {
     int nsplit; long rpb;
-    wgrad_split(M, N, K, &nsplit, &rpb);
+    if (stream_wgrad_ok(N, K)) swgrad_split(M, &nsplit, &rpb);
+    else wgrad_split(M, N, K, &nsplit, &rpb);
     return (int64_t)nsplit * ((int64_t)N * K + N);
 }
 
@@ -437,13 +740,21 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
     p.dy_contig = (d->dy_bstride == p.rows_per_batch);
     p.slab = d->slab; p.has_bias = d->dbias != nullptr;
     int nsplit; long rpb;
-    wgrad_split(p.a.M, d->N, d->K, &nsplit, &rpb);
+    const bool streaming = stream_wgrad_ok(d->N, d->K);
+    if (streaming) swgrad_split(p.a.M, &nsplit, &rpb);
+    else wgrad_split(p.a.M, d->N, d->K, &nsplit, &rpb);
     RL_REQUIRE(d->slab_floats >= (int64_t)nsplit * ((int64_t)d->N * d->K + d->N), RL_ERR_ARGS,
                "rl_wgrad: slab too small (%ld floats)", (long)d->slab_floats);
     p.rows_per_block = rpb;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(nsplit, rl_cdiv(d->N, WG_T), rl_cdiv(d->K, WG_T));
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
+    if (streaming) {
+        if (d->K <= 16)      launch_swgrad<1>(d->N, dim3(nsplit), st, p);
+        else if (d->K <= 32) launch_swgrad<2>(d->N, dim3(nsplit), st, p);
+        else                 launch_swgrad<4>(d->N, dim3(nsplit), st, p);
+    } else {
+        dim3 grid(nsplit, rl_cdiv(d->N, WG_T), rl_cdiv(d->K, WG_T));
+        hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
+    }
     RL_LAUNCH_CHECK("rl_wgrad");
     const long per = (long)d->N * d->K + d->N;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rl_cdiv(per, 16)), dim3(256), 0, st, d->slab, nsplit,

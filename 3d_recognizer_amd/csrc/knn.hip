@@ -8,7 +8,7 @@
 // monotone, and exact-distance ties resolve to the lowest index, independent of scan order.
 //
 // Two searches with identical results: the tiled scan below (small supports, or no workspace) and
-// the uniform-grid search of knn_grid.hip (supports >= 1024 points when a workspace is given).
+// the uniform-grid search of knn_grid.hip (supports >= 512 points when a workspace is given).
 //
 // Tiled brute-force search: a workgroup owns 256 queries (one per lane, 4 wavefronts); support
 // points stream through LDS in tiles of 1024 (x,y,z,pad) read back as wave-wide broadcasts
@@ -100,7 +100,7 @@ int rl_knn_grid_run(const float* S, long s_bs, const float* Q, long q_bs, int B,
 
 namespace {
 
-constexpr int KNN_GRID_MIN_SUPPORT = 1024;  // below this the tiled scan is cheaper than building a grid
+constexpr int KNN_GRID_MIN_SUPPORT = 512;  // below this the tiled scan is cheaper than building a grid
 
 int knn_dispatch(const float* S, long s_bs, const float* Q, long q_bs, int B, int Ns, int Nq, int k,
                  int32_t* i32, int64_t* i64, float* d2, void* workspace, int64_t workspace_bytes, void* stream) {

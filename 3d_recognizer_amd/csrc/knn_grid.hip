@@ -34,9 +34,13 @@ __device__ __forceinline__ float dec(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-__global__ void grid_init_kernel(unsigned* bbox, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// resets the bounding boxes and the cell histogram (a kernel rather than hipMemsetAsync: the
+// whole search must replay from a captured hipGraph)
+__global__ __launch_bounds__(256) void grid_init_kernel(unsigned* __restrict__ bbox, int B, int* __restrict__ count,
+                                                        long ncount) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < B * 6) bbox[i] = (i % 6 < 3) ? 0xffffffffu : 0u;
+    for (long e = i; e < ncount; e += (long)gridDim.x * 256) count[e] = 0;
 }
 
 __global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict__ S, long s_bs, int Ns,
@@ -333,9 +337,10 @@ int rl_knn_grid_run(const float* S, long s_bs, const float* Q, long q_bs, int B,
     int* cursor = (int*)(w + p.off_cursor);
     float4* sorted = (float4*)(w + p.off_sorted);
 
-    hipLaunchKernelGGL(grid_init_kernel, dim3(rl_cdiv(B * 6, 64)), dim3(64), 0, st, bbox, B);
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(int) * (size_t)p.cstride * B, st);
-    RL_REQUIRE(e == hipSuccess, RL_ERR_LAUNCH, "rl_knn: memset failed: %s", hipGetErrorString(e));
+    const long ncount = (long)p.cstride * B;
+    int gi = rl_cdiv(ncount > B * 6 ? ncount : B * 6, 256);
+    if (gi > 1024) gi = 1024;
+    hipLaunchKernelGGL(grid_init_kernel, dim3(gi), dim3(256), 0, st, bbox, B, count, ncount);
     int gb = rl_cdiv(Ns, 256);
     if (gb > 256) gb = 256;
     hipLaunchKernelGGL(grid_bbox_kernel, dim3(gb, B), dim3(256), 0, st, S, s_bs, Ns, bbox);

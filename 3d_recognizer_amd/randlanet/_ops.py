@@ -81,6 +81,8 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+FORCE_BRUTE_KNN = bool(int(__import__("os").environ.get("RL_KNN_BRUTE", "0")))         # diagnostics only
+DEBUG_SYNC = bool(int(__import__("os").environ.get("RL_DEBUG_SYNC", "0")))   # print + sync around every launch
 
 
 class _rec:
@@ -91,11 +93,15 @@ class _rec:
         self.args = (cat, key, nbytes, flops)
 
     def __enter__(self):
+        if DEBUG_SYNC:
+            print("launch", self.args[0], self.args[1], flush=True)
         if TIMER is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *exc):
+        if DEBUG_SYNC:
+            torch.cuda.synchronize()
         if TIMER is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -106,7 +112,7 @@ class _rec:
 # ------------------------------------------------------------------------------------- knn
 def _knn_workspace(device, B: int, Ns: int, Nq: int, k: int, brute: bool):
     """Scratch for the grid search (None -> tiled brute force inside the library)."""
-    if brute or k > H.KNN_MAX_K or Ns < k:
+    if brute or FORCE_BRUTE_KNN or k > H.KNN_MAX_K or Ns < k:
         return None, 0
     nbytes = H.lib().rl_knn_workspace_bytes(B, Ns, Nq, k)
     if nbytes <= 0:

@@ -71,7 +71,7 @@ int rl_row_blocks(int64_t rows, int rows_per_tile);
  * contiguous fp32; idx_out (B,Nq,k) int64, d2_out (B,Nq,k) fp32.  k <= RL_KNN_MAX_K.
  * Replaces knn_tpk.knn (bindings.cpp:5-7).
  * workspace: device scratch of rl_knn_workspace_bytes(B,Ns,Nq,k) bytes, 256-byte aligned; with it
- * supports of >= 1024 points are searched through a uniform grid (same answer, ~100x fewer
+ * supports of >= 512 points are searched through a uniform grid (same answer, ~100x fewer
  * distance evaluations); NULL selects the tiled brute-force scan.                           */
 int64_t rl_knn_workspace_bytes(int B, int Ns, int Nq, int k);
 int rl_knn_f32(const float* support, const float* query, int B, int Ns, int Nq, int k,
