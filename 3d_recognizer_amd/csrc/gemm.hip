@@ -686,6 +686,204 @@ void launch_swgrad(int N, dim3 grid, hipStream_t st, const WgradParams& p) {
     else              hipLaunchKernelGGL((swgrad_kernel<KT, 4>), grid, dim3(256), 0, st, p);
 }
 
+// ===========================================================================================
+// Pipelined LDS kernel for the wide layers (K > 64 or N > 64): 128 x (16*NT) tile, K in chunks
+// of 32, the next chunk's global loads (16 B per lane, A and W alike) are issued into registers
+// before the MFMA loop of the current chunk and written to LDS after it, so HBM/L2 latency hides
+// under 128 MFMAs per wavefront instead of stalling every 16 columns of K.
+// LDS strides: A rows 34 floats (fragment reads of 16 rows x 2 k hit 32 distinct banks),
+// W rows BN+16 (stride % 32 == 16: the two k rows of a half-wave read disjoint bank halves).
+// ===========================================================================================
+constexpr int PG_BK = 32;
+constexpr int PG_AS = 34;
+
+template <int NT>
+__global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
+    constexpr int BN = 16 * NT;
+    constexpr int WS = BN + ((BN % 32 == 0) ? 16 : 0);
+    constexpr int WQ_N = (PG_BK * BN / 4 + 255) / 256;   // float4 per lane, W rows contiguous in n
+    constexpr int WQ_K = (BN * 8 + 255) / 256;           // float4 per lane, W rows contiguous in k
+    constexpr int WQ = WQ_N > WQ_K ? WQ_N : WQ_K;
+    __shared__ __attribute__((aligned(16))) float As[GM_BM * PG_AS];
+    __shared__ __attribute__((aligned(16))) float Ws[PG_BK * WS];
+    __shared__ double red[4][2][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int col0 = blockIdx.y * BN;
+    const int K = p.a.K, N = p.N;
+    const long M = p.a.M;
+    const long ntiles = (M + GM_BM - 1) / GM_BM;
+    const bool lazy = p.a.lazy.scale != nullptr;
+    const bool w_ncontig = (p.w_ns == 1);
+    const int aq = tid & 7;            // this lane's k-quad inside a chunk (same for its 4 rows)
+
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * GM_BM;
+        long aoff[4];
+        bool aval[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long R = row0 + (tid >> 3) + 32 * i;
+            aval[i] = R < M;
+            aoff[i] = aval[i] ? a_row_offset(p.a, R) : 0;
+        }
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float4 ra[4], rw[WQ];
+        auto fetch = [&](int k0) {
+            const int ka = k0 + aq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (aval[i] && ka < K) ra[i] = *reinterpret_cast<const float4*>(p.a.A + aoff[i] + ka);
+            }
+            if (w_ncontig) {
+#pragma unroll
+                for (int i = 0; i < WQ_N; ++i) {
+                    const int e = tid + i * 256;
+                    const int kk = e / (BN / 4), q = e - kk * (BN / 4);
+                    rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < PG_BK * BN / 4 && k0 + kk < K && col0 + q * 4 < N)
+                        rw[i] = *reinterpret_cast<const float4*>(p.W + (long)(k0 + kk) * p.w_ks + col0 + q * 4);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < WQ_K; ++i) {
+                    const int e = tid + i * 256;
+                    const int n = e >> 3, q = e & 7;
+                    rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < BN * 8 && col0 + n < N && k0 + q * 4 < K)
+                        rw[i] = *reinterpret_cast<const float4*>(p.W + (long)(col0 + n) * p.w_ns + k0 + q * 4);
+                }
+            }
+        };
+        auto commit = [&](int k0) {
+            const int ka = k0 + aq * 4;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lazy && ka < K) {
+                sc = *reinterpret_cast<const float4*>(p.a.lazy.scale + ka);
+                sh = *reinterpret_cast<const float4*>(p.a.lazy.shift + ka);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = ra[i];
+                if (lazy && aval[i] && ka < K) {
+                    v.x = rl_act(v.x * sc.x + sh.x, p.a.lazy.act, p.a.lazy.slope);
+                    v.y = rl_act(v.y * sc.y + sh.y, p.a.lazy.act, p.a.lazy.slope);
+                    v.z = rl_act(v.z * sc.z + sh.z, p.a.lazy.act, p.a.lazy.slope);
+                    v.w = rl_act(v.w * sc.w + sh.w, p.a.lazy.act, p.a.lazy.slope);
+                }
+                float* dst = As + ((tid >> 3) + 32 * i) * PG_AS + aq * 4;
+                *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+            }
+            if (w_ncontig) {
+#pragma unroll
+                for (int i = 0; i < WQ_N; ++i) {
+                    const int e = tid + i * 256;
+                    const int kk = e / (BN / 4), q = e - kk * (BN / 4);
+                    if (e < PG_BK * BN / 4) *reinterpret_cast<float4*>(Ws + kk * WS + q * 4) = rw[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < WQ_K; ++i) {
+                    const int e = tid + i * 256;
+                    const int n = e >> 3, q = e & 7;
+                    if (e < BN * 8) {
+                        Ws[(q * 4 + 0) * WS + n] = rw[i].x;
+                        Ws[(q * 4 + 1) * WS + n] = rw[i].y;
+                        Ws[(q * 4 + 2) * WS + n] = rw[i].z;
+                        Ws[(q * 4 + 3) * WS + n] = rw[i].w;
+                    }
+                }
+            }
+        };
+
+        fetch(0);
+        for (int k0 = 0; k0 < K; k0 += PG_BK) {
+            __syncthreads();
+            commit(k0);
+            __syncthreads();
+            if (k0 + PG_BK < K) fetch(k0 + PG_BK);
+#pragma unroll
+            for (int ks = 0; ks < PG_BK / 4; ++ks) {
+                const int kc = ks * 4 + lq;
+                const float a0 = As[(wave * 32 + lr) * PG_AS + kc];
+                const float a1 = As[(wave * 32 + 16 + lr) * PG_AS + kc];
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) {
+                    const float bv = Ws[kc * WS + nb * 16 + lr];
+                    acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][nb], 0, 0, 0);
+                    acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nb], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long R = row0 + wave * 32 + rb * 16 + lq * 4 + r;
+                if (R < M) {
+                    long yoff;
+                    if (p.y_contig) yoff = R * p.ldy;
+                    else {
+                        const int b = (int)(R / p.rows_per_batch);
+                        const int i = (int)(R - (long)b * p.rows_per_batch);
+                        yoff = ((long)b * p.y_bstride + i) * p.ldy;
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        const int c = col0 + nb * 16 + lr;
+                        if (c < N) {
+                            float v = acc[rb][nb][r];
+                            if (p.bias) v += p.bias[c];
+                            if (p.accumulate) v += p.Y[yoff + c];
+                            p.Y[yoff + c] = v;
+                            ssum[nb] += v;
+                            ssq[nb] += v * v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            float s = ssum[nb], q = ssq[nb];
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (lane < 16) {
+                red[wave][0][nb * 16 + lane] = (double)s;
+                red[wave][1][nb * 16 + lane] = (double)q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && col0 + tid < N) {
+            p.stats[((long)blockIdx.x * 2 + 0) * N + col0 + tid] = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+            p.stats[((long)blockIdx.x * 2 + 1) * N + col0 + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+        }
+    }
+}
+
+inline bool pgemm_ok(const GemmParams& p) {
+    if (p.a.a_mode != 0 || !p.a.vec4) return false;
+    if (((uintptr_t)p.W & 15) != 0) return false;
+    if (p.a.lazy.scale && ((((uintptr_t)p.a.lazy.scale) | ((uintptr_t)p.a.lazy.shift)) & 15)) return false;
+    if (p.w_ns == 1) return (p.N % 4 == 0) && (p.w_ks % 4 == 0);
+    if (p.w_ks == 1) return (p.a.K % 4 == 0) && (p.w_ns % 4 == 0);
+    return false;
+}
+
 }  // namespace
 
 extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
@@ -709,6 +907,14 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         else if (d->K <= 32) launch_sgemm<2>(d->N, gx, st, p);
         else                 launch_sgemm<4>(d->N, gx, st, p);
         RL_LAUNCH_CHECK("rl_gemm(stream)");
+        return RL_OK;
+    }
+    if (pgemm_ok(p)) {
+        if (d->N <= 16)      hipLaunchKernelGGL((pgemm_kernel<1>), dim3(gx, 1), dim3(256), 0, st, p);
+        else if (d->N <= 32) hipLaunchKernelGGL((pgemm_kernel<2>), dim3(gx, 1), dim3(256), 0, st, p);
+        else if (d->N <= 64) hipLaunchKernelGGL((pgemm_kernel<4>), dim3(gx, 1), dim3(256), 0, st, p);
+        else                 hipLaunchKernelGGL((pgemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128)), dim3(256), 0, st, p);
+        RL_LAUNCH_CHECK("rl_gemm(pipelined)");
         return RL_OK;
     }
     if (d->N <= 16)      hipLaunchKernelGGL((gemm_kernel<1>), dim3(gx, 1), dim3(256), 0, st, p);

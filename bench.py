@@ -178,8 +178,8 @@ def main():
     xyz, labels = synthetic_batch(B, N, C, 1234 + rank)
     stepper.set_batch(torch.from_numpy(xyz).to(dev), torch.from_numpy(labels).to(dev))
     np.random.seed(1234 + rank)                # rank-distinct permutation streams
-    if world > 1:                              # replicas must start identical
-        dist.broadcast(stepper.flat.param, 0)
+    from randlanet._train import broadcast_flat
+    broadcast_flat(stepper.flat.param, world)  # replicas must start identical
     stepper.capture()
 
     def barrier():
