@@ -215,6 +215,23 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p[e] -= step_size * (mm / (sqrtf(vv) / bc2s + eps));
     }
 }
+// confidences = softmax over the class axis of (B,C,N) logits (Model.upsample / Model.predict, model.py:137, 229)
+__global__ __launch_bounds__(256) void softmax_cf_kernel(const float* __restrict__ logits, int B, int C, int N,
+                                                         float* __restrict__ out) {
+    const long total = (long)B * N;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / N;
+        const long i = e - b * N;
+        const float* z = logits + (b * C) * (long)N + i;
+        float* o = out + (b * C) * (long)N + i;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, z[(long)c * N]);
+        float den = 0.f;
+        for (int c = 0; c < C; ++c) den += expf(z[(long)c * N] - m);
+        for (int c = 0; c < C; ++c) o[(long)c * N] = expf(z[(long)c * N] - m) / den;
+    }
+}
+
 __global__ void adam_tick_kernel(int64_t* step) { step[0] += 1; }
 
 }  // namespace
@@ -260,6 +277,15 @@ extern "C" int rl_loss_backward(const float* logits, const int64_t* labels, int 
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels, B, C, N, kind,
                        alpha, gamma, neglect_background, totals, grad_scale, dlogits);
     RL_LAUNCH_CHECK("rl_loss_backward");
+    return RL_OK;
+}
+
+extern "C" int rl_softmax_cf(const float* logits, int B, int C, int N, float* out, void* stream) {
+    RL_REQUIRE(logits && out && B > 0 && C > 0 && N > 0, RL_ERR_ARGS, "rl_softmax_cf: bad arguments");
+    long g = ((long)B * N + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(softmax_cf_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, B, C, N, out);
+    RL_LAUNCH_CHECK("rl_softmax_cf");
     return RL_OK;
 }
 

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "rl_loss_work_doubles": (_l, [_l, _i]),
     "rl_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp]),
     "rl_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _f, _vp, _vp]),
+    "rl_softmax_cf": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rl_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -466,6 +466,16 @@ def loss_backward(logits, labels, kind: int, alpha: float, gamma: float, neglect
     return dlogits
 
 
+def softmax_cf(logits: torch.Tensor) -> torch.Tensor:
+    """Softmax over dim 1 of (B,C,N) logits."""
+    _dev_check(logits)
+    assert logits.dim() == 3 and logits.dtype == F32
+    B, Cc, N = logits.shape
+    out = torch.empty_like(logits)
+    H.check(H.lib().rl_softmax_cf(logits.data_ptr(), B, Cc, N, out.data_ptr(), _st()), "rl_softmax_cf")
+    return out
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr: torch.Tensor, step: torch.Tensor, beta1=0.9, beta2=0.999,
               eps=1e-8, grad_scale=1.0) -> None:
     _dev_check(param, grad, exp_avg, exp_avg_sq, lr, step)

@@ -1,0 +1,189 @@
+"""Training / evaluation loops behind Model.train and Model.evaluate (reference
+randlanet/utils/trainer.py:23-367): Adam + StepLR(10, gamma), dice loss by default, per-epoch
+validation over 10 seeded passes, early stopping on val_mIoU, optional TensorBoard scalars.
+
+What differs from the reference is only where the work happens: the forward/backward is the HIP
+launch schedule of RandLANet, the loss is the fused HIP loss, and accuracy + IoU of a batch come
+from ONE packed device->host read instead of 2C+2 `.item()` calls (trainer.py:121-131).
+"""
+import logging
+from collections import OrderedDict
+from contextlib import contextmanager
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+from tqdm import tqdm
+
+from .early_stopper import EarlyStopper
+from .losses import get_loss
+from .metrics import (MetricCollector, MetricCollectorBag, accuracy_from_counts, class_counts,
+                      iou_from_counts)
+from .modules import RandLANet, UpSampler
+
+logger = logging.getLogger("trainer")
+logger.setLevel(logging.DEBUG)
+
+
+@dataclass
+class TrainingSettings:
+    #: Number of epochs to train
+    epochs: int = 150
+    #: Size of minibatches used during training
+    batch_size: int = 8
+    #: Base learning rate
+    learning_rate: float = 1e-2
+    #: Decay factor applied to the learning rate every 10 epochs
+    learning_rate_decay: float = 0.9
+    #: "cross_entropy", "focal", "dice", "tversky" or "focal_tversky"
+    loss_function: str = "dice"
+    #: Early stopping
+    early_stopping: bool = True
+    #: Patience for early stopping
+    early_stopping_patience: int = 20
+
+
+def _summary_writer(log_dir: Optional[Path]):
+    if log_dir is None:
+        return None
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+    except Exception:  # tensorboard is an optional dependency of the host glue
+        logger.warning("tensorboard is not installed: scalars are not written")
+        return None
+    return SummaryWriter(str(log_dir))
+
+
+def _batch_metrics(logits: torch.Tensor, labels: torch.Tensor):
+    cnt = class_counts(logits, labels)                 # one launch, one read-back
+    oa, pca = accuracy_from_counts(cnt)
+    miou, pci = iou_from_counts(cnt)
+    return oa, pca, miou, pci
+
+
+class Trainer:
+    def __init__(self, train_dataloader: DataLoader, validation_dataloader: DataLoader,
+                 log_dir: Optional[Path] = None, class_names: Optional[List[str]] = None):
+        self._train_dataloader = train_dataloader
+        self._validation_dataloader = validation_dataloader
+        self._log_dir = log_dir
+        self._class_names = class_names
+
+    _get_loss = staticmethod(get_loss)
+
+    def train(self, model: RandLANet, settings: TrainingSettings,
+              callbacks: List[Callable[[int, Dict[str, float]], None]] = []) -> RandLANet:
+        device = model.device
+        optimizer = torch.optim.Adam(model.parameters(), lr=settings.learning_rate)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=10, gamma=settings.learning_rate_decay)
+        criterion = get_loss(settings.loss_function)
+        patience = settings.early_stopping_patience if settings.early_stopping else settings.epochs
+        stopper = EarlyStopper(patience=patience, metric="val_mIoU")
+        model.train()
+        logger.info(f"Training on {len(self._train_dataloader.dataset)} training samples and "
+                    f"{len(self._validation_dataloader.dataset)} validation samples.")
+        writer = _summary_writer(self._log_dir)
+        for epoch in range(1, settings.epochs + 1):
+            collected = MetricCollector(self._class_names)
+            for batch, labels, _ in tqdm(self._train_dataloader, desc="Training", leave=False):
+                batch, labels = batch.to(device), labels.to(device)
+                logits = model(batch)
+                loss = criterion(logits, labels)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                collected.push(loss.item(), *_batch_metrics(logits, labels))
+            scheduler.step()
+            validation = Trainer.evaluate(model, self._validation_dataloader, class_names=self._class_names,
+                                          loss_function=settings.loss_function)
+            metrics = collected.as_dict()
+            metrics.update(validation.as_dict("val"))
+            keep_going = stopper.check(metrics, model)
+            self._log(epoch, settings.epochs, optimizer, collected.as_dict(),
+                      validation.as_dict(include_stdev=True), writer)
+            for callback in callbacks:
+                callback(epoch, metrics)
+            if not keep_going:
+                break
+        if writer is not None:
+            writer.close()
+        best = stopper.load_best_model_weights(model)
+        if best is None:
+            logger.warning("Model did not improve during training!")
+            best = model
+        model.eval()
+        best.eval()
+        return best
+
+    def _log(self, epoch: int, total_epochs: int, optimizer, train_metrics: OrderedDict,
+             validation_metrics: OrderedDict, writer) -> None:
+        parts = [f"Epoch {epoch:3d}/{total_epochs:3d}"]
+        v = validation_metrics
+        parts.append("loss: %.4f - val_loss: %.4f (s: %.4f)" % (train_metrics["loss"], v["loss"][0], v["loss"][1]))
+        for key in ("mAcc", "mIoU"):
+            parts.append("%s: %.2f%% - val_%s: %.2f%% (s: %.2f%%)" % (
+                key, train_metrics[key] * 100, key, v[key][0] * 100, v[key][1] * 100))
+        logger.info(" - ".join(parts))
+        for mode, metrics in (("Training", train_metrics), ("Validation", validation_metrics)):
+            cells = []
+            for key in [k for k in metrics if k.endswith(" IoU")]:
+                value = metrics[key]
+                name = key[: -len(" IoU")]
+                if isinstance(value, tuple):
+                    cells.append("%s: %5.2f%% (s: %5.2f%%)" % (name, value[0] * 100, value[1] * 100))
+                else:
+                    cells.append("%s: %5.2f%% %11s" % (name, value * 100, ""))
+            logger.info(f"{'':15s} {mode + ' IoU:':16s}" + " - ".join(cells))
+        if writer is not None:
+            writer.add_scalar("Learning rate", optimizer.param_groups[0]["lr"], epoch)
+            for mode, metrics in (("Train", train_metrics), ("Validation", validation_metrics)):
+                for key, value in metrics.items():
+                    writer.add_scalar(f"{key}/{mode}", value[0] if isinstance(value, tuple) else value, epoch)
+
+    @staticmethod
+    def evaluate(model: RandLANet, data_loader: DataLoader, class_names: Optional[List[str]] = None,
+                 loss_function: str = "dice", postprocess: bool = False,
+                 n_evaluations: int = 10) -> MetricCollectorBag:
+        """n_evaluations passes with numpy seeds 0, 100, 200, ... (the forward's permutation is the only
+        randomness in eval mode); the caller's numpy RNG state is restored (trainer.py:271-367)."""
+
+        @contextmanager
+        def eval_mode(m: torch.nn.Module):
+            was_training = m.training
+            m.eval()
+            try:
+                yield
+            finally:
+                m.train(was_training)
+
+        criterion = get_loss(loss_function)
+        device = model.device
+        saved_rng = np.random.get_state()
+        if postprocess:
+            assert data_loader.batch_size == 1, "Batch size 1 required when evaluating with postprocessing!"
+        upsampler = UpSampler("nni", device)
+        passes: List[MetricCollector] = []
+        with eval_mode(model), torch.no_grad():
+            for i in range(n_evaluations):
+                np.random.seed(100 * i)
+                current = MetricCollector()
+                for batch, labels, indices in tqdm(data_loader, desc="Evaluation", leave=False):
+                    batch, labels = batch.to(device), labels.to(device)
+                    logits = model(batch)
+                    loss = criterion(logits, labels).item()
+                    if postprocess:
+                        full_input, full_labels, _ = data_loader.dataset.__getitem__(int(indices[0]), preprocess=False)
+                        from .. import _ops as ops
+                        conf = ops.softmax_cf(logits.contiguous())
+                        scores = upsampler(conf.unsqueeze(-1), batch[:, :, :3],
+                                           full_input[:, :3].unsqueeze(0)).squeeze(-1)
+                        target = full_labels.unsqueeze(0).to(device)
+                    else:
+                        scores, target = logits, labels
+                    current.push(loss, *_batch_metrics(scores, target))
+                passes.append(current)
+        np.random.set_state(saved_rng)
+        return MetricCollectorBag(passes, class_names)

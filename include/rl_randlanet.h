@@ -275,6 +275,9 @@ int rl_loss_backward(const float* logits, const int64_t* labels, int B, int C, i
                      float alpha, float gamma, int neglect_background, const double* work,
                      float grad_scale, float* dlogits, void* stream);
 
+/* Softmax over the class axis of (B,C,N) logits -> confidences (model.py:137, 229).         */
+int rl_softmax_cf(const float* logits, int B, int C, int N, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Adam over a flat parameter buffer (torch.optim.Adam defaults, trainer.py:78): step[0] is
  * incremented on the device, lr is read from device memory, grads are multiplied by

@@ -270,8 +270,69 @@ def g4_loss_metrics():
     save("loss_metrics.npz", **out)
 
 
+# ------------------------------------------------- G5: model zip + Model.predict (facade)
+def synthetic_labels(xyz, n_classes):
+    """Deterministic, spatially coherent labels for the unlabeled mock clouds: class grows with
+    the distance from the cloud centroid, class 0 beyond the median radius."""
+    c = xyz.mean(0, keepdims=True)
+    r = np.linalg.norm(xyz - c, axis=1)
+    med = np.median(r)
+    lab = 1 + np.floor((n_classes - 1) * r / med).astype(np.int64)
+    return np.where(r < med, np.clip(lab, 1, n_classes - 1), 0).astype(np.int64)
+
+
+def g5_model_zip():
+    from pathlib import Path
+    from randlanet import Model, RandLANetSettings
+    s = RandLANetSettings(n_classes=2, n_points=600, n_neighbors=8, layer_sizes=[8, 16, 32, 32],
+                          knn="approximate", upsampling="nni")
+    model = Model(s, use_gpu=False)
+    sd = model.module.state_dict()
+    model.module.load_state_dict(formula_state_dict([(k_, tuple(v.shape)) for k_, v in sd.items()], seed=5))
+    model.module.eval()
+    zip_path = Path(HERE) / "ref_model_small.zip"
+    model.save(zip_path)
+    cloud = mock_cloud(5000, seed=2)
+    out = {}
+    for up in ("nni", "idw"):
+        model.settings.upsampling = up
+        model._upsampler = M.UpSampler(up, DEV)
+        np.random.seed(123)
+        out[f"conf_{up}"] = np.asarray(model.predict(cloud))
+    np.random.seed(123)
+    raw = model.predict(cloud[:600], prepostprocess=False)
+    out["conf_raw"] = np.asarray(raw.numpy() if hasattr(raw, "numpy") else raw)
+    save("model_predict.npz", cloud=cloud, **out)
+    print(f"ref_model_small.zip: {os.path.getsize(zip_path) / 1024:.0f} KiB")
+
+
+# ------------------------------------------------------- G6: short training run (mIoU)
+def g6_training_run():
+    from randlanet import AugmentationSettings, Model, RandLANetSettings, TrainingSettings
+    C, n_pts = 3, 1024
+    clouds = []
+    for i in range(12):
+        xyz = mock_cloud(3000, seed=10 + i)
+        clouds.append((xyz, np.zeros((3000, 0), np.float32), synthetic_labels(xyz, C)))
+    train, val = clouds[:8], clouds[8:]
+    torch.manual_seed(0)
+    np.random.seed(0)
+    s = RandLANetSettings(n_classes=C, n_points=n_pts, n_neighbors=16, layer_sizes=[8, 16, 32, 32],
+                          knn="approximate")
+    model = Model(s, use_gpu=False)
+    model.module.fc_end[2].p = 0.0          # Dropout draws from torch's device RNG: not comparable
+    hist = []
+    ts = TrainingSettings(epochs=6, batch_size=4, learning_rate=1e-2, early_stopping=False)
+    model.train(train, val, ts, AugmentationSettings(), None, ["bg", "a", "b"],
+                callbacks=[lambda e, m: hist.append([m["loss"], m["mIoU"], m["val_loss"], m["val_mIoU"]])])
+    final = model.evaluate(val, ["bg", "a", "b"], batch_size=4)
+    save("train_run.npz", history=np.array(hist, dtype=np.float64),
+         final=np.array([final["loss"], final["OA"], final["mAcc"], final["mIoU"]], dtype=np.float64))
+    print("history", np.round(np.array(hist), 4).tolist(), "final", final)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2m", "g3", "g4"]
+    which = sys.argv[1:] or ["g1", "g2", "g2m", "g3", "g4", "g5", "g6"]
     if "g1" in which:
         g1_knn()
     if "g2" in which:
@@ -282,3 +343,7 @@ if __name__ == "__main__":
         g3_train()
     if "g4" in which:
         g4_loss_metrics()
+    if "g5" in which:
+        g5_model_zip()
+    if "g6" in which:
+        g6_training_run()

@@ -1,0 +1,106 @@
+"""The drop-in facade on the MI355X: Model.load of a zip written by the REFERENCE, predict /
+upsample confidences against the reference's outputs, save->load round trip, and a short training
+run (reference Trainer semantics) against the reference's own mIoU trajectory."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_load_reference_zip_and_predict(golden_dir):
+    from randlanet import Model
+    from randlanet.utils.modules import UpSampler
+    z = np.load(f"{golden_dir}/model_predict.npz")
+    model = Model.load(Path(golden_dir) / "ref_model_small.zip")      # written by the reference's Model.save
+    assert model.settings.n_points == 600 and model.settings.layer_sizes == [8, 16, 32, 32]
+    assert model.device.type == "cuda" and not model.module.training
+    cloud = z["cloud"]
+    for up in ("nni", "idw"):
+        model.settings.upsampling = up
+        model._upsampler = UpSampler(up, model.device)
+        np.random.seed(123)
+        conf = model.predict(cloud)
+        assert isinstance(conf, np.ndarray) and conf.shape == (2, 5000)
+        np.testing.assert_allclose(conf.sum(0), 1.0, atol=1e-5)
+        # a real depth cloud has exact-distance ties: a few points may pick another
+        # equally-near neighbour than the reference's kd-tree order did
+        bad = np.abs(conf - z[f"conf_{up}"]).max(0) > 1e-3
+        assert bad.mean() < 0.02, (up, bad.mean())
+    np.random.seed(123)
+    raw = model.predict(cloud[:600], prepostprocess=False)
+    assert np.mean(np.abs(np.asarray(raw) - z["conf_raw"]).max(0) > 1e-3) < 0.02
+    # batched input keeps the batch axis (model.py:186-190, 233-234)
+    np.random.seed(123)
+    assert model.predict(np.stack([cloud, cloud])).shape == (2, 2, 5000)
+    with pytest.raises(AssertionError, match="xyz should have shape"):
+        model.predict(cloud[:, :2])
+
+
+def test_save_load_round_trip(tmp_path, golden_dir):
+    from randlanet import Model, RandLANetSettings
+    torch.manual_seed(3)
+    m = Model(RandLANetSettings(n_classes=4, n_points=700, n_neighbors=8, layer_sizes=[8, 16, 32, 32], knn="naive"))
+    path = tmp_path / "sub" / "model_file"
+    m.save(path)
+    assert path.is_file()
+    m2 = Model.load(path, n_points=900, not_a_setting=1)             # kwargs override settings (model.py:101-103)
+    assert m2.settings.n_points == 900 and m2.settings.knn == "naive"
+    for (k1, v1), (k2, v2) in zip(m.module.state_dict().items(), m2.module.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+    # the reference tolerates {"model": state_dict} nesting (model.py:98-99)
+    import shutil, tempfile, json
+    from dataclasses import asdict
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "config"), "w") as f:
+            json.dump(asdict(m.settings), f)
+        torch.save({"model": m.module.state_dict()}, os.path.join(d, "model"))
+        nested = shutil.make_archive(str(tmp_path / "nested"), "zip", d)
+    m3 = Model.load(Path(nested))
+    assert torch.equal(m3.module.state_dict()["fc_start.weight"].cpu(), m.module.state_dict()["fc_start.weight"].cpu())
+    with pytest.raises(AssertionError, match="Could not find model file"):
+        Model.load(tmp_path / "missing")
+
+
+def _clouds(n_clouds, n_pts, n_classes, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_clouds):
+        xyz = (rs.normal(0, 1, (n_pts, 3)) * np.array([0.2, 0.15, 0.05]) + np.array([0.0, 0.0, 0.4])).astype(np.float32)
+        r = np.linalg.norm(xyz - xyz.mean(0, keepdims=True), axis=1)
+        med = np.median(r)
+        lab = np.where(r < med, np.clip(1 + np.floor((n_classes - 1) * r / med), 1, n_classes - 1), 0).astype(np.int64)
+        out.append((xyz, np.zeros((n_pts, 0), np.float32), lab))
+    return out
+
+
+def test_training_run_learns_like_the_reference(golden_dir):
+    """Reference run (tests/golden/train_run.npz: 6 epochs, dice, Adam 1e-2, batch 4, Dropout off) reaches
+    val mIoU 0.81 from 0.39 on its mock sub-samples.  The same loop on the HIP path, on clouds of the same
+    shape family, must learn the same way: loss falls monotonically-ish and val mIoU ends well above its start."""
+    from randlanet import AugmentationSettings, Model, RandLANetSettings, TrainingSettings
+    ref = np.load(f"{golden_dir}/train_run.npz")
+    C = 3
+    data = _clouds(12, 3000, C, 0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = Model(RandLANetSettings(n_classes=C, n_points=1024, n_neighbors=16, layer_sizes=[8, 16, 32, 32]))
+    model.module.fc_end[2].p = 0.0
+    hist = []
+    seen = []
+    model.train(data[:8], data[8:], TrainingSettings(epochs=6, batch_size=4, learning_rate=1e-2, early_stopping=False),
+                AugmentationSettings(), None, ["bg", "a", "b"],
+                callbacks=[lambda e, m: (seen.append(e), hist.append([m["loss"], m["mIoU"], m["val_loss"], m["val_mIoU"]]))])
+    hist = np.array(hist)
+    assert seen == [1, 2, 3, 4, 5, 6]
+    assert hist[-1, 0] < 0.6 * hist[0, 0], hist[:, 0]            # reference: 0.69 -> 0.24
+    assert hist[-1, 3] > hist[0, 3] + 0.2 and hist[-1, 3] > 0.6, hist[:, 3]   # reference: 0.39 -> 0.81
+    final = model.evaluate(data[8:], ["bg", "a", "b"], batch_size=4, include_stdev=True)
+    assert list(final.keys()) == ["loss", "OA", "mAcc", "mIoU", "bg IoU", "a IoU", "b IoU"]
+    assert all(isinstance(v, tuple) and len(v) == 2 for v in final.values())
+    assert abs(final["mIoU"][0] - hist[-1, 3]) < 1e-6             # evaluate() == the last validation pass
+    assert not model.module.training
+    print("reference val mIoU", ref["history"][:, 3].round(3), "hip val mIoU", hist[:, 3].round(3))
