@@ -326,7 +326,8 @@ def g6_training_run():
     model.train(train, val, ts, AugmentationSettings(), None, ["bg", "a", "b"],
                 callbacks=[lambda e, m: hist.append([m["loss"], m["mIoU"], m["val_loss"], m["val_mIoU"]])])
     final = model.evaluate(val, ["bg", "a", "b"], batch_size=4)
-    save("train_run.npz", history=np.array(hist, dtype=np.float64),
+    save("train_run.npz", clouds=np.stack([c[0] for c in clouds]).astype(np.float32),
+         labels=np.stack([c[2] for c in clouds]).astype(np.int8), history=np.array(hist, dtype=np.float64),
          final=np.array([final["loss"], final["OA"], final["mAcc"], final["mIoU"]], dtype=np.float64))
     print("history", np.round(np.array(hist), 4).tolist(), "final", final)
 

@@ -65,42 +65,34 @@ def test_save_load_round_trip(tmp_path, golden_dir):
         Model.load(tmp_path / "missing")
 
 
-def _clouds(n_clouds, n_pts, n_classes, seed):
-    rs = np.random.RandomState(seed)
-    out = []
-    for _ in range(n_clouds):
-        xyz = (rs.normal(0, 1, (n_pts, 3)) * np.array([0.2, 0.15, 0.05]) + np.array([0.0, 0.0, 0.4])).astype(np.float32)
-        r = np.linalg.norm(xyz - xyz.mean(0, keepdims=True), axis=1)
-        med = np.median(r)
-        lab = np.where(r < med, np.clip(1 + np.floor((n_classes - 1) * r / med), 1, n_classes - 1), 0).astype(np.int64)
-        out.append((xyz, np.zeros((n_pts, 0), np.float32), lab))
-    return out
-
-
-def test_training_run_learns_like_the_reference(golden_dir):
-    """Reference run (tests/golden/train_run.npz: 6 epochs, dice, Adam 1e-2, batch 4, Dropout off) reaches
-    val mIoU 0.81 from 0.39 on its mock sub-samples.  The same loop on the HIP path, on clouds of the same
-    shape family, must learn the same way: loss falls monotonically-ish and val mIoU ends well above its start."""
+def test_training_run_tracks_the_reference(golden_dir):
+    """The reference's own Trainer on 12 labelled mock sub-samples (tests/golden/train_run.npz: 6 epochs,
+    dice, Adam 1e-2, batch 4, Dropout off, torch/numpy seeds 0) against the same loop on the HIP path with
+    the same data, seeds, initial weights (same construction order -> same default init), shuffling,
+    sampling, augmentation and permutations.  Early epochs agree closely; later ones drift the way any two
+    fp32 implementations do under Adam (see test_net_gpu)."""
     from randlanet import AugmentationSettings, Model, RandLANetSettings, TrainingSettings
     ref = np.load(f"{golden_dir}/train_run.npz")
     C = 3
-    data = _clouds(12, 3000, C, 0)
+    data = [(xyz, np.zeros((xyz.shape[0], 0), np.float32), lab.astype(np.int64))
+            for xyz, lab in zip(ref["clouds"], ref["labels"])]
     torch.manual_seed(0)
     np.random.seed(0)
     model = Model(RandLANetSettings(n_classes=C, n_points=1024, n_neighbors=16, layer_sizes=[8, 16, 32, 32]))
     model.module.fc_end[2].p = 0.0
-    hist = []
-    seen = []
+    hist, seen = [], []
     model.train(data[:8], data[8:], TrainingSettings(epochs=6, batch_size=4, learning_rate=1e-2, early_stopping=False),
                 AugmentationSettings(), None, ["bg", "a", "b"],
                 callbacks=[lambda e, m: (seen.append(e), hist.append([m["loss"], m["mIoU"], m["val_loss"], m["val_mIoU"]]))])
     hist = np.array(hist)
+    print("reference [loss, mIoU, val_loss, val_mIoU] per epoch\n", ref["history"].round(4), "\nhip\n", hist.round(4))
     assert seen == [1, 2, 3, 4, 5, 6]
-    assert hist[-1, 0] < 0.6 * hist[0, 0], hist[:, 0]            # reference: 0.69 -> 0.24
-    assert hist[-1, 3] > hist[0, 3] + 0.2 and hist[-1, 3] > 0.6, hist[:, 3]   # reference: 0.39 -> 0.81
+    # epoch 1: two Adam steps from identical weights on identical batches
+    np.testing.assert_allclose(hist[0, 0], ref["history"][0, 0], atol=5e-3)
+    assert abs(hist[-1, 0] - ref["history"][-1, 0]) < 0.08, (hist[:, 0], ref["history"][:, 0])
+    assert abs(hist[-1, 3] - ref["history"][-1, 3]) < 0.10, (hist[:, 3], ref["history"][:, 3])
     final = model.evaluate(data[8:], ["bg", "a", "b"], batch_size=4, include_stdev=True)
     assert list(final.keys()) == ["loss", "OA", "mAcc", "mIoU", "bg IoU", "a IoU", "b IoU"]
     assert all(isinstance(v, tuple) and len(v) == 2 for v in final.values())
     assert abs(final["mIoU"][0] - hist[-1, 3]) < 1e-6             # evaluate() == the last validation pass
     assert not model.module.training
-    print("reference val mIoU", ref["history"][:, 3].round(3), "hip val mIoU", hist[:, 3].round(3))
