@@ -358,8 +358,7 @@ void wgrad_split(long M, int N, int K, int* nsplit, long* rows_per_block) {
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
     long rpb = (M + want - 1) / want;
-    rpb = ((rpb + WG_RB - 1) / WG_RB) * WG_RB;
-    if (rpb < WG_RB) rpb = WG_RB;
+    rpb = ((rpb + 63) / 64) * 64;   // multiple of both kernels' row chunks (32 / 64)
     *rows_per_block = rpb;
     *nsplit = (int)((M + rpb - 1) / rpb);
     if (*nsplit < 1) *nsplit = 1;
@@ -884,6 +883,122 @@ inline bool pgemm_ok(const GemmParams& p) {
     return false;
 }
 
+// Pipelined wide weight-gradient: 64 (n) x 64 (k) tile of dW per workgroup, rows streamed in chunks
+// of 64 through LDS with the next chunk's dwordx4 loads in flight during the 64 MFMAs per wavefront
+// of the current one (same structure as pgemm_kernel; rows are the reduction index).
+constexpr int PW_RB = 64;
+
+__global__ __launch_bounds__(256) void pwgrad_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float dYs[PW_RB * WG_S];
+    __shared__ __attribute__((aligned(16))) float As[PW_RB * WG_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = p.N, K = p.a.K;
+    const int n0 = blockIdx.y * WG_T, k0 = blockIdx.z * WG_T;
+    const int nvalid = min(WG_T, N - n0), kvalid = min(WG_T, K - k0);
+    const int nkb = (kvalid + 15) >> 4;
+    const bool wave_active = wave * 16 < nvalid;
+    const long r_begin = (long)blockIdx.x * p.rows_per_block;
+    const long r_end = min(p.a.M, r_begin + p.rows_per_block);
+    const int q4 = (tid & 15) * 4;          // this lane's column quad (same for its 4 rows)
+    const bool lazy = p.a.lazy.scale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lazy && q4 < kvalid) {
+        sc = *reinterpret_cast<const float4*>(p.a.lazy.scale + k0 + q4);
+        sh = *reinterpret_cast<const float4*>(p.a.lazy.shift + k0 + q4);
+    }
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    float4 rd[4], ra[4];
+
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long R = r0 + (tid >> 4) + 16 * i;
+            rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (R < r_end) {
+                if (q4 < nvalid) {
+                    long off;
+                    if (p.dy_contig) off = R * p.lddy;
+                    else {
+                        const int b = (int)(R / p.rows_per_batch);
+                        const int ii = (int)(R - (long)b * p.rows_per_batch);
+                        off = ((long)b * p.dy_bstride + ii) * p.lddy;
+                    }
+                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + q4);
+                }
+                if (q4 < kvalid) {
+                    float4 v = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + q4);
+                    if (lazy) {
+                        v.x = rl_act(v.x * sc.x + sh.x, p.a.lazy.act, p.a.lazy.slope);
+                        v.y = rl_act(v.y * sc.y + sh.y, p.a.lazy.act, p.a.lazy.slope);
+                        v.z = rl_act(v.z * sc.z + sh.z, p.a.lazy.act, p.a.lazy.slope);
+                        v.w = rl_act(v.w * sc.w + sh.w, p.a.lazy.act, p.a.lazy.slope);
+                    }
+                    ra[i] = v;
+                }
+            }
+        }
+    };
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (long r0 = r_begin; r0 < r_end; r0 += PW_RB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            *reinterpret_cast<float4*>(dYs + r * WG_S + q4) = rd[i];
+            *reinterpret_cast<float4*>(As + r * WG_S + q4) = ra[i];
+        }
+        __syncthreads();
+        if (r0 + PW_RB < r_end) fetch(r0 + PW_RB);
+        if (p.has_bias && blockIdx.z == 0 && tid < WG_T) {
+#pragma unroll 16
+            for (int r = 0; r < PW_RB; ++r) bsum += dYs[r * WG_S + tid];
+        }
+        if (wave_active) {
+#pragma unroll
+            for (int rs = 0; rs < PW_RB / 4; ++rs) {
+                const int rr = rs * 4 + lq;
+                const float av = dYs[rr * WG_S + wave * 16 + lr];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb < nkb) {
+                        const float bv = As[rr * WG_S + kb * 16 + lr];
+                        acc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[kb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float* out = p.slab + (long)blockIdx.x * ((long)N * K + N);
+    if (wave_active) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb < nkb) {
+                const int k = k0 + kb * 16 + lr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wave * 16 + lq * 4 + r;
+                    if (n < N && k < K) out[(long)n * K + k] = acc[kb][r];
+                }
+            }
+        }
+    }
+    if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
+}
+
+inline bool pwgrad_ok(const WgradParams& p) {
+    if (p.a.a_mode != 0 || !p.a.vec4) return false;
+    if ((p.N % 4) || (p.lddy % 4) || (((uintptr_t)p.dY) & 15)) return false;
+    if (p.a.lazy.scale && ((((uintptr_t)p.a.lazy.scale) | ((uintptr_t)p.a.lazy.shift)) & 15)) return false;
+    return true;
+}
+
 }  // namespace
 
 extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
@@ -959,7 +1074,8 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         else                 launch_swgrad<4>(d->N, dim3(nsplit), st, p);
     } else {
         dim3 grid(nsplit, rl_cdiv(d->N, WG_T), rl_cdiv(d->K, WG_T));
-        hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
+        if (pwgrad_ok(p)) hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
     }
     RL_LAUNCH_CHECK("rl_wgrad");
     const long per = (long)d->N * d->K + d->N;
