@@ -1,0 +1,400 @@
+// Fused attentive pooling for the narrow levels (d = 16 / 32 / 64 channels, 16 neighbours):
+// PointFeatureAugmentation gather + concat, the score Linear, the softmax over the K neighbours
+// and the weighted sum (reference randlanet/utils/modules.py:213-221, 246-253) in one kernel, and
+// the whole backward of that block in another.  The (points*K) x d tensors X = [rpe, gathered],
+// S = X.W^T, dS and dX never reach HBM: a wavefront owns one point at a time, i.e. one 16-row
+// MFMA block, so the softmax over K is a reduction over the 16 rows of its own accumulator tile
+// (4 registers x the 4 lane groups: two __shfl_xor).
+//
+// Layouts (v_mfma_f32_16x16x4_f32):
+//   "A layout"  lane (i = l&15, j = l>>4) holds a float4 = X[row i][16c + 4j .. +3]   (coalesced loads)
+//   "C layout"  lane (lr = l&15, lq = l>>4), reg r -> element [row 4*lq + r][col 16*nb + lr]
+// Tiles move between the two through a wavefront-private LDS tile (row stride d+4 floats: the
+// C-layout reads of a half-wave fall in disjoint bank halves).  W and W^T sit in LDS for the
+// whole kernel (stride d+4 as well), read as MFMA B fragments.
+//
+// Backward, per point:  recompute X, S, A = softmax_K(S), P;  dS = A*dP*(X - P);
+//   dX = dP*A + dS.W  ->  first half to the rpe-branch gradient (plain stores), second half
+//   scatter-added to the gathered features' gradient (fp32 atomics);  dW += dS^T.X accumulates in
+//   registers over all points of the wavefront and leaves the workgroup as one partial slab.
+#include "rl_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PoolParams {
+    const float* U;        // (P*16) x h raw rpe-branch features
+    RlLazy ulazy;
+    const float* G;        // per-point features, row (b, i) at (b*g_bstride + i)*h
+    long g_bstride;
+    RlLazy glazy;
+    const int32_t* idx;    // (P, 16) neighbour indices inside the cloud
+    const float* W;        // (d, d) score weight, [out][in] row-major
+    long P;                // points = B*n
+    int n;                 // points per cloud
+    int d;
+    // forward output / backward input
+    float* Pout;           // (P, d)
+    const float* dP;       // (P, d)
+    // backward outputs
+    float* GU;             // (P*16) x h
+    int gu_accumulate;
+    float* GG;             // same addressing as G (zeroed by the caller)
+    float* slab;           // per-workgroup partial dW: [grid][d*d]
+};
+
+template <int DT>
+struct Tile {
+    static constexpr int D = 16 * DT;
+    static constexpr int H = D / 2;
+    static constexpr int XS = D + 4;
+};
+
+// lane-constant lazy parameters for the float4 this lane loads in chunk c
+template <int DT>
+__device__ __forceinline__ void lane_lazy(const PoolParams& p, int lj, float (&sc)[DT][4], float (&sh)[DT][4]) {
+    constexpr int H = Tile<DT>::H;
+#pragma unroll
+    for (int c = 0; c < DT; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * c + 4 * lj + s;
+            if (k < H) {
+                sc[c][s] = p.ulazy.scale ? p.ulazy.scale[k] : 1.f;
+                sh[c][s] = p.ulazy.scale ? p.ulazy.shift[k] : 0.f;
+            } else {
+                sc[c][s] = p.glazy.scale ? p.glazy.scale[k - H] : 1.f;
+                sh[c][s] = p.glazy.scale ? p.glazy.shift[k - H] : 0.f;
+            }
+        }
+}
+
+// Load the 16 x d tile of X for point pt in A layout (already activated) and park it in LDS.
+template <int DT>
+__device__ __forceinline__ void load_x(const PoolParams& p, long pt, int li, int lj, int my_idx,
+                                       const float (&sc)[DT][4], const float (&sh)[DT][4], float4 (&xa)[DT],
+                                       float* Xs) {
+    constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
+    const long row = pt * 16 + li;
+    const long b = pt / p.n;
+#pragma unroll
+    for (int c = 0; c < DT; ++c) {
+        const int k = 16 * c + 4 * lj;
+        float4 v;
+        int act;
+        float slope;
+        if (k < H) {
+            v = *reinterpret_cast<const float4*>(p.U + row * H + k);
+            act = p.ulazy.scale ? p.ulazy.act : RL_ACT_NONE;
+            slope = p.ulazy.slope;
+        } else {
+            v = *reinterpret_cast<const float4*>(p.G + (b * p.g_bstride + my_idx) * H + (k - H));
+            act = p.glazy.scale ? p.glazy.act : RL_ACT_NONE;
+            slope = p.glazy.slope;
+        }
+        v.x = rl_act(v.x * sc[c][0] + sh[c][0], act, slope);
+        v.y = rl_act(v.y * sc[c][1] + sh[c][1], act, slope);
+        v.z = rl_act(v.z * sc[c][2] + sh[c][2], act, slope);
+        v.w = rl_act(v.w * sc[c][3] + sh[c][3], act, slope);
+        xa[c] = v;
+        *reinterpret_cast<float4*>(Xs + li * XS + k) = v;
+    }
+}
+
+// acc[nb] += tile(A layout) . B, with B fragments read from an LDS matrix Bm[k][n] (stride XS)
+template <int DT>
+__device__ __forceinline__ void tile_gemm(const float4 (&a)[DT], const float* Bm, int li, int lj, f32x4 (&acc)[DT]) {
+    constexpr int XS = Tile<DT>::XS;
+#pragma unroll
+    for (int c = 0; c < DT; ++c) {
+        const float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * c + 4 * lj + s;
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bm[k * XS + nb * 16 + li], acc[nb], 0, 0, 0);
+        }
+    }
+}
+
+// softmax over the 16 rows of a C-layout tile, in place: s -> A
+template <int DT>
+__device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
+#pragma unroll
+    for (int nb = 0; nb < DT; ++nb) {
+        float m = fmaxf(fmaxf(s[nb][0], s[nb][1]), fmaxf(s[nb][2], s[nb][3]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float den = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[nb][r] = expf(s[nb][r] - m);
+            den += s[nb][r];
+        }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float inv = 1.f / den;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[nb][r] *= inv;
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* Wn) {
+    constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS;
+    // Wt[k][n] = W[n][k] (B operand of S = X.W^T);  Wn[k'][n'] = W[k'][n'] (B operand of dX = dS.W)
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int o = e / D, i = e - o * D;
+        const float w = p.W[e];
+        Wn[o * XS + i] = w;
+        if (Wt) Wt[i * XS + o] = w;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
+    constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS;
+    __shared__ __attribute__((aligned(16))) float Wt[D * XS];
+    __shared__ __attribute__((aligned(16))) float Xt[4][16 * XS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int o = e / D, i = e - o * D;
+        Wt[i * XS + o] = p.W[e];
+    }
+    __syncthreads();
+    float sc[DT][4], sh[DT][4];
+    lane_lazy<DT>(p, lj, sc, sh);
+    float* Xs = Xt[wave];
+    for (long pt = (long)blockIdx.x * 4 + wave; pt < p.P; pt += (long)gridDim.x * 4) {
+        const int my_idx = p.idx[pt * 16 + li];
+        float4 xa[DT];
+        load_x<DT>(p, pt, li, lj, my_idx, sc, sh, xa, Xs);
+        f32x4 s[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) s[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile_gemm<DT>(xa, Wt, li, lj, s);
+        softmax_rows<DT>(s);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc += s[nb][r] * Xs[(lj * 4 + r) * XS + nb * 16 + li];
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            if (lj == 0) p.Pout[pt * D + nb * 16 + li] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
+    constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS;
+    // LDS: W^T, W, and per wavefront an X tile and a dS tile; after the main loop the W region is
+    // reused to combine the four wavefronts' dW tiles
+    __shared__ __attribute__((aligned(16))) float Wmem[2 * D * XS];
+    __shared__ __attribute__((aligned(16))) float Tiles[4][2][16 * XS];
+    float* Wt = Wmem;
+    float* Wn = Wmem + D * XS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    stage_w<DT>(p, Wt, Wn);
+    __syncthreads();
+    float sc[DT][4], sh[DT][4];
+    lane_lazy<DT>(p, lj, sc, sh);
+    float* Xs = Tiles[wave][0];
+    float* Ds = Tiles[wave][1];
+    f32x4 accw[DT][DT];
+#pragma unroll
+    for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (long pt = (long)blockIdx.x * 4 + wave; pt < p.P; pt += (long)gridDim.x * 4) {
+        const int my_idx = p.idx[pt * 16 + li];
+        const long b = pt / p.n;
+        float4 xa[DT];
+        load_x<DT>(p, pt, li, lj, my_idx, sc, sh, xa, Xs);
+        f32x4 a[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile_gemm<DT>(xa, Wt, li, lj, a);
+        softmax_rows<DT>(a);
+        __builtin_amdgcn_wave_barrier();
+        // C-layout pass: P, dS (to LDS), dXa kept in registers as the start of dX
+        f32x4 dx[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) {
+            const int col = nb * 16 + li;
+            float xc[4];
+            float pool = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xc[r] = Xs[(lj * 4 + r) * XS + col];
+                pool += a[nb][r] * xc[r];
+            }
+            pool += __shfl_xor(pool, 16, 64);
+            pool += __shfl_xor(pool, 32, 64);
+            const float g = p.dP[pt * D + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ag = a[nb][r] * g;
+                dx[nb][r] = ag;                                   // direct path dP*A
+                Ds[(lj * 4 + r) * XS + col] = ag * (xc[r] - pool);  // dS = A*dP*(X-P)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dX += dS . W   (dS re-read in A layout)
+        float4 da[DT];
+#pragma unroll
+        for (int c = 0; c < DT; ++c) da[c] = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
+        tile_gemm<DT>(da, Wn, li, lj, dx);
+        // dW[n][k] += sum_rows dS[row][n] * X[row][k]   (rows are the MFMA reduction index)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float bx[DT];
+#pragma unroll
+            for (int kb = 0; kb < DT; ++kb) bx[kb] = Xs[(4 * t + lj) * XS + kb * 16 + li];
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) {
+                const float ad = Ds[(4 * t + lj) * XS + nb * 16 + li];
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb)
+                    accw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, bx[kb], accw[nb][kb], 0, 0, 0);
+            }
+        }
+        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> scatter to the gathered rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rowi = lj * 4 + r;
+            const int nbr = __shfl(my_idx, rowi, 64);
+            const long urow = (pt * 16 + rowi) * H;
+            const long grow = (b * p.g_bstride + nbr) * H;
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) {
+                const int col = nb * 16 + li;
+                const float v = dx[nb][r];
+                if (col < H) {
+                    if (p.gu_accumulate) p.GU[urow + col] += v;
+                    else p.GU[urow + col] = v;
+                } else {
+                    atomicAdd(p.GG + grow + (col - H), v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // combine the four wavefronts' dW tiles in a fixed order (W region is free now)
+    __syncthreads();
+    float* red = Wmem;  // needs DT*DT*256 floats <= 2*D*XS: 16*DT*DT*16 <= 2*16*DT*(16*DT+4) always holds
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((nb * DT + kb) * 4 + r) * 64 + lane] = accw[nb][kb][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accw[nb][kb][r] += red[((nb * DT + kb) * 4 + r) * 64 + lane];
+        }
+    }
+    if (wave == 0) {
+        float* out = p.slab + (long)blockIdx.x * D * D;
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+            for (int kb = 0; kb < DT; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(long)(nb * 16 + lj * 4 + r) * D + kb * 16 + li] = accw[nb][kb][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __restrict__ slab, int nsplit, int count,
+                                                             float* __restrict__ dW) {
+    __shared__ float red[16][17];
+    const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + ex;
+    float s = 0.f;
+    if (e < count)
+        for (int i = sy; i < nsplit; i += 16) s += slab[(long)i * count + e];
+    red[sy][ex] = s;
+    __syncthreads();
+    if (sy == 0 && e < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][ex];
+        dW[e] = t;
+    }
+}
+
+int pool_grid(long P) {
+    long g = (P + 15) / 16;  // >= 4 points per wavefront
+    if (g < 1) g = 1;
+    return (int)(g < 1024 ? g : 1024);
+}
+
+int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
+    RL_REQUIRE(d && d->U && d->G && d->idx && d->W && d->points > 0 && d->n > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
+    RL_REQUIRE(d->nbr_k == 16, RL_ERR_UNSUPPORTED, "%s: the fused kernel needs 16 neighbours (got %d)", who, d->nbr_k);
+    RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64, RL_ERR_UNSUPPORTED, "%s: d must be 16, 32 or 64 (got %d)", who, d->d);
+    RL_REQUIRE(d->g_bstride >= d->n && d->points % d->n == 0, RL_ERR_ARGS, "%s: bad cloud geometry", who);
+    RL_REQUIRE(((uintptr_t)d->U & 15) == 0 && ((uintptr_t)d->G & 15) == 0, RL_ERR_ARGS, "%s: U/G must be 16-byte aligned", who);
+    RL_REQUIRE((d->u_scale == nullptr) == (d->u_shift == nullptr) && (d->g_scale == nullptr) == (d->g_shift == nullptr),
+               RL_ERR_ARGS, "%s: scale/shift must come together", who);
+    p->U = d->U; p->ulazy.scale = d->u_scale; p->ulazy.shift = d->u_shift; p->ulazy.act = d->u_act; p->ulazy.slope = d->u_slope;
+    p->G = d->G; p->g_bstride = d->g_bstride;
+    p->glazy.scale = d->g_scale; p->glazy.shift = d->g_shift; p->glazy.act = d->g_act; p->glazy.slope = d->g_slope;
+    p->idx = d->idx; p->W = d->W; p->P = d->points; p->n = d->n; p->d = d->d;
+    p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->GG = d->GG; p->slab = d->slab;
+    if (!backward) RL_REQUIRE(d->Pout, RL_ERR_ARGS, "%s: null output", who);
+    else RL_REQUIRE(d->dP && d->GU && d->GG && d->dW && d->slab, RL_ERR_ARGS, "%s: null gradient buffers", who);
+    return RL_OK;
+}
+
+}  // namespace
+
+extern "C" int rl_pool_supported(int d, int nbr_k) { return (nbr_k == 16 && (d == 16 || d == 32 || d == 64)) ? 1 : 0; }
+
+extern "C" int64_t rl_pool_slab_floats(int64_t points, int d) { return (int64_t)pool_grid(points) * d * d; }
+
+extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
+    PoolParams p;
+    int rc = fill(&p, d, "rl_pool_fwd", false);
+    if (rc) return rc;
+    const int g = pool_grid(p.P);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1>), dim3(g), dim3(256), 0, st, p);
+    else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2>), dim3(g), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pool_fwd_kernel<4>), dim3(g), dim3(256), 0, st, p);
+    RL_LAUNCH_CHECK("rl_pool_fwd");
+    return RL_OK;
+}
+
+extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
+    PoolParams p;
+    int rc = fill(&p, d, "rl_pool_bwd", true);
+    if (rc) return rc;
+    const int g = pool_grid(p.P);
+    RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1>), dim3(g), dim3(256), 0, st, p);
+    else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2>), dim3(g), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((pool_bwd_kernel<4>), dim3(g), dim3(256), 0, st, p);
+    RL_LAUNCH_CHECK("rl_pool_bwd");
+    hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
+    RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
+    return RL_OK;
+}

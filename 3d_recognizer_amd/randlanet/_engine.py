@@ -96,10 +96,15 @@ class Engine:
         """PointFeatureAugmentation + AttentivePooling (modules.py:213-221, 246-253)."""
         B, K, h = u.B, self.K, d // 2
         rows = B * n * K
+        Ws = self.P[f"{name}.score_fn.0.weight"]
+        if ops.pool_supported(d, K):
+            # narrow levels: one fused kernel, nothing of size rows x d touches HBM
+            pooled = ops.plain(ops.pool_fwd(u, g, idx, Ws, n, d), B, n)
+            ctx.tape.append(("pool_fused", name, u, g, idx, pooled, n, d))
+            return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
         X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
         ops.copy_rows(u.raw, (0, h), n * K, X, (0, h), rows, n * K, lazy=u)
         ops.copy_rows(g.raw, (0, h), g.bstride, X, (h, h), rows, n * K, index=idx, lazy=g)
-        Ws = self.P[f"{name}.score_fn.0.weight"]
         S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None)
         Pt = ops.attpool_fwd(X, S, B * n, K)
         pooled = ops.plain(Pt, B, n)
@@ -217,6 +222,17 @@ class Engine:
                 self._bwd_linear(ctx, grads, *rec[1:])
             elif kind == "pool":
                 self._bwd_pool(ctx, grads, *rec[1:])
+            elif kind == "pool_fused":
+                _, name, u, g, idx, pooled, n, d = rec
+                GP, init = self._gbuf(ctx, pooled)
+                assert init
+                gu, gg = self._gbuf(ctx, u), self._gbuf(ctx, g)
+                if not gg[1]:
+                    gg[0].zero_()
+                    gg[1] = True
+                ops.pool_bwd(u, g, idx, self.P[f"{name}.score_fn.0.weight"], n, d, GP, gu[0], gu[1], gg[0],
+                             grads[f"{name}.score_fn.0.weight"])
+                gu[1] = True
             elif kind == "add_act":
                 _, m2, sc, O = rec
                 G, init = self._gbuf(ctx, O)

@@ -67,6 +67,19 @@ class BnBwdDesc(C.Structure):
     ]
 
 
+class PoolDesc(C.Structure):
+    _fields_ = [
+        ("U", C.c_void_p), ("u_scale", C.c_void_p), ("u_shift", C.c_void_p), ("u_act", C.c_int32),
+        ("u_slope", C.c_float),
+        ("G", C.c_void_p), ("g_bstride", C.c_int64), ("g_scale", C.c_void_p), ("g_shift", C.c_void_p),
+        ("g_act", C.c_int32), ("g_slope", C.c_float),
+        ("idx", C.c_void_p), ("W", C.c_void_p), ("points", C.c_int64),
+        ("n", C.c_int32), ("d", C.c_int32), ("nbr_k", C.c_int32),
+        ("Pout", C.c_void_p), ("dP", C.c_void_p), ("GU", C.c_void_p), ("gu_accumulate", C.c_int32),
+        ("GG", C.c_void_p), ("dW", C.c_void_p), ("slab", C.c_void_p), ("slab_floats", C.c_int64),
+    ]
+
+
 class RowsDesc(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("lds", C.c_int64), ("src_bstride", C.c_int64),
@@ -97,6 +110,10 @@ _SIGNATURES = {
     "rl_bn_bwd_apply": (_i, [C.POINTER(BnBwdDesc), _vp]),
     "rl_copy_rows": (_i, [C.POINTER(RowsDesc), _vp]),
     "rl_scatter_add_rows": (_i, [C.POINTER(RowsDesc), _vp]),
+    "rl_pool_supported": (_i, [_i, _i]),
+    "rl_pool_slab_floats": (_l, [_l, _i]),
+    "rl_pool_fwd": (_i, [C.POINTER(PoolDesc), _vp]),
+    "rl_pool_bwd": (_i, [C.POINTER(PoolDesc), _vp]),
     "rl_attpool_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
     "rl_attpool_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp]),
     "rl_add_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp, _vp]),

@@ -81,6 +81,7 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+NO_FUSED_POOL = bool(int(__import__("os").environ.get("RL_NO_FUSED_POOL", "0")))         # diagnostics only
 FORCE_BRUTE_KNN = bool(int(__import__("os").environ.get("RL_KNN_BRUTE", "0")))         # diagnostics only
 DEBUG_SYNC = bool(int(__import__("os").environ.get("RL_DEBUG_SYNC", "0")))   # print + sync around every launch
 
@@ -356,6 +357,52 @@ def scatter_add_rows(src: torch.Tensor, src_cols: Tuple[int, int], dst: torch.Te
 
 
 # ------------------------------------------------------------------------- pooling, residual
+def pool_supported(d: int, K: int) -> bool:
+    return (not NO_FUSED_POOL) and bool(H.lib().rl_pool_supported(d, K))
+
+
+def _pool_desc(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int) -> H.PoolDesc:
+    _dev_check(u.raw, g.raw, idx, W, u.scale, u.shift, g.scale, g.shift)
+    h = d // 2
+    B = u.B
+    assert idx.dtype == torch.int32 and idx.shape == (B, n, 16)
+    assert u.raw.shape == (B * n * 16, h) and u.bstride == u.n == n * 16 and u.C == h
+    assert g.raw.shape[1] == h and g.C == h and g.n == n and g.raw.shape[0] >= (B - 1) * g.bstride + n
+    assert W.numel() == d * d
+    pd = H.PoolDesc()
+    pd.U, pd.u_scale, pd.u_shift, pd.u_act, pd.u_slope = u.raw.data_ptr(), H.ptr(u.scale), H.ptr(u.shift), u.act, u.slope
+    pd.G, pd.g_bstride = g.raw.data_ptr(), g.bstride
+    pd.g_scale, pd.g_shift, pd.g_act, pd.g_slope = H.ptr(g.scale), H.ptr(g.shift), g.act, g.slope
+    pd.idx, pd.W, pd.points, pd.n, pd.d, pd.nbr_k = idx.data_ptr(), W.data_ptr(), B * n, n, d, 16
+    return pd
+
+
+def pool_fwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int) -> torch.Tensor:
+    """Fused gather+concat -> score Linear -> softmax over K -> weighted sum: (B*n, d)."""
+    pd = _pool_desc(u, g, idx, W, n, d)
+    out = torch.empty((u.B * n, d), dtype=F32, device=W.device)
+    pd.Pout = out.data_ptr()
+    P = u.B * n
+    with _rec("pool_fwd", (P, 16, d), 4 * (P * 16 * (d // 2) + P * 16 * (d // 2) + P * 16 + P * d), 2 * P * 16 * d * d):
+        H.check(H.lib().rl_pool_fwd(C.byref(pd), _st()), "rl_pool_fwd")
+    return out
+
+
+def pool_bwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP: torch.Tensor,
+             GU: torch.Tensor, gu_accumulate: bool, GG: torch.Tensor, dW: torch.Tensor) -> None:
+    pd = _pool_desc(u, g, idx, W, n, d)
+    _dev_check(dP, GU, GG, dW)
+    P = u.B * n
+    assert dP.shape == (P, d) and GU.shape == u.raw.shape and GG.shape == g.raw.shape and dW.numel() == d * d
+    floats = H.lib().rl_pool_slab_floats(P, d)
+    slab = _slab(W.device, floats)
+    pd.dP, pd.GU, pd.gu_accumulate, pd.GG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), GG.data_ptr(), dW.data_ptr()
+    pd.slab, pd.slab_floats = slab.data_ptr(), slab.numel()
+    with _rec("pool_bwd", (P, 16, d), 4 * (3 * P * 16 * (d // 2) + P * 16 * (d // 2) * (1 + int(gu_accumulate)) + P * 16 + 2 * P * d),
+              6 * P * 16 * d * d):
+        H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
+
+
 def attpool_fwd(X: torch.Tensor, S: torch.Tensor, P: int, K: int) -> torch.Tensor:
     _dev_check(X, S)
     Cc = X.shape[1]

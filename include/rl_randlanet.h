@@ -29,6 +29,7 @@
  *                         PointFeatureAugmentation gather+concat (modules.py:213-221), permutation /
  *                         prefix slicing (modules.py:571-573, 608), nearest-neighbour interpolation
  *                         gather + skip concat (modules.py:359-364, 600-602) and their backward
+ *   rl_pool_fwd/_bwd      PointFeatureAugmentation + AttentivePooling fused (modules.py:213-253)
  *   rl_attpool_*          AttentivePooling softmax over K + weighted sum (modules.py:246-253)
  *   rl_add_act_*          LocalFeatureAggregation residual + LeakyReLU (modules.py:325)
  *   rl_scale_mask         Dropout of fc_end (modules.py:528)
@@ -231,6 +232,46 @@ int rl_attpool_fwd(const float* X, const float* S, int64_t P, int K, int C, floa
                    void* stream);
 int rl_attpool_bwd(const float* X, const float* S, const float* Pout, const float* dP, int64_t P,
                    int K, int C, float* dS, float* dXa, void* stream);
+
+/* Fused attentive pooling for narrow levels (d = 16 / 32 / 64, 16 neighbours): gather + concat
+ * (modules.py:213-221), score Linear + softmax over K + weighted sum (modules.py:246-253) without
+ * materialising the (points*K) x d tensors.
+ *   U   (points*16) x d/2 lazy rpe-branch features;  G  lazy per-point features, row (b,i) at
+ *   (b*g_bstride + i)*(d/2), gathered through idx (points,16) int32;  W (d,d) score weight.
+ * rl_pool_fwd : Pout (points, d).
+ * rl_pool_bwd : given dP (points, d) recomputes the block and produces GU (gradient w.r.t. the
+ *   activated U, stored or accumulated), GG += (gradient w.r.t. the activated G rows, fp32 atomics,
+ *   zeroed by the caller) and dW (d,d) through per-workgroup slabs (rl_pool_slab_floats floats).  */
+typedef struct rl_pool_desc {
+    const float* U;
+    const float* u_scale;
+    const float* u_shift;
+    int32_t u_act;
+    float u_slope;
+    const float* G;
+    int64_t g_bstride;
+    const float* g_scale;
+    const float* g_shift;
+    int32_t g_act;
+    float g_slope;
+    const int32_t* idx;
+    const float* W;
+    int64_t points;
+    int32_t n, d, nbr_k;
+    float* Pout;
+    const float* dP;
+    float* GU;
+    int32_t gu_accumulate;
+    float* GG;
+    float* dW;
+    float* slab;
+    int64_t slab_floats;
+} rl_pool_desc;
+
+int rl_pool_supported(int d, int nbr_k);
+int64_t rl_pool_slab_floats(int64_t points, int d);
+int rl_pool_fwd(const rl_pool_desc* d, void* stream);
+int rl_pool_bwd(const rl_pool_desc* d, void* stream);
 
 /* Residual sum of two lazy tensors + LeakyReLU (modules.py:325):
  *   O = lrelu(Y1*s1+b1 + Y2*s2+b2);  backward (in place): G <- G * (O > 0 ? 1 : slope)       */

@@ -345,6 +345,45 @@ def test_attpool(ops, P, K, Cc):
     assert float((dS - S.grad).abs().max()) < 1e-5 and float((dXa - X.grad).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("d,B,n_parent,n", [(16, 2, 700, 300), (32, 1, 257, 257), (64, 3, 400, 130)])
+def test_fused_pool_forward_backward(ops, d, B, n_parent, n):
+    """rl_pool_fwd / rl_pool_bwd against a plain PyTorch statement of gather + concat + score Linear +
+    softmax over K + weighted sum (modules.py:213-221, 246-253) and its autograd."""
+    torch.manual_seed(d + n)
+    K, h = 16, d // 2
+    U = torch.randn(B * n * K, h, device=DEV)
+    Gf = torch.randn(B * n_parent, h, device=DEV)
+    idx = torch.randint(0, n, (B, n, K), device=DEV, dtype=torch.int32)
+    W = (torch.randn(d, d, device=DEV) / d ** 0.5).requires_grad_(True)
+    us, ub = torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.3
+    gs, gb = torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.3
+    u = ops.Lazy(U, B, n * K, n * K, h, us, ub, 1, 0.0)
+    g = ops.Lazy(Gf, B, n, n_parent, h, gs, gb, 2, 0.2)
+    # reference with autograd on the ACTIVATED operands
+    ua = torch.relu(U * us + ub).requires_grad_(True)
+    ga = torch.nn.functional.leaky_relu(Gf * gs + gb, 0.2).requires_grad_(True)
+    gath = torch.gather(ga.view(B, n_parent, h), 1, idx.long().reshape(B, n * K, 1).expand(-1, -1, h)).reshape(B * n * K, h)
+    X = torch.cat([ua, gath], 1)
+    S = X @ W.t()
+    A = torch.softmax(S.view(B * n, K, d), 1)
+    Pref = (A * X.view(B * n, K, d)).sum(1)
+    P = ops.pool_fwd(u, g, idx, W.detach(), n, d)
+    assert float((P - Pref).abs().max()) < 2e-5
+    dP = torch.randn(B * n, d, device=DEV)
+    Pref.backward(dP)
+    GU = torch.full_like(U, 3.0)
+    GG = torch.zeros_like(Gf)
+    dW = torch.empty(d, d, device=DEV)
+    ops.pool_bwd(u, g, idx, W.detach(), n, d, dP, GU, False, GG, dW)
+    assert float((GU - ua.grad).abs().max()) < 2e-5 * max(1.0, float(ua.grad.abs().max()))
+    assert float((GG - ga.grad).abs().max()) < 1e-4 * max(1.0, float(ga.grad.abs().max()))
+    assert float((dW - W.grad).abs().max()) < 2e-4 * max(1.0, float(W.grad.abs().max()))
+    GU2 = torch.ones_like(U)
+    GG.zero_()
+    ops.pool_bwd(u, g, idx, W.detach(), n, d, dP, GU2, True, GG, dW)          # accumulate into GU
+    assert float((GU2 - 1.0 - ua.grad).abs().max()) < 2e-5 * max(1.0, float(ua.grad.abs().max()))
+
+
 def test_add_act_and_logits_layout(ops):
     torch.manual_seed(9)
     rows, Cc = 1234, 32
