@@ -68,6 +68,7 @@ struct BwdParams {
     const float* invstd;
     double* stats;
     const float* coef;
+    int tile;
 };
 
 __device__ __forceinline__ long row_off(const BwdParams& p, long R) {
@@ -77,7 +78,9 @@ __device__ __forceinline__ long row_off(const BwdParams& p, long R) {
     return ((long)b * p.bstride + i) * p.ld;
 }
 
-constexpr int BN_ROWS = 256;  // rows per tile (rl_row_blocks(M, 256) partial slots)
+// rows per tile of the backward sweeps: small tensors get small tiles so that they still spread over
+// the chip (a 2560 x 512 tensor in 256-row tiles would run on 10 of 256 CUs)
+static inline int bn_tile(long M) { return M >= 32768 ? 256 : 16; }
 
 // thread layout shared by reduce and apply: tpr threads sweep one row, 256/tpr rows in flight
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
@@ -87,12 +90,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
     const int rpar = 256 / tpr;
     const int col = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
     const bool active = rsub < rpar;
-    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    const long ntiles = (p.M + p.tile - 1) / p.tile;
     float sg[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            const long rend = min(p.M, (tile + 1) * BN_ROWS);
-            for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+            const long rend = min(p.M, (tile + 1) * p.tile);
+            for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
                 const long off = row_off(p, R);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
@@ -157,10 +160,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
     const int rpar = 256 / tpr;
     const int col = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
     if (rsub >= rpar) return;
-    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    const long ntiles = (p.M + p.tile - 1) / p.tile;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long rend = min(p.M, (tile + 1) * BN_ROWS);
-        for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+        const long rend = min(p.M, (tile + 1) * p.tile);
+        for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
             const long off = row_off(p, R);
             for (int c = col; c < C; c += 256) {
                 const float y = p.Y[off + c];
@@ -201,11 +204,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BwdParams 
     const int rpar = 256 / tpr;
     const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
     const int c = q * 4;
-    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    const long ntiles = (p.M + p.tile - 1) / p.tile;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long rend = min(p.M, (tile + 1) * BN_ROWS);
-        for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+        const long rend = min(p.M, (tile + 1) * p.tile);
+        for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
             const long off = row_off(p, R) + c;
             const float4 y = *reinterpret_cast<const float4*>(p.Y + off);
             const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
@@ -250,10 +253,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BwdParams p
         k0 = *reinterpret_cast<const float4*>(p.coef + c);
         k1 = *reinterpret_cast<const float4*>(p.coef + C + c);
     }
-    const long ntiles = (p.M + BN_ROWS - 1) / BN_ROWS;
+    const long ntiles = (p.M + p.tile - 1) / p.tile;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long rend = min(p.M, (tile + 1) * BN_ROWS);
-        for (long R = tile * BN_ROWS + rsub; R < rend; R += rpar) {
+        const long rend = min(p.M, (tile + 1) * p.tile);
+        for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
             const long off = row_off(p, R) + c;
             const float4 y = *reinterpret_cast<const float4*>(p.Y + off);
             const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
@@ -282,6 +285,7 @@ int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
     p->M = (long)d->B * d->n; p->contig = d->bstride == d->n;
     p->act = d->act; p->slope = d->slope; p->scale = d->scale; p->shift = d->shift;
     p->mean = d->mean; p->invstd = d->invstd; p->stats = d->stats; p->coef = d->coef;
+    p->tile = bn_tile(p->M);
     return RL_OK;
 }
 
@@ -301,16 +305,18 @@ extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, in
     return RL_OK;
 }
 
+extern "C" int rl_bn_bwd_slots(int64_t rows) { return rl_row_blocks_host(rows, bn_tile(rows)); }
+
 extern "C" int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream) {
     BwdParams p;
     int rc = fill(&p, d, "rl_bn_bwd_reduce");
     if (rc) return rc;
     RL_REQUIRE(p.stats && p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_reduce: needs stats/mean/invstd");
     if (vec_ok(p))
-        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
     RL_LAUNCH_CHECK("rl_bn_bwd_reduce");
     return RL_OK;
@@ -331,10 +337,10 @@ extern "C" int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream) {
     if (rc) return rc;
     if (p.coef) RL_REQUIRE(p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_apply: coef needs mean/invstd");
     if (vec_ok(p))
-        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, BN_ROWS)), dim3(256), 0,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
     RL_LAUNCH_CHECK("rl_bn_bwd_apply");
     return RL_OK;

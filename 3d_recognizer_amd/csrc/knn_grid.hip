@@ -187,25 +187,46 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
     sorted[(size_t)b * Ns + pos] = make_float4(p[0], p[1], p[2], __int_as_float(j));
 }
 
+// Scan candidates [begin, end).  Loads are issued eight at a time before any of them is used: with
+// ~8 points per cell one cell costs one memory round trip instead of eight (at small clouds there
+// is a single wavefront per SIMD and nothing else hides that latency).
 template <int KMAX>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int begin, int end, float qx, float qy,
                                            float qz, unsigned long long (&best)[KMAX]) {
-    for (int t = begin; t < end; ++t) {
-        const float4 c = pts[t];
-        const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
-        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
-        if (key < best[KMAX - 1]) {
+    for (int t = begin; t < end; t += 8) {
+        float4 cand[8];
 #pragma unroll
-            for (int s = 0; s < KMAX; ++s) {
-                const bool lt = key < best[s];
-                const unsigned long long lo = lt ? key : best[s];
-                const unsigned long long hi = lt ? best[s] : key;
-                best[s] = lo;
-                key = hi;
+        for (int i = 0; i < 8; ++i) cand[i] = pts[min(t + i, end - 1)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (t + i < end) {
+                const float4 c = cand[i];
+                const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
+                const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
+                if (key < best[KMAX - 1]) {
+#pragma unroll
+                    for (int s = 0; s < KMAX; ++s) {
+                        const bool lt = key < best[s];
+                        const unsigned long long lo = lt ? key : best[s];
+                        const unsigned long long hi = lt ? best[s] : key;
+                        best[s] = lo;
+                        key = hi;
+                    }
+                }
             }
         }
     }
+}
+
+// distance from coordinate q to the slab of cells `ci` along axis a (0 inside), shrunk by the
+// rounding slack so that it never over-estimates the distance to a point binned into that cell
+__device__ __forceinline__ float axis_gap(const GridGeom& g, int a, int ci, float q) {
+    const float lo = g.lo[a] + (float)ci * g.h[a];
+    const float hi = lo + g.h[a];
+    float gap = fmaxf(lo - q, q - hi);   // support points never lie outside the grid (it is their bbox)
+    gap -= g.slack;
+    return gap > 0.f ? gap : 0.f;
 }
 
 template <int KMAX>
@@ -237,20 +258,35 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
 
+    const float q3[3] = {qx, qy, qz};
     for (int r = 0;; ++r) {
         const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.n[2] - 1);
         const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
         const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.n[0] - 1);
         for (int z = z0; z <= z1; ++z) {
             const bool zedge = (z == c[2] - r) || (z == c[2] + r);
+            const float dz = axis_gap(g, 2, z, qz);
             for (int y = y0; y <= y1; ++y) {
+                const bool full_row = zedge || y == c[1] - r || y == c[1] + r;
+                const float dy = axis_gap(g, 1, y, qy);
+                const float dyz = dy * dy + dz * dz;
                 const int row = (z * g.n[1] + y) * g.n[0];
-                if (zedge || y == c[1] - r || y == c[1] + r) {
-                    // the whole x-run of this row lies on the ring: one contiguous candidate range
-                    scan_range<KMAX>(pts, st[row + x0], st[row + x1 + 1], qx, qy, qz, best);
-                } else {
-                    if (c[0] - r >= 0) scan_range<KMAX>(pts, st[row + c[0] - r], st[row + c[0] - r + 1], qx, qy, qz, best);
-                    if (c[0] + r < g.n[0]) scan_range<KMAX>(pts, st[row + c[0] + r], st[row + c[0] + r + 1], qx, qy, qz, best);
+                // cells of this row that lie on ring r: the whole x-run, or its two end cells
+                const int step = full_row ? 1 : max(2 * r, 1);
+                for (int x = c[0] - r; x <= c[0] + r; x += step) {
+                    if (x < x0 || x > x1) continue;
+                    // lower bound of the distance to anything in the cell; skip it when even that exceeds
+                    // the current K-th distance (strictly, with a rounding margin: ties must be looked at)
+                    const float dxg = axis_gap(g, 0, x, qx);
+                    const float lb = dxg * dxg + dyz;
+                    unsigned long long kth = best[KMAX - 1];
+                    if (k != KMAX) {
+#pragma unroll
+                        for (int s = 0; s < KMAX; ++s)
+                            if (s == k - 1) kth = best[s];
+                    }
+                    if (kth != ~0ull && lb > __uint_as_float((unsigned)(kth >> 32)) * 1.00001f + 1e-30f) continue;
+                    scan_range<KMAX>(pts, st[row + x], st[row + x + 1], qx, qy, qz, best);
                 }
             }
         }
@@ -263,11 +299,10 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
             if (s == k - 1) kth = best[s];
         if (kth != ~0ull) {
             float bound = INFINITY;
-            const float q[3] = {qx, qy, qz};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                if (c[a] - r > 0) bound = fminf(bound, q[a] - (g.lo[a] + (float)(c[a] - r) * g.h[a]));
-                if (c[a] + r < g.n[a] - 1) bound = fminf(bound, (g.lo[a] + (float)(c[a] + r + 1) * g.h[a]) - q[a]);
+                if (c[a] - r > 0) bound = fminf(bound, q3[a] - (g.lo[a] + (float)(c[a] - r) * g.h[a]));
+                if (c[a] + r < g.n[a] - 1) bound = fminf(bound, (g.lo[a] + (float)(c[a] + r + 1) * g.h[a]) - q3[a]);
             }
             bound -= g.slack;
             const float kd = __uint_as_float((unsigned)(kth >> 32));

@@ -54,6 +54,7 @@ class Engine:
         self.F = int(n_features)
         self.P = params      # reference state_dict names -> tensors (parameters)
         self.Bf = buffers    # running_mean / running_var / num_batches_tracked
+        self._side: Optional[torch.cuda.Stream] = None   # weight gradients run beside the dgrad chain
 
     # ------------------------------------------------------------------------ forward pieces
     def _w2(self, name: str) -> torch.Tensor:
@@ -216,6 +217,13 @@ class Engine:
         assert dlogits.shape == (B, self.C, N) and dlogits.is_cuda
         dlogits = dlogits.contiguous().float()
         ctx.grads[id(ctx.logits_perm.raw)] = [ops.logits_permute_grad(dlogits, ctx.perm), True]
+        # Weight gradients are off the critical path (only the optimiser needs them); with RL_SIDE_STREAM=1
+        # they run on a side stream beside the dY -> dX chain (everything they read stays referenced until
+        # the join below).  Off by default: under hipGraph replay the forks/joins cost more than they hide.
+        self._main = torch.cuda.current_stream(dlogits.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dlogits.device)
+        ctx.hold = []
         for rec in reversed(ctx.tape):
             kind = rec[0]
             if kind == "linear":
@@ -262,9 +270,23 @@ class Engine:
                 ctx.grads[id(src.raw)] = [G, True]
             else:
                 raise AssertionError(kind)
+        self._main.wait_stream(self._side)
         ctx.tape.clear()
         ctx.grads.clear()
         ctx.keep.clear()
+        ctx.hold.clear()
+
+    def _beside(self, ctx: Context, fn, *keep) -> None:
+        """Run fn() on the side stream, ordered after everything issued so far on the main stream."""
+        if not ops.SIDE_STREAM_WGRAD:
+            fn()
+            return
+        ctx.hold.extend(keep)
+        ev = torch.cuda.Event()
+        ev.record(self._main)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            fn()
 
     def _bwd_linear(self, ctx, grads, a, out: Lazy, wname, bname, ks, ns, a_grad):
         G, init = self._gbuf(ctx, out)
@@ -272,7 +294,8 @@ class Engine:
         if out.scale is not None:
             ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True)
         n_out = out.C
-        ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns, grads[bname] if bname else None)
+        self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,
+                                            grads[bname] if bname else None), G)
         if a_grad and isinstance(a, Lazy):
             ga = self._gbuf(ctx, a)
             if not ga[1]:
@@ -289,7 +312,8 @@ class Engine:
         assert init
         dS, dX = ops.attpool_bwd(X, S, pooled.raw, GP, B * n, K)
         Ws = self.P[f"{name}.score_fn.0.weight"]
-        ops.wgrad(ops.plain(X, B, n * K), dS, n * K, d, grads[f"{name}.score_fn.0.weight"], 1, d, None)
+        self._beside(ctx, lambda: ops.wgrad(ops.plain(X, B, n * K), dS, n * K, d,
+                                            grads[f"{name}.score_fn.0.weight"], 1, d, None), X, dS)
         ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
         gu = self._gbuf(ctx, u)
         ops.copy_rows(dX, (0, h), n * K, gu[0], (0, h), rows, n * K, accumulate=gu[1])

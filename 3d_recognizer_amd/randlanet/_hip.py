@@ -105,6 +105,7 @@ _SIGNATURES = {
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rl_bn_bwd_slots": (_i, [_l]),
     "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),
     "rl_bn_bwd_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp]),
     "rl_bn_bwd_apply": (_i, [C.POINTER(BnBwdDesc), _vp]),

@@ -141,7 +141,7 @@ def roofline_pass(stepper, eager_steps=2):
                      top_shapes=[dict(kernel=f"{r['category']}{list(r['shape'])}",
                                       ms_per_step=round(r["ms"] / eager_steps, 3),
                                       launches_per_step=r["launches"] // eager_steps,
-                                      GBps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)) for r in rows[:12]])
+                                      GBps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)) for r in rows[:80]])
     return roof, breakdown
 
 

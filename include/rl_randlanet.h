@@ -63,7 +63,7 @@ const char* rl_last_error(void);
 int rl_version(void);
 
 /* Number of partial-statistics slots a row-streaming kernel writes for `rows` rows:
- * rl_gemm uses rows_per_tile = 128, the rl_bn_bwd / rl_loss reductions use 256.          */
+ * rl_gemm uses rows_per_tile = 128, rl_loss 256; rl_bn_bwd_reduce has its own rl_bn_bwd_slots. */
 int rl_row_blocks(int64_t rows, int rows_per_tile);
 
 /* ------------------------------------------------------------------------------------------
@@ -170,7 +170,7 @@ int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const 
 /* BatchNorm + activation backward for a lazy tensor Y (rows x C, row (b,i) at (b*bstride+i)*ld)
  * whose activated value received gradient G (same addressing):
  *   g = G * act'(Y*scale+shift);  xhat = (Y-mean)*invstd
- *   rl_bn_bwd_reduce : partial sums of g and g*xhat -> stats[slot][0|1][c], slot < rl_row_blocks(M,256)
+ *   rl_bn_bwd_reduce : partial sums of g and g*xhat -> stats[slot][0|1][c], slot < rl_bn_bwd_slots(M)
  *   rl_bn_bwd_finalize: dgamma = sum g*xhat, dbeta = sum g, coef[0][c] = mean g, coef[1][c] = mean g*xhat
  *   rl_bn_bwd_apply  : G <- scale * (g - coef0 - xhat*coef1)      (training)
  *                      G <- scale * g                              (coef == NULL: eval / no BN)  */
@@ -189,6 +189,7 @@ typedef struct rl_bn_bwd_desc {
     const float* coef;  /* apply: in, 2*C floats, or NULL */
 } rl_bn_bwd_desc;
 
+int rl_bn_bwd_slots(int64_t rows);
 int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream);
 int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, float* dgamma,
                        float* dbeta, float* coef, void* stream);
