@@ -100,8 +100,11 @@ def cpu_baseline(steps=2, B=2):
                        "+ single-threaded exact C KNN (oracle/knn_oracle.c)")
 
 
-def roofline_pass(stepper, eager_steps=2):
-    """Instrumented eager steps: HIP events around every launch, on the launch stream."""
+def roofline_pass(stepper, eager_steps=3):
+    """Instrumented eager steps: HIP events around every launch, on the launch stream.  Per kernel
+    shape the MEDIAN launch duration is used (robust against a stray host hiccup between two events).
+    The reported kernel is the one with the largest share of the step; its bound follows its arithmetic
+    intensity against the ridge point (157.3 TFLOP/s fp32 MFMA / 8 TB/s = 19.7 flop/B)."""
     from randlanet import _ops as ops
     ops.TIMER = ops.KernelTimer()
     g_main, g_adam = stepper._g_main, stepper._g_adam
@@ -109,39 +112,54 @@ def roofline_pass(stepper, eager_steps=2):
     try:
         for _ in range(eager_steps):
             stepper.step(np.random.permutation(stepper.N))
-        rows = ops.TIMER.summary()
+        torch.cuda.synchronize()
+        records = ops.TIMER.records
     finally:
         ops.TIMER = None
         stepper._g_main, stepper._g_adam = g_main, g_adam
-    total_ms = sum(r["ms"] for r in rows)
-    by_cat = {}
-    for r in rows:
-        c = by_cat.setdefault(r["category"], dict(ms=0.0, launches=0, bytes=0, flops=0))
-        c["ms"] += r["ms"]; c["launches"] += r["launches"]; c["bytes"] += r["bytes"]; c["flops"] += r["flops"]
+    shapes = {}
+    for cat, key, nbytes, flops, e0, e1 in records:
+        a = shapes.setdefault((cat, key), dict(category=cat, shape=key, times=[], bytes=nbytes, flops=flops))
+        a["times"].append(e0.elapsed_time(e1))
+    rows = []
+    for a in shapes.values():
+        per_launch = float(np.median(a["times"]))
+        launches = len(a["times"]) / eager_steps
+        rows.append(dict(category=a["category"], shape=a["shape"], ms_per_launch=per_launch, launches_per_step=launches,
+                         ms_per_step=per_launch * launches, bytes=a["bytes"], flops=a["flops"]))
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    total_ms = sum(r["ms_per_step"] for r in rows)
     top = rows[0]
-    per_launch_ms = top["ms"] / top["launches"]
-    per_launch_bytes = top["bytes"] / top["launches"]
-    achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-    roof = dict(bound="hbm", kernel=f"{top['category']}{list(top['shape'])}", achieved=round(achieved, 2),
-                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
-                bytes_per_launch=int(per_launch_bytes), ms_per_launch=round(per_launch_ms, 4),
-                share_of_step=round(top["ms"] / total_ms, 3))
-    pmc = os.path.join(REPO, "profiles", "r01_pmc_dominant.json")
+    secs = top["ms_per_launch"] * 1e-3
+    ai = top["flops"] / max(top["bytes"], 1)
+    if ai > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+        achieved, peak, unit, bound = top["flops"] / secs / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
+    else:
+        achieved, peak, unit, bound = top["bytes"] / secs / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+    roof = dict(bound=bound, kernel=f"{top['category']}{list(top['shape'])}", achieved=round(achieved, 2), peak=peak,
+                unit=unit, frac=round(achieved / peak, 5), traffic=None, bytes_per_launch=int(top["bytes"]),
+                flops_per_launch=int(top["flops"]), ms_per_launch=round(top["ms_per_launch"], 4),
+                launches_per_step=top["launches_per_step"], share_of_step=round(top["ms_per_step"] / total_ms, 3))
+    pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roof["traffic"] = json.load(open(pmc)).get(top["category"])
+            roof["traffic"] = json.load(open(pmc)).get(roof["kernel"])
         except Exception:
             pass
-    breakdown = dict(step_kernel_ms=round(total_ms / eager_steps, 3),
-                     categories={k: dict(ms_per_step=round(v["ms"] / eager_steps, 3),
-                                         launches_per_step=v["launches"] // eager_steps,
+    by_cat = {}
+    for r in rows:
+        c = by_cat.setdefault(r["category"], dict(ms=0.0, launches=0.0, bytes=0.0, flops=0.0))
+        c["ms"] += r["ms_per_step"]; c["launches"] += r["launches_per_step"]
+        c["bytes"] += r["bytes"] * r["launches_per_step"]; c["flops"] += r["flops"] * r["launches_per_step"]
+    breakdown = dict(step_kernel_ms=round(total_ms, 3),
+                     categories={k: dict(ms_per_step=round(v["ms"], 3), launches_per_step=round(v["launches"], 1),
                                          GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
                                          TFLOPs=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2))
                                  for k, v in sorted(by_cat.items(), key=lambda kv: -kv[1]["ms"])},
-                     top_shapes=[dict(kernel=f"{r['category']}{list(r['shape'])}",
-                                      ms_per_step=round(r["ms"] / eager_steps, 3),
-                                      launches_per_step=r["launches"] // eager_steps,
-                                      GBps=round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)) for r in rows[:80]])
+                     top_shapes=[dict(kernel=f"{r['category']}{list(r['shape'])}", ms_per_step=round(r["ms_per_step"], 3),
+                                      launches_per_step=r["launches_per_step"],
+                                      GBps=round(r["bytes"] / max(r["ms_per_launch"], 1e-9) / 1e6, 1),
+                                      TFLOPs=round(r["flops"] / max(r["ms_per_launch"], 1e-9) / 1e9, 2)) for r in rows[:80]])
     return roof, breakdown
 
 
