@@ -350,8 +350,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+inline int wgrad_tile(int N, int K) { return (N >= 128 && K >= 128) ? 128 : WG_T; }
+
 void wgrad_split(long M, int N, int K, int* nsplit, long* rows_per_block) {
-    const int ny = rl_cdiv(N, WG_T), nz = rl_cdiv(K, WG_T);
+    const int T = wgrad_tile(N, K);
+    const int ny = rl_cdiv(N, T), nz = rl_cdiv(K, T);
     long want = 1024 / ((long)ny * nz);
     if (want < 1) want = 1;
     long maxs = (M + 255) / 256;
@@ -992,6 +995,123 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(const WgradParams p) {
     if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
 }
 
+// Wide weight gradient with a 128 (n) x 128 (k) tile of dW per workgroup (both N and K >= 128): every
+// element of dY and A' is staged once per 128-wide slice instead of once per 64-wide one, i.e. the same
+// 128 MFMAs per wavefront per 32 KB staged as the forward kernel.  Wavefront w owns n-blocks 2w, 2w+1.
+constexpr int PW2_RB = 32;
+constexpr int PW2_T = 128;
+constexpr int PW2_S = 144;
+
+__global__ __launch_bounds__(256) void pwgrad128_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float dYs[PW2_RB * PW2_S];
+    __shared__ __attribute__((aligned(16))) float As[PW2_RB * PW2_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = p.N, K = p.a.K;
+    const int n0 = blockIdx.y * PW2_T, k0 = blockIdx.z * PW2_T;
+    const int nvalid = min(PW2_T, N - n0), kvalid = min(PW2_T, K - k0);
+    const int nkb = (kvalid + 15) >> 4;
+    const bool act0 = (2 * wave) * 16 < nvalid, act1 = (2 * wave + 1) * 16 < nvalid;
+    const long r_begin = (long)blockIdx.x * p.rows_per_block;
+    const long r_end = min(p.a.M, r_begin + p.rows_per_block);
+    const int q4 = (tid & 31) * 4;
+    const bool lazy = p.a.lazy.scale != nullptr;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lazy && q4 < kvalid) {
+        sc = *reinterpret_cast<const float4*>(p.a.lazy.scale + k0 + q4);
+        sh = *reinterpret_cast<const float4*>(p.a.lazy.shift + k0 + q4);
+    }
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) acc[i][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    float4 rd[4], ra[4];
+
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long R = r0 + (tid >> 5) + 8 * i;
+            rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (R < r_end) {
+                if (q4 < nvalid) {
+                    long off;
+                    if (p.dy_contig) off = R * p.lddy;
+                    else {
+                        const int b = (int)(R / p.rows_per_batch);
+                        const int ii = (int)(R - (long)b * p.rows_per_batch);
+                        off = ((long)b * p.dy_bstride + ii) * p.lddy;
+                    }
+                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + q4);
+                }
+                if (q4 < kvalid) {
+                    float4 v = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + q4);
+                    if (lazy) {
+                        v.x = rl_act(v.x * sc.x + sh.x, p.a.lazy.act, p.a.lazy.slope);
+                        v.y = rl_act(v.y * sc.y + sh.y, p.a.lazy.act, p.a.lazy.slope);
+                        v.z = rl_act(v.z * sc.z + sh.z, p.a.lazy.act, p.a.lazy.slope);
+                        v.w = rl_act(v.w * sc.w + sh.w, p.a.lazy.act, p.a.lazy.slope);
+                    }
+                    ra[i] = v;
+                }
+            }
+        }
+    };
+
+    if (r_begin < r_end) fetch(r_begin);
+    for (long r0 = r_begin; r0 < r_end; r0 += PW2_RB) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 5) + 8 * i;
+            *reinterpret_cast<float4*>(dYs + r * PW2_S + q4) = rd[i];
+            *reinterpret_cast<float4*>(As + r * PW2_S + q4) = ra[i];
+        }
+        __syncthreads();
+        if (r0 + PW2_RB < r_end) fetch(r0 + PW2_RB);
+        if (p.has_bias && blockIdx.z == 0 && tid < PW2_T) {
+#pragma unroll 8
+            for (int r = 0; r < PW2_RB; ++r) bsum += dYs[r * PW2_S + tid];
+        }
+        if (act0) {
+#pragma unroll
+            for (int rs = 0; rs < PW2_RB / 4; ++rs) {
+                const int rr = rs * 4 + lq;
+                const float a0 = dYs[rr * PW2_S + (2 * wave) * 16 + lr];
+                const float a1 = dYs[rr * PW2_S + (2 * wave + 1) * 16 + lr];
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) {
+                    if (kb < nkb) {
+                        const float bv = As[rr * PW2_S + kb * 16 + lr];
+                        acc[0][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][kb], 0, 0, 0);
+                        acc[1][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][kb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float* out = p.slab + (long)blockIdx.x * ((long)N * K + N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i == 0 ? act0 : act1) {
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                if (kb < nkb) {
+                    const int k = k0 + kb * 16 + lr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + (2 * wave + i) * 16 + lq * 4 + r;
+                        if (n < N && k < K) out[(long)n * K + k] = acc[i][kb][r];
+                    }
+                }
+            }
+        }
+    }
+    if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
+}
+
 inline bool pwgrad_ok(const WgradParams& p) {
     if (p.a.a_mode != 0 || !p.a.vec4) return false;
     if ((p.N % 4) || (p.lddy % 4) || (((uintptr_t)p.dY) & 15)) return false;
@@ -1073,8 +1193,11 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         else if (d->K <= 32) launch_swgrad<2>(d->N, dim3(nsplit), st, p);
         else                 launch_swgrad<4>(d->N, dim3(nsplit), st, p);
     } else {
-        dim3 grid(nsplit, rl_cdiv(d->N, WG_T), rl_cdiv(d->K, WG_T));
-        if (pwgrad_ok(p)) hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, p);
+        const bool pipelined = pwgrad_ok(p);
+        const int T = pipelined ? wgrad_tile(d->N, d->K) : WG_T;
+        dim3 grid(nsplit, rl_cdiv(d->N, T), rl_cdiv(d->K, T));
+        if (pipelined && T == 128) hipLaunchKernelGGL(pwgrad128_kernel, grid, dim3(256), 0, st, p);
+        else if (pipelined) hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
     }
     RL_LAUNCH_CHECK("rl_wgrad");
