@@ -34,21 +34,56 @@ __device__ __forceinline__ float dec(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// resets the bounding boxes and the cell histogram (a kernel rather than hipMemsetAsync: the
-// whole search must replay from a captured hipGraph)
-__global__ __launch_bounds__(256) void grid_init_kernel(unsigned* __restrict__ bbox, int B, int* __restrict__ count,
-                                                        long ncount) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < B * 6) bbox[i] = (i % 6 < 3) ? 0xffffffffu : 0u;
-    for (long e = i; e < ncount; e += (long)gridDim.x * 256) count[e] = 0;
+// One search = one TASK (support prefix, query prefix, k); a launch set handles up to KNN_MAX_TASKS tasks
+// of B clouds each: blockIdx.y = task * B + cloud.  A forward pass needs eight searches that depend on
+// nothing but the coordinates (encoder K-NN on four levels, decoder 1-NN on four): batching them makes
+// the small levels - a few wavefronts each, latency-bound - run beside the big one instead of after it.
+constexpr int KNN_MAX_TASKS = 8;
+
+struct KTask {
+    const float* S;
+    long s_bs;
+    const float* Q;
+    long q_bs;
+    int Ns, Nq, k, self_mode;
+    int32_t* idx32;
+    int64_t* idx64;
+    float* d2;
+    GridGeom* geom;   // [B]
+    unsigned* bbox;   // [B][6]
+    int* count;       // [B][cstride]
+    int* start;
+    int* cursor;
+    float4* sorted;   // [B][Ns]
+    int cstride, maxcells;
+    float per_cell;
+};
+
+struct KMulti {
+    int ntasks, B;
+    KTask t[KNN_MAX_TASKS];
+};
+
+__device__ __forceinline__ int kmax_of(int k) { return k == 1 ? 1 : k <= 4 ? 4 : k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64; }
+
+// resets the bounding boxes and the cell histograms (a kernel rather than hipMemsetAsync: the whole
+// search must replay from a captured hipGraph)
+__global__ __launch_bounds__(256) void grid_init_kernel(const KMulti m) {
+    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const KTask& T = m.t[task];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 6) T.bbox[b * 6 + i] = (i < 3) ? 0xffffffffu : 0u;
+    int* cnt = T.count + (size_t)b * T.cstride;
+    for (int e = i; e < T.cstride; e += gridDim.x * 256) cnt[e] = 0;
 }
 
-__global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict__ S, long s_bs, int Ns,
-                                                        unsigned* __restrict__ bbox) {
-    const int b = blockIdx.y;
-    const float* Sb = S + (size_t)b * s_bs * 3;
+__global__ __launch_bounds__(256) void grid_bbox_kernel(const KMulti m) {
+    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const KTask& T = m.t[task];
+    if (blockIdx.x * 256 >= T.Ns) return;
+    const float* Sb = T.S + (size_t)b * T.s_bs * 3;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < Ns; j += gridDim.x * 256) {
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < T.Ns; j += gridDim.x * 256) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float v = Sb[(size_t)j * 3 + a];
@@ -67,29 +102,30 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&bbox[b * 6 + a], enc(mn[a]));
-            atomicMax(&bbox[b * 6 + 3 + a], enc(mx[a]));
+            atomicMin(&T.bbox[b * 6 + a], enc(mn[a]));
+            atomicMax(&T.bbox[b * 6 + 3 + a], enc(mx[a]));
         }
     }
 }
 
-__global__ void grid_geom_kernel(const unsigned* __restrict__ bbox, GridGeom* __restrict__ geom, int B, int Ns,
-                                 float per_cell, int maxcells) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__global__ void grid_geom_kernel(const KMulti m) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m.ntasks * m.B) return;
+    const int task = c / m.B, b = c % m.B;
+    const KTask& T = m.t[task];
     GridGeom g;
     float ext[3];
     double vol = 1.0;
     int flat = 0;
     float extent = 0.f;
     for (int a = 0; a < 3; ++a) {
-        g.lo[a] = dec(bbox[b * 6 + a]);
-        const float hi = dec(bbox[b * 6 + 3 + a]);
+        g.lo[a] = dec(T.bbox[b * 6 + a]);
+        const float hi = dec(T.bbox[b * 6 + 3 + a]);
         ext[a] = hi - g.lo[a];
         if (!(ext[a] > 0.f)) { ext[a] = 0.f; flat++; } else vol *= (double)ext[a];
         extent = fmaxf(extent, ext[a]);
     }
-    double want = (double)Ns / (double)per_cell;
+    double want = (double)T.Ns / (double)T.per_cell;
     if (want < 1.0) want = 1.0;
     const double side = (flat == 3) ? 1.0 : pow(vol / want, 1.0 / (double)(3 - flat));
     long total = 1;
@@ -100,7 +136,7 @@ __global__ void grid_geom_kernel(const unsigned* __restrict__ bbox, GridGeom* __
         g.n[a] = n;
         total *= n;
     }
-    while (total > maxcells) {  // ceil() overshoot on thin clouds: halve the longest axis
+    while (total > T.maxcells) {  // ceil() overshoot on thin clouds: halve the longest axis
         int a = 0;
         if (g.n[1] > g.n[a]) a = 1;
         if (g.n[2] > g.n[a]) a = 2;
@@ -113,7 +149,7 @@ __global__ void grid_geom_kernel(const unsigned* __restrict__ bbox, GridGeom* __
     }
     g.ncell = (int)total;
     g.slack = 1e-5f * extent + 1e-30f;
-    geom[b] = g;
+    T.geom[b] = g;
 }
 
 __device__ __forceinline__ void cell_coords(const GridGeom& g, float x, float y, float z, int c[3]) {
@@ -130,28 +166,27 @@ __device__ __forceinline__ int cell_id(const GridGeom& g, const int c[3]) {
     return (c[2] * g.n[1] + c[1]) * g.n[0] + c[0];
 }
 
-__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ S, long s_bs, int Ns,
-                                                         const GridGeom* __restrict__ geom,
-                                                         int* __restrict__ count, int cstride) {
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(256) void grid_count_kernel(const KMulti m) {
+    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const KTask& T = m.t[task];
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Ns) return;
-    const GridGeom g = geom[b];
-    const float* p = S + ((size_t)b * s_bs + j) * 3;
+    if (j >= T.Ns) return;
+    const GridGeom g = T.geom[b];
+    const float* p = T.S + ((size_t)b * T.s_bs + j) * 3;
     int c[3];
     cell_coords(g, p[0], p[1], p[2], c);
-    atomicAdd(&count[(size_t)b * cstride + cell_id(g, c)], 1);
+    atomicAdd(&T.count[(size_t)b * T.cstride + cell_id(g, c)], 1);
 }
 
 // exclusive scan of count[0..ncell) -> start[0..ncell], cursor copy; one workgroup per cloud
-__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridGeom* __restrict__ geom, const int* __restrict__ count,
-                                                         int* __restrict__ start, int* __restrict__ cursor, int cstride) {
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const KMulti m) {
     __shared__ int part[1024];
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int ncell = geom[b].ncell;
-    const int* cnt = count + (size_t)b * cstride;
-    int* st = start + (size_t)b * cstride;
-    int* cu = cursor + (size_t)b * cstride;
+    const int task = blockIdx.x / m.B, b = blockIdx.x % m.B, t = threadIdx.x;
+    const KTask& T = m.t[task];
+    const int ncell = T.geom[b].ncell;
+    const int* cnt = T.count + (size_t)b * T.cstride;
+    int* st = T.start + (size_t)b * T.cstride;
+    int* cu = T.cursor + (size_t)b * T.cstride;
     const int chunk = (ncell + 1023) / 1024;
     const int lo = t * chunk, hi = min(ncell, lo + chunk);
     int s = 0;
@@ -173,18 +208,17 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const GridGeom* __restr
     if (t == 1023) st[ncell] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ S, long s_bs, int Ns,
-                                                           const GridGeom* __restrict__ geom, int* __restrict__ cursor,
-                                                           int cstride, float4* __restrict__ sorted) {
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const KMulti m) {
+    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const KTask& T = m.t[task];
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Ns) return;
-    const GridGeom g = geom[b];
-    const float* p = S + ((size_t)b * s_bs + j) * 3;
+    if (j >= T.Ns) return;
+    const GridGeom g = T.geom[b];
+    const float* p = T.S + ((size_t)b * T.s_bs + j) * 3;
     int c[3];
     cell_coords(g, p[0], p[1], p[2], c);
-    const int pos = atomicAdd(&cursor[(size_t)b * cstride + cell_id(g, c)], 1);
-    sorted[(size_t)b * Ns + pos] = make_float4(p[0], p[1], p[2], __int_as_float(j));
+    const int pos = atomicAdd(&T.cursor[(size_t)b * T.cstride + cell_id(g, c)], 1);
+    T.sorted[(size_t)b * T.Ns + pos] = make_float4(p[0], p[1], p[2], __int_as_float(j));
 }
 
 // Scan candidates [begin, end).  Loads are issued eight at a time before any of them is used: with
@@ -230,17 +264,22 @@ __device__ __forceinline__ float axis_gap(const GridGeom& g, int a, int ci, floa
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ Q, long q_bs, int Nq, int Ns, int k,
-                                                         int self_mode, const GridGeom* __restrict__ geom,
-                                                         const int* __restrict__ start, int cstride,
-                                                         const float4* __restrict__ sorted, int32_t* __restrict__ idx32,
-                                                         int64_t* __restrict__ idx64, float* __restrict__ d2out) {
-    const int b = blockIdx.y;
+__global__ __launch_bounds__(256) void grid_query_kernel(const KMulti m) {
+    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const KTask& T = m.t[task];
+    const int k = T.k, Nq = T.Nq, Ns = T.Ns;
+    if (kmax_of(k) != KMAX) return;            // another instantiation of this kernel serves that task
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= Nq) return;
-    const GridGeom g = geom[b];
-    const float4* pts = sorted + (size_t)b * Ns;
-    const int* st = start + (size_t)b * cstride;
+    const int self_mode = T.self_mode;
+    const float* Q = T.Q;
+    const long q_bs = T.q_bs;
+    int32_t* idx32 = T.idx32;
+    int64_t* idx64 = T.idx64;
+    float* d2out = T.d2;
+    const GridGeom g = T.geom[b];
+    const float4* pts = T.sorted + (size_t)b * Ns;
+    const int* st = T.start + (size_t)b * T.cstride;
     float qx, qy, qz;
     int qi;
     if (self_mode) {  // queries are the support points themselves: walk them in cell order
@@ -345,12 +384,48 @@ Plan make_plan(int B, int Ns, int k) {
     return p;
 }
 
-template <int KMAX>
-void launch_query(dim3 grid, hipStream_t st, const float* Q, long q_bs, int Nq, int Ns, int k, int self_mode,
-                  const GridGeom* geom, const int* start, int cstride, const float4* sorted, int32_t* i32, int64_t* i64,
-                  float* d2) {
-    hipLaunchKernelGGL((grid_query_kernel<KMAX>), grid, dim3(256), 0, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start,
-                       cstride, sorted, i32, i64, d2);
+void bind(KTask* t, const Plan& p, char* w) {
+    t->geom = (GridGeom*)(w + p.off_geom);
+    t->bbox = (unsigned*)(w + p.off_bbox);
+    t->count = (int*)(w + p.off_count);
+    t->start = (int*)(w + p.off_start);
+    t->cursor = (int*)(w + p.off_cursor);
+    t->sorted = (float4*)(w + p.off_sorted);
+    t->cstride = p.cstride;
+    t->maxcells = p.maxcells;
+    t->per_cell = p.per_cell;
+}
+
+int run_multi(const KMulti& m, hipStream_t st) {
+    int maxNs = 1, maxNq = 1, maxc = 1;
+    bool need[6] = {false, false, false, false, false, false};
+    for (int i = 0; i < m.ntasks; ++i) {
+        maxNs = max(maxNs, m.t[i].Ns);
+        maxNq = max(maxNq, m.t[i].Nq);
+        maxc = max(maxc, m.t[i].cstride);
+        const int k = m.t[i].k;
+        need[k == 1 ? 0 : k <= 4 ? 1 : k <= 8 ? 2 : k <= 16 ? 3 : k <= 32 ? 4 : 5] = true;
+    }
+    const int clouds = m.ntasks * m.B;
+    int gi = rl_cdiv(maxc, 256);
+    if (gi > 64) gi = 64;
+    hipLaunchKernelGGL(grid_init_kernel, dim3(gi, clouds), dim3(256), 0, st, m);
+    int gb = rl_cdiv(maxNs, 256);
+    if (gb > 256) gb = 256;
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(gb, clouds), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(grid_geom_kernel, dim3(rl_cdiv(clouds, 64)), dim3(64), 0, st, m);
+    hipLaunchKernelGGL(grid_count_kernel, dim3(rl_cdiv(maxNs, 256), clouds), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(clouds), dim3(1024), 0, st, m);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(rl_cdiv(maxNs, 256), clouds), dim3(256), 0, st, m);
+    dim3 grid(rl_cdiv(maxNq, 256), clouds);
+    if (need[0]) hipLaunchKernelGGL((grid_query_kernel<1>), grid, dim3(256), 0, st, m);
+    if (need[1]) hipLaunchKernelGGL((grid_query_kernel<4>), grid, dim3(256), 0, st, m);
+    if (need[2]) hipLaunchKernelGGL((grid_query_kernel<8>), grid, dim3(256), 0, st, m);
+    if (need[3]) hipLaunchKernelGGL((grid_query_kernel<16>), grid, dim3(256), 0, st, m);
+    if (need[4]) hipLaunchKernelGGL((grid_query_kernel<32>), grid, dim3(256), 0, st, m);
+    if (need[5]) hipLaunchKernelGGL((grid_query_kernel<64>), grid, dim3(256), 0, st, m);
+    RL_LAUNCH_CHECK("rl_knn(grid)");
+    return RL_OK;
 }
 
 }  // namespace
@@ -364,34 +439,48 @@ int rl_knn_grid_run(const float* S, long s_bs, const float* Q, long q_bs, int B,
     RL_REQUIRE(workspace && workspace_bytes >= (int64_t)p.bytes, RL_ERR_ARGS, "rl_knn: workspace too small (%ld < %ld bytes)",
                (long)workspace_bytes, (long)p.bytes);
     RL_REQUIRE(((uintptr_t)workspace & 255) == 0, RL_ERR_ARGS, "rl_knn: workspace must be 256-byte aligned");
-    char* w = (char*)workspace;
-    GridGeom* geom = (GridGeom*)(w + p.off_geom);
-    unsigned* bbox = (unsigned*)(w + p.off_bbox);
-    int* count = (int*)(w + p.off_count);
-    int* start = (int*)(w + p.off_start);
-    int* cursor = (int*)(w + p.off_cursor);
-    float4* sorted = (float4*)(w + p.off_sorted);
+    KMulti m;
+    m.ntasks = 1;
+    m.B = B;
+    KTask& t = m.t[0];
+    t.S = S; t.s_bs = s_bs; t.Q = Q; t.q_bs = q_bs; t.Ns = Ns; t.Nq = Nq; t.k = k;
+    t.self_mode = (S == Q && s_bs == q_bs && Ns == Nq) ? 1 : 0;
+    t.idx32 = i32; t.idx64 = i64; t.d2 = d2;
+    bind(&t, p, (char*)workspace);
+    return run_multi(m, st);
+}
 
-    const long ncount = (long)p.cstride * B;
-    int gi = rl_cdiv(ncount > B * 6 ? ncount : B * 6, 256);
-    if (gi > 1024) gi = 1024;
-    hipLaunchKernelGGL(grid_init_kernel, dim3(gi), dim3(256), 0, st, bbox, B, count, ncount);
-    int gb = rl_cdiv(Ns, 256);
-    if (gb > 256) gb = 256;
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(gb, B), dim3(256), 0, st, S, s_bs, Ns, bbox);
-    hipLaunchKernelGGL(grid_geom_kernel, dim3(rl_cdiv(B, 64)), dim3(64), 0, st, bbox, geom, B, Ns, p.per_cell, p.maxcells);
-    hipLaunchKernelGGL(grid_count_kernel, dim3(rl_cdiv(Ns, 256), B), dim3(256), 0, st, S, s_bs, Ns, geom, count, p.cstride);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(B), dim3(1024), 0, st, geom, count, start, cursor, p.cstride);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(rl_cdiv(Ns, 256), B), dim3(256), 0, st, S, s_bs, Ns, geom, cursor,
-                       p.cstride, sorted);
-    const int self_mode = (S == Q && s_bs == q_bs && Ns == Nq) ? 1 : 0;
-    dim3 grid(rl_cdiv(Nq, 256), B);
-    if (k == 1) launch_query<1>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
-    else if (k <= 4) launch_query<4>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
-    else if (k <= 8) launch_query<8>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
-    else if (k <= 16) launch_query<16>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
-    else if (k <= 32) launch_query<32>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
-    else launch_query<64>(grid, st, Q, q_bs, Nq, Ns, k, self_mode, geom, start, p.cstride, sorted, i32, i64, d2);
-    RL_LAUNCH_CHECK("rl_knn(grid)");
-    return RL_OK;
+extern "C" int64_t rl_knn_multi_workspace_bytes(const rl_knn_task* tasks, int ntasks, int B) {
+    if (!tasks || ntasks <= 0 || B <= 0) return 0;
+    int64_t total = 0;
+    for (int i = 0; i < ntasks; ++i) total += (int64_t)make_plan(B, tasks[i].Ns, tasks[i].k).bytes;
+    return total;
+}
+
+extern "C" int rl_knn_multi(const rl_knn_task* tasks, int ntasks, int B, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+    RL_REQUIRE(tasks && ntasks > 0 && ntasks <= KNN_MAX_TASKS && B > 0 && B * ntasks <= 65535, RL_ERR_ARGS,
+               "rl_knn_multi: 1..%d tasks expected", KNN_MAX_TASKS);
+    RL_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, RL_ERR_ARGS, "rl_knn_multi: workspace must be 256-byte aligned");
+    KMulti m;
+    m.ntasks = ntasks;
+    m.B = B;
+    size_t off = 0;
+    for (int i = 0; i < ntasks; ++i) {
+        const rl_knn_task& u = tasks[i];
+        RL_REQUIRE(u.support && u.query && u.idx_out && u.d2_out && u.Nq > 0 && u.k > 0, RL_ERR_ARGS, "rl_knn_multi: bad task %d", i);
+        RL_REQUIRE(u.Ns >= u.k, RL_ERR_FEW_SUPPORT, "Not enough points in support to find %d neighboors", u.k);
+        RL_REQUIRE(u.k <= RL_KNN_MAX_K, RL_ERR_UNSUPPORTED, "rl_knn_multi: k=%d exceeds RL_KNN_MAX_K=%d", u.k, RL_KNN_MAX_K);
+        RL_REQUIRE(u.support_bstride >= u.Ns && u.query_bstride >= u.Nq, RL_ERR_ARGS, "rl_knn_multi: batch stride smaller than the cloud");
+        const Plan p = make_plan(B, u.Ns, u.k);
+        RL_REQUIRE((int64_t)(off + p.bytes) <= workspace_bytes, RL_ERR_ARGS, "rl_knn_multi: workspace too small");
+        KTask& t = m.t[i];
+        t.S = u.support; t.s_bs = u.support_bstride; t.Q = u.query; t.q_bs = u.query_bstride;
+        t.Ns = u.Ns; t.Nq = u.Nq; t.k = u.k;
+        t.self_mode = (u.support == u.query && u.support_bstride == u.query_bstride && u.Ns == u.Nq) ? 1 : 0;
+        t.idx32 = u.idx_out; t.idx64 = nullptr; t.d2 = u.d2_out;
+        bind(&t, p, (char*)workspace + off);
+        off += p.bytes;
+    }
+    return run_multi(m, (hipStream_t)stream);
 }

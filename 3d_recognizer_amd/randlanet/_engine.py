@@ -112,11 +112,10 @@ class Engine:
         ctx.tape.append(("pool", name, u, g, idx, X, S, pooled, n, d))
         return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
 
-    def _lfa(self, ctx, l: int, xin: Lazy, xyz: torch.Tensor, n: int, d: int) -> Lazy:
-        """LocalFeatureAggregation (modules.py:298-325)."""
+    def _lfa(self, ctx, l: int, xin: Lazy, xyz: torch.Tensor, n: int, d: int, idx, d2) -> Lazy:
+        """LocalFeatureAggregation (modules.py:298-325); idx / d2 = its K nearest neighbours."""
         e = f"encoder.{l}"
         B, K, h = xin.B, self.K, d // 2
-        idx, d2 = ops.knn_i32(xyz, xyz, n, n, K)
         ctx.keep += [idx, d2]
         f0 = self._mlp(ctx, xin, f"{e}.mlp1", h, H.ACT_LRELU, 0.2)
         sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
@@ -157,6 +156,17 @@ class Engine:
             ops.copy_rows(inp_p, (0, 3), N, xyz.view(B * N, 3), (0, 3), B * N, N)
         ctx.keep += [inp_p, xyz]
 
+        # every neighbour search of this forward depends on the coordinates only: the K-NN of the L encoder
+        # levels (modules.py:309) and the 1-NN of the L decoder steps (modules.py:358) go out as one batch
+        tasks, ratio = [], 1
+        for _ in self.layers:
+            tasks.append((N // ratio, N // ratio, self.K))
+            ratio *= dec
+        for _ in self.layers:
+            tasks.append((N // ratio, dec * N // ratio, 1))
+            ratio //= dec
+        searches = ops.knn_multi(xyz, tasks)
+
         # fc_start + bn_start (modules.py:565-566)
         x = self._linear(ctx, ops.plain(inp_p, B, N), "fc_start.weight", "fc_start.bias", 8, bn="bn_start.0",
                          act=H.ACT_LRELU, slope=0.2, a_grad=False)
@@ -165,14 +175,15 @@ class Engine:
         ratio = 1
         for l, d in enumerate(self.layers):
             n_l = N // ratio
-            x = self._lfa(ctx, l, x.prefix(n_l), xyz, n_l, d)
+            x = self._lfa(ctx, l, x.prefix(n_l), xyz, n_l, d, *searches[l])
             skips.append(x)
             ratio *= dec
         x = self._mlp(ctx, x.prefix(N // ratio), "mlp", x.C, H.ACT_RELU)        # modules.py:591
         # decoder (modules.py:594-605)
         for j in range(L):
             n_c, n_f = N // ratio, dec * N // ratio
-            nn, _ = ops.knn_i32(xyz, xyz, n_c, n_f, 1)
+            nn = searches[L + j][0]
+            assert nn.shape == (B, n_f, 1)
             skip = skips.pop()
             assert skip.n == n_f and x.n == n_c
             cat = torch.empty((B * n_f, x.C + skip.C), dtype=torch.float32, device=dev)

@@ -67,6 +67,17 @@ class BnBwdDesc(C.Structure):
     ]
 
 
+class KnnTask(C.Structure):
+    _fields_ = [
+        ("support", C.c_void_p), ("support_bstride", C.c_int64), ("query", C.c_void_p), ("query_bstride", C.c_int64),
+        ("Ns", C.c_int32), ("Nq", C.c_int32), ("k", C.c_int32),
+        ("idx_out", C.c_void_p), ("d2_out", C.c_void_p),
+    ]
+
+
+KNN_MAX_TASKS = 8
+
+
 class PoolDesc(C.Structure):
     _fields_ = [
         ("U", C.c_void_p), ("u_scale", C.c_void_p), ("u_shift", C.c_void_p), ("u_act", C.c_int32),
@@ -101,6 +112,8 @@ _SIGNATURES = {
     "rl_knn_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "rl_knn_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
+    "rl_knn_multi_workspace_bytes": (_l, [C.POINTER(KnnTask), _i, _i]),
+    "rl_knn_multi": (_i, [C.POINTER(KnnTask), _i, _i, _vp, _l, _vp]),
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),

@@ -141,6 +141,35 @@ def knn_i32(support: torch.Tensor, query: torch.Tensor, Ns: int, Nq: int, k: int
     return idx, d2
 
 
+def knn_multi(xyz: torch.Tensor, tasks):
+    """Several prefix searches over the same (B, N, 3) clouds in one launch set: tasks is a list of
+    (Ns, Nq, k) - support = first Ns points, queries = first Nq points of every cloud.
+    Returns [(idx int32 (B,Nq,k), d2 fp32 (B,Nq,k)), ...]."""
+    _dev_check(xyz)
+    assert xyz.dtype == F32 and xyz.dim() == 3 and xyz.shape[2] == 3
+    B, N, _ = xyz.shape
+    out = []
+    for c0 in range(0, len(tasks), H.KNN_MAX_TASKS):
+        chunk = tasks[c0:c0 + H.KNN_MAX_TASKS]
+        arr = (H.KnnTask * len(chunk))()
+        res = []
+        nbytes_io = 0
+        for t, (Ns, Nq, k) in zip(arr, chunk):
+            assert 0 < k <= Ns <= N and 0 < Nq <= N and k <= H.KNN_MAX_K
+            idx = torch.empty((B, Nq, k), dtype=torch.int32, device=xyz.device)
+            d2 = torch.empty((B, Nq, k), dtype=F32, device=xyz.device)
+            t.support, t.support_bstride, t.query, t.query_bstride = xyz.data_ptr(), N, xyz.data_ptr(), N
+            t.Ns, t.Nq, t.k, t.idx_out, t.d2_out = Ns, Nq, k, idx.data_ptr(), d2.data_ptr()
+            res.append((idx, d2))
+            nbytes_io += B * (12 * (Ns + Nq) + 8 * Nq * k)
+        nbytes = H.lib().rl_knn_multi_workspace_bytes(arr, len(chunk), B)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=xyz.device)
+        with _rec("knn_multi", tuple(chunk), nbytes_io, sum(8 * B * a * b for a, b, _ in chunk)):
+            H.check(H.lib().rl_knn_multi(arr, len(chunk), B, ws.data_ptr(), ws.numel(), _st()), "rl_knn_multi")
+        out.extend(res)
+    return out
+
+
 def knn_f32(support: torch.Tensor, query: torch.Tensor, k: int, brute: bool = False
             ) -> Tuple[torch.Tensor, torch.Tensor]:
     _dev_check(support, query)

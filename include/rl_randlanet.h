@@ -85,6 +85,23 @@ int rl_knn_i32(const float* support, int64_t support_bstride, const float* query
                int64_t query_bstride, int B, int Ns, int Nq, int k, int32_t* idx_out,
                float* d2_out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Several searches over the same B clouds in one launch set (a forward pass needs eight that depend
+ * only on the coordinates: encoder K-NN on every level, decoder 1-NN between levels).  Each task is
+ * one rl_knn_i32 call; the small ones run beside the large one instead of after it.  At most 8 tasks. */
+typedef struct rl_knn_task {
+    const float* support;
+    int64_t support_bstride;
+    const float* query;
+    int64_t query_bstride;
+    int32_t Ns, Nq, k;
+    int32_t* idx_out;
+    float* d2_out;
+} rl_knn_task;
+
+int64_t rl_knn_multi_workspace_bytes(const rl_knn_task* tasks, int ntasks, int B);
+int rl_knn_multi(const rl_knn_task* tasks, int ntasks, int B, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-point linear layer (1x1 conv / conv-transpose / Linear):   Y = A' . W (+ bias)
  *   A' [M x K] : A-operand, M = B*n rows.

@@ -94,6 +94,19 @@ def test_knn_grid_equals_brute_force_on_hard_clouds(ops, k):
         assert torch.equal(bi, gi) and torch.equal(bd, gd), (name, "cross")
 
 
+def test_knn_multi_equals_single_searches(ops):
+    """rl_knn_multi (all searches of a forward in one launch set) gives the bits of the one-by-one calls."""
+    rs = np.random.RandomState(11)
+    xyz = _t(rs.uniform(0, 1, (3, 4096, 3)).astype(np.float32))
+    tasks = [(4096, 4096, 16), (1024, 1024, 16), (256, 256, 16), (64, 64, 16), (16, 64, 1), (64, 256, 1),
+             (256, 1024, 1), (1024, 4096, 1), (4096, 4096, 5), (300, 4000, 32)]          # 10 tasks -> two chunks
+    got = ops.knn_multi(xyz, tasks)
+    assert len(got) == len(tasks)
+    for (Ns, Nq, k), (idx, d2) in zip(tasks, got):
+        ri, rd = ops.knn_i32(xyz, xyz, Ns, Nq, k, brute=True)
+        assert torch.equal(idx, ri) and torch.equal(d2, rd), (Ns, Nq, k)
+
+
 def test_knn_prefix_strides_and_errors(ops, H):
     from oracle import randlanet_oracle as O
     rs = np.random.RandomState(1)
