@@ -123,6 +123,9 @@ struct GemmParams {
     int y_contig;
     int accumulate;
     double* stats;
+    int ksplit;        // > 1: blockIdx.z owns a K range and writes raw partial tiles to kslab
+    int kchunk;        // K range per split (multiple of 32)
+    float* kslab;      // [ksplit][M][N]
 };
 
 template <int NT>
@@ -357,7 +360,11 @@ void wgrad_split(long M, int N, int K, int* nsplit, long* rows_per_block) {
     const int ny = rl_cdiv(N, T), nz = rl_cdiv(K, T);
     long want = 1024 / ((long)ny * nz);
     if (want < 1) want = 1;
+    // row ranges of >= 256 rows keep the partial slabs small; shorter ones (down to 64 rows) only where
+    // the launch would otherwise leave most of the 256 CUs idle
     long maxs = (M + 255) / 256;
+    const long fill = 256 / ((long)ny * nz) + 1;
+    if (maxs < fill) maxs = fill < (M + 63) / 64 ? fill : (M + 63) / 64;
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
     long rpb = (M + want - 1) / want;
@@ -810,12 +817,14 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
             }
         };
 
-        fetch(0);
-        for (int k0 = 0; k0 < K; k0 += PG_BK) {
+        const int k_begin = (p.ksplit > 1) ? blockIdx.z * p.kchunk : 0;
+        const int k_end = (p.ksplit > 1) ? min(K, k_begin + p.kchunk) : K;
+        fetch(k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += PG_BK) {
             __syncthreads();
             commit(k0);
             __syncthreads();
-            if (k0 + PG_BK < K) fetch(k0 + PG_BK);
+            if (k0 + PG_BK < k_end) fetch(k0 + PG_BK);
 #pragma unroll
             for (int ks = 0; ks < PG_BK / 4; ++ks) {
                 const int kc = ks * 4 + lq;
@@ -828,6 +837,24 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
                     acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nb], 0, 0, 0);
                 }
             }
+        }
+        if (p.ksplit > 1) {
+            // split-K: raw partial tile to this split's slab; bias / accumulate / statistics happen in the reducer
+            float* slab = p.kslab + (long)blockIdx.z * M * N;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long R = row0 + wave * 32 + rb * 16 + lq * 4 + r;
+                    if (R < M) {
+#pragma unroll
+                        for (int nb = 0; nb < NT; ++nb) {
+                            const int c = col0 + nb * 16 + lr;
+                            if (c < N) slab[R * N + c] = acc[rb][nb][r];
+                        }
+                    }
+                }
+            continue;
         }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
@@ -858,7 +885,7 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
             }
         }
     }
-    if (p.stats) {
+    if (p.stats && p.ksplit <= 1) {
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) {
             float s = ssum[nb], q = ssq[nb];
@@ -875,6 +902,79 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
             p.stats[((long)blockIdx.x * 2 + 1) * N + col0 + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
         }
     }
+}
+
+// Split-K reducer: Y = sum over splits (fixed order) + bias (+ Y when accumulating), plus the BatchNorm
+// partial statistics, one slot per workgroup exactly like the single-pass kernels (rl_row_blocks(M,128)).
+// Needs N % 4 == 0 and N/4 a power of two <= 256.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParams p) {
+    // workgroup (x, y): row tiles x, x + gridDim.x, ... (x = the statistics slot) and columns [64y, 64y+64)
+    __shared__ float red[256][9];
+    const int N = p.N;
+    const long M = p.a.M;
+    const int q = threadIdx.x & 15, rsub = threadIdx.x >> 4;   // 16 column quads x 16 rows in flight
+    const int c = blockIdx.y * 64 + q * 4;
+    const bool cvalid = c < N;
+    const long ntiles = (M + GM_BM - 1) / GM_BM;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && cvalid) bias = make_float4(p.bias[c], p.bias[c + 1], p.bias[c + 2], p.bias[c + 3]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cvalid) {
+        for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const long rend = min(M, (tile + 1) * GM_BM);
+            for (long R = tile * GM_BM + rsub; R < rend; R += 16) {
+                float4 v = bias;
+                for (int s = 0; s < p.ksplit; ++s) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.kslab + ((long)s * M + R) * N + c);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                long yoff;
+                if (p.y_contig) yoff = R * p.ldy;
+                else {
+                    const int b = (int)(R / p.rows_per_batch);
+                    const int i = (int)(R - (long)b * p.rows_per_batch);
+                    yoff = ((long)b * p.y_bstride + i) * p.ldy;
+                }
+                float* y = p.Y + yoff + c;
+                if (p.accumulate) { v.x += y[0]; v.y += y[1]; v.z += y[2]; v.w += y[3]; }
+                y[0] = v.x; y[1] = v.y; y[2] = v.z; y[3] = v.w;
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                acc[4] += v.x * v.x; acc[5] += v.y * v.y; acc[6] += v.z * v.z; acc[7] += v.w * v.w;
+            }
+        }
+    }
+    if (!p.stats) return;
+    // lanes l, l^16, l^32 share a column quad inside a wavefront; then the four wavefronts through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j] += __shfl_xor(acc[j], 16, 64);
+        acc[j] += __shfl_xor(acc[j], 32, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 16 && cvalid) {
+        double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm[j] += (double)red[w * 64 + threadIdx.x][j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p.stats[((long)blockIdx.x * 2 + 0) * N + c + j] = sm[j];
+            p.stats[((long)blockIdx.x * 2 + 1) * N + c + j] = sm[4 + j];
+        }
+    }
+}
+
+// how many K splits a wide GEMM with few output tiles should use (1 = none)
+inline int gemm_ksplit(long M, int N, int K) {
+    if (N % 4) return 1;
+    const long tiles = ((M + GM_BM - 1) / GM_BM) * ((N + 127) / 128);
+    if (tiles >= 128 || K < 256) return 1;
+    long s = 256 / tiles;
+    if (s > K / 64) s = K / 64;      // at least two 32-deep chunks per split
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
 }
 
 inline bool pgemm_ok(const GemmParams& p) {
@@ -1144,6 +1244,21 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         RL_LAUNCH_CHECK("rl_gemm(stream)");
         return RL_OK;
     }
+    p.ksplit = 1; p.kchunk = 0; p.kslab = nullptr;
+    if (pgemm_ok(p) && d->N > 64 && d->kslab != nullptr) {
+        const int ks = gemm_ksplit(p.a.M, d->N, d->K);
+        if (ks > 1 && d->kslab_floats >= (int64_t)ks * p.a.M * d->N) {
+            p.ksplit = ks;
+            p.kchunk = ((d->K + ks - 1) / ks + 31) / 32 * 32;
+            p.ksplit = (d->K + p.kchunk - 1) / p.kchunk;
+            p.kslab = d->kslab;
+            hipLaunchKernelGGL((pgemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128), p.ksplit), dim3(256), 0, st, p);
+            RL_LAUNCH_CHECK("rl_gemm(split-K)");
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, rl_cdiv(d->N, 64)), dim3(256), 0, st, p);
+            RL_LAUNCH_CHECK("rl_gemm(split-K reduce)");
+            return RL_OK;
+        }
+    }
     if (pgemm_ok(p)) {
         if (d->N <= 16)      hipLaunchKernelGGL((pgemm_kernel<1>), dim3(gx, 1), dim3(256), 0, st, p);
         else if (d->N <= 32) hipLaunchKernelGGL((pgemm_kernel<2>), dim3(gx, 1), dim3(256), 0, st, p);
@@ -1158,6 +1273,11 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     else                 hipLaunchKernelGGL((gemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128)), dim3(256), 0, st, p);
     RL_LAUNCH_CHECK("rl_gemm");
     return RL_OK;
+}
+
+extern "C" int64_t rl_gemm_kslab_floats(int64_t M, int N, int K) {
+    const int ks = gemm_ksplit(M, N, K);
+    return ks > 1 ? (int64_t)ks * M * N : 0;
 }
 
 extern "C" int64_t rl_wgrad_slab_floats(int64_t M, int N, int K) {

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("Y", C.c_void_p), ("ldy", C.c_int64), ("y_bstride", C.c_int64),
         ("accumulate", C.c_int32),
         ("stats", C.c_void_p),
+        ("kslab", C.c_void_p), ("kslab_floats", C.c_int64),
     ]
 
 
@@ -114,6 +115,7 @@ _SIGNATURES = {
     "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "rl_knn_multi_workspace_bytes": (_l, [C.POINTER(KnnTask), _i, _i]),
     "rl_knn_multi": (_i, [C.POINTER(KnnTask), _i, _i, _vp, _l, _vp]),
+    "rl_gemm_kslab_floats": (_l, [_l, _i, _i]),
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),

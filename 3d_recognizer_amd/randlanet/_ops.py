@@ -254,6 +254,10 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     d.N, d.W, d.w_ks, d.w_ns, d.bias = N, W.data_ptr(), w_ks, w_ns, H.ptr(bias)
     d.Y, d.ldy, d.y_bstride, d.accumulate = out.data_ptr(), out.shape[1], out_bstride, int(accumulate)
     d.stats = H.ptr(stats)
+    kfloats = H.lib().rl_gemm_kslab_floats(M, N, K) if (N > 64 and not isinstance(a, Rpe)) else 0
+    if kfloats > 0:
+        kslab = _slab(W.device, kfloats)
+        d.kslab, d.kslab_floats = kslab.data_ptr(), kslab.numel()
     with _rec("gemm_rpe" if isinstance(a, Rpe) else "gemm", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N * (2 if accumulate else 1) + K * N), 2 * M * K * N):
         H.check(H.lib().rl_gemm(C.byref(d), _st()), "rl_gemm")
     return out

@@ -138,8 +138,13 @@ typedef struct rl_gemm_desc {
     int64_t ldy, y_bstride;
     int32_t accumulate;
     double* stats;
+    /* optional scratch of rl_gemm_kslab_floats(M,N,K) floats: lets a wide layer with few rows split K
+     * over workgroups (deterministic two-pass reduction); NULL or too small = single pass */
+    float* kslab;
+    int64_t kslab_floats;
 } rl_gemm_desc;
 
+int64_t rl_gemm_kslab_floats(int64_t M, int N, int K);
 int rl_gemm(const rl_gemm_desc* d, void* stream);
 
 /* Weight / bias gradient of the same layer:  dW(k,c) = sum_r A'[r][k] * dY[r][c],
