@@ -64,30 +64,58 @@ def sync_gradients(flat_grad: torch.Tensor, world: int, group=None) -> None:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
 
 
+class TrainState:
+    """Everything a training run mutates, once per model: the flat parameter / gradient buffers, both
+    Adam moments, the step counter and the learning rate (device scalars, so captured graphs read the
+    current values).  Several TrainStep objects (one per batch shape) share one TrainState."""
+
+    def __init__(self, module, lr: float = 1e-2, process_group=None, world_size: int = 1):
+        self.module = module
+        self.dev = module.device
+        if self.dev.type != "cuda":
+            raise H.HipKernelError("training needs an MI355X (HIP) device")
+        self.flat = FlatParameters(module)
+        self.engine = module.engine()
+        self.world, self.pg = world_size, process_group
+        self.exp_avg = torch.zeros_like(self.flat.param)
+        self.exp_avg_sq = torch.zeros_like(self.flat.param)
+        self.lr = torch.tensor([lr], dtype=torch.float32, device=self.dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+
+    def set_lr(self, lr: float) -> None:
+        self.lr.fill_(float(lr))
+
+    def snapshot(self):
+        return (self.flat.param.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.step_count.clone(),
+                {k: v.clone() for k, v in self.module.named_buffers()})
+
+    def restore(self, snap) -> None:
+        self.flat.param.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
+        self.step_count.copy_(snap[3])
+        for k, v in self.module.named_buffers():
+            v.copy_(snap[4][k])
+
+
 class TrainStep:
-    """One data-parallel training step on the HIP kernels.
+    """One data-parallel training step on the HIP kernels, for one batch shape (B, N).
 
     step(perm) consumes a host permutation (np.random.permutation(N), drawn by the caller from
     the global numpy RNG like the reference, modules.py:571), runs the schedule and leaves the
     packed loss/metric record in `self.out` (device) / `self.out_host` (pinned, asynchronous)."""
 
     def __init__(self, module, B: int, N: int, loss: str = "dice", lr: float = 1e-2, use_graph: bool = True,
-                 process_group=None, world_size: int = 1):
+                 process_group=None, world_size: int = 1, state: Optional[TrainState] = None):
+        self.state = state if state is not None else TrainState(module, lr, process_group, world_size)
+        st = self.state
         self.module = module
-        self.dev = module.device
-        if self.dev.type != "cuda":
-            raise H.HipKernelError("TrainStep needs an MI355X (HIP) device")
+        self.dev = st.dev
         s = module.settings
         self.B, self.N, self.C = B, N, s.n_classes
         self.kind, self.alpha, self.gamma = ops.LOSS_KINDS[loss]
-        self.flat = FlatParameters(module)
-        self.engine = module.engine()
+        self.flat, self.engine = st.flat, st.engine
         self.p_drop = float(module.fc_end[2].p)
-        self.world, self.pg = world_size, process_group
-        self.exp_avg = torch.zeros_like(self.flat.param)
-        self.exp_avg_sq = torch.zeros_like(self.flat.param)
-        self.lr = torch.tensor([lr], dtype=torch.float32, device=self.dev)
-        self.step_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.world, self.pg = st.world, st.pg
+        self.exp_avg, self.exp_avg_sq, self.lr, self.step_count = st.exp_avg, st.exp_avg_sq, st.lr, st.step_count
         # static buffers; all start VALID (the capture pass launches kernels that index with them)
         self.inp = torch.rand((B, N, 3 + s.n_features), dtype=torch.float32, device=self.dev)
         self.labels = torch.zeros((B, N), dtype=torch.int64, device=self.dev)
@@ -119,8 +147,7 @@ class TrainStep:
         self.module.train()
         if not self.use_graph:
             return
-        snap = (self.flat.param.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.step_count.clone())
-        bufs = {k: v.clone() for k, v in self.module.named_buffers()}
+        snap = self.state.snapshot()
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
@@ -139,10 +166,7 @@ class TrainStep:
             with torch.cuda.graph(self._g_adam):
                 self._adam()
         # the warm-up and capture passes must not count as training: restore the state
-        self.flat.param.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
-        self.step_count.copy_(snap[3])
-        for k, v in self.module.named_buffers():
-            v.copy_(bufs[k])
+        self.state.restore(snap)
         torch.cuda.synchronize(self.dev)
 
     def set_batch(self, inp: torch.Tensor, labels: torch.Tensor) -> None:
@@ -164,11 +188,20 @@ class TrainStep:
         self.out_host.copy_(self.out, non_blocking=True)
 
     def last_metrics(self) -> Dict[str, float]:
-        """Synchronises and unpacks the record of the last step (reference metrics.py:8-59)."""
+        """Synchronises and unpacks the record of the last step (reference metrics.py:8-59).  With several
+        ranks the counts are summed and the loss averaged over the ranks first."""
         from .utils.metrics import accuracy_from_counts, iou_from_counts
-        torch.cuda.current_stream(self.dev).synchronize()
-        rec = self.out_host.numpy().copy()
+        if self.world > 1:
+            import torch.distributed as dist
+            rec_dev = self.out.clone()
+            dist.all_reduce(rec_dev, op=dist.ReduceOp.SUM, group=self.pg)
+            rec = rec_dev.cpu().numpy()
+            rec[0] /= self.world
+        else:
+            torch.cuda.current_stream(self.dev).synchronize()
+            rec = self.out_host.numpy().copy()
         cnt = rec[1:1 + 3 * self.C].reshape(3, self.C)
         oa, pca = accuracy_from_counts(cnt)
         miou, pci = iou_from_counts(cnt)
-        return dict(loss=float(rec[0]), OA=oa, mAcc=float(np.mean(pca)), mIoU=miou, per_class_iou=pci)
+        return dict(loss=float(rec[0]), OA=oa, mAcc=float(np.mean(pca)), mIoU=miou, per_class_iou=pci,
+                    per_class_acc=pca)

@@ -76,34 +76,55 @@ class Trainer:
 
     def train(self, model: RandLANet, settings: TrainingSettings,
               callbacks: List[Callable[[int, Dict[str, float]], None]] = []) -> RandLANet:
-        device = model.device
-        optimizer = torch.optim.Adam(model.parameters(), lr=settings.learning_rate)
-        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=10, gamma=settings.learning_rate_decay)
-        criterion = get_loss(settings.loss_function)
+        """Reference semantics (trainer.py:62-168): Adam(lr) + StepLR(10, decay), per-batch forward / loss /
+        backward / step / metrics, per-epoch validation, early stopping on val_mIoU, best weights returned.
+        The inner step runs as the fused HIP schedule (`_train.TrainStep`): full batches replay a captured
+        hipGraph, a ragged last batch runs the same schedule eagerly; parameters, gradients and Adam moments
+        live in flat buffers shared by both.  With torch.distributed initialised every rank trains on its
+        shard and gradients are all-reduced once per step."""
+        from .._train import TrainState, TrainStep
+        world, rank = 1, 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
+        state = TrainState(model, settings.learning_rate, None, world)
+        steppers: Dict[tuple, TrainStep] = {}
         patience = settings.early_stopping_patience if settings.early_stopping else settings.epochs
         stopper = EarlyStopper(patience=patience, metric="val_mIoU")
         model.train()
         logger.info(f"Training on {len(self._train_dataloader.dataset)} training samples and "
                     f"{len(self._validation_dataloader.dataset)} validation samples.")
-        writer = _summary_writer(self._log_dir)
+        writer = _summary_writer(self._log_dir) if rank == 0 else None
+        full_batch = self._train_dataloader.batch_size
+        lr = settings.learning_rate
         for epoch in range(1, settings.epochs + 1):
             collected = MetricCollector(self._class_names)
-            for batch, labels, _ in tqdm(self._train_dataloader, desc="Training", leave=False):
-                batch, labels = batch.to(device), labels.to(device)
-                logits = model(batch)
-                loss = criterion(logits, labels)
-                optimizer.zero_grad()
-                loss.backward()
-                optimizer.step()
-                collected.push(loss.item(), *_batch_metrics(logits, labels))
-            scheduler.step()
+            for batch, labels, _ in tqdm(self._train_dataloader, desc="Training", leave=False, disable=rank != 0):
+                if world > 1:           # clouds are independent: each rank takes its contiguous shard
+                    from .._train import shard_range
+                    part = shard_range(batch.shape[0], rank, world)
+                    batch, labels = batch[part.start:part.stop], labels[part.start:part.stop]
+                key = (batch.shape[0], batch.shape[1])
+                if key not in steppers:
+                    steppers[key] = TrainStep(model, key[0], key[1], loss=settings.loss_function,
+                                              use_graph=(key[0] == full_batch or world > 1), state=state)
+                    steppers[key].capture()
+                    model.train()
+                stepper = steppers[key]
+                stepper.set_batch(batch.to(model.device, torch.float32), labels.to(model.device))
+                stepper.step(np.random.permutation(key[1]))      # the forward's permutation (modules.py:571)
+                m = stepper.last_metrics()                       # ONE packed read-back per step
+                pca_count = m["per_class_acc"]
+                collected.push(m["loss"], m["OA"], pca_count, m["mIoU"], m["per_class_iou"])
+            if epoch % 10 == 0:                                  # StepLR(step_size=10, gamma) (trainer.py:81-83)
+                lr *= settings.learning_rate_decay
+                state.set_lr(lr)
             validation = Trainer.evaluate(model, self._validation_dataloader, class_names=self._class_names,
                                           loss_function=settings.loss_function)
             metrics = collected.as_dict()
             metrics.update(validation.as_dict("val"))
             keep_going = stopper.check(metrics, model)
-            self._log(epoch, settings.epochs, optimizer, collected.as_dict(),
-                      validation.as_dict(include_stdev=True), writer)
+            if rank == 0:
+                self._log(epoch, settings.epochs, lr, collected.as_dict(), validation.as_dict(include_stdev=True), writer)
             for callback in callbacks:
                 callback(epoch, metrics)
             if not keep_going:
@@ -118,7 +139,7 @@ class Trainer:
         best.eval()
         return best
 
-    def _log(self, epoch: int, total_epochs: int, optimizer, train_metrics: OrderedDict,
+    def _log(self, epoch: int, total_epochs: int, lr: float, train_metrics: OrderedDict,
              validation_metrics: OrderedDict, writer) -> None:
         parts = [f"Epoch {epoch:3d}/{total_epochs:3d}"]
         v = validation_metrics
@@ -138,7 +159,7 @@ class Trainer:
                     cells.append("%s: %5.2f%% %11s" % (name, value * 100, ""))
             logger.info(f"{'':15s} {mode + ' IoU:':16s}" + " - ".join(cells))
         if writer is not None:
-            writer.add_scalar("Learning rate", optimizer.param_groups[0]["lr"], epoch)
+            writer.add_scalar("Learning rate", lr, epoch)
             for mode, metrics in (("Train", train_metrics), ("Validation", validation_metrics)):
                 for key, value in metrics.items():
                     writer.add_scalar(f"{key}/{mode}", value[0] if isinstance(value, tuple) else value, epoch)
