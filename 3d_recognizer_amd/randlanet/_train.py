@@ -120,7 +120,11 @@ class TrainStep:
         self.inp = torch.rand((B, N, 3 + s.n_features), dtype=torch.float32, device=self.dev)
         self.labels = torch.zeros((B, N), dtype=torch.int64, device=self.dev)
         self.perm = torch.arange(N, dtype=torch.int64, device=self.dev)
-        self.perm_host = torch.empty(N, dtype=torch.int64).pin_memory()
+        # pinned staging ring for the per-step permutation: the host may run a few steps ahead of the GPU,
+        # so a slot is rewritten only after the async copy that last read it has executed (event per slot)
+        self._perm_ring = [torch.empty(N, dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._perm_events = [None] * 4
+        self._perm_slot = 0
         self.out = torch.zeros(1 + 4 * self.C, dtype=torch.float64, device=self.dev)
         self.out_host = torch.zeros(1 + 4 * self.C, dtype=torch.float64).pin_memory()
         self.use_graph = use_graph
@@ -174,8 +178,16 @@ class TrainStep:
         self.labels.copy_(labels, non_blocking=True)
 
     def step(self, perm: np.ndarray) -> None:
-        self.perm_host.copy_(torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int64)))
-        self.perm.copy_(self.perm_host, non_blocking=True)
+        slot = self._perm_slot
+        self._perm_slot = (slot + 1) % len(self._perm_ring)
+        if self._perm_events[slot] is not None:
+            self._perm_events[slot].synchronize()
+        staging = self._perm_ring[slot]
+        staging.copy_(torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int64)))
+        self.perm.copy_(staging, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._perm_events[slot] = ev
         if self._g_main is not None:
             self._g_main.replay()
             if self.world > 1:
