@@ -123,6 +123,7 @@ class TrainStep:
         # pinned staging ring for the per-step permutation: the host may run a few steps ahead of the GPU,
         # so a slot is rewritten only after the async copy that last read it has executed (event per slot)
         self._perm_ring = [torch.empty(N, dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._perm_ring_np = [t.numpy() for t in self._perm_ring]     # plain memcpy, no torch CPU thread pool
         self._perm_events = [None] * 4
         self._perm_slot = 0
         self.out = torch.zeros(1 + 4 * self.C, dtype=torch.float64, device=self.dev)
@@ -183,7 +184,7 @@ class TrainStep:
         if self._perm_events[slot] is not None:
             self._perm_events[slot].synchronize()
         staging = self._perm_ring[slot]
-        staging.copy_(torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int64)))
+        self._perm_ring_np[slot][:] = perm
         self.perm.copy_(staging, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
