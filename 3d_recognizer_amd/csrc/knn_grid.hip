@@ -14,6 +14,7 @@
 // strict and carries a rounding slack).  For a self-search the lanes walk the queries in cell
 // order, so a wavefront's lanes share cells and cache lines.
 #include "rl_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -368,7 +369,8 @@ struct Plan {
 
 Plan make_plan(int B, int Ns, int k) {
     Plan p;
-    p.per_cell = fmaxf(2.f, 0.5f * (float)k);
+    static const float occ = getenv("RL_KNN_OCC") ? (float)atof(getenv("RL_KNN_OCC")) : 0.5f;   // tuning knob (points per cell / k)
+    p.per_cell = fmaxf(2.f, occ * (float)k);
     const long want = (long)((double)Ns / p.per_cell) + 1;
     p.maxcells = (int)(4 * want + 64);
     p.cstride = p.maxcells + 1;

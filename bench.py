@@ -230,7 +230,9 @@ def main():
         raise SystemExit("bench.py: the training loss is not finite - the measurement is invalid")
 
     roof = breakdown = cpu = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the instrumented eager steps (they contain the gradient all-reduce, a collective);
+        # rank 0's timings are the ones reported
         roof, breakdown = roofline_pass(stepper)
     if world > 1:
         dist.barrier()
