@@ -161,14 +161,15 @@ class TrainStep:
                 self._adam()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
+        # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls count
         self._g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_main):
+        with torch.cuda.graph(self._g_main, capture_error_mode="thread_local"):
             self._fwd_bwd()
             if self.world == 1:
                 self._adam()
         if self.world > 1:
             self._g_adam = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_adam):
+            with torch.cuda.graph(self._g_adam, capture_error_mode="thread_local"):
                 self._adam()
         # the warm-up and capture passes must not count as training: restore the state
         self.state.restore(snap)
