@@ -318,6 +318,7 @@ extern "C" int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream) {
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
+    rl_note_kernel(vec_ok(p) ? "bn_bwd_reduce_vec_kernel" : "bn_bwd_reduce_kernel");
     RL_LAUNCH_CHECK("rl_bn_bwd_reduce");
     return RL_OK;
 }
@@ -342,6 +343,7 @@ extern "C" int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream) {
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
+    rl_note_kernel(vec_ok(p) ? "bn_bwd_apply_vec_kernel" : "bn_bwd_apply_kernel");
     RL_LAUNCH_CHECK("rl_bn_bwd_apply");
     return RL_OK;
 }

@@ -1241,6 +1241,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         if (d->K <= 16)      launch_sgemm<1>(d->N, gx, st, p);
         else if (d->K <= 32) launch_sgemm<2>(d->N, gx, st, p);
         else                 launch_sgemm<4>(d->N, gx, st, p);
+        rl_note_kernel("sgemm_kernel");
         RL_LAUNCH_CHECK("rl_gemm(stream)");
         return RL_OK;
     }
@@ -1253,6 +1254,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
             p.ksplit = (d->K + p.kchunk - 1) / p.kchunk;
             p.kslab = d->kslab;
             hipLaunchKernelGGL((pgemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128), p.ksplit), dim3(256), 0, st, p);
+            rl_note_kernel("pgemm_kernel<8>+splitk");
             RL_LAUNCH_CHECK("rl_gemm(split-K)");
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, rl_cdiv(d->N, 64)), dim3(256), 0, st, p);
             RL_LAUNCH_CHECK("rl_gemm(split-K reduce)");
@@ -1264,6 +1266,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         else if (d->N <= 32) hipLaunchKernelGGL((pgemm_kernel<2>), dim3(gx, 1), dim3(256), 0, st, p);
         else if (d->N <= 64) hipLaunchKernelGGL((pgemm_kernel<4>), dim3(gx, 1), dim3(256), 0, st, p);
         else                 hipLaunchKernelGGL((pgemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128)), dim3(256), 0, st, p);
+        rl_note_kernel(d->N <= 16 ? "pgemm_kernel<1>" : d->N <= 32 ? "pgemm_kernel<2>" : d->N <= 64 ? "pgemm_kernel<4>" : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(pipelined)");
         return RL_OK;
     }
@@ -1271,6 +1274,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     else if (d->N <= 32) hipLaunchKernelGGL((gemm_kernel<2>), dim3(gx, 1), dim3(256), 0, st, p);
     else if (d->N <= 64) hipLaunchKernelGGL((gemm_kernel<4>), dim3(gx, 1), dim3(256), 0, st, p);
     else                 hipLaunchKernelGGL((gemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128)), dim3(256), 0, st, p);
+    rl_note_kernel("gemm_kernel");
     RL_LAUNCH_CHECK("rl_gemm");
     return RL_OK;
 }
@@ -1312,6 +1316,7 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         if (d->K <= 16)      launch_swgrad<1>(d->N, dim3(nsplit), st, p);
         else if (d->K <= 32) launch_swgrad<2>(d->N, dim3(nsplit), st, p);
         else                 launch_swgrad<4>(d->N, dim3(nsplit), st, p);
+        rl_note_kernel("swgrad_kernel");
     } else {
         const bool pipelined = pwgrad_ok(p);
         const int T = pipelined ? wgrad_tile(d->N, d->K) : WG_T;
@@ -1319,6 +1324,7 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         if (pipelined && T == 128) hipLaunchKernelGGL(pwgrad128_kernel, grid, dim3(256), 0, st, p);
         else if (pipelined) hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
+        rl_note_kernel(pipelined && T == 128 ? "pwgrad128_kernel" : pipelined ? "pwgrad_kernel" : "wgrad_kernel");
     }
     RL_LAUNCH_CHECK("rl_wgrad");
     const long per = (long)d->N * d->K + d->N;

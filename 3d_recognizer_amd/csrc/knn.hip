@@ -88,6 +88,7 @@ int launch(const float* S, long s_bs, const float* Q, long q_bs, int B, int Ns, 
     dim3 grid(rl_cdiv(Nq, KNN_BLOCK), B);
     hipLaunchKernelGGL((knn_brute_kernel<KMAX>), grid, dim3(KNN_BLOCK), 0, st, S, s_bs, Q, q_bs, Ns,
                        Nq, k, i32, i64, d2);
+    rl_note_kernel("knn_brute_kernel");
     RL_LAUNCH_CHECK("rl_knn");
     return RL_OK;
 }

@@ -426,6 +426,7 @@ int run_multi(const KMulti& m, hipStream_t st) {
     if (need[3]) hipLaunchKernelGGL((grid_query_kernel<16>), grid, dim3(256), 0, st, m);
     if (need[4]) hipLaunchKernelGGL((grid_query_kernel<32>), grid, dim3(256), 0, st, m);
     if (need[5]) hipLaunchKernelGGL((grid_query_kernel<64>), grid, dim3(256), 0, st, m);
+    rl_note_kernel("grid_query_kernel");
     RL_LAUNCH_CHECK("rl_knn(grid)");
     return RL_OK;
 }

@@ -257,6 +257,7 @@ extern "C" int rl_loss_forward(const float* logits, const int64_t* labels, int B
     const int nslots = rl_row_blocks_host((long)B * N, LS_ROWS);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(nslots), dim3(256), 0, st, logits, labels, B, C, N, kind, gamma, work);
+    rl_note_kernel("loss_fwd_kernel");
     RL_LAUNCH_CHECK("rl_loss_forward");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, work, nslots, B, C, N, kind, alpha, gamma,
                        neglect_background, out);
@@ -276,6 +277,7 @@ extern "C" int rl_loss_backward(const float* logits, const int64_t* labels, int 
     const double* totals = work + (long)RL_MAX_SLOTS * (5 * C + 1);
     hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels, B, C, N, kind,
                        alpha, gamma, neglect_background, totals, grad_scale, dlogits);
+    rl_note_kernel("loss_bwd_kernel");
     RL_LAUNCH_CHECK("rl_loss_backward");
     return RL_OK;
 }
@@ -301,6 +303,7 @@ extern "C" int rl_adam_step(float* param, const float* grad, float* exp_avg, flo
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((int)g), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, (long)n, lr,
                        beta1, beta2, eps, grad_scale, step);
+    rl_note_kernel("adam_kernel");
     RL_LAUNCH_CHECK("rl_adam_step");
     return RL_OK;
 }

@@ -10,7 +10,11 @@ void rl_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local const char* g_kernel = "";
+void rl_note_kernel(const char* name) { g_kernel = name; }
+
 extern "C" const char* rl_last_error(void) { return g_err; }
+extern "C" const char* rl_last_kernel(void) { return g_kernel; }
 extern "C" int rl_version(void) { return RL_VERSION; }
 extern "C" int rl_row_blocks(int64_t rows, int rows_per_tile) {
     return rl_row_blocks_host(rows, rows_per_tile);

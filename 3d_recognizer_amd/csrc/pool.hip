@@ -379,6 +379,7 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1>), dim3(g), dim3(256), 0, st, p);
     else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2>), dim3(g), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((pool_fwd_kernel<4>), dim3(g), dim3(256), 0, st, p);
+    rl_note_kernel(p.d == 16 ? "pool_fwd_kernel<1>" : p.d == 32 ? "pool_fwd_kernel<2>" : "pool_fwd_kernel<4>");
     RL_LAUNCH_CHECK("rl_pool_fwd");
     return RL_OK;
 }
@@ -393,6 +394,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1>), dim3(g), dim3(256), 0, st, p);
     else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2>), dim3(g), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((pool_bwd_kernel<4>), dim3(g), dim3(256), 0, st, p);
+    rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1>" : p.d == 32 ? "pool_bwd_kernel<2>" : "pool_bwd_kernel<4>");
     RL_LAUNCH_CHECK("rl_pool_bwd");
     hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
     RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");

@@ -9,6 +9,8 @@
 
 // ---- error plumbing ---------------------------------------------------------------------
 void rl_set_error(const char* fmt, ...);
+// remembers the (main) kernel function an entry point dispatched to; read back by rl_last_kernel()
+void rl_note_kernel(const char* name);
 
 #define RL_REQUIRE(cond, code, ...)      \
     do {                                 \

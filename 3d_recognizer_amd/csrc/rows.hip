@@ -234,6 +234,7 @@ extern "C" int rl_copy_rows(const rl_rows_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (v4) hipLaunchKernelGGL((copy_rows_kernel<4>), dim3(grid_for(p.rows * (p.C / 4))), dim3(256), 0, st, p);
     else    hipLaunchKernelGGL((copy_rows_kernel<1>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
+    rl_note_kernel("copy_rows_kernel");
     RL_LAUNCH_CHECK("rl_copy_rows");
     return RL_OK;
 }
@@ -246,6 +247,7 @@ extern "C" int rl_scatter_add_rows(const rl_rows_desc* d, void* stream) {
     RL_REQUIRE(p.lazy.scale == nullptr, RL_ERR_ARGS, "rl_scatter_add_rows: no lazy transform here");
     if (p.rows == 0) return RL_OK;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(p.rows * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    rl_note_kernel("scatter_add_rows_kernel");
     RL_LAUNCH_CHECK("rl_scatter_add_rows");
     return RL_OK;
 }
@@ -254,6 +256,7 @@ extern "C" int rl_attpool_fwd(const float* X, const float* S, int64_t P, int K, 
     RL_REQUIRE(X && S && Pout && P >= 0 && K > 0 && C > 0, RL_ERR_ARGS, "rl_attpool_fwd: bad arguments");
     if (P == 0) return RL_OK;
     hipLaunchKernelGGL(attpool_fwd_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, (long)P, K, C, Pout);
+    rl_note_kernel("attpool_fwd_kernel");
     RL_LAUNCH_CHECK("rl_attpool_fwd");
     return RL_OK;
 }
@@ -264,6 +267,7 @@ extern "C" int rl_attpool_bwd(const float* X, const float* S, const float* Pout,
     if (P == 0) return RL_OK;
     hipLaunchKernelGGL(attpool_bwd_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, Pout, dP,
                        (long)P, K, C, dS, dXa);
+    rl_note_kernel("attpool_bwd_kernel");
     RL_LAUNCH_CHECK("rl_attpool_bwd");
     return RL_OK;
 }
@@ -274,6 +278,7 @@ extern "C" int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1,
     if (rows == 0) return RL_OK;
     hipLaunchKernelGGL(add_act_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
                        s2, b2, (long)rows * C, C, slope, O);
+    rl_note_kernel("add_act_fwd_kernel");
     RL_LAUNCH_CHECK("rl_add_act_fwd");
     return RL_OK;
 }
@@ -283,6 +288,7 @@ extern "C" int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, flo
     if (rows == 0) return RL_OK;
     hipLaunchKernelGGL(add_act_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, G, O,
                        (long)rows * C, slope);
+    rl_note_kernel("add_act_bwd_kernel");
     RL_LAUNCH_CHECK("rl_add_act_bwd");
     return RL_OK;
 }

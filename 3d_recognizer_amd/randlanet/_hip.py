@@ -108,6 +108,7 @@ class RowsDesc(C.Structure):
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGNATURES = {
     "rl_last_error": (C.c_char_p, []),
+    "rl_last_kernel": (C.c_char_p, []),
     "rl_version": (_i, []),
     "rl_row_blocks": (_i, [_l, _i]),
     "rl_knn_workspace_bytes": (_l, [_i, _i, _i, _i]),

@@ -71,7 +71,7 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for cat, key, nbytes, flops, e0, e1 in self.records:
+        for cat, key, nbytes, flops, e0, e1, _kern in self.records:
             a = agg.setdefault((cat, key), dict(category=cat, shape=key, launches=0, ms=0.0, bytes=0, flops=0))
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
@@ -109,7 +109,8 @@ class _rec:
         if TIMER is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            TIMER.records.append(self.args + (self.e0, e1))
+            kern = H.lib().rl_last_kernel().decode()
+            TIMER.records.append(self.args + (self.e0, e1, kern))
         return False
 
 

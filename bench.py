@@ -100,11 +100,19 @@ def cpu_baseline(steps=2, B=2):
                        "+ single-threaded exact C KNN (oracle/knn_oracle.c)")
 
 
+MFMA_KERNELS = ("pgemm_kernel", "pwgrad", "wgrad_kernel", "sgemm_kernel", "swgrad_kernel", "gemm_kernel", "pool_fwd_kernel",
+                "pool_bwd_kernel")
+
+
 def roofline_pass(stepper, eager_steps=3):
-    """Instrumented eager steps: HIP events around every launch, on the launch stream.  Per kernel
-    shape the MEDIAN launch duration is used (robust against a stray host hiccup between two events).
-    The reported kernel is the one with the largest share of the step; its bound follows its arithmetic
-    intensity against the ridge point (157.3 TFLOP/s fp32 MFMA / 8 TB/s = 19.7 flop/B)."""
+    """Instrumented eager steps: HIP events around every launch, on the launch stream.
+
+    Launches are grouped the way `rocprofv3 --kernel-trace --stats` groups them - by kernel FUNCTION
+    (librandla_hip reports which one each entry point dispatched to) - so the numbers can be held against the
+    committed rocprof summary.  The DOMINANT kernel is the function with the largest share of the step.  Its
+    `achieved` = algorithmic bytes (or flops) of its launches / their measured time, i.e. per-launch average over
+    per-launch average; its bound follows its arithmetic intensity against the ridge point
+    (157.3 TFLOP/s fp32 MFMA / 8 TB/s = 19.7 flop/B).  Per shape the median over the eager steps is used."""
     from randlanet import _ops as ops
     ops.TIMER = ops.KernelTimer()
     g_main, g_adam = stepper._g_main, stepper._g_adam
@@ -118,47 +126,55 @@ def roofline_pass(stepper, eager_steps=3):
         ops.TIMER = None
         stepper._g_main, stepper._g_adam = g_main, g_adam
     shapes = {}
-    for cat, key, nbytes, flops, e0, e1 in records:
-        a = shapes.setdefault((cat, key), dict(category=cat, shape=key, times=[], bytes=nbytes, flops=flops))
+    for cat, key, nbytes, flops, e0, e1, kern in records:
+        a = shapes.setdefault((kern, cat, key), dict(kernel=kern, category=cat, shape=key, times=[], bytes=nbytes, flops=flops))
         a["times"].append(e0.elapsed_time(e1))
     rows = []
     for a in shapes.values():
         per_launch = float(np.median(a["times"]))
         launches = len(a["times"]) / eager_steps
-        rows.append(dict(category=a["category"], shape=a["shape"], ms_per_launch=per_launch, launches_per_step=launches,
-                         ms_per_step=per_launch * launches, bytes=a["bytes"], flops=a["flops"]))
+        rows.append(dict(kernel=a["kernel"], category=a["category"], shape=a["shape"], ms_per_launch=per_launch,
+                         launches_per_step=launches, ms_per_step=per_launch * launches, bytes=a["bytes"], flops=a["flops"]))
     rows.sort(key=lambda r: -r["ms_per_step"])
     total_ms = sum(r["ms_per_step"] for r in rows)
-    top = rows[0]
-    secs = top["ms_per_launch"] * 1e-3
+    funcs = {}
+    for r in rows:
+        f = funcs.setdefault(r["kernel"], dict(ms=0.0, launches=0.0, bytes=0.0, flops=0.0))
+        f["ms"] += r["ms_per_step"]; f["launches"] += r["launches_per_step"]
+        f["bytes"] += r["bytes"] * r["launches_per_step"]; f["flops"] += r["flops"] * r["launches_per_step"]
+    name, top = max(funcs.items(), key=lambda kv: kv[1]["ms"])
+    secs = top["ms"] * 1e-3
     ai = top["flops"] / max(top["bytes"], 1)
-    mfma_kernel = top["category"] in ("gemm", "wgrad", "pool_fwd", "pool_bwd")   # KNN's distance math is VALU, never MFMA
-    if mfma_kernel and ai > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+    if name.startswith(MFMA_KERNELS) and ai > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
         achieved, peak, unit, bound = top["flops"] / secs / 1e12, F32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
     else:
         achieved, peak, unit, bound = top["bytes"] / secs / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-    roof = dict(bound=bound, kernel=f"{top['category']}{list(top['shape'])}", achieved=round(achieved, 2), peak=peak,
-                unit=unit, frac=round(achieved / peak, 5), traffic=None, bytes_per_launch=int(top["bytes"]),
-                flops_per_launch=int(top["flops"]), ms_per_launch=round(top["ms_per_launch"], 4),
-                launches_per_step=top["launches_per_step"], share_of_step=round(top["ms_per_step"] / total_ms, 3))
+    big = max((r for r in rows if r["kernel"] == name), key=lambda r: r["ms_per_step"])
+    roof = dict(bound=bound, kernel=name, achieved=round(achieved, 2), peak=peak, unit=unit,
+                frac=round(achieved / peak, 5), traffic=None,
+                avg_launch_us=round(1e3 * top["ms"] / top["launches"], 2), launches_per_step=round(top["launches"], 1),
+                bytes_per_launch=int(top["bytes"] / top["launches"]), flops_per_launch=int(top["flops"] / top["launches"]),
+                share_of_step=round(top["ms"] / total_ms, 3),
+                largest_shape=dict(op=f"{big['category']}{list(big['shape'])}", us_per_launch=round(1e3 * big["ms_per_launch"], 1),
+                                   TFLOPs=round(big["flops"] / max(big["ms_per_launch"], 1e-9) / 1e9, 2),
+                                   GBps=round(big["bytes"] / max(big["ms_per_launch"], 1e-9) / 1e6, 1)))
     pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            roof["traffic"] = json.load(open(pmc)).get(roof["kernel"])
+            t = json.load(open(pmc)).get(roof["largest_shape"]["op"])
+            if t is not None:
+                roof["traffic"] = t
+                roof["traffic_shape"] = roof["largest_shape"]["op"]
         except Exception:
             pass
-    by_cat = {}
-    for r in rows:
-        c = by_cat.setdefault(r["category"], dict(ms=0.0, launches=0.0, bytes=0.0, flops=0.0))
-        c["ms"] += r["ms_per_step"]; c["launches"] += r["launches_per_step"]
-        c["bytes"] += r["bytes"] * r["launches_per_step"]; c["flops"] += r["flops"] * r["launches_per_step"]
     breakdown = dict(step_kernel_ms=round(total_ms, 3),
-                     categories={k: dict(ms_per_step=round(v["ms"], 3), launches_per_step=round(v["launches"], 1),
-                                         GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
-                                         TFLOPs=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2))
-                                 for k, v in sorted(by_cat.items(), key=lambda kv: -kv[1]["ms"])},
-                     top_shapes=[dict(kernel=f"{r['category']}{list(r['shape'])}", ms_per_step=round(r["ms_per_step"], 3),
-                                      launches_per_step=r["launches_per_step"],
+                     kernels={k: dict(ms_per_step=round(v["ms"], 3), launches_per_step=round(v["launches"], 1),
+                                      avg_launch_us=round(1e3 * v["ms"] / max(v["launches"], 1e-9), 1),
+                                      GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                      TFLOPs=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2))
+                              for k, v in sorted(funcs.items(), key=lambda kv: -kv[1]["ms"])},
+                     top_shapes=[dict(kernel=r["kernel"], op=f"{r['category']}{list(r['shape'])}",
+                                      ms_per_step=round(r["ms_per_step"], 3), launches_per_step=r["launches_per_step"],
                                       GBps=round(r["bytes"] / max(r["ms_per_launch"], 1e-9) / 1e6, 1),
                                       TFLOPs=round(r["flops"] / max(r["ms_per_launch"], 1e-9) / 1e9, 2)) for r in rows[:80]])
     return roof, breakdown

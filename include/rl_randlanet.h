@@ -60,6 +60,9 @@ extern "C" {
 #define RL_KNN_MAX_K 64
 
 const char* rl_last_error(void);
+/* name of the main kernel function the last entry point dispatched to on this thread (profiling aid:
+ * matches the kernel names of a rocprofv3 trace) */
+const char* rl_last_kernel(void);
 int rl_version(void);
 
 /* Number of partial-statistics slots a row-streaming kernel writes for `rows` rows:
