@@ -73,7 +73,7 @@ struct BwdParams {
 
 __device__ __forceinline__ long row_off(const BwdParams& p, long R) {
     if (p.contig) return R * p.ld;
-    const int b = (int)(R / p.n);
+    const int b = (int)((unsigned)R / (unsigned)p.n);   // B * n < 2^31 (checked on the host)
     const int i = (int)(R - (long)b * p.n);
     return ((long)b * p.bstride + i) * p.ld;
 }
@@ -281,6 +281,7 @@ bool vec_ok(const BwdParams& p) {
 int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
     RL_REQUIRE(d && d->G && d->Y && d->B > 0 && d->n > 0 && d->C > 0 && d->C <= 1024, RL_ERR_ARGS, "%s: bad descriptor", who);
     RL_REQUIRE(d->ld >= d->C && d->bstride >= d->n, RL_ERR_ARGS, "%s: bad strides", who);
+    RL_REQUIRE((int64_t)d->B * d->n < (1l << 31), RL_ERR_ARGS, "%s: too many rows", who);
     p->G = d->G; p->Y = d->Y; p->ld = d->ld; p->bstride = d->bstride; p->n = d->n; p->C = d->C;
     p->M = (long)d->B * d->n; p->contig = d->bstride == d->n;
     p->act = d->act; p->slope = d->slope; p->scale = d->scale; p->shift = d->shift;

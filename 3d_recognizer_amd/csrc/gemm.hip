@@ -43,7 +43,7 @@ struct AOperand {
 
 __device__ __forceinline__ long a_row_offset(const AOperand& a, long R) {
     if (a.contig) return R * a.lda;
-    const int b = (int)(R / a.n);
+    const int b = (int)((unsigned)R / (unsigned)a.n);   // R < 2^31 (fill_a)
     const int i = (int)(R - (long)b * a.n);
     return ((long)b * a.a_bstride + i) * a.lda;
 }
@@ -61,8 +61,8 @@ __device__ __forceinline__ void stage_a(const AOperand& a, long row0, int nrows,
 #pragma unroll
             for (int c = 0; c < 10; ++c) v[c] = 0.f;
             if (R < row_limit) {
-                const long p = R / a.nbr_k;
-                const int b = (int)(p / a.n);
+                const long p = (unsigned)R / (unsigned)a.nbr_k;
+                const int b = (int)((unsigned)p / (unsigned)a.n);
                 const int i = (int)(p - (long)b * a.n);
                 const int j = a.nbr_idx[R];
                 const float* xb = a.xyz + (long)b * a.xyz_bstride * 3;
@@ -126,6 +126,7 @@ struct GemmParams {
     int ksplit;        // > 1: blockIdx.z owns a K range and writes raw partial tiles to kslab
     int kchunk;        // K range per split (multiple of 32)
     float* kslab;      // [ksplit][M][N]
+    int stat_slots;    // slots the finalize kernel reads; a smaller grid zero-fills the rest
 };
 
 template <int NT>
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                     long yoff;
                     if (p.y_contig) yoff = R * p.ldy;
                     else {
-                        const int b = (int)(R / p.rows_per_batch);
+                        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                         const int i = (int)(R - (long)b * p.rows_per_batch);
                         yoff = ((long)b * p.y_bstride + i) * p.ldy;
                     }
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
                 long off;
                 if (p.dy_contig) off = R * p.lddy;
                 else {
-                    const int b = (int)(R / p.rows_per_batch);
+                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                     const int i = (int)(R - (long)b * p.rows_per_batch);
                     off = ((long)b * p.dy_bstride + i) * p.lddy;
                 }
@@ -452,9 +453,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
     const float slope = p.a.lazy.slope;
 
     const long nblk = (M + 15) >> 4;
-    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+    const long bstep = (long)gridDim.x * 4;
+    // the rows of the wavefront's next 16-row block are requested before the MFMAs of the current one
+    auto fetch = [&](long blk, float4 (&a)[KC]) {
         const long row = blk * 16 + li;
-        float4 a[KC];
         const bool rvalid = row < M;
         const long aoff = rvalid ? a_row_offset(p.a, row) : 0;
 #pragma unroll
@@ -462,6 +464,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
             a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rvalid && 16 * c + 4 * lj < K) a[c] = *reinterpret_cast<const float4*>(p.a.A + aoff + 16 * c + 4 * lj);
         }
+    };
+    float4 a[KC], an[KC];
+    long blk = (long)blockIdx.x * 4 + wave;
+    if (blk < nblk) fetch(blk, a);
+    for (; blk < nblk; blk += bstep) {
+        const bool rvalid = blk * 16 + li < M;
+        if (blk + bstep < nblk) fetch(blk + bstep, an);
         f32x4 acc[NT];
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -485,7 +494,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
                 long yoff;
                 if (p.y_contig) yoff = R * p.ldy;
                 else {
-                    const int b = (int)(R / p.rows_per_batch);
+                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                     const int i = (int)(R - (long)b * p.rows_per_batch);
                     yoff = ((long)b * p.y_bstride + i) * p.ldy;
                 }
@@ -502,6 +511,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < KC; ++c) a[c] = an[c];
     }
     if (p.stats) {
 #pragma unroll
@@ -518,6 +529,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
         if (tid < 16 * NT && tid < N) {
             p.stats[((long)blockIdx.x * 2 + 0) * N + tid] = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
             p.stats[((long)blockIdx.x * 2 + 1) * N + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+            for (long slot = blockIdx.x + gridDim.x; slot < p.stat_slots; slot += gridDim.x) {
+                p.stats[(slot * 2 + 0) * N + tid] = 0.0;
+                p.stats[(slot * 2 + 1) * N + tid] = 0.0;
+            }
         }
     }
 }
@@ -551,8 +566,9 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
         for (int kb = 0; kb < KT; ++kb) acc[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    for (long base = r_begin + (long)wave * 4 * SW_U; base < r_end; base += 16 * SW_U) {
-        float dy[SW_U][NT], av[SW_U][KT];
+    // one wavefront-iteration = 4*SW_U rows; the loads of iteration i+1 are issued before the MFMAs of
+    // iteration i (register double buffer), so each wavefront keeps two iterations of HBM requests in flight
+    auto fetch = [&](long base, float (&dy)[SW_U][NT], float (&av)[SW_U][KT]) {
 #pragma unroll
         for (int u = 0; u < SW_U; ++u) {
             const long R = base + u * 4 + lr;
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
             if (valid) {
                 if (p.dy_contig) doff = R * p.lddy;
                 else {
-                    const int b = (int)(R / p.rows_per_batch);
+                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                     const int i = (int)(R - (long)b * p.rows_per_batch);
                     doff = ((long)b * p.dy_bstride + i) * p.lddy;
                 }
@@ -577,8 +593,8 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
                 if (valid && lc < 10) {
                     if (lc == 9) v = __fsqrt_rn(a.nbr_d2[R]);
                     else {
-                        const long pt = R / a.nbr_k;
-                        const int b = (int)(pt / a.n);
+                        const long pt = (unsigned)R / (unsigned)a.nbr_k;
+                        const int b = (int)((unsigned)pt / (unsigned)a.n);
                         const int i = (int)(pt - (long)b * a.n);
                         const int ax = lc % 3;
                         const float* xb = a.xyz + (long)b * a.xyz_bstride * 3;
@@ -598,13 +614,20 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
 #pragma unroll
                 for (int kb = 0; kb < KT; ++kb) {
                     const int k = kb * 16 + lc;
-                    float v = 0.f;
-                    if (valid && k < K) {
-                        v = a.A[aoff + k];
-                        if (lazy) v = rl_act(v * sc[kb] + sh[kb], a.lazy.act, a.lazy.slope);
-                    }
-                    av[u][kb] = v;
+                    av[u][kb] = (valid && k < K) ? a.A[aoff + k] : 0.f;
                 }
+            }
+        }
+    };
+    auto consume = [&](long base, float (&dy)[SW_U][NT], float (&av)[SW_U][KT]) {
+        if (a.a_mode != 1 && lazy) {
+#pragma unroll
+            for (int u = 0; u < SW_U; ++u) {
+                const bool valid = base + u * 4 + lr < r_end;
+#pragma unroll
+                for (int kb = 0; kb < KT; ++kb)
+                    if (valid && kb * 16 + lc < K)
+                        av[u][kb] = rl_act(av[u][kb] * sc[kb] + sh[kb], a.lazy.act, a.lazy.slope);
             }
         }
 #pragma unroll
@@ -616,6 +639,21 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
                 for (int kb = 0; kb < KT; ++kb)
                     acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dy[u][nb], av[u][kb], acc[nb][kb], 0, 0, 0);
             }
+    };
+    {
+        float dy0[SW_U][NT], av0[SW_U][KT], dy1[SW_U][NT], av1[SW_U][KT];
+        long base = r_begin + (long)wave * 4 * SW_U;
+        if (base < r_end) fetch(base, dy0, av0);
+        while (base < r_end) {
+            const long nb1 = base + 16 * SW_U;
+            if (nb1 < r_end) fetch(nb1, dy1, av1);
+            consume(base, dy0, av0);
+            if (nb1 >= r_end) break;
+            const long nb2 = nb1 + 16 * SW_U;
+            if (nb2 < r_end) fetch(nb2, dy0, av0);
+            consume(nb1, dy1, av1);
+            base = nb2;
+        }
     }
     // bias partials: lanes sharing a column (same lc) combine first
 #pragma unroll
@@ -671,6 +709,8 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
 // slab split for the streaming wgrad: one slab per workgroup
 void swgrad_split(long M, int* nsplit, long* rows_per_block) {
     long want = (M + 511) / 512;
+    const long fill = (M + 127) / 128 < 256 ? (M + 127) / 128 : 256;   // one workgroup per CU where the rows allow
+    if (want < fill) want = fill;
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
     long rpb = (M + want - 1) / want;
@@ -865,7 +905,7 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
                     long yoff;
                     if (p.y_contig) yoff = R * p.ldy;
                     else {
-                        const int b = (int)(R / p.rows_per_batch);
+                        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                         const int i = (int)(R - (long)b * p.rows_per_batch);
                         yoff = ((long)b * p.y_bstride + i) * p.ldy;
                     }
@@ -931,7 +971,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
                 long yoff;
                 if (p.y_contig) yoff = R * p.ldy;
                 else {
-                    const int b = (int)(R / p.rows_per_batch);
+                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                     const int i = (int)(R - (long)b * p.rows_per_batch);
                     yoff = ((long)b * p.y_bstride + i) * p.ldy;
                 }
@@ -1028,7 +1068,7 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(const WgradParams p) {
                     long off;
                     if (p.dy_contig) off = R * p.lddy;
                     else {
-                        const int b = (int)(R / p.rows_per_batch);
+                        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                         const int ii = (int)(R - (long)b * p.rows_per_batch);
                         off = ((long)b * p.dy_bstride + ii) * p.lddy;
                     }
@@ -1140,7 +1180,7 @@ __global__ __launch_bounds__(256) void pwgrad128_kernel(const WgradParams p) {
                     long off;
                     if (p.dy_contig) off = R * p.lddy;
                     else {
-                        const int b = (int)(R / p.rows_per_batch);
+                        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
                         const int ii = (int)(R - (long)b * p.rows_per_batch);
                         off = ((long)b * p.dy_bstride + ii) * p.lddy;
                     }
@@ -1237,10 +1277,15 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     p.accumulate = d->accumulate; p.stats = d->stats;
     const int gx = rl_row_blocks_host(p.a.M, GM_BM);
     hipStream_t st = (hipStream_t)stream;
+    p.stat_slots = gx;
     if (d->a_mode == 0 && p.a.vec4 && d->K <= 64 && d->N <= 64) {
-        if (d->K <= 16)      launch_sgemm<1>(d->N, gx, st, p);
-        else if (d->K <= 32) launch_sgemm<2>(d->N, gx, st, p);
-        else                 launch_sgemm<4>(d->N, gx, st, p);
+        // every wavefront first loads the whole weight matrix into registers: with >= 2048 weights per
+        // wavefront, fewer and longer-lived workgroups (two per CU) beat one 128-row tile per workgroup
+        int sg = gx;
+        if ((long)d->K * d->N >= 2048) sg = gx > 512 ? 512 : (gx > 256 ? 256 : gx);
+        if (d->K <= 16)      launch_sgemm<1>(d->N, sg, st, p);
+        else if (d->K <= 32) launch_sgemm<2>(d->N, sg, st, p);
+        else                 launch_sgemm<4>(d->N, sg, st, p);
         rl_note_kernel("sgemm_kernel");
         RL_LAUNCH_CHECK("rl_gemm(stream)");
         return RL_OK;

@@ -77,7 +77,7 @@ __device__ __forceinline__ void load_x(const PoolParams& p, long pt, int li, int
                                        float* Xs) {
     constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
     const long row = pt * 16 + li;
-    const long b = pt / p.n;
+    const long b = (unsigned)pt / (unsigned)p.n;   // points * 16 < 2^31 (checked on the host)
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
 
     for (long pt = (long)blockIdx.x * 4 + wave; pt < p.P; pt += (long)gridDim.x * 4) {
         const int my_idx = p.idx[pt * 16 + li];
-        const long b = pt / p.n;
+        const long b = (unsigned)pt / (unsigned)p.n;   // points * 16 < 2^31 (checked on the host)
         float4 xa[DT];
         load_x<DT>(p, pt, li, lj, my_idx, sc, sh, xa, Xs);
         f32x4 a[DT];
@@ -351,6 +351,7 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     RL_REQUIRE(d->nbr_k == 16, RL_ERR_UNSUPPORTED, "%s: the fused kernel needs 16 neighbours (got %d)", who, d->nbr_k);
     RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64, RL_ERR_UNSUPPORTED, "%s: d must be 16, 32 or 64 (got %d)", who, d->d);
     RL_REQUIRE(d->g_bstride >= d->n && d->points % d->n == 0, RL_ERR_ARGS, "%s: bad cloud geometry", who);
+    RL_REQUIRE((int64_t)d->points * 16 < (1l << 31), RL_ERR_ARGS, "%s: too many neighbourhood rows", who);
     RL_REQUIRE(((uintptr_t)d->U & 15) == 0 && ((uintptr_t)d->G & 15) == 0, RL_ERR_ARGS, "%s: U/G must be 16-byte aligned", who);
     RL_REQUIRE((d->u_scale == nullptr) == (d->u_shift == nullptr) && (d->g_scale == nullptr) == (d->g_shift == nullptr),
                RL_ERR_ARGS, "%s: scale/shift must come together", who);

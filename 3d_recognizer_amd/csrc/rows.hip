@@ -27,25 +27,28 @@ struct RowsParams {
     RlLazy lazy;
 };
 
-__device__ __forceinline__ long src_row(const RowsParams& p, long r) {
-    const long b = r / p.rows_per_batch;
-    const long i = r - b * p.rows_per_batch;
+// I = uint32_t when the element count fits 32 bits (64-bit integer division is emulated with
+// ~100 instructions on CDNA; two of them per 16 bytes moved made these kernels ALU-bound), else int64_t
+template <typename I>
+__device__ __forceinline__ long src_row(const RowsParams& p, I r) {
+    const I b = r / (I)p.rows_per_batch;
+    const I i = r - b * (I)p.rows_per_batch;
     long j = i;
     if (p.i32) j = p.shared ? p.i32[i] : p.i32[r];
     else if (p.i64) j = p.shared ? p.i64[i] : p.i64[r];
-    return b * p.src_bstride + j;
+    return (long)b * p.src_bstride + j;
 }
 
 // one thread per (row, channel quad) when C % 4 == 0 and pointers allow, else per element
-template <int VEC>
+template <int VEC, typename I>
 __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
     const int cpr = p.C / VEC;  // chunks per row
     const long total = p.rows * cpr;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long r = e / cpr;
-        const int c = (int)(e - r * cpr) * VEC;
-        const long so = src_row(p, r) * p.lds + c;
-        const long dofs = r * p.ldd + c;
+        const I r = (I)e / (I)cpr;
+        const int c = (int)((I)e - r * (I)cpr) * VEC;
+        const long so = src_row<I>(p, r) * p.lds + c;
+        const long dofs = (long)r * p.ldd + c;
         if (VEC == 4) {
             float4 v = *reinterpret_cast<const float4*>(p.src + so);
             if (p.lazy.scale) {
@@ -69,13 +72,14 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
 }
 
 // dst[(b*dst_bstride + index[r])*ldd + c] += src[r*lds + c]
+template <typename I>
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const RowsParams p) {
     const long total = p.rows * p.C;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long r = e / p.C;
-        const int c = (int)(e - r * p.C);
-        const long drow = src_row(p, r);  // the index addresses the destination here
-        atomicAdd(p.dst + drow * p.ldd + c, p.src[r * p.lds + c]);
+        const I r = (I)e / (I)p.C;
+        const int c = (int)((I)e - r * (I)p.C);
+        const long drow = src_row<I>(p, r);  // the index addresses the destination here
+        atomicAdd(p.dst + drow * p.ldd + c, p.src[(long)r * p.lds + c]);
     }
 }
 
@@ -90,6 +94,8 @@ int fill(RowsParams* p, const rl_rows_desc* d, const char* who) {
     return RL_OK;
 }
 
+inline bool fits32(long elements) { return elements < (1l << 32); }
+
 int grid_for(long work) {
     long g = (work + 255) / 256;
     if (g < 1) g = 1;
@@ -98,11 +104,12 @@ int grid_for(long work) {
 
 // ---------------------------------------------------------------------- attentive pooling
 // thread = (point, channel); the K rows of a point are K*C floats apart by C
+template <typename I>
 __global__ __launch_bounds__(256) void attpool_fwd_kernel(const float* __restrict__ X, const float* __restrict__ S,
                                                           long P, int K, int C, float* __restrict__ Pout) {
     const long total = P * C;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long pt = e / C;
+        const long pt = (long)((I)e / (I)C);
         const int c = (int)(e - pt * C);
         const float* s = S + pt * K * C + c;
         const float* x = X + pt * K * C + c;
@@ -118,13 +125,14 @@ __global__ __launch_bounds__(256) void attpool_fwd_kernel(const float* __restric
     }
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ S,
                                                           const float* __restrict__ Pout, const float* __restrict__ dP,
                                                           long P, int K, int C, float* __restrict__ dS,
                                                           float* __restrict__ dXa) {
     const long total = P * C;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const long pt = e / C;
+        const long pt = (long)((I)e / (I)C);
         const int c = (int)(e - pt * C);
         const long base = pt * K * C + c;
         float m = S[base];
@@ -141,12 +149,13 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restric
     }
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void add_act_fwd_kernel(const float* __restrict__ Y1, const float* __restrict__ s1,
                                                           const float* __restrict__ b1, const float* __restrict__ Y2,
                                                           const float* __restrict__ s2, const float* __restrict__ b2,
                                                           long total, int C, float slope, float* __restrict__ O) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int c = (int)(e % C);
+        const int c = (int)((I)e % (I)C);
         const float z = (Y1[e] * s1[c] + b1[c]) + (Y2[e] * s2[c] + b2[c]);
         O[e] = z > 0.f ? z : z * slope;
     }
@@ -232,8 +241,11 @@ extern "C" int rl_copy_rows(const rl_rows_desc* d, void* stream) {
     const bool v4 = (p.C % 4 == 0) && (p.lds % 4 == 0) && (p.ldd % 4 == 0) &&
                     (((uintptr_t)p.src & 15) == 0) && (((uintptr_t)p.dst & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (v4) hipLaunchKernelGGL((copy_rows_kernel<4>), dim3(grid_for(p.rows * (p.C / 4))), dim3(256), 0, st, p);
-    else    hipLaunchKernelGGL((copy_rows_kernel<1>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
+    const bool small = fits32(p.rows * p.C) && fits32(p.rows_per_batch);
+    if (v4 && small)  hipLaunchKernelGGL((copy_rows_kernel<4, uint32_t>), dim3(grid_for(p.rows * (p.C / 4))), dim3(256), 0, st, p);
+    else if (v4)      hipLaunchKernelGGL((copy_rows_kernel<4, int64_t>), dim3(grid_for(p.rows * (p.C / 4))), dim3(256), 0, st, p);
+    else if (small)   hipLaunchKernelGGL((copy_rows_kernel<1, uint32_t>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
+    else              hipLaunchKernelGGL((copy_rows_kernel<1, int64_t>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
     rl_note_kernel("copy_rows_kernel");
     RL_LAUNCH_CHECK("rl_copy_rows");
     return RL_OK;
@@ -246,7 +258,10 @@ extern "C" int rl_scatter_add_rows(const rl_rows_desc* d, void* stream) {
     RL_REQUIRE(p.i32 || p.i64, RL_ERR_ARGS, "rl_scatter_add_rows: needs an index");
     RL_REQUIRE(p.lazy.scale == nullptr, RL_ERR_ARGS, "rl_scatter_add_rows: no lazy transform here");
     if (p.rows == 0) return RL_OK;
-    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(p.rows * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    if (fits32(p.rows * p.C) && fits32(p.rows_per_batch))
+        hipLaunchKernelGGL(scatter_add_rows_kernel<uint32_t>, dim3(grid_for(p.rows * p.C)), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(scatter_add_rows_kernel<int64_t>, dim3(grid_for(p.rows * p.C)), dim3(256), 0, (hipStream_t)stream, p);
     rl_note_kernel("scatter_add_rows_kernel");
     RL_LAUNCH_CHECK("rl_scatter_add_rows");
     return RL_OK;
@@ -255,7 +270,10 @@ extern "C" int rl_scatter_add_rows(const rl_rows_desc* d, void* stream) {
 extern "C" int rl_attpool_fwd(const float* X, const float* S, int64_t P, int K, int C, float* Pout, void* stream) {
     RL_REQUIRE(X && S && Pout && P >= 0 && K > 0 && C > 0, RL_ERR_ARGS, "rl_attpool_fwd: bad arguments");
     if (P == 0) return RL_OK;
-    hipLaunchKernelGGL(attpool_fwd_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, (long)P, K, C, Pout);
+    if (fits32(P * C))
+        hipLaunchKernelGGL(attpool_fwd_kernel<uint32_t>, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, (long)P, K, C, Pout);
+    else
+        hipLaunchKernelGGL(attpool_fwd_kernel<int64_t>, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, (long)P, K, C, Pout);
     rl_note_kernel("attpool_fwd_kernel");
     RL_LAUNCH_CHECK("rl_attpool_fwd");
     return RL_OK;
@@ -265,8 +283,12 @@ extern "C" int rl_attpool_bwd(const float* X, const float* S, const float* Pout,
                               int C, float* dS, float* dXa, void* stream) {
     RL_REQUIRE(X && S && Pout && dP && dS && dXa && P >= 0 && K > 0 && C > 0, RL_ERR_ARGS, "rl_attpool_bwd: bad arguments");
     if (P == 0) return RL_OK;
-    hipLaunchKernelGGL(attpool_bwd_kernel, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, Pout, dP,
-                       (long)P, K, C, dS, dXa);
+    if (fits32(P * C))
+        hipLaunchKernelGGL(attpool_bwd_kernel<uint32_t>, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, Pout, dP,
+                           (long)P, K, C, dS, dXa);
+    else
+        hipLaunchKernelGGL(attpool_bwd_kernel<int64_t>, dim3(grid_for(P * C)), dim3(256), 0, (hipStream_t)stream, X, S, Pout, dP,
+                           (long)P, K, C, dS, dXa);
     rl_note_kernel("attpool_bwd_kernel");
     RL_LAUNCH_CHECK("rl_attpool_bwd");
     return RL_OK;
@@ -276,8 +298,12 @@ extern "C" int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1,
                               const float* b2, int64_t rows, int C, float slope, float* O, void* stream) {
     RL_REQUIRE(Y1 && s1 && b1 && Y2 && s2 && b2 && O && rows >= 0 && C > 0, RL_ERR_ARGS, "rl_add_act_fwd: bad arguments");
     if (rows == 0) return RL_OK;
-    hipLaunchKernelGGL(add_act_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
-                       s2, b2, (long)rows * C, C, slope, O);
+    if (fits32(rows * C))
+        hipLaunchKernelGGL(add_act_fwd_kernel<uint32_t>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
+                           s2, b2, (long)rows * C, C, slope, O);
+    else
+        hipLaunchKernelGGL(add_act_fwd_kernel<int64_t>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
+                           s2, b2, (long)rows * C, C, slope, O);
     rl_note_kernel("add_act_fwd_kernel");
     RL_LAUNCH_CHECK("rl_add_act_fwd");
     return RL_OK;

@@ -9,6 +9,10 @@ from randlanet import _ops as ops
 
 SHAPES = [(163840, 128, 128), (40960, 256, 256), (10240, 128, 256), (2560, 512, 256), (640, 512, 512),
           (2560, 1024, 256), (10240, 256, 128), (655360, 64, 64), (2621440, 16, 16)]
+NARROW = [(2621440, 8, 8), (2621440, 16, 16), (655360, 32, 32), (655360, 16, 32), (163840, 64, 64), (163840, 32, 64),
+          (163840, 64, 32), (163840, 16, 64), (40960, 64, 64)]
+if os.environ.get("GB_NARROW"):
+    SHAPES = NARROW
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = "cuda"
 for (M, K, N) in SHAPES:
