@@ -744,17 +744,16 @@ void launch_swgrad(int N, dim3 grid, hipStream_t st, const WgradParams& p) {
 // W rows BN+16 (stride % 32 == 16: the two k rows of a half-wave read disjoint bank halves).
 // ===========================================================================================
 constexpr int PG_BK = 32;
-constexpr int PG_AS = 34;
+constexpr int PG_AS = 36;   // LDS row stride (floats): 16-byte aligned rows, 16 rows x b128 hit 64 distinct banks
 
 template <int NT>
-__global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     constexpr int BN = 16 * NT;
-    constexpr int WS = BN + ((BN % 32 == 0) ? 16 : 0);
-    constexpr int WQ_N = (PG_BK * BN / 4 + 255) / 256;   // float4 per lane, W rows contiguous in n
-    constexpr int WQ_K = (BN * 8 + 255) / 256;           // float4 per lane, W rows contiguous in k
-    constexpr int WQ = WQ_N > WQ_K ? WQ_N : WQ_K;
+    constexpr int WQ = (BN * 8 + 255) / 256;              // float4 of W per lane and chunk
+    // both operands sit in LDS with k contiguous ([row][k] and [n][k]); MFMA step s of a chunk takes
+    // k = 8*(lane>>4) + s from either, so a lane's eight values per operand tile are two ds_read_b128
     __shared__ __attribute__((aligned(16))) float As[GM_BM * PG_AS];
-    __shared__ __attribute__((aligned(16))) float Ws[PG_BK * WS];
+    __shared__ __attribute__((aligned(16))) float Wt[BN * PG_AS];
     __shared__ double red[4][2][BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -764,6 +763,8 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
     const long M = p.a.M;
     const long ntiles = (M + GM_BM - 1) / GM_BM;
     const bool lazy = p.a.lazy.scale != nullptr;
+    const bool relu = p.a.lazy.act == RL_ACT_RELU;
+    const float nslope = p.a.lazy.act == RL_ACT_NONE ? 1.f : p.a.lazy.slope;
     const bool w_ncontig = (p.w_ns == 1);
     const int aq = tid & 7;            // this lane's k-quad inside a chunk (same for its 4 rows)
 
@@ -796,17 +797,19 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
                 if (aval[i] && ka < K) ra[i] = *reinterpret_cast<const float4*>(p.a.A + aoff[i] + ka);
             }
             if (w_ncontig) {
+                // W[k][n], n contiguous: unit u = 16 columns x 16 k; lane (q = l&3, kl = l>>2) loads 4 columns of
+                // one k (16 B, four lanes cover 64 contiguous bytes) and writes them transposed (see commit)
 #pragma unroll
-                for (int i = 0; i < WQ_N; ++i) {
-                    const int e = tid + i * 256;
-                    const int kk = e / (BN / 4), q = e - kk * (BN / 4);
+                for (int i = 0; i < WQ; ++i) {
+                    const int u = i * 4 + wave;
+                    const int n4 = (u % NT) * 16 + (lane & 3) * 4, kk = k0 + (u / NT) * 16 + (lane >> 2);
                     rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < PG_BK * BN / 4 && k0 + kk < K && col0 + q * 4 < N)
-                        rw[i] = *reinterpret_cast<const float4*>(p.W + (long)(k0 + kk) * p.w_ks + col0 + q * 4);
+                    if (u < 2 * NT && col0 + n4 < N && kk < K)
+                        rw[i] = *reinterpret_cast<const float4*>(p.W + (long)kk * p.w_ks + col0 + n4);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < WQ_K; ++i) {
+                for (int i = 0; i < WQ; ++i) {
                     const int e = tid + i * 256;
                     const int n = e >> 3, q = e & 7;
                     rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -814,6 +817,10 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
                         rw[i] = *reinterpret_cast<const float4*>(p.W + (long)(col0 + n) * p.w_ns + k0 + q * 4);
                 }
             }
+        };
+        auto actf = [&](float z) {
+            const float neg = relu ? 0.f : z * nslope;
+            return z > 0.f ? z : neg;
         };
         auto commit = [&](int k0) {
             const int ka = k0 + aq * 4;
@@ -826,55 +833,76 @@ __global__ __launch_bounds__(256) void pgemm_kernel(const GemmParams p) {
             for (int i = 0; i < 4; ++i) {
                 float4 v = ra[i];
                 if (lazy && aval[i] && ka < K) {
-                    v.x = rl_act(v.x * sc.x + sh.x, p.a.lazy.act, p.a.lazy.slope);
-                    v.y = rl_act(v.y * sc.y + sh.y, p.a.lazy.act, p.a.lazy.slope);
-                    v.z = rl_act(v.z * sc.z + sh.z, p.a.lazy.act, p.a.lazy.slope);
-                    v.w = rl_act(v.w * sc.w + sh.w, p.a.lazy.act, p.a.lazy.slope);
+                    v.x = actf(v.x * sc.x + sh.x);
+                    v.y = actf(v.y * sc.y + sh.y);
+                    v.z = actf(v.z * sc.z + sh.z);
+                    v.w = actf(v.w * sc.w + sh.w);
                 }
-                float* dst = As + ((tid >> 3) + 32 * i) * PG_AS + aq * 4;
-                *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
-                *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+                *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * i) * PG_AS + aq * 4) = v;
             }
             if (w_ncontig) {
+                // transposed scalar writes: the 64 lanes of a store hit banks 16*(l&3) + (l>>2) + const, all distinct
 #pragma unroll
-                for (int i = 0; i < WQ_N; ++i) {
-                    const int e = tid + i * 256;
-                    const int kk = e / (BN / 4), q = e - kk * (BN / 4);
-                    if (e < PG_BK * BN / 4) *reinterpret_cast<float4*>(Ws + kk * WS + q * 4) = rw[i];
+                for (int i = 0; i < WQ; ++i) {
+                    const int u = i * 4 + wave;
+                    if (u < 2 * NT) {
+                        float* dst = Wt + ((u % NT) * 16 + (lane & 3) * 4) * PG_AS + (u / NT) * 16 + (lane >> 2);
+                        dst[0] = rw[i].x; dst[PG_AS] = rw[i].y; dst[2 * PG_AS] = rw[i].z; dst[3 * PG_AS] = rw[i].w;
+                    }
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < WQ_K; ++i) {
+                for (int i = 0; i < WQ; ++i) {
                     const int e = tid + i * 256;
                     const int n = e >> 3, q = e & 7;
-                    if (e < BN * 8) {
-                        Ws[(q * 4 + 0) * WS + n] = rw[i].x;
-                        Ws[(q * 4 + 1) * WS + n] = rw[i].y;
-                        Ws[(q * 4 + 2) * WS + n] = rw[i].z;
-                        Ws[(q * 4 + 3) * WS + n] = rw[i].w;
-                    }
+                    if (e < BN * 8) *reinterpret_cast<float4*>(Wt + n * PG_AS + q * 4) = rw[i];
                 }
             }
         };
 
         const int k_begin = (p.ksplit > 1) ? blockIdx.z * p.kchunk : 0;
         const int k_end = (p.ksplit > 1) ? min(K, k_begin + p.kchunk) : K;
+        const float* a_frag = As + (wave * 32 + lr) * PG_AS + lq * 8;
+        const float* w_frag = Wt + lr * PG_AS + lq * 8;
         fetch(k_begin);
         for (int k0 = k_begin; k0 < k_end; k0 += PG_BK) {
             __syncthreads();
             commit(k0);
             __syncthreads();
             if (k0 + PG_BK < k_end) fetch(k0 + PG_BK);
+            // A fragments of the whole chunk up front (4 x b128); W fragments in groups of GS column blocks,
+            // group g+1 requested before the 8*GS MFMAs of group g: LDS latency never waits on an idle pipe
+            constexpr int GS = NT < 2 ? NT : 2;
+            constexpr int GH = NT / GS;          // groups per half chunk
+            float4 af[2][2], bf[2][GS];
 #pragma unroll
-            for (int ks = 0; ks < PG_BK / 4; ++ks) {
-                const int kc = ks * 4 + lq;
-                const float a0 = As[(wave * 32 + lr) * PG_AS + kc];
-                const float a1 = As[(wave * 32 + 16 + lr) * PG_AS + kc];
+            for (int h = 0; h < 2; ++h) {
+                af[h][0] = *reinterpret_cast<const float4*>(a_frag + h * 4);
+                af[h][1] = *reinterpret_cast<const float4*>(a_frag + 16 * PG_AS + h * 4);
+            }
 #pragma unroll
-                for (int nb = 0; nb < NT; ++nb) {
-                    const float bv = Ws[kc * WS + nb * 16 + lr];
-                    acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][nb], 0, 0, 0);
-                    acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][nb], 0, 0, 0);
+            for (int j = 0; j < GS; ++j) bf[0][j] = *reinterpret_cast<const float4*>(w_frag + j * 16 * PG_AS);
+#pragma unroll
+            for (int g = 0; g < 2 * GH; ++g) {
+                const int h = g / GH, nb0 = (g % GH) * GS;
+                if (g + 1 < 2 * GH) {
+                    const int h1 = (g + 1) / GH, nb1 = ((g + 1) % GH) * GS;
+#pragma unroll
+                    for (int j = 0; j < GS; ++j)
+                        bf[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(w_frag + (nb1 + j) * 16 * PG_AS + h1 * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler would sink them)
+                const float a0[4] = {af[h][0].x, af[h][0].y, af[h][0].z, af[h][0].w};
+                const float a1[4] = {af[h][1].x, af[h][1].y, af[h][1].z, af[h][1].w};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int j = 0; j < GS; ++j) {
+                        const float4 b4 = bf[g & 1][j];
+                        const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
+                        acc[0][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bv, acc[0][nb0 + j], 0, 0, 0);
+                        acc[1][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv, acc[1][nb0 + j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1135,31 +1163,47 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(const WgradParams p) {
     if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
 }
 
-// Wide weight gradient with a 128 (n) x 128 (k) tile of dW per workgroup (both N and K >= 128): every
-// element of dY and A' is staged once per 128-wide slice instead of once per 64-wide one, i.e. the same
-// 128 MFMAs per wavefront per 32 KB staged as the forward kernel.  Wavefront w owns n-blocks 2w, 2w+1.
+// Wide weight gradient with a 128 (n) x 128 (k) tile of dW per workgroup (both N and K >= 128).  It is the
+// pgemm_kernel loop with the row as the reduction index: dW[n][k] = sum_r dY[r][n] * A'[r][k].  Chunks of 32
+// rows are staged TRANSPOSED in LDS ([n][row] and [k][row], stride 36), so that a lane's eight reduction
+// values per operand tile (rows 8*(lane>>4) .. +7) are two ds_read_b128; wavefront w owns n-blocks 2w, 2w+1.
+// Staging: lane (q = l&3, rl = l>>2) of unit u (16 columns x 16 rows) loads 4 columns of one row (four lanes
+// cover 64 contiguous bytes) and writes them as 4 scalars whose banks 16*q + rl + const are all distinct.
 constexpr int PW2_RB = 32;
 constexpr int PW2_T = 128;
-constexpr int PW2_S = 144;
+constexpr int PW2_S = 36;
 
-__global__ __launch_bounds__(256) void pwgrad128_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float dYs[PW2_RB * PW2_S];
-    __shared__ __attribute__((aligned(16))) float As[PW2_RB * PW2_S];
+__global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float dYt[PW2_T * PW2_S];
+    __shared__ __attribute__((aligned(16))) float At[PW2_T * PW2_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int N = p.N, K = p.a.K;
     const int n0 = blockIdx.y * PW2_T, k0 = blockIdx.z * PW2_T;
     const int nvalid = min(PW2_T, N - n0), kvalid = min(PW2_T, K - k0);
-    const int nkb = (kvalid + 15) >> 4;
-    const bool act0 = (2 * wave) * 16 < nvalid, act1 = (2 * wave + 1) * 16 < nvalid;
     const long r_begin = (long)blockIdx.x * p.rows_per_block;
     const long r_end = min(p.a.M, r_begin + p.rows_per_block);
-    const int q4 = (tid & 31) * 4;
     const bool lazy = p.a.lazy.scale != nullptr;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lazy && q4 < kvalid) {
-        sc = *reinterpret_cast<const float4*>(p.a.lazy.scale + k0 + q4);
-        sh = *reinterpret_cast<const float4*>(p.a.lazy.shift + k0 + q4);
+    const bool relu = p.a.lazy.act == RL_ACT_RELU;
+    const float nslope = p.a.lazy.act == RL_ACT_NONE ? 1.f : p.a.lazy.slope;
+    auto actf = [&](float z) {
+        const float neg = relu ? 0.f : z * nslope;
+        return z > 0.f ? z : neg;
+    };
+    // staging units of this lane: u = i*4 + wave -> columns (u%8)*16 + 4*(l&3), rows (u/8)*16 + (l>>2)
+    int ucol[4], urow[4];
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = i * 4 + wave;
+        ucol[i] = (u & 7) * 16 + (lane & 3) * 4;
+        urow[i] = (u >> 3) * 16 + (lane >> 2);
+        sc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lazy && ucol[i] < kvalid) {
+            sc[i] = *reinterpret_cast<const float4*>(p.a.lazy.scale + k0 + ucol[i]);
+            sh[i] = *reinterpret_cast<const float4*>(p.a.lazy.shift + k0 + ucol[i]);
+        }
     }
     f32x4 acc[2][8];
 #pragma unroll
@@ -1172,11 +1216,11 @@ __global__ __launch_bounds__(256) void pwgrad128_kernel(const WgradParams p) {
     auto fetch = [&](long r0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long R = r0 + (tid >> 5) + 8 * i;
+            const long R = r0 + urow[i];
             rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (R < r_end) {
-                if (q4 < nvalid) {
+                if (ucol[i] < nvalid) {
                     long off;
                     if (p.dy_contig) off = R * p.lddy;
                     else {
@@ -1184,50 +1228,72 @@ __global__ __launch_bounds__(256) void pwgrad128_kernel(const WgradParams p) {
                         const int ii = (int)(R - (long)b * p.rows_per_batch);
                         off = ((long)b * p.dy_bstride + ii) * p.lddy;
                     }
-                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + q4);
+                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + ucol[i]);
                 }
-                if (q4 < kvalid) {
-                    float4 v = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + q4);
-                    if (lazy) {
-                        v.x = rl_act(v.x * sc.x + sh.x, p.a.lazy.act, p.a.lazy.slope);
-                        v.y = rl_act(v.y * sc.y + sh.y, p.a.lazy.act, p.a.lazy.slope);
-                        v.z = rl_act(v.z * sc.z + sh.z, p.a.lazy.act, p.a.lazy.slope);
-                        v.w = rl_act(v.w * sc.w + sh.w, p.a.lazy.act, p.a.lazy.slope);
-                    }
-                    ra[i] = v;
-                }
+                if (ucol[i] < kvalid) ra[i] = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + ucol[i]);
             }
         }
     };
+    auto commit = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = ra[i];
+            if (lazy && r0 + urow[i] < r_end && ucol[i] < kvalid) {
+                v.x = actf(v.x * sc[i].x + sh[i].x);
+                v.y = actf(v.y * sc[i].y + sh[i].y);
+                v.z = actf(v.z * sc[i].z + sh[i].z);
+                v.w = actf(v.w * sc[i].w + sh[i].w);
+            }
+            float* dd = dYt + ucol[i] * PW2_S + urow[i];
+            dd[0] = rd[i].x; dd[PW2_S] = rd[i].y; dd[2 * PW2_S] = rd[i].z; dd[3 * PW2_S] = rd[i].w;
+            float* da = At + ucol[i] * PW2_S + urow[i];
+            da[0] = v.x; da[PW2_S] = v.y; da[2 * PW2_S] = v.z; da[3 * PW2_S] = v.w;
+        }
+    };
 
+    const float* n_frag = dYt + (wave * 32 + lr) * PW2_S + lq * 8;
+    const float* k_frag = At + lr * PW2_S + lq * 8;
     if (r_begin < r_end) fetch(r_begin);
     for (long r0 = r_begin; r0 < r_end; r0 += PW2_RB) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (tid >> 5) + 8 * i;
-            *reinterpret_cast<float4*>(dYs + r * PW2_S + q4) = rd[i];
-            *reinterpret_cast<float4*>(As + r * PW2_S + q4) = ra[i];
-        }
+        commit(r0);
         __syncthreads();
         if (r0 + PW2_RB < r_end) fetch(r0 + PW2_RB);
         if (p.has_bias && blockIdx.z == 0 && tid < PW2_T) {
-#pragma unroll 8
-            for (int r = 0; r < PW2_RB; ++r) bsum += dYs[r * PW2_S + tid];
+#pragma unroll
+            for (int j = 0; j < PW2_RB / 4; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(dYt + tid * PW2_S + j * 4);
+                bsum += (t.x + t.y) + (t.z + t.w);
+            }
         }
-        if (act0) {
+        float4 af[2][2], bf[2][2];
 #pragma unroll
-            for (int rs = 0; rs < PW2_RB / 4; ++rs) {
-                const int rr = rs * 4 + lq;
-                const float a0 = dYs[rr * PW2_S + (2 * wave) * 16 + lr];
-                const float a1 = dYs[rr * PW2_S + (2 * wave + 1) * 16 + lr];
+        for (int h = 0; h < 2; ++h) {
+            af[h][0] = *reinterpret_cast<const float4*>(n_frag + h * 4);
+            af[h][1] = *reinterpret_cast<const float4*>(n_frag + 16 * PW2_S + h * 4);
+        }
 #pragma unroll
-                for (int kb = 0; kb < 8; ++kb) {
-                    if (kb < nkb) {
-                        const float bv = As[rr * PW2_S + kb * 16 + lr];
-                        acc[0][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][kb], 0, 0, 0);
-                        acc[1][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][kb], 0, 0, 0);
-                    }
+        for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const float4*>(k_frag + j * 16 * PW2_S);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int h = g / 4, kb0 = (g % 4) * 2;
+            if (g + 1 < 8) {
+                const int h1 = (g + 1) / 4, kb1 = ((g + 1) % 4) * 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bf[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(k_frag + (kb1 + j) * 16 * PW2_S + h1 * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float a0[4] = {af[h][0].x, af[h][0].y, af[h][0].z, af[h][0].w};
+            const float a1[4] = {af[h][1].x, af[h][1].y, af[h][1].z, af[h][1].w};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 b4 = bf[g & 1][j];
+                    const float bv = s2 == 0 ? b4.x : s2 == 1 ? b4.y : s2 == 2 ? b4.z : b4.w;
+                    acc[0][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], bv, acc[0][kb0 + j], 0, 0, 0);
+                    acc[1][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], bv, acc[1][kb0 + j], 0, 0, 0);
                 }
             }
         }
@@ -1235,17 +1301,13 @@ __global__ __launch_bounds__(256) void pwgrad128_kernel(const WgradParams p) {
     float* out = p.slab + (long)blockIdx.x * ((long)N * K + N);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        if (i == 0 ? act0 : act1) {
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                if (kb < nkb) {
-                    const int k = k0 + kb * 16 + lr;
+        for (int kb = 0; kb < 8; ++kb) {
+            const int k = k0 + kb * 16 + lr;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = n0 + (2 * wave + i) * 16 + lq * 4 + r;
-                        if (n < N && k < K) out[(long)n * K + k] = acc[i][kb][r];
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + (2 * wave + i) * 16 + lq * 4 + r;
+                if (n < N && k < K) out[(long)n * K + k] = acc[i][kb][r];
             }
         }
     }
