@@ -38,7 +38,8 @@ struct AOperand {
     int K;
     long M;       // total rows
     int contig;   // mode 0: a_bstride == n
-    int vec4;     // mode 0: 16-byte loads allowed
+    int vec4;     // mode 0: 16-byte loads allowed (K % 4 == 0)
+    int vec4p;    // mode 0: 16-byte loads allowed up to K rounded up to 4 (the row padding exists: lda >= that)
 };
 
 __device__ __forceinline__ long a_row_offset(const AOperand& a, long R) {
@@ -388,7 +389,7 @@ int fill_a(AOperand* a, const char* who, const float* A, long lda, long a_bstrid
         RL_REQUIRE(K == 10, RL_ERR_ARGS, "%s: relative position encoding source needs K == 10 (got %d)", who, K);
         RL_REQUIRE(xyz && nbr_idx && nbr_d2 && nbr_k > 0 && xyz_bstride >= n, RL_ERR_ARGS, "%s: incomplete RPE source", who);
         a->M = (long)B * n * nbr_k;
-        a->contig = 1; a->vec4 = 0;
+        a->contig = 1; a->vec4 = 0; a->vec4p = 0;
     } else {
         RL_REQUIRE(a_mode == 0, RL_ERR_ARGS, "%s: unknown a_mode %d", who, a_mode);
         RL_REQUIRE(A && lda >= K && a_bstride >= n, RL_ERR_ARGS, "%s: bad A operand", who);
@@ -396,6 +397,7 @@ int fill_a(AOperand* a, const char* who, const float* A, long lda, long a_bstrid
         a->M = (long)B * n;
         a->contig = (a_bstride == n);
         a->vec4 = (lda % 4 == 0) && (K % 4 == 0) && (((uintptr_t)A & 15) == 0);
+        a->vec4p = (lda % 4 == 0) && ((K + 3) / 4 * 4 <= lda) && (((uintptr_t)A & 15) == 0);
     }
     RL_REQUIRE(a->M < (1l << 31), RL_ERR_ARGS, "%s: too many rows", who);
     return RL_OK;
@@ -974,14 +976,16 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
 
 // Split-K reducer: Y = sum over splits (fixed order) + bias (+ Y when accumulating), plus the BatchNorm
 // partial statistics, one slot per workgroup exactly like the single-pass kernels (rl_row_blocks(M,128)).
-// Needs N % 4 == 0 and N/4 a power of two <= 256.
+// Needs N % 4 == 0.
+template <int CB>   // columns per workgroup: 64, or 16 when there are too few row tiles to fill the chip otherwise
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParams p) {
-    // workgroup (x, y): row tiles x, x + gridDim.x, ... (x = the statistics slot) and columns [64y, 64y+64)
+    // workgroup (x, y): row tiles x, x + gridDim.x, ... (x = the statistics slot) and columns [CB*y, CB*y+CB)
+    constexpr int QN = CB / 4, RP = 256 / QN;   // column quads, rows in flight
     __shared__ float red[256][9];
     const int N = p.N;
     const long M = p.a.M;
-    const int q = threadIdx.x & 15, rsub = threadIdx.x >> 4;   // 16 column quads x 16 rows in flight
-    const int c = blockIdx.y * 64 + q * 4;
+    const int q = threadIdx.x & (QN - 1), rsub = threadIdx.x / QN;
+    const int c = blockIdx.y * CB + q * 4;
     const bool cvalid = c < N;
     const long ntiles = (M + GM_BM - 1) / GM_BM;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -990,7 +994,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
     if (cvalid) {
         for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const long rend = min(M, (tile + 1) * GM_BM);
-            for (long R = tile * GM_BM + rsub; R < rend; R += 16) {
+            for (long R = tile * GM_BM + rsub; R < rend; R += RP) {
                 float4 v = bias;
                 for (int s = 0; s < p.ksplit; ++s) {
                     const float4 t = *reinterpret_cast<const float4*>(p.kslab + ((long)s * M + R) * N + c);
@@ -1012,16 +1016,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
         }
     }
     if (!p.stats) return;
-    // lanes l, l^16, l^32 share a column quad inside a wavefront; then the four wavefronts through LDS
+    // lanes with equal (l & (QN-1)) share a column quad inside a wavefront; then the four wavefronts through LDS
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        acc[j] += __shfl_xor(acc[j], 16, 64);
-        acc[j] += __shfl_xor(acc[j], 32, 64);
-    }
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int o = 32; o >= QN; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
     __syncthreads();
-    if (threadIdx.x < 16 && cvalid) {
+    if (threadIdx.x < QN && cvalid) {
         double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int w = 0; w < 4; ++w)
 #pragma unroll
@@ -1340,7 +1343,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     const int gx = rl_row_blocks_host(p.a.M, GM_BM);
     hipStream_t st = (hipStream_t)stream;
     p.stat_slots = gx;
-    if (d->a_mode == 0 && p.a.vec4 && d->K <= 64 && d->N <= 64) {
+    if (d->a_mode == 0 && p.a.vec4p && d->K <= 64 && d->N <= 64) {
         // every wavefront first loads the whole weight matrix into registers: with >= 2048 weights per
         // wavefront, fewer and longer-lived workgroups (two per CU) beat one 128-row tile per workgroup
         int sg = gx;
@@ -1363,7 +1366,10 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
             hipLaunchKernelGGL((pgemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128), p.ksplit), dim3(256), 0, st, p);
             rl_note_kernel("pgemm_kernel<8>+splitk");
             RL_LAUNCH_CHECK("rl_gemm(split-K)");
-            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gx, rl_cdiv(d->N, 64)), dim3(256), 0, st, p);
+            if ((long)gx * rl_cdiv(d->N, 64) >= 256)
+                hipLaunchKernelGGL(gemm_splitk_reduce_kernel<64>, dim3(gx, rl_cdiv(d->N, 64)), dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL(gemm_splitk_reduce_kernel<16>, dim3(gx, rl_cdiv(d->N, 16)), dim3(256), 0, st, p);
             RL_LAUNCH_CHECK("rl_gemm(split-K reduce)");
             return RL_OK;
         }

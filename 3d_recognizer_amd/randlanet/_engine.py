@@ -120,6 +120,9 @@ class Engine:
         f0 = self._mlp(ctx, xin, f"{e}.mlp1", h, H.ACT_LRELU, 0.2)
         sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
         rpe = Rpe(xyz, idx, d2, B, n, K)
+        if h <= 64 and not ops.NO_RPE_TENSOR:
+            # read twice (forward + weight gradient): cheaper as a 48-byte row than re-gathered in both kernels
+            rpe = ops.rpe_build(rpe)
         u1 = self._mlp(ctx, rpe, f"{e}.mlp_rpe1", h, H.ACT_RELU, a_grad=False)
         q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, n, d, h)
         u2 = self._mlp(ctx, u1, f"{e}.mlp_rpe2", h, H.ACT_RELU)

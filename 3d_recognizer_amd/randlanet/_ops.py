@@ -85,6 +85,7 @@ TIMER: Optional[KernelTimer] = None
 # hipGraph replay (every fork/join becomes a cross-branch dependency in the graph), so OFF by default.
 SIDE_STREAM_WGRAD = bool(int(__import__("os").environ.get("RL_SIDE_STREAM", "0")))
 NO_FUSED_POOL = bool(int(__import__("os").environ.get("RL_NO_FUSED_POOL", "0")))         # diagnostics only
+NO_RPE_TENSOR = bool(int(__import__("os").environ.get("RL_NO_RPE_TENSOR", "0")))         # diagnostics only
 FORCE_BRUTE_KNN = bool(int(__import__("os").environ.get("RL_KNN_BRUTE", "0")))         # diagnostics only
 DEBUG_SYNC = bool(int(__import__("os").environ.get("RL_DEBUG_SYNC", "0")))   # print + sync around every launch
 
@@ -199,6 +200,19 @@ class Rpe:
     @property
     def rows(self) -> int:
         return self.B * self.n * self.K
+
+
+def rpe_build(a: "Rpe") -> Lazy:
+    """The relative position encoding of every neighbourhood row, written out once (rows x 12 floats: 10 channels +
+    2 of padding) so that mlp_rpe1's forward and weight gradient read a plain tensor (modules.py:173-186)."""
+    _dev_check(a.xyz, a.idx, a.d2)
+    assert a.idx.dtype == torch.int32 and a.idx.shape == (a.B, a.n, a.K) and a.d2.shape == a.idx.shape
+    assert a.xyz.shape[0] == a.B and a.xyz.shape[1] >= a.n and a.xyz.shape[2] == 3
+    out = torch.empty((a.rows, 12), dtype=F32, device=a.xyz.device)
+    with _rec("rpe_build", (a.rows,), (48 + 8) * a.rows, 0):
+        H.check(H.lib().rl_rpe_build(a.xyz.data_ptr(), a.xyz.shape[1], a.idx.data_ptr(), a.d2.data_ptr(), a.B, a.n, a.K,
+                                     out.data_ptr(), _st()), "rl_rpe_build")
+    return Lazy(out, a.B, a.n * a.K, a.n * a.K, 10)
 
 
 def _fill_a(d, a):

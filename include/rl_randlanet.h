@@ -32,6 +32,7 @@
  *   rl_pool_fwd/_bwd      PointFeatureAugmentation + AttentivePooling fused (modules.py:213-253)
  *   rl_attpool_*          AttentivePooling softmax over K + weighted sum (modules.py:246-253)
  *   rl_add_act_*          LocalFeatureAggregation residual + LeakyReLU (modules.py:325)
+ *   rl_rpe_build          RelativePositionEncoding (modules.py:173-186), materialised
  *   rl_scale_mask         Dropout of fc_end (modules.py:528)
  *   rl_upsample_cf        UpSampler nni / nna / idw / isdw (modules.py:343-456)
  *   rl_logits_*           un-permute + (B,C,N) layout of the logits (modules.py:608-611)
@@ -305,6 +306,14 @@ int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1, const floa
                    const float* s2, const float* b2, int64_t rows, int C, float slope, float* O,
                    void* stream);
 int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, void* stream);
+
+/* RelativePositionEncoding (modules.py:173-186) written out once per level: row (b, i, j) of out, 12 floats
+ * apart, holds [x_i, x_nbr, x_i - x_nbr, sqrt(d2)] (10 channels) and two zeros of padding, so that the row
+ * is 16-byte aligned and the tensor can be the A operand of rl_gemm / rl_wgrad with K = 10, lda = 12.
+ * The a_mode-1 operand source computes the same values inside the kernels; this tensor is the faster choice
+ * when it is read more than once (forward + weight gradient).  xyz (B, xyz_bstride, 3), idx/d2 (B,n,k).   */
+int rl_rpe_build(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_d2, int B,
+                 int n, int k, float* out, void* stream);
 
 /* Dropout (fc_end, modules.py:528) with a keep-mask drawn by the caller (uint8, 1 = keep):
  * x[i] = mask[i] ? x[i]*scale : 0, in place; the same call is its own backward.             */

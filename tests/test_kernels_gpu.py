@@ -237,6 +237,17 @@ def test_gemm_rpe_source_and_wgrad(ops):
     ops.wgrad(rpe, dY, n * K, N, dW, 1, 10, db)
     assert float((dW - dY.t() @ R).abs().max()) < 2e-4 * float((dY.t() @ R).abs().max())
     assert float((db - dY.sum(0)).abs().max()) < 1e-3
+    # the materialised encoding (rows x 12, two floats of padding) holds the same bits and gives the same layer
+    T = ops.rpe_build(rpe)
+    assert T.raw.shape == (B * n * K, 12) and T.C == 10
+    assert torch.equal(T.raw[:, :9], R[:, :9]) and float(T.raw[:, 10:].abs().max()) == 0.0
+    assert float((T.raw[:, 9] - R[:, 9]).abs().max()) < 1e-7          # torch's device sqrt is not correctly rounded
+    Y2 = ops.gemm(T, W, 1, 10, N, b)
+    assert float((Y2 - ref).abs().max()) < 1e-5
+    dW2, db2 = torch.empty_like(W), torch.empty_like(b)
+    ops.wgrad(T, dY, n * K, N, dW2, 1, 10, db2)
+    assert float((dW2 - dY.t() @ R).abs().max()) < 2e-4 * float((dY.t() @ R).abs().max())
+    assert float((db2 - dY.sum(0)).abs().max()) < 1e-3
 
 
 @pytest.mark.parametrize("B,n,K,N,transposed,lazy", [
