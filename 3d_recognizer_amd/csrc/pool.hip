@@ -102,19 +102,26 @@ __device__ __forceinline__ void load_x(const PoolParams& p, long pt, int li, int
     }
 }
 
-// acc[nb] += tile(A layout) . B, with B fragments read from an LDS matrix Bm[k][n] (stride XS)
+// acc[nb] += tile(A layout) . B, with B given TRANSPOSED in LDS: Bt[n][k] (stride XS), so that the four k of an
+// A-layout float4 (k = 16c + 4j .. +3) are one ds_read_b128 per column block.  All reads of a 16-column chunk of k
+// are issued before its MFMAs.  Row stride XS = D+4 floats: 16 rows x b128 fall on 16 distinct bank quads.
 template <int DT>
-__device__ __forceinline__ void tile_gemm(const float4 (&a)[DT], const float* Bm, int li, int lj, f32x4 (&acc)[DT]) {
+__device__ __forceinline__ void tile_gemm(const float4 (&a)[DT], const float* Bt, int li, int lj, f32x4 (&acc)[DT]) {
     constexpr int XS = Tile<DT>::XS;
+    const float* base = Bt + li * XS + 4 * lj;
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
+        float4 b[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) b[nb] = *reinterpret_cast<const float4*>(base + nb * 16 * XS + 16 * c);
         const float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = 16 * c + 4 * lj + s;
 #pragma unroll
-            for (int nb = 0; nb < DT; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bm[k * XS + nb * 16 + li], acc[nb], 0, 0, 0);
+            for (int nb = 0; nb < DT; ++nb) {
+                const float bv = s == 0 ? b[nb].x : s == 1 ? b[nb].y : s == 2 ? b[nb].z : b[nb].w;
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[nb], 0, 0, 0);
+            }
         }
     }
 }
@@ -144,7 +151,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
 template <int DT>
 __device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* Wn) {
     constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS;
-    // Wt[k][n] = W[n][k] (B operand of S = X.W^T);  Wn[k'][n'] = W[k'][n'] (B operand of dX = dS.W)
+    // tile_gemm wants B transposed ([n][k]):  S = X.W^T has B^T = W itself -> Wn;  dX = dS.W has B^T = W^T -> Wt
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int o = e / D, i = e - o * D;
         const float w = p.W[e];
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
     const int li = lane & 15, lj = lane >> 4;
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int o = e / D, i = e - o * D;
-        Wt[i * XS + o] = p.W[e];
+        Wt[o * XS + i] = p.W[e];          // [n][k]: the transposed-B form tile_gemm reads
     }
     __syncthreads();
     float sc[DT][4], sh[DT][4];
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        tile_gemm<DT>(xa, Wt, li, lj, a);
+        tile_gemm<DT>(xa, Wn, li, lj, a);
         softmax_rows<DT>(a);
         __builtin_amdgcn_wave_barrier();
         // C-layout pass: P, dS (to LDS), dXa kept in registers as the start of dX
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
         float4 da[DT];
 #pragma unroll
         for (int c = 0; c < DT; ++c) da[c] = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
-        tile_gemm<DT>(da, Wn, li, lj, dx);
+        tile_gemm<DT>(da, Wt, li, lj, dx);
         // dW[n][k] += sum_rows dS[row][n] * X[row][k]   (rows are the MFMA reduction index)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
