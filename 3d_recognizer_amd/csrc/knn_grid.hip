@@ -100,12 +100,22 @@ __global__ __launch_bounds__(256) void grid_bbox_kernel(const KMulti m) {
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
         }
     }
+    // one set of six atomics per workgroup: hundreds of wavefronts hitting the same six words serialise in L2
+    __shared__ float red[4][6];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&T.bbox[b * 6 + a], enc(mn[a]));
-            atomicMax(&T.bbox[b * 6 + 3 + a], enc(mx[a]));
+            red[threadIdx.x >> 6][a] = mn[a];
+            red[threadIdx.x >> 6][3 + a] = mx[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float lo = fminf(fminf(red[0][a], red[1][a]), fminf(red[2][a], red[3][a]));
+        const float hi = fmaxf(fmaxf(red[0][3 + a], red[1][3 + a]), fmaxf(red[2][3 + a], red[3][3 + a]));
+        atomicMin(&T.bbox[b * 6 + a], enc(lo));
+        atomicMax(&T.bbox[b * 6 + 3 + a], enc(hi));
     }
 }
 
@@ -412,8 +422,8 @@ int run_multi(const KMulti& m, hipStream_t st) {
     int gi = rl_cdiv(maxc, 256);
     if (gi > 64) gi = 64;
     hipLaunchKernelGGL(grid_init_kernel, dim3(gi, clouds), dim3(256), 0, st, m);
-    int gb = rl_cdiv(maxNs, 256);
-    if (gb > 256) gb = 256;
+    int gb = rl_cdiv(maxNs, 2048);   // >= 8 points per lane, at most 16 workgroups (= atomics per word) per cloud
+    if (gb > 16) gb = 16;
     hipLaunchKernelGGL(grid_bbox_kernel, dim3(gb, clouds), dim3(256), 0, st, m);
     hipLaunchKernelGGL(grid_geom_kernel, dim3(rl_cdiv(clouds, 64)), dim3(64), 0, st, m);
     hipLaunchKernelGGL(grid_count_kernel, dim3(rl_cdiv(maxNs, 256), clouds), dim3(256), 0, st, m);
