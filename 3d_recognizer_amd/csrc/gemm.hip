@@ -329,14 +329,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
 // 16 consecutive output elements x 16 slab lanes per workgroup: fixed summation order
 // (lane-strided partial sums, then a fixed LDS tree), so the gradient is deterministic.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit,
-                                                           int N, int K, float* __restrict__ dW,
-                                                           long w_ks, long w_ns,
-                                                           float* __restrict__ dbias) {
-    __shared__ float red[16][17];
+__device__ __forceinline__ void wgrad_reduce_tile(const float* __restrict__ slab, int nsplit, int N, int K,
+                                                  float* __restrict__ dW, long w_ks, long w_ns,
+                                                  float* __restrict__ dbias, long tile, float (*red)[17]) {
     const long per = (long)N * K + N;
     const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
-    const long e = (long)blockIdx.x * 16 + ex;
+    const long e = tile * 16 + ex;
     float s = 0.f;
     if (e < per)
         for (int i = sy; i < nsplit; i += 16) s += slab[(long)i * per + e];
@@ -347,12 +345,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += red[j][ex];
         if (e < (long)N * K) {
-            const int n = (int)(e / K), k = (int)(e - (long)n * K);
+            const int n = (int)((unsigned)e / (unsigned)K), k = (int)(e - (long)n * K);
             dW[(long)k * w_ks + (long)n * w_ns] = t;
         } else if (dbias) {
             dbias[e - (long)N * K] = t;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit,
+                                                           int N, int K, float* __restrict__ dW,
+                                                           long w_ks, long w_ns,
+                                                           float* __restrict__ dbias) {
+    __shared__ float red[16][17];
+    wgrad_reduce_tile(slab, nsplit, N, K, dW, w_ks, w_ns, dbias, blockIdx.x, red);
+}
+
+// the same reduction for up to RB_MAX layers in one launch: workgroup -> (item, tile) through the prefix
+// table in the kernel arguments
+constexpr int RB_MAX = 48;
+struct ReduceBatch {
+    rl_wgrad_reduce_item item[RB_MAX];
+    int first_tile[RB_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
+    __shared__ float red[16][17];
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.first_tile[i + 1]) ++i;
+    const rl_wgrad_reduce_item& it = b.item[i];
+    wgrad_reduce_tile(it.slab, it.nsplit, it.N, it.K, it.dW, (long)it.w_ks, (long)it.w_ns, it.dbias,
+                      (long)blockIdx.x - b.first_tile[i], red);
 }
 
 inline int wgrad_tile(int N, int K) { return (N >= 128 && K >= 128) ? 128 : WG_T; }
@@ -369,6 +392,12 @@ void wgrad_split(long M, int N, int K, int* nsplit, long* rows_per_block) {
     if (maxs < fill) maxs = fill < (M + 63) / 64 ? fill : (M + 63) / 64;
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
+    if (T == 128) {
+        // the 128x128 kernel holds two workgroups per CU: one resident round (512 workgroups) instead of 1.25,
+        // and a quarter less partial-slab traffic
+        const long round = 512 / ((long)ny * nz);
+        if (round >= 1 && want > round) want = round;
+    }
     long rpb = (M + want - 1) / want;
     rpb = ((rpb + 63) / 64) * 64;   // multiple of both kernels' row chunks (32 / 64)
     *rows_per_block = rpb;
@@ -970,6 +999,10 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
         if (tid < BN && col0 + tid < N) {
             p.stats[((long)blockIdx.x * 2 + 0) * N + col0 + tid] = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
             p.stats[((long)blockIdx.x * 2 + 1) * N + col0 + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+            for (long slot = blockIdx.x + gridDim.x; slot < p.stat_slots; slot += gridDim.x) {
+                p.stats[(slot * 2 + 0) * N + col0 + tid] = 0.0;
+                p.stats[(slot * 2 + 1) * N + col0 + tid] = 0.0;
+            }
         }
     }
 }
@@ -1440,9 +1473,41 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         rl_note_kernel(pipelined && T == 128 ? "pwgrad128_kernel" : pipelined ? "pwgrad_kernel" : "wgrad_kernel");
     }
     RL_LAUNCH_CHECK("rl_wgrad");
+    if (d->defer_reduce) return RL_OK;
     const long per = (long)d->N * d->K + d->N;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rl_cdiv(per, 16)), dim3(256), 0, st, d->slab, nsplit,
                        d->N, d->K, d->dW, (long)d->w_ks, (long)d->w_ns, d->dbias);
     RL_LAUNCH_CHECK("rl_wgrad_reduce");
+    return RL_OK;
+}
+
+extern "C" int rl_wgrad_nsplit(int64_t M, int N, int K) {
+    int nsplit; long rpb;
+    if (stream_wgrad_ok(N, K)) swgrad_split(M, &nsplit, &rpb);
+    else wgrad_split(M, N, K, &nsplit, &rpb);
+    return nsplit;
+}
+
+extern "C" int rl_wgrad_reduce_batch(const rl_wgrad_reduce_item* items, int count, void* stream) {
+    RL_REQUIRE(items != nullptr && count >= 0, RL_ERR_ARGS, "rl_wgrad_reduce_batch: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < count; base += RB_MAX) {
+        ReduceBatch b;
+        b.count = count - base < RB_MAX ? count - base : RB_MAX;
+        long tiles = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const rl_wgrad_reduce_item& it = items[base + i];
+            RL_REQUIRE(it.slab && it.dW && it.nsplit > 0 && it.N > 0 && it.K > 0, RL_ERR_ARGS,
+                       "rl_wgrad_reduce_batch: bad item %d", base + i);
+            b.item[i] = it;
+            b.first_tile[i] = (int)tiles;
+            tiles += rl_cdiv((long)it.N * it.K + it.N, 16);
+            RL_REQUIRE(tiles < (1l << 30), RL_ERR_ARGS, "rl_wgrad_reduce_batch: too many tiles");
+        }
+        b.first_tile[b.count] = (int)tiles;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, st, b);
+        RL_LAUNCH_CHECK("rl_wgrad_reduce_batch");
+    }
+    rl_note_kernel("wgrad_reduce_batch_kernel");
     return RL_OK;
 }

@@ -238,6 +238,8 @@ class Engine:
         if self._side is None:
             self._side = torch.cuda.Stream(dlogits.device)
         ctx.hold = []
+        # weight-gradient slabs are summed by ONE launch after the last layer (they are only needed by the optimiser)
+        ctx.pending = None if (ops.SIDE_STREAM_WGRAD or ops.NO_DEFERRED_WGRAD) else []
         for rec in reversed(ctx.tape):
             kind = rec[0]
             if kind == "linear":
@@ -285,6 +287,8 @@ class Engine:
             else:
                 raise AssertionError(kind)
         self._main.wait_stream(self._side)
+        if ctx.pending is not None:
+            ops.wgrad_flush(ctx.pending)
         ctx.tape.clear()
         ctx.grads.clear()
         ctx.keep.clear()
@@ -309,7 +313,7 @@ class Engine:
             ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True)
         n_out = out.C
         self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,
-                                            grads[bname] if bname else None), G)
+                                            grads[bname] if bname else None, pending=ctx.pending), G)
         if a_grad and isinstance(a, Lazy):
             ga = self._gbuf(ctx, a)
             if not ga[1]:
@@ -327,7 +331,7 @@ class Engine:
         dS, dX = ops.attpool_bwd(X, S, pooled.raw, GP, B * n, K)
         Ws = self.P[f"{name}.score_fn.0.weight"]
         self._beside(ctx, lambda: ops.wgrad(ops.plain(X, B, n * K), dS, n * K, d,
-                                            grads[f"{name}.score_fn.0.weight"], 1, d, None), X, dS)
+                                            grads[f"{name}.score_fn.0.weight"], 1, d, None, pending=ctx.pending), X, dS)
         ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
         gu = self._gbuf(ctx, u)
         ops.copy_rows(dX, (0, h), n * K, gu[0], (0, h), rows, n * K, accumulate=gu[1])

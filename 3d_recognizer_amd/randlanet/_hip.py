@@ -55,6 +55,15 @@ class WgradDesc(C.Structure):
         ("dW", C.c_void_p), ("w_ks", C.c_int64), ("w_ns", C.c_int64),
         ("dbias", C.c_void_p),
         ("slab", C.c_void_p), ("slab_floats", C.c_int64),
+        ("defer_reduce", C.c_int32),
+    ]
+
+
+class WgradReduceItem(C.Structure):
+    _fields_ = [
+        ("slab", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p),
+        ("w_ks", C.c_int64), ("w_ns", C.c_int64),
+        ("nsplit", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -120,6 +129,8 @@ _SIGNATURES = {
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
+    "rl_wgrad_nsplit": (_i, [_l, _i, _i]),
+    "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
     "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "rl_bn_bwd_slots": (_i, [_l]),
     "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),

@@ -85,6 +85,7 @@ TIMER: Optional[KernelTimer] = None
 # hipGraph replay (every fork/join becomes a cross-branch dependency in the graph), so OFF by default.
 SIDE_STREAM_WGRAD = bool(int(__import__("os").environ.get("RL_SIDE_STREAM", "0")))
 NO_FUSED_POOL = bool(int(__import__("os").environ.get("RL_NO_FUSED_POOL", "0")))         # diagnostics only
+NO_DEFERRED_WGRAD = bool(int(__import__("os").environ.get("RL_NO_DEFERRED_WGRAD", "0")))  # diagnostics only
 NO_RPE_TENSOR = bool(int(__import__("os").environ.get("RL_NO_RPE_TENSOR", "0")))         # diagnostics only
 FORCE_BRUTE_KNN = bool(int(__import__("os").environ.get("RL_KNN_BRUTE", "0")))         # diagnostics only
 DEBUG_SYNC = bool(int(__import__("os").environ.get("RL_DEBUG_SYNC", "0")))   # print + sync around every launch
@@ -293,7 +294,9 @@ def _slab(device, floats: int) -> torch.Tensor:
 
 
 def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: int, w_ns: int,
-          dbias: Optional[torch.Tensor] = None) -> None:
+          dbias: Optional[torch.Tensor] = None, pending: Optional[list] = None) -> None:
+    """dW / dbias of a layer.  With `pending` (a list) only the per-workgroup partial slabs are produced, in a
+    slab of their own, and the layer is queued for `wgrad_flush` - one reduction launch for a whole backward."""
     d = H.WgradDesc()
     M, K = _fill_a(d, a)
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
@@ -302,12 +305,29 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     assert dY.shape[0] >= (d.B - 1) * dy_bstride + rows_per_batch
     assert dW.numel() == K * N and (dbias is None or dbias.numel() == N)
     floats = H.lib().rl_wgrad_slab_floats(M, N, K)
-    slab = _slab(dY.device, floats)
+    slab = _slab(dY.device, floats) if pending is None else torch.empty(floats, dtype=F32, device=dY.device)
     d.N, d.dY, d.lddy, d.dy_bstride = N, dY.data_ptr(), dY.shape[1], dy_bstride
     d.dW, d.w_ks, d.w_ns, d.dbias = dW.data_ptr(), w_ks, w_ns, H.ptr(dbias)
     d.slab, d.slab_floats = slab.data_ptr(), slab.numel()
+    d.defer_reduce = 0 if pending is None else 1
     with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N + K * N), 2 * M * K * N):
         H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
+    if pending is not None:
+        it = H.WgradReduceItem()
+        it.slab, it.dW, it.dbias, it.w_ks, it.w_ns = slab.data_ptr(), dW.data_ptr(), H.ptr(dbias), w_ks, w_ns
+        it.nsplit, it.N, it.K = H.lib().rl_wgrad_nsplit(M, N, K), N, K
+        pending.append((it, slab, dW, dbias))
+
+
+def wgrad_flush(pending: list) -> None:
+    """Sum the partial slabs of every queued layer (fixed order, deterministic) in one launch per 48 layers."""
+    if not pending:
+        return
+    arr = (H.WgradReduceItem * len(pending))(*[p[0] for p in pending])
+    nbytes = sum(4 * p[1].numel() for p in pending)
+    with _rec("wgrad_reduce_batch", (len(pending),), nbytes, 0):
+        H.check(H.lib().rl_wgrad_reduce_batch(arr, len(pending), _st()), "rl_wgrad_reduce_batch")
+    pending.clear()
 
 
 # -------------------------------------------------------------------------------------- bn

@@ -177,10 +177,30 @@ typedef struct rl_wgrad_desc {
     float* dbias; /* nullable */
     float* slab;
     int64_t slab_floats;
+    /* != 0: only the partial slabs are written; the caller sums them later with
+     * rl_wgrad_reduce_batch (one launch for all layers of a backward pass), so `slab` must be
+     * private to this layer until then */
+    int32_t defer_reduce;
 } rl_wgrad_desc;
 
 int64_t rl_wgrad_slab_floats(int64_t M, int N, int K);
 int rl_wgrad(const rl_wgrad_desc* d, void* stream);
+
+/* Deferred second pass of rl_wgrad for `count` layers in one launch per 48 items: item i sums
+ * the nsplit = slab_floats_used / (N*K + N) partial slabs of its layer in the same fixed order
+ * as the per-layer reducer and writes dW (strides w_ks, w_ns) and dbias (nullable).
+ * `items` is a HOST array (copied into the kernel arguments).                                 */
+typedef struct rl_wgrad_reduce_item {
+    const float* slab;
+    float* dW;
+    float* dbias;
+    int64_t w_ks, w_ns;
+    int32_t nsplit, N, K;
+    int32_t reserved;
+} rl_wgrad_reduce_item;
+
+int rl_wgrad_nsplit(int64_t M, int N, int K);
+int rl_wgrad_reduce_batch(const rl_wgrad_reduce_item* items, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm2d(eps, momentum) folded into per-channel (scale, shift).

@@ -276,6 +276,27 @@ def test_wgrad(ops, B, n, K, N, transposed, lazy):
 
 
 # ------------------------------------------------------------------------------ BatchNorm
+def test_wgrad_deferred_batch_reduce_is_bitwise_the_same(ops):
+    """rl_wgrad(defer_reduce) + rl_wgrad_reduce_batch sums the same slabs in the same order as the per-layer reducer."""
+    torch.manual_seed(11)
+    shapes = [(2, 3000, 8, 16), (1, 700, 64, 128), (2, 640, 256, 128), (2, 500, 10, 8), (1, 900, 32, 2)] * 11   # 55 > 48 items
+    pending, want, got = [], [], []
+    for (B, n, K, N) in shapes:
+        A = torch.randn(B * n, K, device=DEV)
+        dY = torch.randn(B * n, N, device=DEV)
+        a = ops.plain(A, B, n)
+        dW0, db0 = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        ops.wgrad(a, dY, n, N, dW0, 1, K, db0)
+        dW1, db1 = torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV)
+        ops.wgrad(a, dY, n, N, dW1, 1, K, db1, pending=pending)
+        want.append((dW0, db0)); got.append((dW1, db1))
+    assert len(pending) == len(shapes)
+    ops.wgrad_flush(pending)
+    assert pending == []
+    for (w0, b0), (w1, b1) in zip(want, got):
+        assert torch.equal(w0, w1) and torch.equal(b0, b1)
+
+
 @pytest.mark.parametrize("C,rows", [(8, 5000), (64, 999), (512, 300), (1024, 257)])
 def test_bn_forward_backward(ops, C, rows):
     torch.manual_seed(C)
