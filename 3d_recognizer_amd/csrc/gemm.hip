@@ -327,23 +327,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
 }
 
-// 16 consecutive output elements x 16 slab lanes per workgroup: fixed summation order
-// (lane-strided partial sums, then a fixed LDS tree), so the gradient is deterministic.
+// 64 consecutive output elements (256 contiguous bytes per slab row) x 4 slab lanes per workgroup; fixed
+// summation order (lane-strided partial sums in 4 independent chains, then a fixed LDS tree): deterministic.
+constexpr int WR_E = 64;
 __device__ __forceinline__ void wgrad_reduce_tile(const float* __restrict__ slab, int nsplit, int N, int K,
                                                   float* __restrict__ dW, long w_ks, long w_ns,
-                                                  float* __restrict__ dbias, long tile, float (*red)[17]) {
+                                                  float* __restrict__ dbias, long tile, float (*red)[WR_E + 1]) {
     const long per = (long)N * K + N;
-    const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
-    const long e = tile * 16 + ex;
-    float s = 0.f;
-    if (e < per)
-        for (int i = sy; i < nsplit; i += 16) s += slab[(long)i * per + e];
-    red[sy][ex] = s;
+    const int ex = threadIdx.x & (WR_E - 1), sy = threadIdx.x / WR_E;
+    const long e = tile * WR_E + ex;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < per) {
+        const float* src = slab + e;
+        int i = sy;
+        for (; i + 12 < nsplit; i += 16) {
+            s0 += src[(long)i * per];
+            s1 += src[(long)(i + 4) * per];
+            s2 += src[(long)(i + 8) * per];
+            s3 += src[(long)(i + 12) * per];
+        }
+        for (; i < nsplit; i += 4) s0 += src[(long)i * per];
+    }
+    red[sy][ex] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sy == 0 && e < per) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[j][ex];
+        const float t = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
         if (e < (long)N * K) {
             const int n = (int)((unsigned)e / (unsigned)K), k = (int)(e - (long)n * K);
             dW[(long)k * w_ks + (long)n * w_ns] = t;
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int N, int K, float* __restrict__ dW,
                                                            long w_ks, long w_ns,
                                                            float* __restrict__ dbias) {
-    __shared__ float red[16][17];
+    __shared__ float red[4][WR_E + 1];
     wgrad_reduce_tile(slab, nsplit, N, K, dW, w_ks, w_ns, dbias, blockIdx.x, red);
 }
 
@@ -370,7 +378,7 @@ struct ReduceBatch {
     int count;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
-    __shared__ float red[16][17];
+    __shared__ float red[4][WR_E + 1];
     int i = 0;
     while (i + 1 < b.count && (int)blockIdx.x >= b.first_tile[i + 1]) ++i;
     const rl_wgrad_reduce_item& it = b.item[i];
@@ -1475,7 +1483,7 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
     RL_LAUNCH_CHECK("rl_wgrad");
     if (d->defer_reduce) return RL_OK;
     const long per = (long)d->N * d->K + d->N;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rl_cdiv(per, 16)), dim3(256), 0, st, d->slab, nsplit,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rl_cdiv(per, WR_E)), dim3(256), 0, st, d->slab, nsplit,
                        d->N, d->K, d->dW, (long)d->w_ks, (long)d->w_ns, d->dbias);
     RL_LAUNCH_CHECK("rl_wgrad_reduce");
     return RL_OK;
@@ -1501,7 +1509,7 @@ extern "C" int rl_wgrad_reduce_batch(const rl_wgrad_reduce_item* items, int coun
                        "rl_wgrad_reduce_batch: bad item %d", base + i);
             b.item[i] = it;
             b.first_tile[i] = (int)tiles;
-            tiles += rl_cdiv((long)it.N * it.K + it.N, 16);
+            tiles += rl_cdiv((long)it.N * it.K + it.N, WR_E);
             RL_REQUIRE(tiles < (1l << 30), RL_ERR_ARGS, "rl_wgrad_reduce_batch: too many tiles");
         }
         b.first_tile[b.count] = (int)tiles;

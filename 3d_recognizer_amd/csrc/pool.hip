@@ -329,22 +329,27 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     }
 }
 
+// 64 consecutive elements (256 contiguous bytes per slab row) x 4 slab lanes per workgroup, fixed order
 __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __restrict__ slab, int nsplit, int count,
                                                              float* __restrict__ dW) {
-    __shared__ float red[16][17];
-    const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + ex;
-    float s = 0.f;
-    if (e < count)
-        for (int i = sy; i < nsplit; i += 16) s += slab[(long)i * count + e];
-    red[sy][ex] = s;
-    __syncthreads();
-    if (sy == 0 && e < count) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[j][ex];
-        dW[e] = t;
+    __shared__ float red[4][65];
+    const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + ex;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < count) {
+        const float* src = slab + e;
+        int i = sy;
+        for (; i + 12 < nsplit; i += 16) {
+            s0 += src[(long)i * count];
+            s1 += src[(long)(i + 4) * count];
+            s2 += src[(long)(i + 8) * count];
+            s3 += src[(long)(i + 12) * count];
+        }
+        for (; i < nsplit; i += 4) s0 += src[(long)i * count];
     }
+    red[sy][ex] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sy == 0 && e < count) dW[e] = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
 }
 
 int pool_grid(long P) {
@@ -404,7 +409,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     else hipLaunchKernelGGL((pool_bwd_kernel<4>), dim3(g), dim3(256), 0, st, p);
     rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1>" : p.d == 32 ? "pool_bwd_kernel<2>" : "pool_bwd_kernel<4>");
     RL_LAUNCH_CHECK("rl_pool_bwd");
-    hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
+    hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 64)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
     RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
     return RL_OK;
 }
