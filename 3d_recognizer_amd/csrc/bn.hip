@@ -80,7 +80,11 @@ __device__ __forceinline__ long row_off(const BwdParams& p, long R) {
 
 // rows per tile of the backward sweeps: small tensors get small tiles so that they still spread over
 // the chip (a 2560 x 512 tensor in 256-row tiles would run on 10 of 256 CUs)
-static inline int bn_tile(long M) { return M >= 32768 ? 256 : 16; }
+static inline int bn_tile(long M) {
+    int t = 16;
+    while (t < 256 && (long)t * 4096 < M) t <<= 1;   // >= 4 tiles per workgroup slot until tiles reach 256 rows
+    return t;
+}
 
 // thread layout shared by reduce and apply: tpr threads sweep one row, 256/tpr rows in flight
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
