@@ -67,6 +67,15 @@ class WgradReduceItem(C.Structure):
     ]
 
 
+class CloudJob(C.Structure):
+    _fields_ = [
+        ("xyz", C.c_void_p), ("features", C.c_void_p), ("labels", C.c_void_p), ("n_points", C.c_int64),
+        ("xyz_f64", C.c_int32), ("normalization", C.c_int32), ("augment", C.c_int32), ("reserved", C.c_int32),
+        ("jitter_variance", C.c_double), ("jitter_limit", C.c_double), ("scale", C.c_double),
+        ("R", C.c_double * 9), ("shift", C.c_double * 3),
+    ]
+
+
 class BnBwdDesc(C.Structure):
     _fields_ = [
         ("G", C.c_void_p), ("Y", C.c_void_p), ("ld", C.c_int64), ("bstride", C.c_int64),
@@ -147,6 +156,7 @@ _SIGNATURES = {
     "rl_add_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp, _vp]),
     "rl_add_act_bwd": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "rl_rpe_build": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rl_batch_assemble": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
     "rl_upsample_cf": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rl_logits_unpermute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

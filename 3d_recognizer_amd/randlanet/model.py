@@ -17,6 +17,7 @@ import torch
 from . import _ops as ops
 from .utils.augmentation import AugmentationSettings
 from .utils.dataset import get_data_loader
+from .utils.device_dataset import get_device_data_loader
 from .utils.modules import RandLANet, RandLANetSettings, UpSampler
 from .utils.preprocessing import sample_points
 from .utils.trainer import Trainer, TrainingSettings
@@ -137,6 +138,15 @@ class Model:
         return out if batched else out[0]
 
     # ---------------------------------------------------------------------------- training
+    def _loader(self, dataset, n_points: int, batch_size: int, **kw):
+        """get_data_loader (model.py:277-291, 326-332).  On a GPU the clouds live in HBM and every batch is assembled by
+        one kernel (utils/device_dataset.py); the random numbers still come from numpy / torch in the reference's
+        order unless RL_PIPELINE_RNG=device.  RL_HOST_PIPELINE=1 keeps the reference's host pipeline."""
+        if self.device.type == "cuda" and not int(os.environ.get("RL_HOST_PIPELINE", "0")):
+            return get_device_data_loader(dataset, n_points, batch_size, device=self.device,
+                                          rng=os.environ.get("RL_PIPELINE_RNG", "numpy"), **kw)
+        return get_data_loader(dataset, n_points, batch_size, **kw)
+
     def train(self, dataset_train: Sequence[Sample], dataset_validation: Sequence[Sample],
               training_settings: TrainingSettings = TrainingSettings(),
               augmentation_settings: AugmentationSettings = AugmentationSettings(),
@@ -146,15 +156,14 @@ class Model:
         assert class_names is not None and len(class_names) == self.settings.n_classes, (
             "The length of given class names should correspond to the n_classes setting of the model")
         n, bs = self.settings.n_points, training_settings.batch_size
-        train_loader = get_data_loader(dataset_train, n, bs, shuffle=True, consistent_sampling=False,
-                                       augmentation_settings=augmentation_settings)
-        val_loader = get_data_loader(dataset_validation, n, bs, shuffle=False, consistent_sampling=True)
+        train_loader = self._loader(dataset_train, n, bs, shuffle=True, consistent_sampling=False,
+                                    augmentation_settings=augmentation_settings)
+        val_loader = self._loader(dataset_validation, n, bs, shuffle=False, consistent_sampling=True)
         trainer = Trainer(train_loader, val_loader, log_dir, class_names)
         self._model = trainer.train(self._model, training_settings, callbacks=callbacks)
 
     def evaluate(self, dataset: Sequence[Sample], class_names: Optional[List[str]] = None, batch_size: int = 16,
                  loss_function: str = "dice", postprocess: bool = False, include_stdev: bool = False) -> Dict:
-        loader = get_data_loader(dataset, self.settings.n_points, batch_size, shuffle=False,
-                                 consistent_sampling=True)
+        loader = self._loader(dataset, self.settings.n_points, batch_size, shuffle=False, consistent_sampling=True)
         bag = Trainer.evaluate(self._model, loader, class_names, loss_function, postprocess)
         return bag.as_dict(include_stdev=include_stdev)

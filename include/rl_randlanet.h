@@ -34,6 +34,7 @@
  *   rl_add_act_*          LocalFeatureAggregation residual + LeakyReLU (modules.py:325)
  *   rl_rpe_build          RelativePositionEncoding (modules.py:173-186), materialised
  *   rl_scale_mask         Dropout of fc_end (modules.py:528)
+ *   rl_batch_assemble     PointCloudPreprocessor.preprocess + augmentation + collation (dataset.py:61-131)
  *   rl_upsample_cf        UpSampler nni / nna / idw / isdw (modules.py:343-456)
  *   rl_logits_*           un-permute + (B,C,N) layout of the logits (modules.py:608-611)
  *   rl_loss_*             FocalTverskyLoss / FocalLoss / cross entropy (utils/losses.py:17-87,
@@ -334,6 +335,36 @@ int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, v
  * when it is read more than once (forward + weight gradient).  xyz (B, xyz_bstride, 3), idx/d2 (B,n,k).   */
 int rl_rpe_build(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_d2, int B,
                  int n, int k, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline on the device: PointCloudPreprocessor.preprocess
+ * (randlanet/utils/dataset.py:61-97) + perturbate_point_cloud (randlanet/utils/augmentation.py:147-167)
+ * + the DataLoader collation, for a batch of clouds that are resident in HBM.  The caller draws the
+ * random numbers (sample indices, jitter noise, scale, rotation matrix, shift draws), this call applies
+ * them in the reference's order with float64 arithmetic and rounds to float32 at the end, exactly
+ * where the reference does (dataset.py:51).  One rl_cloud_job per cloud, array in DEVICE memory.
+ *   indices (B,n) int64: rows of the source cloud to take (preprocessing.sample_points, :35-62)
+ *   noise   (B,n,3) float64 standard-normal draws for the jitter, or NULL (no jitter)
+ *   scratch (B,n,3) float64 work space
+ *   out_input (B,n,3+F) float32 = [xyz, features], out_labels (B,n) int64                       */
+typedef struct rl_cloud_job {
+    const void* xyz;          /* (n_points,3) float32, or float64 when xyz_f64 != 0 */
+    const float* features;    /* (n_points,F) */
+    const int64_t* labels;    /* (n_points,) */
+    int64_t n_points;
+    int32_t xyz_f64;
+    int32_t normalization;    /* 0 none, 1 "mean", 2 "max", 3 "stdev", 4 any other string (centre only) */
+    int32_t augment;          /* 0: the fields below are ignored */
+    int32_t reserved;
+    double jitter_variance, jitter_limit;
+    double scale;             /* np.random.uniform(1 - scale_limit, 1 + scale_limit) */
+    double R[9];              /* Rz.Ry.Rx, row-major */
+    double shift[3];          /* np.random.uniform(-shift_limit, shift_limit, 3), before the radius factor */
+} rl_cloud_job;
+
+int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int F, const int64_t* indices,
+                      const double* noise, double* scratch, float* out_input, int64_t* out_labels,
+                      void* stream);
 
 /* Dropout (fc_end, modules.py:528) with a keep-mask drawn by the caller (uint8, 1 = keep):
  * x[i] = mask[i] ? x[i]*scale : 0, in place; the same call is its own backward.             */

@@ -332,8 +332,62 @@ def g6_training_run():
     print("history", np.round(np.array(hist), 4).tolist(), "final", final)
 
 
+# --------------------------------------------------------------------- G7: input pipeline
+def g7_pipeline():
+    """The reference's own PointCloudPreprocessor / get_data_loader on small clouds."""
+    from dataclasses import asdict
+    from randlanet.utils.augmentation import AugmentationSettings
+    from randlanet.utils.dataset import PointCloudPreprocessor, get_data_loader
+
+    rs = np.random.RandomState(77)
+    out = {}
+    custom = AugmentationSettings(jitter_variance=0.03, jitter_limit=0.02, scale_limit=0.3, shift_limit=0.25,
+                                  rotation_angle_variances=(0.2, 0.05, 0.4), rotation_angle_limits=(0.1, 0.3, 0.5))
+    cases = [   # tag, n_src, dtype, F, n_sample, consistent, augmentation, normalization, numpy seed
+        ("a", 3000, np.float32, 2, 2048, False, AugmentationSettings(), None, 5),
+        ("b", 1500, np.float32, 0, 2048, True, custom, "mean", 6),
+        ("c", 2500, np.float64, 1, 1024, True, None, "max", 7),
+        ("d", 2200, np.float32, 0, 2048, False, custom, "stdev", 8),
+        ("e", 2100, np.float64, 0, 512, False, AugmentationSettings(), "centre-only", 9),
+    ]
+    meta = []
+    for tag, n_src, dt, F, n, cons, aug, norm, seed in cases:
+        xyz = mock_cloud(n_src, seed=seed).astype(dt)
+        feats = rs.rand(n_src, F).astype(np.float32)
+        labels = rs.randint(0, 3, n_src).astype(np.int64)
+        pre = PointCloudPreprocessor([(xyz, feats, labels)], n, consistent_sampling=cons, augmentation_settings=aug,
+                                     normalization=norm)
+        np.random.seed(seed)
+        inp, lab, _ = pre[0]
+        after = np.random.get_state()[1][:4].astype(np.int64)     # where the reference left the global stream
+        out[f"{tag}_xyz"], out[f"{tag}_features"], out[f"{tag}_labels"] = xyz, feats, labels
+        out[f"{tag}_out_input"], out[f"{tag}_out_labels"] = inp.numpy(), lab.numpy()
+        out[f"{tag}_state_after"] = after
+        meta.append(dict(tag=tag, n_sample=n, consistent=cons, normalization=norm, seed=seed,
+                         augmentation=None if aug is None else asdict(aug)))
+    # a shuffled, augmented epoch through the reference's DataLoader (batch composition + stream order)
+    ds = [(mock_cloud(1200 + 100 * i, seed=20 + i), np.zeros((1200 + 100 * i, 0), np.float32),
+           rs.randint(0, 2, 1200 + 100 * i).astype(np.int64)) for i in range(5)]
+    torch.manual_seed(3)
+    np.random.seed(4)
+    loader = get_data_loader(ds, 1024, 2, shuffle=True, consistent_sampling=False, augmentation_settings=AugmentationSettings())
+    order, batches, blabels = [], [], []
+    for inp, lab, idx in loader:
+        order.append(np.pad(idx.numpy(), (0, 2 - len(idx)), constant_values=-1))
+        batches.append(np.concatenate([inp.numpy(), np.zeros((2 - inp.shape[0],) + tuple(inp.shape[1:]), np.float32)]))
+        blabels.append(np.concatenate([lab.numpy(), np.zeros((2 - lab.shape[0], lab.shape[1]), np.int64)]))
+    for i, c in enumerate(ds):
+        out[f"loader_xyz{i}"], out[f"loader_labels{i}"] = c[0], c[2].astype(np.int8)
+    out["loader_order"], out["loader_inputs"], out["loader_out_labels"] = np.stack(order), np.stack(batches), np.stack(blabels).astype(np.int8)
+    save("pipeline.npz", **out)
+    with open(os.path.join(HERE, "pipeline_cases.json"), "w") as fh:
+        json.dump(meta, fh, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g2m", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g2m", "g3", "g4", "g5", "g6", "g7"]
+    if "g7" in which:
+        g7_pipeline()
     if "g1" in which:
         g1_knn()
     if "g2" in which:

@@ -1,0 +1,152 @@
+"""Device input pipeline (rl_batch_assemble + randlanet.utils.device_dataset) against the reference's own
+PointCloudPreprocessor / get_data_loader outputs (tests/golden/pipeline.npz) and the CPU oracle (oracle/pipeline_oracle.py).
+
+Tolerance: the reference computes the augmentation in float64 and rounds to float32 at the end; the kernel does the same,
+but (a) sums the centres / mean radii in a different (tree) order and (b) is in float64 from the start, whereas numpy
+keeps a float32 cloud in float32 until the jitter noise is added - so the reference's FIRST mean radius (the jitter
+amplitude) carries float32 rounding (~1e-7 relative) when the source cloud is float32.  Before the final rounding the two
+therefore agree to ~1e-9 of the cloud's extent: every coordinate is within ONE float32 ulp (of its own value, or of the
+extent for coordinates near zero) of the reference, and a percent or so of them land on the other side of a rounding boundary.  Where the reference also normalises a float32 cloud (all in float32) the
+bound is 2e-6 relative to the cloud's extent."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "3d_recognizer_amd"))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "pipeline.npz")), json.load(open(os.path.join(GOLDEN, "pipeline_cases.json")))
+
+
+def _settings(d):
+    from randlanet.utils.augmentation import AugmentationSettings
+    if d is None:
+        return None
+    d = dict(d)
+    d["rotation_angle_variances"] = tuple(d["rotation_angle_variances"])
+    d["rotation_angle_limits"] = tuple(d["rotation_angle_limits"])
+    return AugmentationSettings(**d)
+
+
+def _close(got, want, f32_source_normalised):
+    scale = max(1.0, float(np.abs(want).max()))
+    diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    if f32_source_normalised:
+        return float(diff.max()) <= 2e-6 * scale
+    # one float32 ulp of the value, or of the cloud's extent for the coordinates that happen to lie near zero
+    ulp = np.maximum(np.spacing(np.abs(want).astype(np.float32)), np.spacing(np.float32(scale))).astype(np.float64)
+    ok = bool((diff <= ulp).all()) and float((diff > 0).mean()) < 0.05
+    if not ok:
+        print('pipeline mismatch: max diff/ulp', float((diff / ulp).max()), 'over', int((diff > ulp).sum()), 'differing', float((diff > 0).mean()))
+    return ok
+
+
+def test_cases_match_the_reference(gold):
+    from randlanet.utils.device_dataset import DeviceDataLoader
+    z, cases = gold
+    for c in cases:
+        t = c["tag"]
+        xyz = z[f"{t}_xyz"]
+        loader = DeviceDataLoader([(xyz, z[f"{t}_features"], z[f"{t}_labels"])], c["n_sample"], 1,
+                                  consistent_sampling=c["consistent"], augmentation_settings=_settings(c["augmentation"]),
+                                  normalization=c["normalization"], device="cuda")
+        np.random.seed(c["seed"])
+        inp, lab, idx = next(iter(loader))
+        assert inp.is_cuda and inp.dtype == torch.float32 and lab.dtype == torch.int64 and idx.tolist() == [0]
+        want = z[f"{t}_out_input"]
+        got = inp[0].cpu().numpy()
+        assert torch.equal(lab[0].cpu(), torch.from_numpy(z[f"{t}_out_labels"])), t
+        assert np.array_equal(got[:, 3:], want[:, 3:]), t                      # features are gathered, not computed
+        f32norm = c["normalization"] is not None and xyz.dtype == np.float32
+        assert _close(got[:, :3], want[:, :3], f32norm), (t, float(np.abs(got[:, :3] - want[:, :3]).max()))
+        # numpy's global stream was consumed exactly like the reference consumed it
+        assert np.array_equal(np.random.get_state()[1][:4].astype(np.int64), z[f"{t}_state_after"]), t
+
+
+def test_shuffled_augmented_epoch_matches_the_reference_loader(gold):
+    from randlanet.utils.augmentation import AugmentationSettings
+    from randlanet.utils.device_dataset import get_device_data_loader
+    z, _ = gold
+    ds = [(z[f"loader_xyz{i}"], np.zeros((z[f"loader_xyz{i}"].shape[0], 0), np.float32), z[f"loader_labels{i}"].astype(np.int64))
+          for i in range(5)]
+    loader = get_device_data_loader(ds, 1024, 2, shuffle=True, consistent_sampling=False,
+                                    augmentation_settings=AugmentationSettings(), device="cuda")
+    assert len(loader) == 3 and loader.batch_size == 2
+    torch.manual_seed(3)
+    np.random.seed(4)
+    seen = 0
+    for bi, (inp, lab, idx) in enumerate(loader):
+        k = len(idx)
+        assert idx.tolist() == z["loader_order"][bi][:k].tolist()
+        assert _close(inp.cpu().numpy(), z["loader_inputs"][bi][:k], False)
+        assert np.array_equal(lab.cpu().numpy(), z["loader_out_labels"][bi][:k].astype(np.int64))
+        seen += k
+    assert seen == 5
+    # the loader's `dataset` is what Trainer.evaluate reaches into for the un-sampled cloud (trainer.py:331)
+    full, labels, _ = loader.dataset.__getitem__(2, preprocess=False)
+    assert full.shape == (ds[2][0].shape[0], 3) and labels.dtype == torch.int64
+
+
+def test_matches_the_cpu_oracle_on_a_full_size_cloud():
+    """40960 of 120000 points, float32 source, default augmentation: the kernel against oracle/pipeline_oracle.py."""
+    from oracle import pipeline_oracle as PO
+    from randlanet.utils.augmentation import AugmentationSettings
+    from randlanet.utils.device_dataset import DeviceDataLoader
+    from dataclasses import asdict
+    rs = np.random.RandomState(0)
+    ds = [(rs.rand(120000, 3).astype(np.float32) * np.float32(3.0), rs.rand(120000, 1).astype(np.float32),
+           rs.randint(0, 5, 120000).astype(np.int64)) for _ in range(2)]
+    aug = AugmentationSettings()
+    loader = DeviceDataLoader(ds, 40960, 2, consistent_sampling=False, augmentation_settings=aug, device="cuda")
+    np.random.seed(11)
+    inp, lab, _ = next(iter(loader))
+    np.random.seed(11)
+    want_inp, want_lab = PO.collate([PO.preprocess(*c, 40960, consistent_sampling=False, augmentation=asdict(aug)) for c in ds])
+    assert np.array_equal(lab.cpu().numpy(), want_lab)
+    assert _close(inp.cpu().numpy(), want_inp, False)
+
+
+def test_device_rng_mode_is_deterministic_and_well_formed():
+    from randlanet.utils.augmentation import AugmentationSettings
+    from randlanet.utils.device_dataset import DeviceDataLoader
+    rs = np.random.RandomState(1)
+    ds = [(rs.rand(3000, 3).astype(np.float32), np.zeros((3000, 0), np.float32), np.arange(3000, dtype=np.int64))]
+    aug = AugmentationSettings(jitter_variance=0.5, jitter_limit=0.01, scale_limit=0.0, shift_limit=0.0,
+                               rotation_angle_variances=(0.0, 0.0, 0.0), rotation_angle_limits=(0.1, 0.1, 0.1))
+    outs = []
+    for _ in range(2):
+        np.random.seed(5)
+        loader = DeviceDataLoader(ds, 2048, 1, consistent_sampling=False, augmentation_settings=aug, device="cuda", rng="device")
+        inp, lab, _ = next(iter(loader))
+        outs.append((inp.cpu().numpy(), lab.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])    # same seeds, same batch
+    inp, lab = outs[0]
+    assert len(np.unique(lab[0])) == 2048                      # sampled without replacement (labels are the row numbers)
+    # with scale 1, no rotation, no shift the only change is the clipped jitter
+    moved = np.abs(inp[0] - ds[0][0][lab[0]])
+    assert float(moved.max()) <= 0.01 + 1e-6 and float(moved.mean()) > 1e-3
+    # more points requested than the cloud has: every row once, the rest duplicates
+    up = DeviceDataLoader(ds, 4096, 1, consistent_sampling=False, device="cuda", rng="device")
+    _, lab, _ = next(iter(up))
+    assert len(np.unique(lab[0].cpu().numpy())) == 3000
+
+
+def test_bad_arguments_fail_loudly():
+    from randlanet import _hip as H
+    from randlanet.utils.device_dataset import DeviceDataLoader
+    ds = [(np.zeros((10, 3), np.float32), np.zeros((10, 0), np.float32), np.zeros(10, np.int64))]
+    with pytest.raises(ValueError):
+        DeviceDataLoader(ds, 8, 1, device="cuda", rng="mt19937")
+    with pytest.raises(H.HipKernelError):
+        DeviceDataLoader(ds, 8, 1, device="cpu")
+    with pytest.raises(AssertionError):
+        DeviceDataLoader([(np.zeros((10, 2), np.float32), np.zeros((10, 0), np.float32), np.zeros(10, np.int64))], 8, 1, device="cuda")
