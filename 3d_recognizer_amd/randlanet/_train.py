@@ -219,3 +219,55 @@ class TrainStep:
         miou, pci = iou_from_counts(cnt)
         return dict(loss=float(rec[0]), OA=oa, mAcc=float(np.mean(pca)), mIoU=miou, per_class_iou=pci,
                     per_class_acc=pca)
+
+
+class InferStep:
+    """Eval-mode forward for one batch shape (B, N), replayed as one hipGraph: logits (B,C,N) in the original point order
+    (RandLANet.forward in eval mode, modules.py:542-611).  The permutation is drawn by the caller like in training."""
+
+    def __init__(self, module, B: int, N: int, use_graph: bool = True):
+        self.module = module
+        self.dev = module.device
+        s = module.settings
+        self.engine = module.engine()
+        self.inp = torch.rand((B, N, 3 + s.n_features), dtype=torch.float32, device=self.dev)
+        self.perm = torch.arange(N, dtype=torch.int64, device=self.dev)
+        self.logits = torch.zeros((B, s.n_classes, N), dtype=torch.float32, device=self.dev)
+        self._staging = torch.empty(N, dtype=torch.int64).pin_memory()
+        self._staging_np = self._staging.numpy()
+        self._copied: Optional[torch.cuda.Event] = None
+        self.use_graph = use_graph
+        self._g: Optional[torch.cuda.CUDAGraph] = None
+
+    def _fwd(self):
+        logits, _ = self.engine.forward(self.inp, self.perm, False)
+        self.logits.copy_(logits)
+
+    def capture(self, warmup: int = 2) -> None:
+        self.module.eval()
+        if not self.use_graph:
+            return
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._fwd()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self._g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g, capture_error_mode="thread_local"):
+            self._fwd()
+        torch.cuda.synchronize(self.dev)
+
+    def step(self, perm: np.ndarray) -> torch.Tensor:
+        if self._copied is not None:
+            self._copied.synchronize()         # the staging buffer is free again once its copy has executed
+        self._staging_np[:] = perm
+        self.perm.copy_(self._staging, non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record(torch.cuda.current_stream(self.dev))
+        if self._g is not None:
+            self._g.replay()
+        else:
+            self._fwd()
+        return self.logits

@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the secondary eval-forward measurement")
     ap.add_argument("--batch", type=int, default=CFG["per_gpu_batch"], help="clouds per GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box)")
@@ -245,6 +246,27 @@ def main():
     if not np.isfinite(metrics["loss"]):
         raise SystemExit("bench.py: the training loss is not finite - the measurement is invalid")
 
+    # secondary line: eval-mode forward clouds/s with the weights as trained so far, same batch shape
+    infer = None
+    if rank == 0 and not args.no_inference:
+        from randlanet._train import InferStep
+        inf = InferStep(model, B, N, use_graph=not args.no_graph)
+        inf.inp.copy_(stepper.inp)
+        inf.capture()
+        for _ in range(args.warmup):
+            inf.step(np.random.permutation(N))
+        torch.cuda.synchronize(dev)
+        ti = time.perf_counter()
+        for _ in range(args.steps):
+            inf.step(np.random.permutation(N))
+        torch.cuda.synchronize(dev)
+        ti = time.perf_counter() - ti
+        if not bool(torch.isfinite(inf.logits).all()):
+            raise SystemExit("bench.py: eval-mode logits are not finite - the measurement is invalid")
+        infer = {"metric": "inference clouds/sec (eval forward), one GPU", "value": round(B * args.steps / ti, 2),
+                 "ms_per_batch": round(ti / args.steps * 1e3, 3)}
+        model.train()
+
     roof = breakdown = cpu = None
     if not args.no_roofline:
         # every rank runs the instrumented eager steps (they contain the gradient all-reduce, a collective);
@@ -275,6 +297,7 @@ def main():
             "final_mIoU": round(metrics["mIoU"], 4),
             "roofline": roof,
             "cpu_baseline": cpu,
+            "inference": infer,
         }
         if breakdown is not None:
             os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
