@@ -15,6 +15,8 @@
 // xyz / neighbour indices (relative position encoding, modules.py:173-186) without ever being
 // materialised.
 #include "rl_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -785,15 +787,38 @@ void launch_swgrad(int N, dim3 grid, hipStream_t st, const WgradParams& p) {
 constexpr int PG_BK = 32;
 constexpr int PG_AS = 36;   // LDS row stride (floats): 16-byte aligned rows, 16 rows x b128 hit 64 distinct banks
 
-template <int NT>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+// fp32 value -> bf16 head + bf16 tail (v = hi + lo up to 2^-17 relative)
+__device__ __forceinline__ void split_bf16(const float4 v, bf16x4& hi, bf16x4& lo) {
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// TERMS = 0: fp32 MFMA (v_mfma_f32_16x16x4_f32), the exact-product reference mode.
+// TERMS = 3: every fp32 operand is split into a bf16 head and tail on its way into LDS and the product is
+//            a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): products carry
+//            ~2^-16 relative error instead of 2^-24, three MFMAs of 16 cycles replace eight of 32.
+// TERMS = 1: heads only (plain bf16 operands, fp32 accumulate) - the throughput mode.
+template <int NT, int TERMS>
 __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     constexpr int BN = 16 * NT;
+    constexpr int BS = 40;   // bf16 LDS row stride (80 B): 16 rows x ds_read_b128 fall on 16 distinct bank quads
+    constexpr int NSPL = TERMS == 3 ? 2 : 1;
     constexpr int WQ = (BN * 8 + 255) / 256;              // float4 of W per lane and chunk
     // both operands sit in LDS with k contiguous ([row][k] and [n][k]); MFMA step s of a chunk takes
     // k = 8*(lane>>4) + s from either, so a lane's eight values per operand tile are two ds_read_b128
-    __shared__ __attribute__((aligned(16))) float As[GM_BM * PG_AS];
-    __shared__ __attribute__((aligned(16))) float Wt[BN * PG_AS];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[TERMS == 0 ? GM_BM * PG_AS * 4 : GM_BM * BS * 2 * NSPL];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_w[TERMS == 0 ? BN * PG_AS * 4 : BN * BS * 2 * NSPL];
     __shared__ double red[4][2][BN];
+    float* As = reinterpret_cast<float*>(lds_a);
+    float* Wt = reinterpret_cast<float*>(lds_w);
+    __bf16* Ah = reinterpret_cast<__bf16*>(lds_a);
+    __bf16* Al = Ah + GM_BM * BS;       // only touched when TERMS == 3
+    __bf16* Wh = reinterpret_cast<__bf16*>(lds_w);
+    __bf16* Wl = Wh + BN * BS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -877,7 +902,14 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                     v.z = actf(v.z * sc.z + sh.z);
                     v.w = actf(v.w * sc.w + sh.w);
                 }
-                *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * i) * PG_AS + aq * 4) = v;
+                if constexpr (TERMS == 0) {
+                    *reinterpret_cast<float4*>(As + ((tid >> 3) + 32 * i) * PG_AS + aq * 4) = v;
+                } else {
+                    bf16x4 hi, lo;
+                    split_bf16(v, hi, lo);
+                    *reinterpret_cast<bf16x4*>(Ah + ((tid >> 3) + 32 * i) * BS + aq * 4) = hi;
+                    if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(Al + ((tid >> 3) + 32 * i) * BS + aq * 4) = lo;
+                }
             }
             if (w_ncontig) {
                 // transposed scalar writes: the 64 lanes of a store hit banks 16*(l&3) + (l>>2) + const, all distinct
@@ -885,8 +917,19 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                 for (int i = 0; i < WQ; ++i) {
                     const int u = i * 4 + wave;
                     if (u < 2 * NT) {
-                        float* dst = Wt + ((u % NT) * 16 + (lane & 3) * 4) * PG_AS + (u / NT) * 16 + (lane >> 2);
-                        dst[0] = rw[i].x; dst[PG_AS] = rw[i].y; dst[2 * PG_AS] = rw[i].z; dst[3 * PG_AS] = rw[i].w;
+                        if constexpr (TERMS == 0) {
+                            float* dst = Wt + ((u % NT) * 16 + (lane & 3) * 4) * PG_AS + (u / NT) * 16 + (lane >> 2);
+                            dst[0] = rw[i].x; dst[PG_AS] = rw[i].y; dst[2 * PG_AS] = rw[i].z; dst[3 * PG_AS] = rw[i].w;
+                        } else {
+                            bf16x4 hi, lo;
+                            split_bf16(rw[i], hi, lo);
+                            const int o = ((u % NT) * 16 + (lane & 3) * 4) * BS + (u / NT) * 16 + (lane >> 2);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                Wh[o + j * BS] = hi[j];
+                                if constexpr (TERMS == 3) Wl[o + j * BS] = lo[j];
+                            }
+                        }
                     }
                 }
             } else {
@@ -894,7 +937,16 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                 for (int i = 0; i < WQ; ++i) {
                     const int e = tid + i * 256;
                     const int n = e >> 3, q = e & 7;
-                    if (e < BN * 8) *reinterpret_cast<float4*>(Wt + n * PG_AS + q * 4) = rw[i];
+                    if (e < BN * 8) {
+                        if constexpr (TERMS == 0) {
+                            *reinterpret_cast<float4*>(Wt + n * PG_AS + q * 4) = rw[i];
+                        } else {
+                            bf16x4 hi, lo;
+                            split_bf16(rw[i], hi, lo);
+                            *reinterpret_cast<bf16x4*>(Wh + n * BS + q * 4) = hi;
+                            if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(Wl + n * BS + q * 4) = lo;
+                        }
+                    }
                 }
             }
         };
@@ -909,38 +961,90 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
             commit(k0);
             __syncthreads();
             if (k0 + PG_BK < k_end) fetch(k0 + PG_BK);
-            // A fragments of the whole chunk up front (4 x b128); W fragments in groups of GS column blocks,
-            // group g+1 requested before the 8*GS MFMAs of group g: LDS latency never waits on an idle pipe
-            constexpr int GS = NT < 2 ? NT : 2;
-            constexpr int GH = NT / GS;          // groups per half chunk
-            float4 af[2][2], bf[2][GS];
+            if constexpr (TERMS == 0) {
+                // A fragments of the whole chunk up front (4 x b128); W fragments in groups of GS column blocks,
+                // group g+1 requested before the 8*GS MFMAs of group g: LDS latency never waits on an idle pipe
+                constexpr int GS = NT < 2 ? NT : 2;
+                constexpr int GH = NT / GS;          // groups per half chunk
+                float4 af[2][2], bf[2][GS];
+    #pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    af[h][0] = *reinterpret_cast<const float4*>(a_frag + h * 4);
+                    af[h][1] = *reinterpret_cast<const float4*>(a_frag + 16 * PG_AS + h * 4);
+                }
+    #pragma unroll
+                for (int j = 0; j < GS; ++j) bf[0][j] = *reinterpret_cast<const float4*>(w_frag + j * 16 * PG_AS);
+    #pragma unroll
+                for (int g = 0; g < 2 * GH; ++g) {
+                    const int h = g / GH, nb0 = (g % GH) * GS;
+                    if (g + 1 < 2 * GH) {
+                        const int h1 = (g + 1) / GH, nb1 = ((g + 1) % GH) * GS;
+    #pragma unroll
+                        for (int j = 0; j < GS; ++j)
+                            bf[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(w_frag + (nb1 + j) * 16 * PG_AS + h1 * 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler would sink them)
+                    const float a0[4] = {af[h][0].x, af[h][0].y, af[h][0].z, af[h][0].w};
+                    const float a1[4] = {af[h][1].x, af[h][1].y, af[h][1].z, af[h][1].w};
+    #pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+    #pragma unroll
+                        for (int j = 0; j < GS; ++j) {
+                            const float4 b4 = bf[g & 1][j];
+                            const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
+                            acc[0][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bv, acc[0][nb0 + j], 0, 0, 0);
+                            acc[1][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv, acc[1][nb0 + j], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                // bf16 operands: one ds_read_b128 = the lane's 8 k-values of a 16x16x32 MFMA; per column-block pair
+                // the next pair's fragments are requested before the 4*TERMS MFMAs of the current one
+                const __bf16* ah_frag = Ah + (wave * 32 + lr) * BS + lq * 8;
+                const __bf16* wh_frag = Wh + lr * BS + lq * 8;
+                constexpr int LO_A = GM_BM * BS, LO_W = BN * BS;    // offsets of the tail arrays
+                constexpr int GS = NT < 2 ? NT : 2;
+                constexpr int NG = NT / GS;
+                bf16x8 a_h[2], a_l[2], b_h[2][GS], b_l[2][GS];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                af[h][0] = *reinterpret_cast<const float4*>(a_frag + h * 4);
-                af[h][1] = *reinterpret_cast<const float4*>(a_frag + 16 * PG_AS + h * 4);
-            }
+                for (int rb = 0; rb < 2; ++rb) {
+                    a_h[rb] = *reinterpret_cast<const bf16x8*>(ah_frag + rb * 16 * BS);
+                    if constexpr (TERMS == 3) a_l[rb] = *reinterpret_cast<const bf16x8*>(ah_frag + LO_A + rb * 16 * BS);
+                }
 #pragma unroll
-            for (int j = 0; j < GS; ++j) bf[0][j] = *reinterpret_cast<const float4*>(w_frag + j * 16 * PG_AS);
+                for (int j = 0; j < GS; ++j) {
+                    b_h[0][j] = *reinterpret_cast<const bf16x8*>(wh_frag + j * 16 * BS);
+                    if constexpr (TERMS == 3) b_l[0][j] = *reinterpret_cast<const bf16x8*>(wh_frag + LO_W + j * 16 * BS);
+                }
 #pragma unroll
-            for (int g = 0; g < 2 * GH; ++g) {
-                const int h = g / GH, nb0 = (g % GH) * GS;
-                if (g + 1 < 2 * GH) {
-                    const int h1 = (g + 1) / GH, nb1 = ((g + 1) % GH) * GS;
+                for (int g = 0; g < NG; ++g) {
+                    const int nb0 = g * GS;
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int j = 0; j < GS; ++j) {
+                            b_h[(g + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(wh_frag + (nb0 + GS + j) * 16 * BS);
+                            if constexpr (TERMS == 3)
+                                b_l[(g + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(wh_frag + LO_W + (nb0 + GS + j) * 16 * BS);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // term by term over the group's accumulators: dependent MFMAs are 2*GS issues apart
 #pragma unroll
                     for (int j = 0; j < GS; ++j)
-                        bf[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(w_frag + (nb1 + j) * 16 * PG_AS + h1 * 4);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep the reads above the MFMAs (the scheduler would sink them)
-                const float a0[4] = {af[h][0].x, af[h][0].y, af[h][0].z, af[h][0].w};
-                const float a1[4] = {af[h][1].x, af[h][1].y, af[h][1].z, af[h][1].w};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                        for (int rb = 0; rb < 2; ++rb)
+                            acc[rb][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h[rb], b_h[g & 1][j], acc[rb][nb0 + j], 0, 0, 0);
+                    if constexpr (TERMS == 3) {
 #pragma unroll
-                    for (int j = 0; j < GS; ++j) {
-                        const float4 b4 = bf[g & 1][j];
-                        const float bv = s == 0 ? b4.x : s == 1 ? b4.y : s == 2 ? b4.z : b4.w;
-                        acc[0][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], bv, acc[0][nb0 + j], 0, 0, 0);
-                        acc[1][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bv, acc[1][nb0 + j], 0, 0, 0);
+                        for (int j = 0; j < GS; ++j)
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb)
+                                acc[rb][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h[rb], b_l[g & 1][j], acc[rb][nb0 + j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < GS; ++j)
+#pragma unroll
+                            for (int rb = 0; rb < 2; ++rb)
+                                acc[rb][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l[rb], b_h[g & 1][j], acc[rb][nb0 + j], 0, 0, 0);
                     }
                 }
             }
@@ -1089,6 +1193,30 @@ inline int gemm_ksplit(long M, int N, int K) {
     return s < 2 ? 1 : (int)s;
 }
 
+// wide-GEMM arithmetic (see pgemm_kernel): 0 = fp32 MFMA, 3 = bf16x3 (default), 1 = bf16.  Initial value from
+// RL_WIDE_GEMM = fp32 | bf16x3 | bf16; rl_set_wide_gemm() changes it at run time.
+int g_wide_terms = -1;
+inline int parse_wide(const char* e) {
+    if (!e || !strcmp(e, "bf16x3")) return 3;
+    if (!strcmp(e, "fp32")) return 0;
+    if (!strcmp(e, "bf16")) return 1;
+    return -1;
+}
+inline int wide_gemm_terms() {
+    if (g_wide_terms < 0) {
+        const int t = parse_wide(getenv("RL_WIDE_GEMM"));
+        g_wide_terms = t < 0 ? 3 : t;
+    }
+    return g_wide_terms;
+}
+template <int NT>
+void launch_pgemm(dim3 grid, hipStream_t st, const GemmParams& p) {
+    const int t = wide_gemm_terms();
+    if (t == 0)      hipLaunchKernelGGL((pgemm_kernel<NT, 0>), grid, dim3(256), 0, st, p);
+    else if (t == 1) hipLaunchKernelGGL((pgemm_kernel<NT, 1>), grid, dim3(256), 0, st, p);
+    else             hipLaunchKernelGGL((pgemm_kernel<NT, 3>), grid, dim3(256), 0, st, p);
+}
+
 inline bool pgemm_ok(const GemmParams& p) {
     if (p.a.a_mode != 0 || !p.a.vec4) return false;
     if (((uintptr_t)p.W & 15) != 0) return false;
@@ -1217,9 +1345,18 @@ constexpr int PW2_RB = 32;
 constexpr int PW2_T = 128;
 constexpr int PW2_S = 36;
 
+template <int TERMS>   // 0: fp32 MFMA; 3: bf16 head+tail operands, three bf16 MFMAs per product (see pgemm_kernel); 1: bf16
 __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float dYt[PW2_T * PW2_S];
-    __shared__ __attribute__((aligned(16))) float At[PW2_T * PW2_S];
+    constexpr int BS = 40;   // bf16 row stride: 32 reduction rows + 8 pad (80 B)
+    constexpr int NSPL = TERMS == 3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_d[TERMS == 0 ? PW2_T * PW2_S * 4 : PW2_T * BS * 2 * NSPL];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[TERMS == 0 ? PW2_T * PW2_S * 4 : PW2_T * BS * 2 * NSPL];
+    float* dYt = reinterpret_cast<float*>(lds_d);
+    float* At = reinterpret_cast<float*>(lds_a);
+    __bf16* Dh = reinterpret_cast<__bf16*>(lds_d);
+    __bf16* Dl = Dh + PW2_T * BS;
+    __bf16* Xh = reinterpret_cast<__bf16*>(lds_a);
+    __bf16* Xl = Xh + PW2_T * BS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int N = p.N, K = p.a.K;
@@ -1288,10 +1425,26 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
                 v.z = actf(v.z * sc[i].z + sh[i].z);
                 v.w = actf(v.w * sc[i].w + sh[i].w);
             }
-            float* dd = dYt + ucol[i] * PW2_S + urow[i];
-            dd[0] = rd[i].x; dd[PW2_S] = rd[i].y; dd[2 * PW2_S] = rd[i].z; dd[3 * PW2_S] = rd[i].w;
-            float* da = At + ucol[i] * PW2_S + urow[i];
-            da[0] = v.x; da[PW2_S] = v.y; da[2 * PW2_S] = v.z; da[3 * PW2_S] = v.w;
+            if constexpr (TERMS == 0) {
+                float* dd = dYt + ucol[i] * PW2_S + urow[i];
+                dd[0] = rd[i].x; dd[PW2_S] = rd[i].y; dd[2 * PW2_S] = rd[i].z; dd[3 * PW2_S] = rd[i].w;
+                float* da = At + ucol[i] * PW2_S + urow[i];
+                da[0] = v.x; da[PW2_S] = v.y; da[2 * PW2_S] = v.z; da[3 * PW2_S] = v.w;
+            } else {
+                bf16x4 dh, dl, xh, xl;
+                split_bf16(rd[i], dh, dl);
+                split_bf16(v, xh, xl);
+                const int o = ucol[i] * BS + urow[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Dh[o + j * BS] = dh[j];
+                    Xh[o + j * BS] = xh[j];
+                    if constexpr (TERMS == 3) {
+                        Dl[o + j * BS] = dl[j];
+                        Xl[o + j * BS] = xl[j];
+                    }
+                }
+            }
         }
     };
 
@@ -1304,40 +1457,104 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
         __syncthreads();
         if (r0 + PW2_RB < r_end) fetch(r0 + PW2_RB);
         if (p.has_bias && blockIdx.z == 0 && tid < PW2_T) {
+            if constexpr (TERMS == 0) {
 #pragma unroll
-            for (int j = 0; j < PW2_RB / 4; ++j) {
-                const float4 t = *reinterpret_cast<const float4*>(dYt + tid * PW2_S + j * 4);
-                bsum += (t.x + t.y) + (t.z + t.w);
+                for (int j = 0; j < PW2_RB / 4; ++j) {
+                    const float4 t = *reinterpret_cast<const float4*>(dYt + tid * PW2_S + j * 4);
+                    bsum += (t.x + t.y) + (t.z + t.w);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PW2_RB / 8; ++j) {
+                    const bf16x8 h = *reinterpret_cast<const bf16x8*>(Dh + tid * BS + j * 8);
+                    float t = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t += (float)h[e];
+                    if constexpr (TERMS == 3) {
+                        const bf16x8 l = *reinterpret_cast<const bf16x8*>(Dl + tid * BS + j * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t += (float)l[e];
+                    }
+                    bsum += t;
+                }
             }
         }
-        float4 af[2][2], bf[2][2];
+        if constexpr (TERMS == 0) {
+            float4 af[2][2], bf[2][2];
+    #pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                af[h][0] = *reinterpret_cast<const float4*>(n_frag + h * 4);
+                af[h][1] = *reinterpret_cast<const float4*>(n_frag + 16 * PW2_S + h * 4);
+            }
+    #pragma unroll
+            for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const float4*>(k_frag + j * 16 * PW2_S);
+    #pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int h = g / 4, kb0 = (g % 4) * 2;
+                if (g + 1 < 8) {
+                    const int h1 = (g + 1) / 4, kb1 = ((g + 1) % 4) * 2;
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        bf[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(k_frag + (kb1 + j) * 16 * PW2_S + h1 * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float a0[4] = {af[h][0].x, af[h][0].y, af[h][0].z, af[h][0].w};
+                const float a1[4] = {af[h][1].x, af[h][1].y, af[h][1].z, af[h][1].w};
+    #pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+    #pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float4 b4 = bf[g & 1][j];
+                        const float bv = s2 == 0 ? b4.x : s2 == 1 ? b4.y : s2 == 2 ? b4.z : b4.w;
+                        acc[0][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], bv, acc[0][kb0 + j], 0, 0, 0);
+                        acc[1][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], bv, acc[1][kb0 + j], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // one 16x16x32 MFMA covers the chunk's 32 rows; fragments: a lane's rows 8*(lane>>4) .. +7, one ds_read_b128
+            const __bf16* dh_frag = Dh + (wave * 32 + lr) * BS + lq * 8;
+            const __bf16* xh_frag = Xh + lr * BS + lq * 8;
+            constexpr int LO = PW2_T * BS;
+            bf16x8 a_h[2], a_l[2], b_h[2][2], b_l[2][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            af[h][0] = *reinterpret_cast<const float4*>(n_frag + h * 4);
-            af[h][1] = *reinterpret_cast<const float4*>(n_frag + 16 * PW2_S + h * 4);
-        }
+            for (int i = 0; i < 2; ++i) {
+                a_h[i] = *reinterpret_cast<const bf16x8*>(dh_frag + i * 16 * BS);
+                if constexpr (TERMS == 3) a_l[i] = *reinterpret_cast<const bf16x8*>(dh_frag + LO + i * 16 * BS);
+            }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const float4*>(k_frag + j * 16 * PW2_S);
+            for (int j = 0; j < 2; ++j) {
+                b_h[0][j] = *reinterpret_cast<const bf16x8*>(xh_frag + j * 16 * BS);
+                if constexpr (TERMS == 3) b_l[0][j] = *reinterpret_cast<const bf16x8*>(xh_frag + LO + j * 16 * BS);
+            }
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int h = g / 4, kb0 = (g % 4) * 2;
-            if (g + 1 < 8) {
-                const int h1 = (g + 1) / 4, kb1 = ((g + 1) % 4) * 2;
+            for (int g = 0; g < 4; ++g) {
+                const int kb0 = g * 2;
+                if (g + 1 < 4) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        b_h[(g + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(xh_frag + (kb0 + 2 + j) * 16 * BS);
+                        if constexpr (TERMS == 3)
+                            b_l[(g + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(xh_frag + LO + (kb0 + 2 + j) * 16 * BS);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    bf[(g + 1) & 1][j] = *reinterpret_cast<const float4*>(k_frag + (kb1 + j) * 16 * PW2_S + h1 * 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const float a0[4] = {af[h][0].x, af[h][0].y, af[h][0].z, af[h][0].w};
-            const float a1[4] = {af[h][1].x, af[h][1].y, af[h][1].z, af[h][1].w};
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h[i], b_h[g & 1][j], acc[i][kb0 + j], 0, 0, 0);
+                if constexpr (TERMS == 3) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float4 b4 = bf[g & 1][j];
-                    const float bv = s2 == 0 ? b4.x : s2 == 1 ? b4.y : s2 == 2 ? b4.z : b4.w;
-                    acc[0][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], bv, acc[0][kb0 + j], 0, 0, 0);
-                    acc[1][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s2], bv, acc[1][kb0 + j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[i][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h[i], b_l[g & 1][j], acc[i][kb0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            acc[i][kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l[i], b_h[g & 1][j], acc[i][kb0 + j], 0, 0, 0);
                 }
             }
         }
@@ -1366,6 +1583,17 @@ inline bool pwgrad_ok(const WgradParams& p) {
 }
 
 }  // namespace
+
+extern "C" int rl_set_wide_gemm(const char* mode) {
+    const int t = parse_wide(mode);
+    RL_REQUIRE(mode != nullptr && t >= 0, RL_ERR_ARGS, "rl_set_wide_gemm: mode must be \"fp32\", \"bf16x3\" or \"bf16\"");
+    g_wide_terms = t;
+    return RL_OK;
+}
+extern "C" const char* rl_get_wide_gemm(void) {
+    const int t = wide_gemm_terms();
+    return t == 0 ? "fp32" : t == 1 ? "bf16" : "bf16x3";
+}
 
 extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     RL_REQUIRE(d != nullptr, RL_ERR_ARGS, "rl_gemm: null descriptor");
@@ -1404,7 +1632,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
             p.kchunk = ((d->K + ks - 1) / ks + 31) / 32 * 32;
             p.ksplit = (d->K + p.kchunk - 1) / p.kchunk;
             p.kslab = d->kslab;
-            hipLaunchKernelGGL((pgemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128), p.ksplit), dim3(256), 0, st, p);
+            launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p);
             rl_note_kernel("pgemm_kernel<8>+splitk");
             RL_LAUNCH_CHECK("rl_gemm(split-K)");
             if ((long)gx * rl_cdiv(d->N, 64) >= 256)
@@ -1416,10 +1644,10 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         }
     }
     if (pgemm_ok(p)) {
-        if (d->N <= 16)      hipLaunchKernelGGL((pgemm_kernel<1>), dim3(gx, 1), dim3(256), 0, st, p);
-        else if (d->N <= 32) hipLaunchKernelGGL((pgemm_kernel<2>), dim3(gx, 1), dim3(256), 0, st, p);
-        else if (d->N <= 64) hipLaunchKernelGGL((pgemm_kernel<4>), dim3(gx, 1), dim3(256), 0, st, p);
-        else                 hipLaunchKernelGGL((pgemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128)), dim3(256), 0, st, p);
+        if (d->N <= 16)      launch_pgemm<1>(dim3(gx, 1), st, p);
+        else if (d->N <= 32) launch_pgemm<2>(dim3(gx, 1), st, p);
+        else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
+        else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
         rl_note_kernel(d->N <= 16 ? "pgemm_kernel<1>" : d->N <= 32 ? "pgemm_kernel<2>" : d->N <= 64 ? "pgemm_kernel<4>" : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(pipelined)");
         return RL_OK;
@@ -1475,7 +1703,12 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         const bool pipelined = pwgrad_ok(p);
         const int T = pipelined ? wgrad_tile(d->N, d->K) : WG_T;
         dim3 grid(nsplit, rl_cdiv(d->N, T), rl_cdiv(d->K, T));
-        if (pipelined && T == 128) hipLaunchKernelGGL(pwgrad128_kernel, grid, dim3(256), 0, st, p);
+        if (pipelined && T == 128) {
+            const int t = wide_gemm_terms();
+            if (t == 0)      hipLaunchKernelGGL(pwgrad128_kernel<0>, grid, dim3(256), 0, st, p);
+            else if (t == 1) hipLaunchKernelGGL(pwgrad128_kernel<1>, grid, dim3(256), 0, st, p);
+            else             hipLaunchKernelGGL(pwgrad128_kernel<3>, grid, dim3(256), 0, st, p);
+        }
         else if (pipelined) hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
         rl_note_kernel(pipelined && T == 128 ? "pwgrad128_kernel" : pipelined ? "pwgrad_kernel" : "wgrad_kernel");

@@ -137,6 +137,8 @@ _SIGNATURES = {
     "rl_gemm_kslab_floats": (_l, [_l, _i, _i]),
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
+    "rl_set_wide_gemm": (_i, [C.c_char_p]),
+    "rl_get_wide_gemm": (C.c_char_p, []),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "rl_wgrad_nsplit": (_i, [_l, _i, _i]),
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),

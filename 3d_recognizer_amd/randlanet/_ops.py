@@ -203,6 +203,15 @@ class Rpe:
         return self.B * self.n * self.K
 
 
+def set_wide_gemm(mode: str) -> None:
+    """Arithmetic of the wide GEMM / weight-gradient kernels: "bf16x3" (default), "fp32" or "bf16" (rl_set_wide_gemm)."""
+    H.check(H.lib().rl_set_wide_gemm(mode.encode()), "rl_set_wide_gemm")
+
+
+def get_wide_gemm() -> str:
+    return H.lib().rl_get_wide_gemm().decode()
+
+
 def rpe_build(a: "Rpe") -> Lazy:
     """The relative position encoding of every neighbourhood row, written out once (rows x 12 floats: 10 channels +
     2 of padding) so that mlp_rpe1's forward and weight gradient read a plain tensor (modules.py:173-186)."""

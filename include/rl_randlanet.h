@@ -150,6 +150,17 @@ typedef struct rl_gemm_desc {
 } rl_gemm_desc;
 
 int64_t rl_gemm_kslab_floats(int64_t M, int N, int K);
+
+/* Arithmetic of the wide kernels (K or N > 64: rl_gemm's LDS-tiled kernel, rl_wgrad's 128x128 kernel):
+ *   "bf16x3" (default)  every fp32 operand is split into a bf16 head and tail on its way into LDS and a product is
+ *                       a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate: ~2^-16
+ *                       relative product error; network logits within 2.5e-6 of the fp32 CPU forward
+ *   "fp32"              v_mfma_f32_16x16x4_f32, bitwise an fp32 FMA chain
+ *   "bf16"              heads only: plain bf16 operands, fp32 accumulate (does NOT meet the 1e-3 logits bound)
+ * The environment variable RL_WIDE_GEMM sets the initial mode.  Storage, accumulation, statistics and the
+ * narrow (streaming) kernels are fp32 in every mode.  Not thread-safe against concurrent launches.           */
+int rl_set_wide_gemm(const char* mode);
+const char* rl_get_wide_gemm(void);
 int rl_gemm(const rl_gemm_desc* d, void* stream);
 
 /* Weight / bias gradient of the same layer:  dW(k,c) = sum_r A'[r][k] * dY[r][c],

@@ -39,6 +39,7 @@ def test_full_size_eval_logits_match_oracle(tag, C, N, K, layers):
     assert logits.shape == (1, C, N)
     err = (logits - ref).abs()
     # north_star: per-point logits within 1e-3 of the CPU forward on the same cloud
+    print(f"[parity] config {tag}: max |logit - oracle| = {float(err.max()):.3e} (logit range {float(ref.abs().max()):.2f})")
     assert float(err.max()) < 1e-3, (tag, float(err.max()))
     assert torch.equal(logits.argmax(1), ref.argmax(1)) or float((logits.argmax(1) != ref.argmax(1)).float().mean()) < 1e-4
 
