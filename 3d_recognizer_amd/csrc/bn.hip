@@ -12,6 +12,27 @@
 
 namespace {
 
+// Sum of the per-workgroup partials of channel c over all slots, by one wavefront, in a fixed order.  Four
+// independent chains keep 8 loads in flight per lane: these kernels are pure latency (a few KB of doubles).
+__device__ __forceinline__ void slot_sums(const double* __restrict__ stats, int nslots, int C, int c, int lane,
+                                          double& s_out, double& q_out) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    const double* base = stats + c;
+    int i = lane;
+    for (; i + 192 < nslots; i += 256) {
+        s0 += base[((long)i * 2 + 0) * C];          q0 += base[((long)i * 2 + 1) * C];
+        s1 += base[((long)(i + 64) * 2 + 0) * C];   q1 += base[((long)(i + 64) * 2 + 1) * C];
+        s2 += base[((long)(i + 128) * 2 + 0) * C];  q2 += base[((long)(i + 128) * 2 + 1) * C];
+        s3 += base[((long)(i + 192) * 2 + 0) * C];  q3 += base[((long)(i + 192) * 2 + 1) * C];
+    }
+    for (; i < nslots; i += 64) {
+        s0 += base[((long)i * 2 + 0) * C];
+        q0 += base[((long)i * 2 + 1) * C];
+    }
+    s_out = rl_wave_sum((s0 + s1) + (s2 + s3));
+    q_out = rl_wave_sum((q0 + q1) + (q2 + q3));
+}
+
 // one wavefront per channel
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const double* __restrict__ stats, int nslots, double count, int C, const float* __restrict__ gamma,
@@ -23,13 +44,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     if (c >= C) return;
     double mean, var;
     if (training) {
-        double s = 0.0, q = 0.0;
-        for (int i = lane; i < nslots; i += 64) {
-            s += stats[((long)i * 2 + 0) * C + c];
-            q += stats[((long)i * 2 + 1) * C + c];
-        }
-        s = rl_wave_sum(s);
-        q = rl_wave_sum(q);
+        double s, q;
+        slot_sums(stats, nslots, C, c, lane, s, q);
         mean = s / count;
         var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -144,13 +160,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int i = lane; i < nslots; i += 64) {
-        s += stats[((long)i * 2 + 0) * C + c];
-        q += stats[((long)i * 2 + 1) * C + c];
-    }
-    s = rl_wave_sum(s);
-    q = rl_wave_sum(q);
+    double s, q;
+    slot_sums(stats, nslots, C, c, lane, s, q);
     if (lane != 0) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
