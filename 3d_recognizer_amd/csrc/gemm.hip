@@ -388,7 +388,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBat
                       (long)blockIdx.x - b.first_tile[i], red);
 }
 
-inline int wgrad_tile(int N, int K) { return (N >= 128 && K >= 128) ? 128 : WG_T; }
+// 128 x 128 tiles of dW as soon as one side reaches 128: a partly empty tile on the transposed-staging kernel is
+// 2-3x faster than full 64 x 64 tiles on the older one (40960x256x32: 91 -> 34 us)
+inline int wgrad_tile(int N, int K) { return (N >= 128 || K >= 128) ? 128 : WG_T; }
 
 void wgrad_split(long M, int N, int K, int* nsplit, long* rows_per_block) {
     const int T = wgrad_tile(N, K);
