@@ -130,6 +130,11 @@ struct GemmParams {
     int kchunk;        // K range per split (multiple of 32)
     float* kslab;      // [ksplit][M][N]
     int stat_slots;    // slots the finalize kernel reads; a smaller grid zero-fills the rest
+    const float* addend;       // split-scatter epilogue (pgemm only), see rl_gemm_desc
+    float* out2;
+    const int32_t* out2_index;
+    long out2_bstride;
+    int split_col;
 };
 
 template <int NT>
@@ -1082,16 +1087,26 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                         const int i = (int)(R - (long)b * p.rows_per_batch);
                         yoff = ((long)b * p.y_bstride + i) * p.ldy;
                     }
+                    long o2 = 0;
+                    if (p.out2) {
+                        const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                        o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
+                    }
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) {
                         const int c = col0 + nb * 16 + lr;
                         if (c < N) {
                             float v = acc[rb][nb][r];
                             if (p.bias) v += p.bias[c];
-                            if (p.accumulate) v += p.Y[yoff + c];
-                            p.Y[yoff + c] = v;
-                            ssum[nb] += v;
-                            ssq[nb] += v * v;
+                            if (p.addend) v += p.addend[R * N + c];
+                            if (p.out2 && c >= p.split_col) {
+                                atomicAdd(p.out2 + o2 + c, v);
+                            } else {
+                                if (p.accumulate) v += p.Y[yoff + c];
+                                p.Y[yoff + c] = v;
+                                ssum[nb] += v;
+                                ssq[nb] += v * v;
+                            }
                         }
                     }
                 }
@@ -1604,16 +1619,40 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
                     d->in_scale, d->in_shift, d->xyz, d->xyz_bstride, d->nbr_idx, d->nbr_d2, d->nbr_k,
                     d->B, d->n, d->K);
     if (rc) return rc;
-    RL_REQUIRE(d->N > 0 && d->W && d->Y && d->ldy >= d->N, RL_ERR_ARGS, "rl_gemm: bad W/Y");
+    RL_REQUIRE(d->N > 0 && d->W && d->Y && d->ldy > 0, RL_ERR_ARGS, "rl_gemm: bad W/Y");
     p.N = d->N; p.W = d->W; p.w_ks = d->w_ks; p.w_ns = d->w_ns; p.bias = d->bias;
     p.Y = d->Y; p.ldy = d->ldy; p.y_bstride = d->y_bstride;
     p.rows_per_batch = (d->a_mode == 1) ? d->n * d->nbr_k : d->n;
     RL_REQUIRE(d->y_bstride >= p.rows_per_batch, RL_ERR_ARGS, "rl_gemm: y_bstride smaller than rows per cloud");
     p.y_contig = (d->y_bstride == p.rows_per_batch);
     p.accumulate = d->accumulate; p.stats = d->stats;
+    p.addend = d->addend; p.out2 = d->out2; p.out2_index = d->out2_index; p.out2_bstride = d->out2_bstride;
+    p.split_col = d->out2 ? d->split_col : d->N;
+    const bool split = d->addend != nullptr || d->out2 != nullptr;
+    if (split) {
+        RL_REQUIRE(!d->out2 || (d->out2_index && d->split_col > 0 && d->split_col < d->N && d->out2_bstride > 0), RL_ERR_ARGS,
+                   "rl_gemm: bad split-scatter fields");
+        RL_REQUIRE(d->ldy >= (d->out2 ? d->split_col : d->N), RL_ERR_ARGS, "rl_gemm: ldy smaller than the columns stored to Y");
+        RL_REQUIRE(d->stats == nullptr, RL_ERR_UNSUPPORTED, "rl_gemm: split-scatter epilogue has no statistics");
+    } else {
+        RL_REQUIRE(d->ldy >= d->N, RL_ERR_ARGS, "rl_gemm: bad W/Y");
+    }
     const int gx = rl_row_blocks_host(p.a.M, GM_BM);
     hipStream_t st = (hipStream_t)stream;
     p.stat_slots = gx;
+    if (split) {
+        RL_REQUIRE((d->K > 64 || d->N > 64), RL_ERR_UNSUPPORTED, "rl_gemm: split-scatter epilogue needs K or N > 64");
+        p.ksplit = 1; p.kchunk = 0; p.kslab = nullptr;
+        RL_REQUIRE(pgemm_ok(p), RL_ERR_UNSUPPORTED,
+                   "rl_gemm: split-scatter epilogue needs the LDS-tiled kernel (aligned operands, K % 4 == 0)");
+        if (d->N <= 16)      launch_pgemm<1>(dim3(gx, 1), st, p);
+        else if (d->N <= 32) launch_pgemm<2>(dim3(gx, 1), st, p);
+        else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
+        else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
+        rl_note_kernel("pgemm_kernel<8>");
+        RL_LAUNCH_CHECK("rl_gemm(split-scatter)");
+        return RL_OK;
+    }
     if (d->a_mode == 0 && p.a.vec4p && d->K <= 64 && d->N <= 64) {
         // every wavefront first loads the whole weight matrix into registers: with >= 2048 weights per
         // wavefront, fewer and longer-lived workgroups (two per CU) beat one 128-row tile per workgroup

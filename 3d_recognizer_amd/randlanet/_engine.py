@@ -332,12 +332,18 @@ class Engine:
         Ws = self.P[f"{name}.score_fn.0.weight"]
         self._beside(ctx, lambda: ops.wgrad(ops.plain(X, B, n * K), dS, n * K, d,
                                             grads[f"{name}.score_fn.0.weight"], 1, d, None, pending=ctx.pending), X, dS)
-        ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
         gu = self._gbuf(ctx, u)
-        ops.copy_rows(dX, (0, h), n * K, gu[0], (0, h), rows, n * K, accumulate=gu[1])
-        gu[1] = True
         gg = self._gbuf(ctx, g)
         if not gg[1]:
             gg[0].zero_()
             gg[1] = True
-        ops.scatter_add_rows(dX, (h, h), gg[0], g.bstride, rows, n * K, idx)
+        if ops.NO_SPLIT_SCATTER or d <= 64:      # the epilogue lives in the wide (LDS-tiled) kernel only
+            ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
+            ops.copy_rows(dX, (0, h), n * K, gu[0], (0, h), rows, n * K, accumulate=gu[1])
+            ops.scatter_add_rows(dX, (h, h), gg[0], g.bstride, rows, n * K, idx)
+        else:
+            # dX = dP*A + dS.W leaves the GEMM epilogue straight for its two destinations: the rpe-branch half is stored
+            # (or accumulated), the gathered half is scatter-added to the rows it came from
+            ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=gu[0], out_bstride=n * K, accumulate=gu[1],
+                     addend=dX, out2=gg[0], out2_index=idx.view(-1), out2_bstride=g.bstride, split_col=h)
+        gu[1] = True

@@ -40,6 +40,8 @@ class GemmDesc(C.Structure):
         ("accumulate", C.c_int32),
         ("stats", C.c_void_p),
         ("kslab", C.c_void_p), ("kslab_floats", C.c_int64),
+        ("addend", C.c_void_p), ("out2", C.c_void_p), ("out2_index", C.c_void_p), ("out2_bstride", C.c_int64),
+        ("split_col", C.c_int32),
     ]
 
 

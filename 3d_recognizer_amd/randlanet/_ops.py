@@ -86,6 +86,7 @@ TIMER: Optional[KernelTimer] = None
 SIDE_STREAM_WGRAD = bool(int(__import__("os").environ.get("RL_SIDE_STREAM", "0")))
 NO_FUSED_POOL = bool(int(__import__("os").environ.get("RL_NO_FUSED_POOL", "0")))         # diagnostics only
 NO_DEFERRED_WGRAD = bool(int(__import__("os").environ.get("RL_NO_DEFERRED_WGRAD", "0")))  # diagnostics only
+NO_SPLIT_SCATTER = bool(int(__import__("os").environ.get("RL_NO_SPLIT_SCATTER", "0")))   # diagnostics only
 NO_RPE_TENSOR = bool(int(__import__("os").environ.get("RL_NO_RPE_TENSOR", "0")))         # diagnostics only
 FORCE_BRUTE_KNN = bool(int(__import__("os").environ.get("RL_KNN_BRUTE", "0")))         # diagnostics only
 DEBUG_SYNC = bool(int(__import__("os").environ.get("RL_DEBUG_SYNC", "0")))   # print + sync around every launch
@@ -259,7 +260,12 @@ def weight_strides(W: torch.Tensor, transposed: bool, K: int, N: int) -> Tuple[i
 
 def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, out_bstride: Optional[int] = None,
-         accumulate: bool = False, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+         accumulate: bool = False, stats: Optional[torch.Tensor] = None,
+         addend: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+         out2_index: Optional[torch.Tensor] = None, out2_bstride: int = 0, split_col: int = 0) -> torch.Tensor:
+    """Y = A'.W (+ bias).  With `out2` (split-scatter epilogue, wide layers only): v = A'.W + addend; columns < split_col
+    go to `out` (which then has split_col columns), the others are atomically added to the rows out2_index names of
+    out2 - the gradient of a gather + concat written where it belongs in one pass."""
     d = H.GemmDesc()
     M, K = _fill_a(d, a)
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
@@ -269,7 +275,7 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
         out = torch.empty((M, N), dtype=F32, device=W.device)
         out_bstride = rows_per_batch
     else:
-        assert out.dtype == F32 and out.dim() == 2 and out.shape[1] >= N
+        assert out.dtype == F32 and out.dim() == 2 and out.shape[1] >= (split_col if out2 is not None else N)
         out_bstride = rows_per_batch if out_bstride is None else out_bstride
         assert out.shape[0] >= (d.B - 1) * out_bstride + rows_per_batch, "Y rows out of range"
     if bias is not None:
@@ -279,7 +285,16 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     d.N, d.W, d.w_ks, d.w_ns, d.bias = N, W.data_ptr(), w_ks, w_ns, H.ptr(bias)
     d.Y, d.ldy, d.y_bstride, d.accumulate = out.data_ptr(), out.shape[1], out_bstride, int(accumulate)
     d.stats = H.ptr(stats)
-    kfloats = H.lib().rl_gemm_kslab_floats(M, N, K) if (N > 64 and not isinstance(a, Rpe)) else 0
+    if addend is not None or out2 is not None:
+        _dev_check(addend, out2, out2_index)
+        assert addend is None or (addend.dtype == F32 and addend.shape == (M, N))
+        if out2 is not None:
+            assert out2.dtype == F32 and out2_index is not None and out2_index.dtype == torch.int32
+            assert out2_index.numel() == M and 0 < split_col < N and out2.shape[1] == N - split_col
+            assert out2.shape[0] >= (d.B - 1) * out2_bstride + 1
+        d.addend, d.out2, d.out2_index = H.ptr(addend), H.ptr(out2), H.ptr(out2_index)
+        d.out2_bstride, d.split_col = out2_bstride, split_col
+    kfloats = H.lib().rl_gemm_kslab_floats(M, N, K) if (N > 64 and not isinstance(a, Rpe) and out2 is None and addend is None) else 0
     if kfloats > 0:
         kslab = _slab(W.device, kfloats)
         d.kslab, d.kslab_floats = kslab.data_ptr(), kslab.numel()

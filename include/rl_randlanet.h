@@ -147,6 +147,18 @@ typedef struct rl_gemm_desc {
      * over workgroups (deterministic two-pass reduction); NULL or too small = single pass */
     float* kslab;
     int64_t kslab_floats;
+    /* optional "split-scatter" epilogue (the dX of PointFeatureAugmentation's concat, modules.py:213-221):
+     *   addend  != NULL : v += addend[R*N + c] before anything else (row stride N, row R = global row)
+     *   out2    != NULL : columns c >= split_col are not stored to Y but atomically added to
+     *                     out2[(b*out2_bstride + out2_index[R])*(N - split_col) + c - split_col], b = R / rows per
+     *                     cloud - the gradient of the gathered half goes straight to the rows it was gathered from;
+     *                     columns c < split_col go to Y as usual (ldy, y_bstride, accumulate apply to them only).
+     * Needs the LDS-tiled kernel (K or N > 64, 16-byte aligned operands) and no statistics; else RL_ERR_UNSUPPORTED. */
+    const float* addend;
+    float* out2;
+    const int32_t* out2_index;
+    int64_t out2_bstride;
+    int32_t split_col;
 } rl_gemm_desc;
 
 int64_t rl_gemm_kslab_floats(int64_t M, int N, int K);

@@ -221,6 +221,41 @@ def test_wide_gemm_modes(ops, M, K, N):
         ops.set_wide_gemm("fp16")
 
 
+@pytest.mark.parametrize("d,B,n_parent,n,accumulate", [(128, 2, 500, 300, False), (256, 1, 400, 200, True)])
+def test_gemm_split_scatter_epilogue(ops, d, B, n_parent, n, accumulate):
+    """dX = addend + dS.W, first half stored / accumulated, second half scatter-added to the gathered rows, in one launch,
+    against the three-launch composition (GEMM accumulate, copy_rows, scatter_add_rows)."""
+    torch.manual_seed(d)
+    K, h = 16, d // 2
+    rows = B * n * K
+    dS = torch.randn(rows, d, device=DEV)
+    W = torch.randn(d, d, device=DEV) / d ** 0.5
+    addend = torch.randn(rows, d, device=DEV)
+    idx = torch.randint(0, n_parent, (B, n, K), device=DEV, dtype=torch.int32)
+    gu0 = torch.randn(rows, h, device=DEV)
+    # composition
+    dX = addend.clone()
+    ops.gemm(ops.plain(dS, B, n * K), W, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
+    gu_ref = gu0.clone() if accumulate else torch.empty_like(gu0)
+    ops.copy_rows(dX, (0, h), n * K, gu_ref, (0, h), rows, n * K, accumulate=accumulate)
+    gg_ref = torch.zeros(B * n_parent, h, device=DEV)
+    ops.scatter_add_rows(dX, (h, h), gg_ref, n_parent, rows, n * K, idx)
+    # fused epilogue
+    gu = gu0.clone() if accumulate else torch.full_like(gu0, float("nan"))
+    gg = torch.zeros(B * n_parent, h, device=DEV)
+    ops.gemm(ops.plain(dS, B, n * K), W, d, 1, d, None, out=gu, out_bstride=n * K, accumulate=accumulate,
+             addend=addend, out2=gg, out2_index=idx.view(-1), out2_bstride=n_parent, split_col=h)
+    # same products; the composition may have split K over workgroups (few row tiles), so the order can differ
+    assert float((gu - gu_ref).abs().max()) < 1e-5 * float(gu_ref.abs().max())
+    assert float((gg - gg_ref).abs().max()) < 1e-4 * float(gg_ref.abs().max())   # fp32 atomics: order differs
+    # narrow layers have no such epilogue: loud error, no silent fallback
+    small = torch.randn(64, 32, device=DEV)
+    with pytest.raises(Exception, match="split-scatter"):
+        ops.gemm(ops.plain(small, 1, 64), torch.randn(32, 32, device=DEV), 32, 1, 32, None, out=torch.empty(64, 16, device=DEV),
+                 addend=torch.zeros(64, 32, device=DEV), out2=torch.zeros(10, 16, device=DEV),
+                 out2_index=torch.zeros(64, dtype=torch.int32, device=DEV), out2_bstride=10, split_col=16)
+
+
 def test_gemm_asymmetric_identity(ops):
     """A = I with an asymmetric W catches a transposed C/D fragment map."""
     n = 128
