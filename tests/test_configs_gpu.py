@@ -75,3 +75,43 @@ def test_train_step_k32_matches_oracle_autograd():
         e = float((p.grad.cpu() - r).abs().max())
         # conv biases in front of a BatchNorm have a zero true gradient: rounding noise on both sides
         assert e < 5e-3 * float(r.abs().max()) + 2e-5, (name, e, float(r.abs().max()))
+
+
+@pytest.mark.parametrize("C,N,K,F,layers,B,loss_name", [
+    (5, 4100, 16, 3, [8, 16, 32, 64], 3, "focal_tversky"),     # ragged: N is no multiple of 4^L; extra features; odd batch
+    (3, 1029, 8, 1, [16, 32, 64], 1, "cross_entropy"),         # three levels, 8 neighbours, a single cloud
+])
+def test_ragged_sizes_features_and_losses_match_oracle_autograd(C, N, K, F, layers, B, loss_name):
+    """Shapes the tiles do not divide (N_l = N // 4^l with remainders, rows that are no multiple of 16 / 128), extra
+    point features, other losses: train-mode logits, loss and every parameter gradient against the oracle's autograd."""
+    from oracle import randlanet_oracle as O
+    from oracle.init_formula import formula_state_dict
+    from oracle.loss_metrics_oracle import loss_by_name
+    from randlanet.utils.losses import get_loss
+    from randlanet.utils.modules import RandLANet, RandLANetSettings
+    sd = formula_state_dict(O.state_dict_layout(C, F, layers), seed=C + N)
+    net = RandLANet(RandLANetSettings(n_classes=C, n_points=N, n_features=F, n_neighbors=K, layer_sizes=list(layers)), DEV)
+    net.load_state_dict(sd)
+    net.fc_end[2].p = 0.0
+    net.train()
+    rs = np.random.RandomState(N)
+    x = rs.uniform(0, 1, (B, N, 3 + F)).astype(np.float32)
+    y = np.minimum((x[..., 2] * C).astype(np.int64), C - 1)
+    np.random.seed(21)
+    perm = np.random.permutation(N)
+    np.random.seed(21)
+    logits = net(torch.from_numpy(x).to(DEV))
+    assert logits.shape == (B, C, N)
+    loss = get_loss(loss_name)(logits, torch.from_numpy(y).to(DEV))
+    loss.backward()
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+         for k, v in sd.items()}
+    ref = O.forward(P, torch.from_numpy(x), perm, layer_sizes=layers, n_neighbors=K, training=True, dropout_p=0.0)
+    ref_loss = loss_by_name(loss_name, ref, torch.from_numpy(y))
+    ref_loss.backward()
+    assert float((logits.detach().cpu() - ref.detach()).abs().max()) < 1e-3
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-5 * max(1.0, abs(float(ref_loss.detach())))
+    for name, p in net.named_parameters():
+        r = P[name].grad
+        e = float((p.grad.cpu() - r).abs().max())
+        assert e < 5e-3 * float(r.abs().max()) + 2e-5, (name, e, float(r.abs().max()))
