@@ -238,12 +238,13 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const KMulti m) {
 template <int KMAX>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int begin, int end, float qx, float qy,
                                            float qz, unsigned long long (&best)[KMAX]) {
-    for (int t = begin; t < end; t += 8) {
-        float4 cand[8];
+    constexpr int SB = 8;      // candidates per round trip (16 measured no better)
+    for (int t = begin; t < end; t += SB) {
+        float4 cand[SB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cand[i] = pts[min(t + i, end - 1)];
+        for (int i = 0; i < SB; ++i) cand[i] = pts[min(t + i, end - 1)];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < SB; ++i) {
             if (t + i < end) {
                 const float4 c = cand[i];
                 const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
@@ -321,22 +322,41 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const KMulti m) {
                 const float dy = axis_gap(g, 1, y, qy);
                 const float dyz = dy * dy + dz * dz;
                 const int row = (z * g.n[1] + y) * g.n[0];
-                // cells of this row that lie on ring r: the whole x-run, or its two end cells
-                const int step = full_row ? 1 : max(2 * r, 1);
-                for (int x = c[0] - r; x <= c[0] + r; x += step) {
-                    if (x < x0 || x > x1) continue;
-                    // lower bound of the distance to anything in the cell; skip it when even that exceeds
-                    // the current K-th distance (strictly, with a rounding margin: ties must be looked at)
-                    const float dxg = axis_gap(g, 0, x, qx);
-                    const float lb = dxg * dxg + dyz;
-                    unsigned long long kth = best[KMAX - 1];
-                    if (k != KMAX) {
+                // K-th distance so far (one look per row: cells of a row are scanned as one run below)
+                unsigned long long kth = best[KMAX - 1];
+                if (k != KMAX) {
 #pragma unroll
-                        for (int s = 0; s < KMAX; ++s)
-                            if (s == k - 1) kth = best[s];
+                    for (int s = 0; s < KMAX; ++s)
+                        if (s == k - 1) kth = best[s];
+                }
+                // strict test with a rounding margin: ties must be looked at
+                const bool have = kth != ~0ull;
+                const float lim = have ? __uint_as_float((unsigned)(kth >> 32)) * 1.00001f + 1e-30f : INFINITY;
+                if (dyz > lim) continue;            // nothing in this row of cells can be closer than the K-th
+                if (full_row) {
+                    // the whole x-run lies on ring r.  Its cells are consecutive in the sorted array, so the run is ONE
+                    // candidate range: two dependent loads per row instead of two per cell.  Cells whose lower
+                    // bound already exceeds the K-th distance are cut from both ends first (arithmetic only).
+                    int xa = x0, xb = x1;
+                    while (xa <= xb) {
+                        const float gx = axis_gap(g, 0, xa, qx);
+                        if (gx * gx + dyz > lim) ++xa; else break;
                     }
-                    if (kth != ~0ull && lb > __uint_as_float((unsigned)(kth >> 32)) * 1.00001f + 1e-30f) continue;
-                    scan_range<KMAX>(pts, st[row + x], st[row + x + 1], qx, qy, qz, best);
+                    while (xb >= xa) {
+                        const float gx = axis_gap(g, 0, xb, qx);
+                        if (gx * gx + dyz > lim) --xb; else break;
+                    }
+                    if (xa <= xb) scan_range<KMAX>(pts, st[row + xa], st[row + xb + 1], qx, qy, qz, best);
+                } else {
+                    // only the two end cells of the run are on ring r
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int x = e == 0 ? c[0] - r : c[0] + r;
+                        if (x < x0 || x > x1 || (e == 1 && r == 0)) continue;
+                        const float dxg = axis_gap(g, 0, x, qx);
+                        if (dxg * dxg + dyz > lim) continue;
+                        scan_range<KMAX>(pts, st[row + x], st[row + x + 1], qx, qy, qz, best);
+                    }
                 }
             }
         }
