@@ -1601,6 +1601,8 @@ inline bool pwgrad_ok(const WgradParams& p) {
 
 }  // namespace
 
+int rl_wide_terms() { return wide_gemm_terms(); }
+
 extern "C" int rl_set_wide_gemm(const char* mode) {
     const int t = parse_wide(mode);
     RL_REQUIRE(mode != nullptr && t >= 0, RL_ERR_ARGS, "rl_set_wide_gemm: mode must be \"fp32\", \"bf16x3\" or \"bf16\"");

@@ -22,6 +22,26 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// fp32 -> bf16 head + bf16 tail (value = hi + lo up to 2^-17 relative); the products of the score / gradient GEMMs are
+// then a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMAs with fp32 accumulation ("bf16x3", as in gemm.hip)
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+__device__ __forceinline__ bf16x8 cat8(const bf16x4 a, const bf16x4 b) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; }
+    return r;
+}
+__device__ __forceinline__ f32x4 mfma16(const bf16x4 a, const bf16x4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
 
 struct PoolParams {
     const float* U;        // (P*16) x h raw rpe-branch features
@@ -49,6 +69,7 @@ struct Tile {
     static constexpr int D = 16 * DT;
     static constexpr int H = D / 2;
     static constexpr int XS = D + 4;
+    static constexpr int XSB = D + 8;   // bf16 row stride of the split weights: 16-byte aligned rows
 };
 
 // lane-constant lazy parameters for the float4 this lane loads in chunk c
@@ -126,6 +147,47 @@ __device__ __forceinline__ void tile_gemm(const float4 (&a)[DT], const float* Bt
     }
 }
 
+// The same product with bf16x3 arithmetic.  Bh / Bl: head and tail of the TRANSPOSED B ([n][k], stride XSB bf16).
+// D >= 32: v_mfma_f32_16x16x32_bf16 on pairs of 16-column chunks - the lane's A-layout float4s of chunks 2b and
+// 2b+1 are its 8 k-values (k = 32b + 4j..+3 and 32b + 16 + 4j..+3; any k order is valid when A and B agree), the B
+// fragment is the two matching 8-byte pieces of row n.  D = 16: one v_mfma_f32_16x16x16_bf16 per column block.
+template <int DT>
+__device__ __forceinline__ void tile_gemm_bf(const float4 (&a)[DT], const __bf16* Bh, const __bf16* Bl, int li, int lj,
+                                             f32x4 (&acc)[DT]) {
+    constexpr int XSB = Tile<DT>::XSB;
+    const int off = li * XSB + 4 * lj;
+    if constexpr (DT == 1) {
+        bf16x4 ah, al;
+        split4(a[0], ah, al);
+        const bf16x4 bh = *reinterpret_cast<const bf16x4*>(Bh + off);
+        const bf16x4 bl = *reinterpret_cast<const bf16x4*>(Bl + off);
+        acc[0] = mfma16(ah, bh, acc[0]);
+        acc[0] = mfma16(ah, bl, acc[0]);
+        acc[0] = mfma16(al, bh, acc[0]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < DT / 2; ++b) {
+            bf16x4 h0, l0, h1, l1;
+            split4(a[2 * b], h0, l0);
+            split4(a[2 * b + 1], h1, l1);
+            const bf16x8 ah = cat8(h0, h1), al = cat8(l0, l1);
+            bf16x8 bh[DT], bl[DT];
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) {
+                const int o = off + nb * 16 * XSB + 32 * b;
+                bh[nb] = cat8(*reinterpret_cast<const bf16x4*>(Bh + o), *reinterpret_cast<const bf16x4*>(Bh + o + 16));
+                bl[nb] = cat8(*reinterpret_cast<const bf16x4*>(Bl + o), *reinterpret_cast<const bf16x4*>(Bl + o + 16));
+            }
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[nb], 0, 0, 0);
+        }
+    }
+}
+
 // softmax over the 16 rows of a C-layout tile, in place: s -> A
 template <int DT>
 __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
@@ -160,16 +222,26 @@ __device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* W
     }
 }
 
-template <int DT>
+template <int DT, int TERMS>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product)
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
-    constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS;
-    __shared__ __attribute__((aligned(16))) float Wt[D * XS];
+    constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
+    __shared__ __attribute__((aligned(16))) unsigned char wmem[TERMS == 0 ? D * XS * 4 : 2 * D * XSB * 2];
     __shared__ __attribute__((aligned(16))) float Xt[4][16 * XS];
+    float* Wt = reinterpret_cast<float*>(wmem);
+    __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
+    __bf16* Wl = Wh + D * XSB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int o = e / D, i = e - o * D;
-        Wt[o * XS + i] = p.W[e];          // [n][k]: the transposed-B form tile_gemm reads
+        const float w = p.W[e];            // [n][k]: the transposed-B form the tile GEMMs read
+        if constexpr (TERMS == 0) {
+            Wt[o * XS + i] = w;
+        } else {
+            const __bf16 h = (__bf16)w;
+            Wh[o * XSB + i] = h;
+            Wl[o * XSB + i] = (__bf16)(w - (float)h);
+        }
     }
     __syncthreads();
     float sc[DT][4], sh[DT][4];
@@ -182,7 +254,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
         f32x4 s[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) s[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        tile_gemm<DT>(xa, Wt, li, lj, s);
+        if constexpr (TERMS == 0) tile_gemm<DT>(xa, Wt, li, lj, s);
+        else tile_gemm_bf<DT>(xa, Wh, Wl, li, lj, s);
         softmax_rows<DT>(s);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -198,18 +271,32 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
     }
 }
 
-template <int DT>
+template <int DT, int TERMS>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
-    constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS;
+    constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     // LDS: W^T, W, and per wavefront an X tile and a dS tile; after the main loop the W region is
     // reused to combine the four wavefronts' dW tiles
-    __shared__ __attribute__((aligned(16))) float Wmem[2 * D * XS];
+    __shared__ __attribute__((aligned(16))) float Wmem[TERMS == 0 ? 2 * D * XS : 2 * D * XSB];   // bf16: 4 arrays of D*XSB
     __shared__ __attribute__((aligned(16))) float Tiles[4][2][16 * XS];
     float* Wt = Wmem;
     float* Wn = Wmem + D * XS;
+    __bf16* Wnh = reinterpret_cast<__bf16*>(Wmem);      // [n][k] head / tail: S = X.W^T
+    __bf16* Wnl = Wnh + D * XSB;
+    __bf16* Wth = Wnl + D * XSB;                          // [n'][k'] = W[k'][n'] head / tail: dX = dS.W
+    __bf16* Wtl = Wth + D * XSB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    stage_w<DT>(p, Wt, Wn);
+    if constexpr (TERMS == 0) {
+        stage_w<DT>(p, Wt, Wn);
+    } else {
+        for (int e = threadIdx.x; e < D * D; e += 256) {
+            const int o = e / D, i = e - o * D;
+            const float w = p.W[e];
+            const __bf16 h = (__bf16)w, l = (__bf16)(w - (float)h);
+            Wnh[o * XSB + i] = h; Wnl[o * XSB + i] = l;
+            Wth[i * XSB + o] = h; Wtl[i * XSB + o] = l;
+        }
+    }
     __syncthreads();
     float sc[DT][4], sh[DT][4];
     lane_lazy<DT>(p, lj, sc, sh);
@@ -229,11 +316,12 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        tile_gemm<DT>(xa, Wn, li, lj, a);
+        if constexpr (TERMS == 0) tile_gemm<DT>(xa, Wn, li, lj, a);
+        else tile_gemm_bf<DT>(xa, Wnh, Wnl, li, lj, a);
         softmax_rows<DT>(a);
         __builtin_amdgcn_wave_barrier();
         // C-layout pass: P, dS (to LDS), dXa kept in registers as the start of dX
-        f32x4 dx[DT];
+        f32x4 dx[DT], dsr[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) {
             const int col = nb * 16 + li;
@@ -251,7 +339,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
             for (int r = 0; r < 4; ++r) {
                 const float ag = a[nb][r] * g;
                 dx[nb][r] = ag;                                   // direct path dP*A
-                Ds[(lj * 4 + r) * XS + col] = ag * (xc[r] - pool);  // dS = A*dP*(X-P)
+                dsr[nb][r] = ag * (xc[r] - pool);                   // dS = A*dP*(X-P)
+                Ds[(lj * 4 + r) * XS + col] = dsr[nb][r];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -259,19 +348,44 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
         float4 da[DT];
 #pragma unroll
         for (int c = 0; c < DT; ++c) da[c] = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
-        tile_gemm<DT>(da, Wt, li, lj, dx);
+        if constexpr (TERMS == 0) tile_gemm<DT>(da, Wt, li, lj, dx);
+        else tile_gemm_bf<DT>(da, Wth, Wtl, li, lj, dx);
         // dW[n][k] += sum_rows dS[row][n] * X[row][k]   (rows are the MFMA reduction index)
+        if constexpr (TERMS == 0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float bx[DT];
+            for (int t = 0; t < 4; ++t) {
+                float bx[DT];
 #pragma unroll
-            for (int kb = 0; kb < DT; ++kb) bx[kb] = Xs[(4 * t + lj) * XS + kb * 16 + li];
+                for (int kb = 0; kb < DT; ++kb) bx[kb] = Xs[(4 * t + lj) * XS + kb * 16 + li];
+#pragma unroll
+                for (int nb = 0; nb < DT; ++nb) {
+                    const float ad = Ds[(4 * t + lj) * XS + nb * 16 + li];
+#pragma unroll
+                    for (int kb = 0; kb < DT; ++kb)
+                        accw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, bx[kb], accw[nb][kb], 0, 0, 0);
+                }
+            }
+        } else {
+            // v_mfma_f32_16x16x16_bf16: the lane's four reduction rows are 4*lj .. 4*lj+3 - for the A operand (dS^T) those
+            // are exactly its C-layout registers of dS, no LDS round trip; the B operand is X at the same four rows
+            bf16x4 xh[DT], xl[DT];
+#pragma unroll
+            for (int kb = 0; kb < DT; ++kb) {
+                float4 v;
+                v.x = Xs[(4 * lj + 0) * XS + kb * 16 + li]; v.y = Xs[(4 * lj + 1) * XS + kb * 16 + li];
+                v.z = Xs[(4 * lj + 2) * XS + kb * 16 + li]; v.w = Xs[(4 * lj + 3) * XS + kb * 16 + li];
+                split4(v, xh[kb], xl[kb]);
+            }
 #pragma unroll
             for (int nb = 0; nb < DT; ++nb) {
-                const float ad = Ds[(4 * t + lj) * XS + nb * 16 + li];
+                bf16x4 dh, dl;
+                split4(make_float4(dsr[nb][0], dsr[nb][1], dsr[nb][2], dsr[nb][3]), dh, dl);
 #pragma unroll
-                for (int kb = 0; kb < DT; ++kb)
-                    accw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, bx[kb], accw[nb][kb], 0, 0, 0);
+                for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dh, xh[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dh, xl[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dl, xh[kb], accw[nb][kb]);
             }
         }
         // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> scatter to the gathered rows
@@ -393,9 +507,15 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     if (rc) return rc;
     const int g = pool_grid(p.P, p.d, false);
     hipStream_t st = (hipStream_t)stream;
-    if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1>), dim3(g), dim3(256), 0, st, p);
-    else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2>), dim3(g), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pool_fwd_kernel<4>), dim3(g), dim3(256), 0, st, p);
+    if (rl_wide_terms() == 0) {
+        if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
+        else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pool_fwd_kernel<4, 0>), dim3(g), dim3(256), 0, st, p);
+    } else {
+        if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 3>), dim3(g), dim3(256), 0, st, p);
+        else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 3>), dim3(g), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pool_fwd_kernel<4, 3>), dim3(g), dim3(256), 0, st, p);
+    }
     rl_note_kernel(p.d == 16 ? "pool_fwd_kernel<1>" : p.d == 32 ? "pool_fwd_kernel<2>" : "pool_fwd_kernel<4>");
     RL_LAUNCH_CHECK("rl_pool_fwd");
     return RL_OK;
@@ -408,9 +528,15 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     const int g = pool_grid(p.P, p.d, true);
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
     hipStream_t st = (hipStream_t)stream;
-    if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1>), dim3(g), dim3(256), 0, st, p);
-    else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2>), dim3(g), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((pool_bwd_kernel<4>), dim3(g), dim3(256), 0, st, p);
+    if (rl_wide_terms() == 0) {
+        if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
+        else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pool_bwd_kernel<4, 0>), dim3(g), dim3(256), 0, st, p);
+    } else {
+        if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3>), dim3(g), dim3(256), 0, st, p);
+        else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3>), dim3(g), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pool_bwd_kernel<4, 3>), dim3(g), dim3(256), 0, st, p);
+    }
     rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1>" : p.d == 32 ? "pool_bwd_kernel<2>" : "pool_bwd_kernel<4>");
     RL_LAUNCH_CHECK("rl_pool_bwd");
     hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 64)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);

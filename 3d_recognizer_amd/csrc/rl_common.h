@@ -29,6 +29,9 @@ void rl_note_kernel(const char* name);
         }                                                                            \
     } while (0)
 
+// arithmetic mode of the MFMA-heavy kernels (gemm.hip owns it, rl_set_wide_gemm): 0 fp32, 3 bf16x3, 1 bf16
+int rl_wide_terms();
+
 static inline int rl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Number of row blocks a row-streaming kernel uses for M rows (one partial-statistics slot per
