@@ -91,26 +91,35 @@ __device__ __forceinline__ void lane_lazy(const PoolParams& p, int lj, float (&s
         }
 }
 
-// Load the 16 x d tile of X for point pt in A layout (already activated) and park it in LDS.
+// The 16 x d tile of X for point pt in A layout, in two steps so that the loads of the NEXT point can be in flight
+// while the current one is computed: fetch_x issues the raw loads (rpe-branch rows + gathered rows),
+// finish_x applies the lazy BatchNorm / activation and parks the tile in LDS.
 template <int DT>
-__device__ __forceinline__ void load_x(const PoolParams& p, long pt, int li, int lj, int my_idx,
-                                       const float (&sc)[DT][4], const float (&sh)[DT][4], float4 (&xa)[DT],
-                                       float* Xs) {
-    constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
+__device__ __forceinline__ void fetch_x(const PoolParams& p, long pt, int li, int lj, int my_idx, float4 (&raw)[DT]) {
+    constexpr int H = Tile<DT>::H;
     const long row = pt * 16 + li;
     const long b = (unsigned)pt / (unsigned)p.n;   // points * 16 < 2^31 (checked on the host)
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
-        float4 v;
+        if (k < H) raw[c] = *reinterpret_cast<const float4*>(p.U + row * H + k);
+        else raw[c] = *reinterpret_cast<const float4*>(p.G + (b * p.g_bstride + my_idx) * H + (k - H));
+    }
+}
+template <int DT>
+__device__ __forceinline__ void finish_x(const PoolParams& p, int li, int lj, const float4 (&raw)[DT],
+                                         const float (&sc)[DT][4], const float (&sh)[DT][4], float4 (&xa)[DT], float* Xs) {
+    constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
+#pragma unroll
+    for (int c = 0; c < DT; ++c) {
+        const int k = 16 * c + 4 * lj;
+        float4 v = raw[c];
         int act;
         float slope;
         if (k < H) {
-            v = *reinterpret_cast<const float4*>(p.U + row * H + k);
             act = p.ulazy.scale ? p.ulazy.act : RL_ACT_NONE;
             slope = p.ulazy.slope;
         } else {
-            v = *reinterpret_cast<const float4*>(p.G + (b * p.g_bstride + my_idx) * H + (k - H));
             act = p.glazy.scale ? p.glazy.act : RL_ACT_NONE;
             slope = p.glazy.slope;
         }
@@ -247,10 +256,19 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
     float sc[DT][4], sh[DT][4];
     lane_lazy<DT>(p, lj, sc, sh);
     float* Xs = Xt[wave];
-    for (long pt = (long)blockIdx.x * 4 + wave; pt < p.P; pt += (long)gridDim.x * 4) {
-        const int my_idx = p.idx[pt * 16 + li];
+    // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
+    const long pstep = (long)gridDim.x * 4;
+    long pt = (long)blockIdx.x * 4 + wave;
+    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    float4 raw[DT];
+    if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+    for (; pt < p.P; pt += pstep) {
         float4 xa[DT];
-        load_x<DT>(p, pt, li, lj, my_idx, sc, sh, xa, Xs);
+        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        if (pt + pstep < p.P) fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+        idx_cur = idx_nxt; idx_nxt = idx_n2;
         f32x4 s[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) s[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -308,11 +326,21 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (long pt = (long)blockIdx.x * 4 + wave; pt < p.P; pt += (long)gridDim.x * 4) {
-        const int my_idx = p.idx[pt * 16 + li];
+    // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
+    const long pstep = (long)gridDim.x * 4;
+    long pt = (long)blockIdx.x * 4 + wave;
+    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    float4 raw[DT];
+    if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+    for (; pt < p.P; pt += pstep) {
+        const int my_idx = idx_cur;
         const long b = (unsigned)pt / (unsigned)p.n;   // points * 16 < 2^31 (checked on the host)
         float4 xa[DT];
-        load_x<DT>(p, pt, li, lj, my_idx, sc, sh, xa, Xs);
+        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        if (pt + pstep < p.P) fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+        idx_cur = idx_nxt; idx_nxt = idx_n2;
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
