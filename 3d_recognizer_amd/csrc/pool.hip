@@ -341,6 +341,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
         idx_cur = idx_nxt; idx_nxt = idx_n2;
+        float gp[DT];          // dP of this point: requested now, needed after the score GEMM and the softmax
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
             }
             pool += __shfl_xor(pool, 16, 64);
             pool += __shfl_xor(pool, 32, 64);
-            const float g = p.dP[pt * D + col];
+            const float g = gp[nb];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ag = a[nb][r] * g;
