@@ -58,6 +58,7 @@ struct KTask {
     float4* sorted;   // [B][Ns]
     int cstride, maxcells;
     float per_cell;
+    int lanes;        // lanes that share a query in the ring walk: 1, 2 or 4 (k <= 16 only)
 };
 
 struct KMulti {
@@ -235,33 +236,60 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const KMulti m) {
 // Scan candidates [begin, end).  Loads are issued eight at a time before any of them is used: with
 // ~8 points per cell one cell costs one memory round trip instead of eight (at small clouds there
 // is a single wavefront per SIMD and nothing else hides that latency).
+// sorted insertion of one key (ascending (d2, index) order; a key that is not smaller than the last entry falls out)
+template <int KMAX>
+__device__ __forceinline__ void insert_key(unsigned long long key, unsigned long long (&best)[KMAX]) {
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        const bool lt = key < best[s];
+        const unsigned long long lo = lt ? key : best[s];
+        const unsigned long long hi = lt ? best[s] : key;
+        best[s] = lo;
+        key = hi;
+    }
+}
+
+// One batch of SB candidates: keys for all of them first, then insertions only for those that beat the lane's current
+// K-th entry.  The insertion network is ~100 instructions and a wavefront runs it whenever ANY lane needs it: done
+// per candidate slot that is practically always; done per "next passing candidate of each lane" the trip count is the
+// largest number of passing candidates of any lane in the batch (2-3 of 8 instead of 8 of 8).
+template <int KMAX, int SB>
+__device__ __forceinline__ void take_batch(const float4 (&cand)[SB], unsigned valid, float qx, float qy, float qz,
+                                           unsigned long long (&best)[KMAX]) {
+    unsigned long long key[SB];
+    unsigned pass = 0;
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+        const float4 c = cand[i];
+        const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        key[i] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
+        if (((valid >> i) & 1u) && key[i] < best[KMAX - 1]) pass |= 1u << i;
+    }
+    while (pass) {
+        const int i = __ffs(pass) - 1;
+        pass &= pass - 1;
+        unsigned long long kk = key[0];
+#pragma unroll
+        for (int j = 1; j < SB; ++j)
+            if (j == i) kk = key[j];
+        insert_key<KMAX>(kk, best);
+    }
+}
+
 template <int KMAX>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int begin, int end, float qx, float qy,
                                            float qz, unsigned long long (&best)[KMAX]) {
     constexpr int SB = 8;      // candidates per round trip (16 measured no better)
     for (int t = begin; t < end; t += SB) {
         float4 cand[SB];
-#pragma unroll
-        for (int i = 0; i < SB; ++i) cand[i] = pts[min(t + i, end - 1)];
+        unsigned valid = 0;
 #pragma unroll
         for (int i = 0; i < SB; ++i) {
-            if (t + i < end) {
-                const float4 c = cand[i];
-                const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y), dz = __fsub_rn(qz, c.z);
-                const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w);
-                if (key < best[KMAX - 1]) {
-#pragma unroll
-                    for (int s = 0; s < KMAX; ++s) {
-                        const bool lt = key < best[s];
-                        const unsigned long long lo = lt ? key : best[s];
-                        const unsigned long long hi = lt ? best[s] : key;
-                        best[s] = lo;
-                        key = hi;
-                    }
-                }
-            }
+            cand[i] = pts[min(t + i, end - 1)];
+            if (t + i < end) valid |= 1u << i;
         }
+        take_batch<KMAX, SB>(cand, valid, qx, qy, qz, best);
     }
 }
 
@@ -276,11 +304,8 @@ __device__ __forceinline__ float axis_gap(const GridGeom& g, int a, int ci, floa
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(256) void grid_query_kernel(const KMulti m) {
-    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
-    const KTask& T = m.t[task];
+__device__ __forceinline__ void query_one_lane(const KTask& T, int b) {
     const int k = T.k, Nq = T.Nq, Ns = T.Ns;
-    if (kmax_of(k) != KMAX) return;            // another instantiation of this kernel serves that task
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= Nq) return;
     const int self_mode = T.self_mode;
@@ -391,6 +416,199 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const KMulti m) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// Four lanes per query (k <= 16).  With one lane per query the 163840-query level of config A is 2.5 wavefronts
+// per SIMD walking long chains of dependent loads: latency-bound with nothing to hide it.  Here lanes 4q..4q+3 of a
+// wavefront share query q: they walk the same rings / rows (uniform control flow inside the quad), each scans
+// every fourth candidate of a run into its OWN sorted top-K, and the quad agrees on the pruning bound
+//     B = min( min_j kth_j ,  max_j best_j[ceil(k/4) - 1] )
+// (the union's k-th best is <= every lane's own k-th, and <= the largest of the four ceil(k/4)-th entries because
+// the four lists then hold >= k entries below it; candidates are interleaved, so the second bound is tight).
+// B only ever over-estimates the true k-th distance: the quad visits a superset of the cells the exact bound would,
+// results stay exact.  At the end the four disjoint sorted lists are merged by RANK through LDS: the position of a
+// key in the union = its index in its own list + the number of smaller keys in the other three (binary search).
+// -------------------------------------------------------------------------------------------------------------
+template <int LANES>
+__device__ __forceinline__ unsigned long long group_min(unsigned long long v) {
+#pragma unroll
+    for (int o = 1; o < LANES; o <<= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+template <int LANES>
+__device__ __forceinline__ unsigned long long group_max(unsigned long long v) {
+#pragma unroll
+    for (int o = 1; o < LANES; o <<= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+template <int KMAX, int LANES>
+__device__ __forceinline__ unsigned long long group_bound(const unsigned long long (&best)[KMAX], int k) {
+    const int q = (k + LANES - 1) / LANES - 1;
+    unsigned long long own_k = best[KMAX - 1], own_q = best[0];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        if (s == k - 1) own_k = best[s];
+        if (s == q) own_q = best[s];
+    }
+    const unsigned long long a = group_min<LANES>(own_k), b = group_max<LANES>(own_q);
+    return a < b ? a : b;
+}
+
+// this lane's share of the candidates [begin, end): begin + sub, begin + sub + LANES, ...
+template <int KMAX, int LANES>
+__device__ __forceinline__ void scan_range_n(const float4* __restrict__ pts, int begin, int end, int sub, float qx, float qy,
+                                            float qz, unsigned long long (&best)[KMAX]) {
+    constexpr int SB = 8;
+    for (int t = begin + sub; t < end; t += LANES * SB) {
+        float4 cand[SB];
+        unsigned valid = 0;
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+            cand[i] = pts[min(t + LANES * i, end - 1)];
+            if (t + LANES * i < end) valid |= 1u << i;
+        }
+        take_batch<KMAX, SB>(cand, valid, qx, qy, qz, best);
+    }
+}
+
+template <int KMAX, int LANES>
+__device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned long long* lds) {
+    constexpr int QPB = 256 / LANES;           // queries per workgroup
+    unsigned long long (*lists)[LANES][KMAX] = reinterpret_cast<unsigned long long (*)[LANES][KMAX]>(lds);
+    const int k = T.k, Nq = T.Nq, Ns = T.Ns;
+    const int qslot = threadIdx.x / LANES, sub = threadIdx.x % LANES;
+    const int t = blockIdx.x * QPB + qslot;
+    if (blockIdx.x * QPB >= Nq) return;        // whole workgroup
+    const bool active = t < Nq;                // same for the four lanes of a query; every lane reaches the barrier
+    unsigned long long best[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
+    int qi = 0;
+    if (active) {
+        const GridGeom g = T.geom[b];
+        const float4* pts = T.sorted + (size_t)b * Ns;
+        const int* st = T.start + (size_t)b * T.cstride;
+        float qx, qy, qz;
+        if (T.self_mode) {  // queries are the support points themselves: walk them in cell order
+            const float4 me = pts[t];
+            qx = me.x; qy = me.y; qz = me.z;
+            qi = __float_as_int(me.w);
+        } else {
+            const float* p = T.Q + ((size_t)b * T.q_bs + t) * 3;
+            qx = p[0]; qy = p[1]; qz = p[2];
+            qi = t;
+        }
+        int c[3];
+        cell_coords(g, qx, qy, qz, c);
+        const float q3[3] = {qx, qy, qz};
+        for (int r = 0;; ++r) {
+            const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.n[2] - 1);
+            const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
+            const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.n[0] - 1);
+            for (int z = z0; z <= z1; ++z) {
+                const bool zedge = (z == c[2] - r) || (z == c[2] + r);
+                const float dz = axis_gap(g, 2, z, qz);
+                for (int y = y0; y <= y1; ++y) {
+                    const bool full_row = zedge || y == c[1] - r || y == c[1] + r;
+                    const float dy = axis_gap(g, 1, y, qy);
+                    const float dyz = dy * dy + dz * dz;
+                    const int row = (z * g.n[1] + y) * g.n[0];
+                    const unsigned long long kth = group_bound<KMAX, LANES>(best, k);
+                    const float lim = kth != ~0ull ? __uint_as_float((unsigned)(kth >> 32)) * 1.00001f + 1e-30f : INFINITY;
+                    if (dyz > lim) continue;
+                    if (full_row) {
+                        int xa = x0, xb = x1;
+                        while (xa <= xb) {
+                            const float gx = axis_gap(g, 0, xa, qx);
+                            if (gx * gx + dyz > lim) ++xa; else break;
+                        }
+                        while (xb >= xa) {
+                            const float gx = axis_gap(g, 0, xb, qx);
+                            if (gx * gx + dyz > lim) --xb; else break;
+                        }
+                        if (xa <= xb) scan_range_n<KMAX, LANES>(pts, st[row + xa], st[row + xb + 1], sub, qx, qy, qz, best);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int x = e == 0 ? c[0] - r : c[0] + r;
+                            if (x < x0 || x > x1 || (e == 1 && r == 0)) continue;
+                            const float dxg = axis_gap(g, 0, x, qx);
+                            if (dxg * dxg + dyz > lim) continue;
+                            scan_range_n<KMAX, LANES>(pts, st[row + x], st[row + x + 1], sub, qx, qy, qz, best);
+                        }
+                    }
+                }
+            }
+            const bool covers = (c[0] - r <= 0) && (c[0] + r >= g.n[0] - 1) && (c[1] - r <= 0) && (c[1] + r >= g.n[1] - 1) &&
+                                (c[2] - r <= 0) && (c[2] + r >= g.n[2] - 1);
+            if (covers) break;
+            const unsigned long long kth = group_bound<KMAX, LANES>(best, k);
+            if (kth != ~0ull) {
+                float bound = INFINITY;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    if (c[a] - r > 0) bound = fminf(bound, q3[a] - (g.lo[a] + (float)(c[a] - r) * g.h[a]));
+                    if (c[a] + r < g.n[a] - 1) bound = fminf(bound, (g.lo[a] + (float)(c[a] + r + 1) * g.h[a]) - q3[a]);
+                }
+                bound -= g.slack;
+                const float kd = __uint_as_float((unsigned)(kth >> 32));
+                if (bound > 0.f && kd < bound * bound * 0.999999f) break;
+            }
+        }
+    }
+    // merge the four disjoint sorted lists of a query by rank
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) lists[qslot][sub][s] = best[s];
+    __syncthreads();
+    if (active) {
+        const size_t o = ((size_t)b * Nq + qi) * k;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            const unsigned long long key = best[s];
+            if (key == ~0ull) continue;
+            int rank = s;
+#pragma unroll
+            for (int j = 1; j < LANES; ++j) {
+                const unsigned long long* L = lists[qslot][(sub + j) % LANES];
+                int lo = 0;                      // number of keys in L smaller than `key` (L is sorted, sentinels last)
+#pragma unroll
+                for (int w = KMAX / 2; w >= 1; w >>= 1)
+                    if (L[lo + w - 1] < key) lo += w;
+                if (lo < KMAX && L[lo] < key) ++lo;   // KMAX a power of two: the halving above covers KMAX - 1 entries
+                rank += lo;
+            }
+            if (rank < k) {
+                const unsigned id = (unsigned)(key & 0xffffffffull);
+                if (T.idx32) T.idx32[o + rank] = (int32_t)id;
+                if (T.idx64) T.idx64[o + rank] = (int64_t)id;
+                T.d2[o + rank] = __uint_as_float((unsigned)(key >> 32));
+            }
+        }
+    }
+}
+
+// one launch serves every task of a k bucket, whatever its lane count: the tasks run side by side
+template <int KMAX>
+__global__ __launch_bounds__(256) void grid_query_kernel(const KMulti m) {
+    __shared__ unsigned long long lds[KMAX <= 16 ? 256 * KMAX : 1];
+    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const KTask& T = m.t[task];
+    if (kmax_of(T.k) != KMAX) return;            // another instantiation of this kernel serves that task
+    if constexpr (KMAX <= 16) {
+        if (T.lanes == 4) { query_n_lanes<KMAX, 4>(T, b, lds); return; }
+        if (T.lanes == 2) { query_n_lanes<KMAX, 2>(T, b, lds); return; }
+    }
+    query_one_lane<KMAX>(T, b);
+}
+
 struct Plan {
     int maxcells, cstride;
     float per_cell;
@@ -428,7 +646,18 @@ void bind(KTask* t, const Plan& p, char* w) {
     t->per_cell = p.per_cell;
 }
 
-int run_multi(const KMulti& m, hipStream_t st) {
+// lanes per query: the more queries a search has, the less it gains from splitting one (the split costs a weaker
+// pruning bound and a merge); RL_KNN_LANES = 1 | 2 | 4 forces one choice
+inline int lanes_for(long queries, int k) {
+    static const int force = getenv("RL_KNN_LANES") ? atoi(getenv("RL_KNN_LANES")) : 0;
+    if (k > 16) return 1;
+    if (force == 1 || force == 2 || force == 4) return force;
+    return queries >= 131072 ? 1 : 4;
+}
+
+int run_multi(const KMulti& m_in, hipStream_t st) {
+    KMulti m = m_in;
+    for (int i = 0; i < m.ntasks; ++i) m.t[i].lanes = lanes_for((long)m.B * m.t[i].Nq, m.t[i].k);
     int maxNs = 1, maxNq = 1, maxc = 1;
     bool need[6] = {false, false, false, false, false, false};
     for (int i = 0; i < m.ntasks; ++i) {
@@ -449,7 +678,9 @@ int run_multi(const KMulti& m, hipStream_t st) {
     hipLaunchKernelGGL(grid_count_kernel, dim3(rl_cdiv(maxNs, 256), clouds), dim3(256), 0, st, m);
     hipLaunchKernelGGL(grid_scan_kernel, dim3(clouds), dim3(1024), 0, st, m);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(rl_cdiv(maxNs, 256), clouds), dim3(256), 0, st, m);
-    dim3 grid(rl_cdiv(maxNq, 256), clouds);
+    int gxq = 1;
+    for (int i = 0; i < m.ntasks; ++i) gxq = max(gxq, rl_cdiv((long)m.t[i].Nq * m.t[i].lanes, 256));
+    dim3 grid(gxq, clouds);
     if (need[0]) hipLaunchKernelGGL((grid_query_kernel<1>), grid, dim3(256), 0, st, m);
     if (need[1]) hipLaunchKernelGGL((grid_query_kernel<4>), grid, dim3(256), 0, st, m);
     if (need[2]) hipLaunchKernelGGL((grid_query_kernel<8>), grid, dim3(256), 0, st, m);
