@@ -1,5 +1,7 @@
 """Kernel-level parity on the MI355X: every C-ABI entry point against the oracle (KNN, losses)
 or a plain PyTorch fp32 statement of the same op.  Tolerances are written at each assert."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -199,7 +201,8 @@ def test_wide_gemm_modes(ops, M, K, N):
     ref = A.double() @ W.double().t()
     ref_w = dY.double().t() @ A.double()
     bound = {"fp32": 2e-6, "bf16x3": 4e-5, "bf16": 2e-2}     # relative to sqrt(K) * max|ref|: 2^-24, 2^-16, 2^-8 products
-    assert ops.get_wide_gemm() == "bf16x3"
+    initial = ops.get_wide_gemm()
+    assert initial == os.environ.get("RL_WIDE_GEMM", "bf16x3")       # bf16x3 unless the environment chose another mode
     errs = {}
     try:
         for mode in ("fp32", "bf16x3", "bf16"):
@@ -215,7 +218,7 @@ def test_wide_gemm_modes(ops, M, K, N):
             errs[mode] = (e, ew)
             assert e < bound[mode] and ew < bound[mode], (mode, e, ew)
     finally:
-        ops.set_wide_gemm("bf16x3")
+        ops.set_wide_gemm(initial)
     assert errs["fp32"][0] < errs["bf16x3"][0] < errs["bf16"][0]
     with pytest.raises(Exception):
         ops.set_wide_gemm("fp16")
