@@ -62,6 +62,8 @@ struct PoolParams {
     int gu_accumulate;
     float* GG;             // same addressing as G (zeroed by the caller)
     float* slab;           // per-workgroup partial dW: [grid][d*d]
+    float* X_out;          // d = 128 backward: X and dS leave the kernel ((P*16) x d each); dW = dS^T.X is the caller's
+    float* dS_out;         //   weight-gradient GEMM (64 accumulator tiles do not fit one wavefront)
 };
 
 template <int DT>
@@ -180,19 +182,23 @@ __device__ __forceinline__ void tile_gemm_bf(const float4 (&a)[DT], const __bf16
             split4(a[2 * b], h0, l0);
             split4(a[2 * b + 1], h1, l1);
             const bf16x8 ah = cat8(h0, h1), al = cat8(l0, l1);
-            bf16x8 bh[DT], bl[DT];
+            constexpr int NG = DT < 4 ? DT : 4;      // column blocks per round: bounds the fragment registers
 #pragma unroll
-            for (int nb = 0; nb < DT; ++nb) {
-                const int o = off + nb * 16 * XSB + 32 * b;
-                bh[nb] = cat8(*reinterpret_cast<const bf16x4*>(Bh + o), *reinterpret_cast<const bf16x4*>(Bh + o + 16));
-                bl[nb] = cat8(*reinterpret_cast<const bf16x4*>(Bl + o), *reinterpret_cast<const bf16x4*>(Bl + o + 16));
+            for (int n0 = 0; n0 < DT; n0 += NG) {
+                bf16x8 bh[NG], bl[NG];
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int o = off + (n0 + j) * 16 * XSB + 32 * b;
+                    bh[j] = cat8(*reinterpret_cast<const bf16x4*>(Bh + o), *reinterpret_cast<const bf16x4*>(Bh + o + 16));
+                    bl[j] = cat8(*reinterpret_cast<const bf16x4*>(Bl + o), *reinterpret_cast<const bf16x4*>(Bl + o + 16));
+                }
+#pragma unroll
+                for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[n0 + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[n0 + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[n0 + j], 0, 0, 0);
             }
-#pragma unroll
-            for (int nb = 0; nb < DT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], acc[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < DT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < DT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[nb], 0, 0, 0);
         }
     }
 }
@@ -231,17 +237,17 @@ __device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* W
     }
 }
 
-template <int DT, int TERMS>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product)
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
+template <int DT, int TERMS, int NW = 4>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product); NW wavefronts
+__global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     __shared__ __attribute__((aligned(16))) unsigned char wmem[TERMS == 0 ? D * XS * 4 : 2 * D * XSB * 2];
-    __shared__ __attribute__((aligned(16))) float Xt[4][16 * XS];
+    __shared__ __attribute__((aligned(16))) float Xt[NW][16 * XS];
     float* Wt = reinterpret_cast<float*>(wmem);
     __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
     __bf16* Wl = Wh + D * XSB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
-    for (int e = threadIdx.x; e < D * D; e += 256) {
+    for (int e = threadIdx.x; e < D * D; e += 64 * NW) {
         const int o = e / D, i = e - o * D;
         const float w = p.W[e];            // [n][k]: the transposed-B form the tile GEMMs read
         if constexpr (TERMS == 0) {
@@ -257,8 +263,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolParams p) {
     lane_lazy<DT>(p, lj, sc, sh);
     float* Xs = Xt[wave];
     // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
-    const long pstep = (long)gridDim.x * 4;
-    long pt = (long)blockIdx.x * 4 + wave;
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
@@ -474,6 +480,146 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// d = 128 backward (bf16x3 / bf16 arithmetic only).  LDS holds ONE image of W, [o][i] as bf16 head + tail (70 KB):
+//   S  = X.W^T   reads it row-wise    (tile_gemm_bf: B^T[n = o][k = i], 8-byte pieces)
+//   dX = dS.W    reads it column-wise (B[k = o][n = i]: a lane's four o of one column are four 2-byte reads) with
+//                v_mfma_f32_16x16x16_bf16, whose A-operand lane (row, o-group) holds 4 consecutive o = the float4 of
+//                the A-layout dS tile
+// dW[o][i] = sum_rows dS[row][o] X[row][i] is 64 accumulator tiles - too many for a wavefront that also carries the
+// rest - so X and dS are written out ((P*16) x 128 each, coalesced 16-byte rows) and the caller runs its ordinary wide
+// weight-gradient kernel on them.  Everything else is pool_bwd_kernel: one point per wavefront, loads of the next
+// point in flight.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
+    constexpr int NW = 8;    // 70 KB of W in LDS: one workgroup per CU, so it brings eight wavefronts
+    constexpr int TERMS = 3;
+    constexpr int DT = 8, D = 128, H = 64, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
+    __shared__ __attribute__((aligned(16))) __bf16 Wh[D * XSB];
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[D * XSB];
+    __shared__ __attribute__((aligned(16))) float Tiles[NW][16 * XS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    for (int e = threadIdx.x; e < D * D; e += 64 * NW) {
+        const int o = e / D, i = e - o * D;
+        const float w = p.W[e];
+        const __bf16 h = (__bf16)w;
+        Wh[o * XSB + i] = h;
+        if constexpr (TERMS == 3) Wl[o * XSB + i] = (__bf16)(w - (float)h);
+    }
+    __syncthreads();
+    float sc[DT][4], sh[DT][4];
+    lane_lazy<DT>(p, lj, sc, sh);
+    // one tile per wavefront: X in C layout is read and dS written by the SAME lane at the same element, so dS
+    // replaces X in place (nothing needs X afterwards - the weight gradient is external)
+    float* Xs = Tiles[wave];
+    float* Ds = Tiles[wave];
+
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
+    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    float4 raw[DT];
+    if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+    for (; pt < p.P; pt += pstep) {
+        const int my_idx = idx_cur;
+        const long b = (unsigned)pt / (unsigned)p.n;
+        float4 xa[DT];
+        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        if (pt + pstep < p.P) fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+        idx_cur = idx_nxt; idx_nxt = idx_n2;
+        float gp[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
+        // X leaves the kernel for the weight-gradient GEMM: row li, 16 bytes per 16-column chunk
+#pragma unroll
+        for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(p.X_out + (pt * 16 + li) * D + 16 * c + 4 * lj) = xa[c];
+        f32x4 a[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile_gemm_bf<DT>(xa, Wh, Wl, li, lj, a);
+        softmax_rows<DT>(a);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 dx[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) {
+            const int col = nb * 16 + li;
+            float xc[4];
+            float pool = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xc[r] = Xs[(lj * 4 + r) * XS + col];
+                pool += a[nb][r] * xc[r];
+            }
+            pool += __shfl_xor(pool, 16, 64);
+            pool += __shfl_xor(pool, 32, 64);
+            const float g = gp[nb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ag = a[nb][r] * g;
+                dx[nb][r] = ag;                                      // direct path dP*A
+                Ds[(lj * 4 + r) * XS + col] = ag * (xc[r] - pool);   // dS = A*dP*(X-P)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dS in A layout: out to HBM for the weight gradient, and the A operand of dX += dS.W
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            const float4 da = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
+            *reinterpret_cast<float4*>(p.dS_out + (pt * 16 + li) * D + 16 * c + 4 * lj) = da;
+            bf16x4 ah, al;
+            split4(da, ah, al);
+            // B fragment of column block nb: W[o = 16c + 4lj + j][nb*16 + li], j = 0..3 - four rows of one column.
+            // ds_read_b64_tr_b16 does that gather: per 16-lane group it reads a 4-row x 16-column block of 16-bit
+            // elements (lane 4q+p supplies the address of row q, columns 4p..4p+3) and hands lane i column i.
+            const int tq = li >> 2, tp = li & 3;
+            const __bf16* trh = Wh + (16 * c + 4 * lj + tq) * XSB + 4 * tp;
+            const __bf16* trl = Wl + (16 * c + 4 * lj + tq) * XSB + 4 * tp;
+#pragma unroll
+            for (int n0 = 0; n0 < DT; n0 += 4) {
+                bf16x4 bh[4], bl[4];
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    bh[j4] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(trh + (n0 + j4) * 16)));
+                    if constexpr (TERMS == 3)
+                        bl[j4] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(trl + (n0 + j4) * 16)));
+                }
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) dx[n0 + j4] = mfma16(ah, bh[j4], dx[n0 + j4]);
+                if constexpr (TERMS == 3) {
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) dx[n0 + j4] = mfma16(ah, bl[j4], dx[n0 + j4]);
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) dx[n0 + j4] = mfma16(al, bh[j4], dx[n0 + j4]);
+                }
+            }
+        }
+        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> scatter to the gathered rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rowi = lj * 4 + r;
+            const int nbr = __shfl(my_idx, rowi, 64);
+            const long urow = (pt * 16 + rowi) * H;
+            const long grow = (b * p.g_bstride + nbr) * H;
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) {
+                const int col = nb * 16 + li;
+                const float v = dx[nb][r];
+                if (col < H) {
+                    if (p.gu_accumulate) p.GU[urow + col] += v;
+                    else p.GU[urow + col] = v;
+                } else {
+                    atomicAdd(p.GG + grow + (col - H), v);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // 64 consecutive elements (256 contiguous bytes per slab row) x 4 slab lanes per workgroup, fixed order
 __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __restrict__ slab, int nsplit, int count,
                                                              float* __restrict__ dW) {
@@ -503,6 +649,7 @@ __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __rest
 int pool_grid(long P, int d, bool backward) {
     const long cap = (!backward && d <= 16) ? 2048 : 1024;
     long g = (P + 15) / 16;  // >= 4 points per wavefront
+    if (d == 128) g = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;   // 8 wavefronts per workgroup, one workgroup per CU
     if (g < 1) g = 1;
     return (int)(g < cap ? g : cap);
 }
@@ -510,7 +657,8 @@ int pool_grid(long P, int d, bool backward) {
 int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     RL_REQUIRE(d && d->U && d->G && d->idx && d->W && d->points > 0 && d->n > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
     RL_REQUIRE(d->nbr_k == 16, RL_ERR_UNSUPPORTED, "%s: the fused kernel needs 16 neighbours (got %d)", who, d->nbr_k);
-    RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64, RL_ERR_UNSUPPORTED, "%s: d must be 16, 32 or 64 (got %d)", who, d->d);
+    RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64 || (d->d == 128 && rl_wide_terms() != 0), RL_ERR_UNSUPPORTED,
+               "%s: d must be 16, 32 or 64, or 128 outside the fp32 arithmetic mode (got %d)", who, d->d);
     RL_REQUIRE(d->g_bstride >= d->n && d->points % d->n == 0, RL_ERR_ARGS, "%s: bad cloud geometry", who);
     RL_REQUIRE((int64_t)d->points * 16 < (1l << 31), RL_ERR_ARGS, "%s: too many neighbourhood rows", who);
     RL_REQUIRE(((uintptr_t)d->U & 15) == 0 && ((uintptr_t)d->G & 15) == 0, RL_ERR_ARGS, "%s: U/G must be 16-byte aligned", who);
@@ -521,14 +669,20 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->glazy.scale = d->g_scale; p->glazy.shift = d->g_shift; p->glazy.act = d->g_act; p->glazy.slope = d->g_slope;
     p->idx = d->idx; p->W = d->W; p->P = d->points; p->n = d->n; p->d = d->d;
     p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->GG = d->GG; p->slab = d->slab;
+    p->X_out = nullptr; p->dS_out = nullptr;
     if (!backward) RL_REQUIRE(d->Pout, RL_ERR_ARGS, "%s: null output", who);
-    else RL_REQUIRE(d->dP && d->GU && d->GG && d->dW && d->slab, RL_ERR_ARGS, "%s: null gradient buffers", who);
+    else RL_REQUIRE(d->dP && d->GU && d->GG, RL_ERR_ARGS, "%s: null gradient buffers", who);
     return RL_OK;
 }
 
 }  // namespace
 
-extern "C" int rl_pool_supported(int d, int nbr_k) { return (nbr_k == 16 && (d == 16 || d == 32 || d == 64)) ? 1 : 0; }
+// d = 128 keeps both weight images (head + tail, 70 KB) in LDS as bf16: only in the bf16x3 / bf16 arithmetic modes
+extern "C" int rl_pool_supported(int d, int nbr_k) {
+    if (nbr_k != 16) return 0;
+    if (d == 16 || d == 32 || d == 64) return 1;
+    return (d == 128 && rl_wide_terms() != 0) ? 1 : 0;
+}
 
 extern "C" int64_t rl_pool_slab_floats(int64_t points, int d) { return (int64_t)pool_grid(points, d, true) * d * d; }
 
@@ -545,9 +699,10 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     } else {
         if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 3>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 3>), dim3(g), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((pool_fwd_kernel<4, 3>), dim3(g), dim3(256), 0, st, p);
+        else if (p.d == 64) hipLaunchKernelGGL((pool_fwd_kernel<4, 3>), dim3(g), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pool_fwd_kernel<8, 3, 8>), dim3(g), dim3(512), 0, st, p);   // 70 KB of W: 8 wavefronts share it
     }
-    rl_note_kernel(p.d == 16 ? "pool_fwd_kernel<1>" : p.d == 32 ? "pool_fwd_kernel<2>" : "pool_fwd_kernel<4>");
+    rl_note_kernel(p.d == 16 ? "pool_fwd_kernel<1>" : p.d == 32 ? "pool_fwd_kernel<2>" : p.d == 64 ? "pool_fwd_kernel<4>" : "pool_fwd_kernel<8>");
     RL_LAUNCH_CHECK("rl_pool_fwd");
     return RL_OK;
 }
@@ -556,9 +711,21 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     PoolParams p;
     int rc = fill(&p, d, "rl_pool_bwd", true);
     if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.d == 128) {
+        // no dW here: X and dS are written out for the caller's wide weight-gradient kernel
+        RL_REQUIRE(d->X_out && d->dS_out, RL_ERR_ARGS, "rl_pool_bwd: d = 128 needs X_out and dS_out");
+        RL_REQUIRE((((uintptr_t)d->X_out | (uintptr_t)d->dS_out) & 15) == 0, RL_ERR_ARGS, "rl_pool_bwd: X_out / dS_out must be 16-byte aligned");
+        p.X_out = d->X_out; p.dS_out = d->dS_out;
+        const int g = pool_grid(p.P, p.d, true);
+        hipLaunchKernelGGL(pool128_bwd_kernel, dim3(g), dim3(512), 0, st, p);
+        rl_note_kernel("pool128_bwd_kernel");
+        RL_LAUNCH_CHECK("rl_pool_bwd(128)");
+        return RL_OK;
+    }
+    RL_REQUIRE(d->dW && d->slab, RL_ERR_ARGS, "rl_pool_bwd: null gradient buffers");
     const int g = pool_grid(p.P, p.d, true);
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
-    hipStream_t st = (hipStream_t)stream;
     if (rl_wide_terms() == 0) {
         if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);

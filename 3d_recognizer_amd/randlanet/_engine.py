@@ -255,7 +255,7 @@ class Engine:
                     gg[0].zero_()
                     gg[1] = True
                 ops.pool_bwd(u, g, idx, self.P[f"{name}.score_fn.0.weight"], n, d, GP, gu[0], gu[1], gg[0],
-                             grads[f"{name}.score_fn.0.weight"])
+                             grads[f"{name}.score_fn.0.weight"], pending=ctx.pending)
                 gu[1] = True
             elif kind == "add_act":
                 _, m2, sc, O = rec

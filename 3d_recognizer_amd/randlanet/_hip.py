@@ -109,6 +109,7 @@ class PoolDesc(C.Structure):
         ("n", C.c_int32), ("d", C.c_int32), ("nbr_k", C.c_int32),
         ("Pout", C.c_void_p), ("dP", C.c_void_p), ("GU", C.c_void_p), ("gu_accumulate", C.c_int32),
         ("GG", C.c_void_p), ("dW", C.c_void_p), ("slab", C.c_void_p), ("slab_floats", C.c_int64),
+        ("X_out", C.c_void_p), ("dS_out", C.c_void_p),
     ]
 
 

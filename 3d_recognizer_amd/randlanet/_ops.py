@@ -486,17 +486,27 @@ def pool_fwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: in
 
 
 def pool_bwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP: torch.Tensor,
-             GU: torch.Tensor, gu_accumulate: bool, GG: torch.Tensor, dW: torch.Tensor) -> None:
+             GU: torch.Tensor, gu_accumulate: bool, GG: torch.Tensor, dW: torch.Tensor, pending: Optional[list] = None) -> None:
+    """Backward of the fused pooling block.  d <= 64: dW comes out of the kernel.  d = 128: the kernel writes X and dS
+    and the weight gradient is the ordinary wide kernel on them (queued on `pending` like every other layer's)."""
     pd = _pool_desc(u, g, idx, W, n, d)
     _dev_check(dP, GU, GG, dW)
     P = u.B * n
     assert dP.shape == (P, d) and GU.shape == u.raw.shape and GG.shape == g.raw.shape and dW.numel() == d * d
+    pd.dP, pd.GU, pd.gu_accumulate, pd.GG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), GG.data_ptr(), dW.data_ptr()
+    nbytes = 4 * (3 * P * 16 * (d // 2) + P * 16 * (d // 2) * (1 + int(gu_accumulate)) + P * 16 + 2 * P * d)
+    if d == 128:
+        X = torch.empty((P * 16, d), dtype=F32, device=W.device)
+        dS = torch.empty((P * 16, d), dtype=F32, device=W.device)
+        pd.X_out, pd.dS_out = X.data_ptr(), dS.data_ptr()
+        with _rec("pool_bwd", (P, 16, d), nbytes + 8 * P * 16 * d, 4 * P * 16 * d * d):
+            H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
+        wgrad(plain(X, u.B, n * 16), dS, n * 16, d, dW, 1, d, None, pending=pending)
+        return
     floats = H.lib().rl_pool_slab_floats(P, d)
     slab = _slab(W.device, floats)
-    pd.dP, pd.GU, pd.gu_accumulate, pd.GG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), GG.data_ptr(), dW.data_ptr()
     pd.slab, pd.slab_floats = slab.data_ptr(), slab.numel()
-    with _rec("pool_bwd", (P, 16, d), 4 * (3 * P * 16 * (d // 2) + P * 16 * (d // 2) * (1 + int(gu_accumulate)) + P * 16 + 2 * P * d),
-              6 * P * 16 * d * d):
+    with _rec("pool_bwd", (P, 16, d), nbytes, 6 * P * 16 * d * d):
         H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
 
 

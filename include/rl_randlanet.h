@@ -304,7 +304,7 @@ int rl_attpool_fwd(const float* X, const float* S, int64_t P, int K, int C, floa
 int rl_attpool_bwd(const float* X, const float* S, const float* Pout, const float* dP, int64_t P,
                    int K, int C, float* dS, float* dXa, void* stream);
 
-/* Fused attentive pooling for narrow levels (d = 16 / 32 / 64, 16 neighbours): gather + concat
+/* Fused attentive pooling (d = 16 / 32 / 64, and 128 in the bf16x3 / bf16 arithmetic modes; 16 neighbours): gather + concat
  * (modules.py:213-221), score Linear + softmax over K + weighted sum (modules.py:246-253) without
  * materialising the (points*K) x d tensors.
  *   U   (points*16) x d/2 lazy rpe-branch features;  G  lazy per-point features, row (b,i) at
@@ -337,6 +337,11 @@ typedef struct rl_pool_desc {
     float* dW;
     float* slab;
     int64_t slab_floats;
+    /* d = 128 (supported outside the fp32 arithmetic mode): rl_pool_bwd does not produce dW; it writes the block's
+     * X = [rpe, gathered] and dS, (points*16) x 128 floats each, and the caller computes dW = dS^T.X with rl_wgrad
+     * (dY = dS_out, A = X_out).  dW / slab are ignored then. */
+    float* X_out;
+    float* dS_out;
 } rl_pool_desc;
 
 int rl_pool_supported(int d, int nbr_k);

@@ -463,7 +463,7 @@ def test_attpool(ops, P, K, Cc):
     assert float((dS - S.grad).abs().max()) < 1e-5 and float((dXa - X.grad).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("d,B,n_parent,n", [(16, 2, 700, 300), (32, 1, 257, 257), (64, 3, 400, 130)])
+@pytest.mark.parametrize("d,B,n_parent,n", [(16, 2, 700, 300), (32, 1, 257, 257), (64, 3, 400, 130), (128, 2, 300, 150)])
 def test_fused_pool_forward_backward(ops, d, B, n_parent, n):
     """rl_pool_fwd / rl_pool_bwd against a plain PyTorch statement of gather + concat + score Linear +
     softmax over K + weighted sum (modules.py:213-221, 246-253) and its autograd."""
