@@ -130,6 +130,7 @@ struct GemmParams {
     int kchunk;        // K range per split (multiple of 32)
     float* kslab;      // [ksplit][M][N]
     int stat_slots;    // slots the finalize kernel reads; a smaller grid zero-fills the rest
+    int gx, ny;                // pgemm: logical grid (row-tile workgroups, column tiles); see the index mapping there
     const float* addend;       // split-scatter epilogue (pgemm only), see rl_gemm_desc
     float* out2;
     const int32_t* out2_index;
@@ -829,7 +830,17 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int col0 = blockIdx.y * BN;
+    // Workgroup -> (row-tile slot bx, column tile by).  With several column tiles the tiles of one row tile share the
+    // A operand: they get consecutive slots on the SAME XCD (workgroup ids go round-robin over the 8 XCDs, each with
+    // its own L2), so the second one finds A in that L2 instead of fetching it from HBM again.
+    int bx = blockIdx.x, by = 0;
+    if (p.ny > 1) {
+        const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+        by = s % p.ny;
+        bx = (s / p.ny) * 8 + xcd;
+        if (bx >= p.gx) return;      // padding of the last group of eight
+    }
+    const int col0 = by * BN;
     const int K = p.a.K, N = p.N;
     const long M = p.a.M;
     const long ntiles = (M + GM_BM - 1) / GM_BM;
@@ -843,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = bx; tile < ntiles; tile += p.gx) {
         const long row0 = tile * GM_BM;
         long aoff[4];
         bool aval[4];
@@ -1126,9 +1137,9 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
         }
         __syncthreads();
         if (tid < BN && col0 + tid < N) {
-            p.stats[((long)blockIdx.x * 2 + 0) * N + col0 + tid] = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
-            p.stats[((long)blockIdx.x * 2 + 1) * N + col0 + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
-            for (long slot = blockIdx.x + gridDim.x; slot < p.stat_slots; slot += gridDim.x) {
+            p.stats[((long)bx * 2 + 0) * N + col0 + tid] = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
+            p.stats[((long)bx * 2 + 1) * N + col0 + tid] = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
+            for (long slot = bx + p.gx; slot < p.stat_slots; slot += p.gx) {
                 p.stats[(slot * 2 + 0) * N + col0 + tid] = 0.0;
                 p.stats[(slot * 2 + 1) * N + col0 + tid] = 0.0;
             }
@@ -1227,7 +1238,9 @@ inline int wide_gemm_terms() {
     return g_wide_terms;
 }
 template <int NT>
-void launch_pgemm(dim3 grid, hipStream_t st, const GemmParams& p) {
+void launch_pgemm(dim3 logical, hipStream_t st, GemmParams p) {
+    p.gx = (int)logical.x; p.ny = (int)logical.y;
+    const dim3 grid(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : logical.x, 1, logical.z);
     const int t = wide_gemm_terms();
     if (t == 0)      hipLaunchKernelGGL((pgemm_kernel<NT, 0>), grid, dim3(256), 0, st, p);
     else if (t == 1) hipLaunchKernelGGL((pgemm_kernel<NT, 1>), grid, dim3(256), 0, st, p);
