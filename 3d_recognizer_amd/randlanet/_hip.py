@@ -202,7 +202,16 @@ def check(rc: int, what: str = "") -> None:
         raise HipKernelError(f"{what or 'librandla_hip'} failed ({rc}): {msg}")
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr(device=None) -> int:
+    """hipStream_t of torch's current stream as an integer.  The C-level accessors are used when torch has them:
+    torch.cuda.current_stream() costs ~0.1 ms of Python per call (it re-checks torch.cuda.is_available() through
+    os.environ every time), which was most of an eager forward's host time at ~130 launches."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None and device is None:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream(device).cuda_stream
 
 

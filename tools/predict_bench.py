@@ -9,6 +9,9 @@ import numpy as np, torch
 from randlanet import Model, RandLANetSettings
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+# a one-GPU box shows 256 cores but grants 16: torch's CPU thread pool must not be sized for 256 (the few host-side
+# tensor ops of predict - fancy indexing, .cpu() - then cost 25 ms instead of 0.2 ms)
+torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 rs = np.random.RandomState(0)
 cloud = rs.rand(150000, 3).astype(np.float32)
 for up in ("nni", "idw"):
