@@ -287,6 +287,119 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BwdParams p
     }
 }
 
+// ---- residual junction: one gradient, two BatchNorms (see rl_resid_bn_bwd_desc) ------------------------------
+struct ResidParams {
+    float* G; float* G2; const float* O; float slope; long M; int C;
+    const float* Y1; const float* sc1; const float* mu1; const float* is1;
+    const float* Y2; const float* sc2; const float* mu2; const float* is2;
+    double* stats1; double* stats2; const float* coef1; const float* coef2;
+    int tile;
+};
+
+__global__ __launch_bounds__(256) void resid_bn_bwd_reduce_kernel(const ResidParams p) {
+    __shared__ float red[256][13];
+    const int C = p.C, c4 = C >> 2;
+    const int tpr = c4 < 256 ? c4 : 256;
+    const int rpar = 256 / tpr;
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int c = q * 4;
+    const float4 mu1 = *reinterpret_cast<const float4*>(p.mu1 + c), is1 = *reinterpret_cast<const float4*>(p.is1 + c);
+    const float4 mu2 = *reinterpret_cast<const float4*>(p.mu2 + c), is2 = *reinterpret_cast<const float4*>(p.is2 + c);
+    const long ntiles = (p.M + p.tile - 1) / p.tile;
+    float acc[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long rend = min(p.M, (tile + 1) * p.tile);
+        for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
+            const long off = R * C + c;
+            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
+            const float4 o = *reinterpret_cast<const float4*>(p.O + off);
+            const float4 y1 = *reinterpret_cast<const float4*>(p.Y1 + off);
+            const float4 y2 = *reinterpret_cast<const float4*>(p.Y2 + off);
+            const float g[4] = {o.x > 0.f ? gi.x : gi.x * p.slope, o.y > 0.f ? gi.y : gi.y * p.slope,
+                                o.z > 0.f ? gi.z : gi.z * p.slope, o.w > 0.f ? gi.w : gi.w * p.slope};
+            const float x1[4] = {(y1.x - mu1.x) * is1.x, (y1.y - mu1.y) * is1.y, (y1.z - mu1.z) * is1.z, (y1.w - mu1.w) * is1.w};
+            const float x2[4] = {(y2.x - mu2.x) * is2.x, (y2.y - mu2.y) * is2.y, (y2.z - mu2.z) * is2.z, (y2.w - mu2.w) * is2.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] += g[j];
+                acc[4 + j] += g[j] * x1[j];
+                acc[8 + j] += g[j] * x2[j];
+            }
+        }
+    }
+    for (int o = 32; o >= tpr && o >= 1; o >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < tpr) {
+        const int step = tpr < 64 ? 64 : tpr;
+        double s[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = threadIdx.x; t < 256; t += step)
+#pragma unroll
+            for (int j = 0; j < 12; ++j) s[j] += (double)red[t][j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p.stats1[((long)blockIdx.x * 2 + 0) * C + c + j] = s[j];
+            p.stats1[((long)blockIdx.x * 2 + 1) * C + c + j] = s[4 + j];
+            p.stats2[((long)blockIdx.x * 2 + 0) * C + c + j] = s[j];
+            p.stats2[((long)blockIdx.x * 2 + 1) * C + c + j] = s[8 + j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void resid_bn_bwd_apply_kernel(const ResidParams p) {
+    const int C = p.C, c4 = C >> 2;
+    const int tpr = c4 < 256 ? c4 : 256;
+    const int rpar = 256 / tpr;
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int c = q * 4;
+    const float4 mu1 = *reinterpret_cast<const float4*>(p.mu1 + c), is1 = *reinterpret_cast<const float4*>(p.is1 + c);
+    const float4 mu2 = *reinterpret_cast<const float4*>(p.mu2 + c), is2 = *reinterpret_cast<const float4*>(p.is2 + c);
+    const float4 s1 = *reinterpret_cast<const float4*>(p.sc1 + c), s2 = *reinterpret_cast<const float4*>(p.sc2 + c);
+    const float4 a0 = *reinterpret_cast<const float4*>(p.coef1 + c), a1 = *reinterpret_cast<const float4*>(p.coef1 + C + c);
+    const float4 b0 = *reinterpret_cast<const float4*>(p.coef2 + c), b1 = *reinterpret_cast<const float4*>(p.coef2 + C + c);
+    const long ntiles = (p.M + p.tile - 1) / p.tile;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long rend = min(p.M, (tile + 1) * p.tile);
+        for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
+            const long off = R * C + c;
+            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
+            const float4 o = *reinterpret_cast<const float4*>(p.O + off);
+            const float4 y1 = *reinterpret_cast<const float4*>(p.Y1 + off);
+            const float4 y2 = *reinterpret_cast<const float4*>(p.Y2 + off);
+            float4 g;
+            g.x = o.x > 0.f ? gi.x : gi.x * p.slope; g.y = o.y > 0.f ? gi.y : gi.y * p.slope;
+            g.z = o.z > 0.f ? gi.z : gi.z * p.slope; g.w = o.w > 0.f ? gi.w : gi.w * p.slope;
+            float4 r1, r2;
+            r1.x = (g.x - a0.x - (y1.x - mu1.x) * is1.x * a1.x) * s1.x; r1.y = (g.y - a0.y - (y1.y - mu1.y) * is1.y * a1.y) * s1.y;
+            r1.z = (g.z - a0.z - (y1.z - mu1.z) * is1.z * a1.z) * s1.z; r1.w = (g.w - a0.w - (y1.w - mu1.w) * is1.w * a1.w) * s1.w;
+            r2.x = (g.x - b0.x - (y2.x - mu2.x) * is2.x * b1.x) * s2.x; r2.y = (g.y - b0.y - (y2.y - mu2.y) * is2.y * b1.y) * s2.y;
+            r2.z = (g.z - b0.z - (y2.z - mu2.z) * is2.z * b1.z) * s2.z; r2.w = (g.w - b0.w - (y2.w - mu2.w) * is2.w * b1.w) * s2.w;
+            *reinterpret_cast<float4*>(p.G + off) = r1;
+            *reinterpret_cast<float4*>(p.G2 + off) = r2;
+        }
+    }
+}
+
+int resid_fill(ResidParams* p, const rl_resid_bn_bwd_desc* d, const char* who) {
+    RL_REQUIRE(d && d->G && d->O && d->Y1 && d->Y2 && d->rows > 0 && d->C > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
+    RL_REQUIRE(d->scale1 && d->mean1 && d->invstd1 && d->scale2 && d->mean2 && d->invstd2, RL_ERR_ARGS, "%s: needs both BatchNorms' scale / mean / invstd", who);
+    RL_REQUIRE(rl_resid_bn_bwd_supported(d->rows, d->C), RL_ERR_UNSUPPORTED, "%s: C = %d is not a multiple of 4 with C/4 a power of two <= 256", who, d->C);
+    const uintptr_t al = (uintptr_t)d->G | (uintptr_t)d->O | (uintptr_t)d->Y1 | (uintptr_t)d->Y2 | (uintptr_t)d->scale1 | (uintptr_t)d->scale2 |
+                         (uintptr_t)d->mean1 | (uintptr_t)d->mean2 | (uintptr_t)d->invstd1 | (uintptr_t)d->invstd2 | (uintptr_t)d->G2 |
+                         (uintptr_t)d->coef1 | (uintptr_t)d->coef2;
+    RL_REQUIRE((al & 15) == 0, RL_ERR_ARGS, "%s: tensors must be 16-byte aligned", who);
+    p->G = d->G; p->G2 = d->G2; p->O = d->O; p->slope = d->slope; p->M = d->rows; p->C = d->C;
+    p->Y1 = d->Y1; p->sc1 = d->scale1; p->mu1 = d->mean1; p->is1 = d->invstd1;
+    p->Y2 = d->Y2; p->sc2 = d->scale2; p->mu2 = d->mean2; p->is2 = d->invstd2;
+    p->stats1 = d->stats1; p->stats2 = d->stats2; p->coef1 = d->coef1; p->coef2 = d->coef2;
+    p->tile = bn_tile(d->rows);
+    return RL_OK;
+}
+
 bool vec_ok(const BwdParams& p) {
     const int c4 = p.C >> 2;
     return (p.C % 4 == 0) && c4 <= 256 && (c4 & (c4 - 1)) == 0 && (p.ld % 4 == 0) &&
@@ -361,5 +474,32 @@ extern "C" int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream) {
                            (hipStream_t)stream, p);
     rl_note_kernel(vec_ok(p) ? "bn_bwd_apply_vec_kernel" : "bn_bwd_apply_kernel");
     RL_LAUNCH_CHECK("rl_bn_bwd_apply");
+    return RL_OK;
+}
+
+extern "C" int rl_resid_bn_bwd_supported(int64_t rows, int C) {
+    const int c4 = C >> 2;
+    return (rows > 0 && rows < (1l << 31) && C % 4 == 0 && c4 >= 1 && c4 <= 256 && (c4 & (c4 - 1)) == 0) ? 1 : 0;
+}
+
+extern "C" int rl_resid_bn_bwd_reduce(const rl_resid_bn_bwd_desc* d, void* stream) {
+    ResidParams p;
+    int rc = resid_fill(&p, d, "rl_resid_bn_bwd_reduce");
+    if (rc) return rc;
+    RL_REQUIRE(p.stats1 && p.stats2, RL_ERR_ARGS, "rl_resid_bn_bwd_reduce: needs stats1 and stats2");
+    hipLaunchKernelGGL(resid_bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
+    rl_note_kernel("resid_bn_bwd_reduce_kernel");
+    RL_LAUNCH_CHECK("rl_resid_bn_bwd_reduce");
+    return RL_OK;
+}
+
+extern "C" int rl_resid_bn_bwd_apply(const rl_resid_bn_bwd_desc* d, void* stream) {
+    ResidParams p;
+    int rc = resid_fill(&p, d, "rl_resid_bn_bwd_apply");
+    if (rc) return rc;
+    RL_REQUIRE(p.G2 && p.coef1 && p.coef2, RL_ERR_ARGS, "rl_resid_bn_bwd_apply: needs G2, coef1 and coef2");
+    hipLaunchKernelGGL(resid_bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
+    rl_note_kernel("resid_bn_bwd_apply_kernel");
+    RL_LAUNCH_CHECK("rl_resid_bn_bwd_apply");
     return RL_OK;
 }

@@ -238,6 +238,7 @@ class Engine:
         if self._side is None:
             self._side = torch.cuda.Stream(dlogits.device)
         ctx.hold = []
+        ctx.bn_done = set()       # raw tensors whose BatchNorm backward already happened (fused at the residual junction)
         # weight-gradient slabs are summed by ONE launch after the last layer (they are only needed by the optimiser)
         ctx.pending = None if (ops.SIDE_STREAM_WGRAD or ops.NO_DEFERRED_WGRAD) else []
         for rec in reversed(ctx.tape):
@@ -261,9 +262,15 @@ class Engine:
                 _, m2, sc, O = rec
                 G, init = self._gbuf(ctx, O)
                 assert init
-                ops.add_act_bwd(G, O.raw, 0.01)
-                g2 = torch.empty_like(G)
-                ops.copy_rows(G, (0, O.C), O.n, g2, (0, O.C), O.rows, O.n)
+                if not ops.NO_RESID_BN and ops.resid_bn_supported(m2, sc):
+                    # the junction's derivative and both BatchNorm backwards behind it in two sweeps
+                    g2 = ops.resid_bn_backward(G, O.raw, 0.01, m2, sc, grads[f"{m2.bn}.weight"], grads[f"{m2.bn}.bias"],
+                                               grads[f"{sc.bn}.weight"], grads[f"{sc.bn}.bias"])
+                    ctx.bn_done.update((id(m2.raw), id(sc.raw)))
+                else:
+                    ops.add_act_bwd(G, O.raw, 0.01)
+                    g2 = torch.empty_like(G)
+                    ops.copy_rows(G, (0, O.C), O.n, g2, (0, O.C), O.rows, O.n)
                 ctx.grads[id(m2.raw)] = [G, True]
                 ctx.grads[id(sc.raw)] = [g2, True]
             elif kind == "interp_concat":
@@ -309,7 +316,7 @@ class Engine:
     def _bwd_linear(self, ctx, grads, a, out: Lazy, wname, bname, ks, ns, a_grad):
         G, init = self._gbuf(ctx, out)
         assert init, f"no gradient reached {wname}"
-        if out.scale is not None:
+        if out.scale is not None and id(out.raw) not in ctx.bn_done:
             ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True)
         n_out = out.C
         self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,

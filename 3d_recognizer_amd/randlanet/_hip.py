@@ -113,6 +113,15 @@ class PoolDesc(C.Structure):
     ]
 
 
+class ResidBnBwdDesc(C.Structure):
+    _fields_ = [
+        ("G", C.c_void_p), ("G2", C.c_void_p), ("O", C.c_void_p), ("slope", C.c_float), ("rows", C.c_int64), ("C", C.c_int32),
+        ("Y1", C.c_void_p), ("scale1", C.c_void_p), ("mean1", C.c_void_p), ("invstd1", C.c_void_p),
+        ("Y2", C.c_void_p), ("scale2", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
+        ("stats1", C.c_void_p), ("stats2", C.c_void_p), ("coef1", C.c_void_p), ("coef2", C.c_void_p),
+    ]
+
+
 class RowsDesc(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("lds", C.c_int64), ("src_bstride", C.c_int64),
@@ -150,6 +159,9 @@ _SIGNATURES = {
     "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),
     "rl_bn_bwd_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp]),
     "rl_bn_bwd_apply": (_i, [C.POINTER(BnBwdDesc), _vp]),
+    "rl_resid_bn_bwd_supported": (_i, [_l, _i]),
+    "rl_resid_bn_bwd_reduce": (_i, [C.POINTER(ResidBnBwdDesc), _vp]),
+    "rl_resid_bn_bwd_apply": (_i, [C.POINTER(ResidBnBwdDesc), _vp]),
     "rl_copy_rows": (_i, [C.POINTER(RowsDesc), _vp]),
     "rl_scatter_add_rows": (_i, [C.POINTER(RowsDesc), _vp]),
     "rl_pool_supported": (_i, [_i, _i]),

@@ -87,6 +87,7 @@ SIDE_STREAM_WGRAD = bool(int(__import__("os").environ.get("RL_SIDE_STREAM", "0")
 NO_FUSED_POOL = bool(int(__import__("os").environ.get("RL_NO_FUSED_POOL", "0")))         # diagnostics only
 NO_DEFERRED_WGRAD = bool(int(__import__("os").environ.get("RL_NO_DEFERRED_WGRAD", "0")))  # diagnostics only
 NO_SPLIT_SCATTER = bool(int(__import__("os").environ.get("RL_NO_SPLIT_SCATTER", "0")))   # diagnostics only
+NO_RESID_BN = bool(int(__import__("os").environ.get("RL_NO_RESID_BN", "0")))             # diagnostics only
 NO_RPE_TENSOR = bool(int(__import__("os").environ.get("RL_NO_RPE_TENSOR", "0")))         # diagnostics only
 FORCE_BRUTE_KNN = bool(int(__import__("os").environ.get("RL_KNN_BRUTE", "0")))         # diagnostics only
 DEBUG_SYNC = bool(int(__import__("os").environ.get("RL_DEBUG_SYNC", "0")))   # print + sync around every launch
@@ -402,6 +403,36 @@ def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta:
         d.coef = coef.data_ptr()
     with _rec("bn_bwd_apply", (y.rows, y.C), 12 * y.rows * y.C, 0):
         H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
+
+
+def resid_bn_supported(y1: Lazy, y2: Lazy) -> bool:
+    dense = all(y.bstride == y.n and y.raw.shape == (y.B * y.n, y.C) and y.mean is not None and y.act == H.ACT_NONE for y in (y1, y2))
+    return dense and y1.C == y2.C and y1.rows == y2.rows and bool(H.lib().rl_resid_bn_bwd_supported(y1.rows, y1.C))
+
+
+def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, y2: Lazy, dgamma1, dbeta1, dgamma2, dbeta2):
+    """Backward of O = LeakyReLU(BN1(y1) + BN2(y2)) down to the two raw tensors: G (dL/dO) becomes the gradient
+    w.r.t. y1.raw in place, the returned tensor is the gradient w.r.t. y2.raw (modules.py:325 + two BatchNorm2d)."""
+    _dev_check(G, O, y1.raw, y2.raw)
+    rows, Cc = y1.rows, y1.C
+    assert G.shape == O.shape == (rows, Cc)
+    d = H.ResidBnBwdDesc()
+    G2 = torch.empty_like(G)
+    st1, st2 = new_stats(G.device, Cc), new_stats(G.device, Cc)
+    c1 = torch.empty(2 * Cc, dtype=F32, device=G.device)
+    c2 = torch.empty(2 * Cc, dtype=F32, device=G.device)
+    d.G, d.G2, d.O, d.slope, d.rows, d.C = G.data_ptr(), G2.data_ptr(), O.data_ptr(), slope, rows, Cc
+    d.Y1, d.scale1, d.mean1, d.invstd1 = y1.raw.data_ptr(), y1.scale.data_ptr(), y1.mean.data_ptr(), y1.invstd.data_ptr()
+    d.Y2, d.scale2, d.mean2, d.invstd2 = y2.raw.data_ptr(), y2.scale.data_ptr(), y2.mean.data_ptr(), y2.invstd.data_ptr()
+    d.stats1, d.stats2, d.coef1, d.coef2 = st1.data_ptr(), st2.data_ptr(), c1.data_ptr(), c2.data_ptr()
+    with _rec("resid_bn_bwd_reduce", (rows, Cc), 16 * rows * Cc, 0):
+        H.check(H.lib().rl_resid_bn_bwd_reduce(C.byref(d), _st()), "rl_resid_bn_bwd_reduce")
+    slots = H.lib().rl_bn_bwd_slots(rows)
+    H.check(H.lib().rl_bn_bwd_finalize(st1.data_ptr(), slots, rows, Cc, H.ptr(dgamma1), H.ptr(dbeta1), c1.data_ptr(), _st()), "rl_bn_bwd_finalize")
+    H.check(H.lib().rl_bn_bwd_finalize(st2.data_ptr(), slots, rows, Cc, H.ptr(dgamma2), H.ptr(dbeta2), c2.data_ptr(), _st()), "rl_bn_bwd_finalize")
+    with _rec("resid_bn_bwd_apply", (rows, Cc), 24 * rows * Cc, 0):
+        H.check(H.lib().rl_resid_bn_bwd_apply(C.byref(d), _st()), "rl_resid_bn_bwd_apply")
+    return G2
 
 
 # ------------------------------------------------------------------------------------ rows

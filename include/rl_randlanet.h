@@ -32,6 +32,7 @@
  *   rl_pool_fwd/_bwd      PointFeatureAugmentation + AttentivePooling fused (modules.py:213-253)
  *   rl_attpool_*          AttentivePooling softmax over K + weighted sum (modules.py:246-253)
  *   rl_add_act_*          LocalFeatureAggregation residual + LeakyReLU (modules.py:325)
+ *   rl_resid_bn_bwd_*     its backward fused with the two BatchNorm backwards behind it
  *   rl_rpe_build          RelativePositionEncoding (modules.py:173-186), materialised
  *   rl_scale_mask         Dropout of fc_end (modules.py:528)
  *   rl_batch_assemble     PointCloudPreprocessor.preprocess + augmentation + collation (dataset.py:61-131)
@@ -264,6 +265,31 @@ int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream);
 int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, float* dgamma,
                        float* dbeta, float* coef, void* stream);
 int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream);
+
+/* Backward of the residual junction of LocalFeatureAggregation (modules.py:325):
+ *     O = LeakyReLU_slope( BN1(Y1) + BN2(Y2) ),   Y1 = mlp2 output, Y2 = shortcut output, no activation of their own.
+ * Both branches receive the same g = G * (O > 0 ? 1 : slope); one sweep reduces both BatchNorms' sums
+ * (rl_resid_bn_bwd_reduce fills stats1 / stats2 in the slot layout of rl_bn_bwd_reduce, to be finished by
+ * rl_bn_bwd_finalize each) and one sweep writes both results (rl_resid_bn_bwd_apply):
+ *     G  <- scale1 * (g - coef1[0] - xhat1 * coef1[1]),   G2 <- scale2 * (g - coef2[0] - xhat2 * coef2[1]).
+ * All tensors are dense rows x C (C % 4 == 0, C/4 a power of two <= 256, 16-byte aligned); this replaces
+ * rl_add_act_bwd + a copy + two rl_bn_bwd_reduce + two rl_bn_bwd_apply (15 passes over the tensor -> 10).       */
+typedef struct rl_resid_bn_bwd_desc {
+    float* G;                /* in: dL/dO;  apply: out, gradient w.r.t. Y1 */
+    float* G2;               /* apply: out, gradient w.r.t. Y2 */
+    const float* O;
+    float slope;
+    int64_t rows;
+    int32_t C;
+    const float* Y1; const float* scale1; const float* mean1; const float* invstd1;
+    const float* Y2; const float* scale2; const float* mean2; const float* invstd2;
+    double* stats1; double* stats2;          /* reduce: out */
+    const float* coef1; const float* coef2;  /* apply: in (2*C floats each) */
+} rl_resid_bn_bwd_desc;
+
+int rl_resid_bn_bwd_supported(int64_t rows, int C);
+int rl_resid_bn_bwd_reduce(const rl_resid_bn_bwd_desc* d, void* stream);
+int rl_resid_bn_bwd_apply(const rl_resid_bn_bwd_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row movement.  dst row r of `rows` rows (r = b*rows_per_batch + i) receives `C` channels:

@@ -412,6 +412,37 @@ def test_bn_forward_backward(ops, C, rows):
 
 
 # ----------------------------------------------------------------------------- rows, pool
+@pytest.mark.parametrize("C,rows", [(32, 5000), (128, 999), (512, 300)])
+def test_residual_junction_bn_backward(ops, C, rows):
+    """O = LeakyReLU_0.01(BN1(Y1) + BN2(Y2)) backward in two sweeps against torch autograd."""
+    torch.manual_seed(C + rows)
+    Y = [(torch.randn(rows, C, device=DEV) * 1.5 + 0.3).requires_grad_(True) for _ in range(2)]
+    gam = [(torch.rand(C, device=DEV) + 0.5).requires_grad_(True) for _ in range(2)]
+    bet = [torch.randn(C, device=DEV).requires_grad_(True) for _ in range(2)]
+    bn = [torch.nn.functional.batch_norm(Y[i].t()[None], None, None, gam[i], bet[i], True, 0.99, 1e-6)[0].t() for i in range(2)]
+    O = torch.nn.functional.leaky_relu(bn[0] + bn[1], 0.01)
+    G = torch.randn(rows, C, device=DEV)
+    O.backward(G)
+    lz = []
+    for i in range(2):
+        mean = Y[i].detach().mean(0)
+        invstd = 1.0 / torch.sqrt(Y[i].detach().var(0, unbiased=False) + 1e-6)
+        scale = gam[i].detach() * invstd
+        lz.append(ops.Lazy(Y[i].detach().contiguous(), 1, rows, rows, C, scale, bet[i].detach() - mean * scale, 0, 0.0, mean, invstd))
+    assert ops.resid_bn_supported(lz[0], lz[1])
+    g = G.clone()
+    dg = [torch.empty(C, device=DEV) for _ in range(4)]
+    g2 = ops.resid_bn_backward(g, O.detach().contiguous(), 0.01, lz[0], lz[1], dg[0], dg[1], dg[2], dg[3])
+    for got, want in ((g, Y[0].grad), (g2, Y[1].grad)):
+        assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max()) + 1e-6
+    np.testing.assert_allclose(dg[0].cpu().numpy(), gam[0].grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(dg[1].cpu().numpy(), bet[0].grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(dg[2].cpu().numpy(), gam[1].grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(dg[3].cpu().numpy(), bet[1].grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    assert not ops.resid_bn_supported(ops.Lazy(Y[0].detach()[:, :6].contiguous(), 1, rows, rows, 6, scale[:6], scale[:6], 0, 0.0, mean[:6], invstd[:6]),
+                                      ops.Lazy(Y[1].detach()[:, :6].contiguous(), 1, rows, rows, 6, scale[:6], scale[:6], 0, 0.0, mean[:6], invstd[:6]))
+
+
 def test_copy_rows_gather_concat_scatter(ops):
     torch.manual_seed(5)
     B, n_src, n, K, Cc = 2, 500, 200, 16, 8
