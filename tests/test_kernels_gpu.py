@@ -498,6 +498,9 @@ def test_attpool(ops, P, K, Cc):
 def test_fused_pool_forward_backward(ops, d, B, n_parent, n):
     """rl_pool_fwd / rl_pool_bwd against a plain PyTorch statement of gather + concat + score Linear +
     softmax over K + weighted sum (modules.py:213-221, 246-253) and its autograd."""
+    if not ops.pool_supported(d, 16):
+        assert d == 128 and ops.get_wide_gemm() == "fp32"      # the 128-channel kernels exist in the bf16 modes only
+        pytest.skip("d = 128 fused pooling needs the bf16x3 / bf16 arithmetic mode")
     torch.manual_seed(d + n)
     K, h = 16, d // 2
     U = torch.randn(B * n * K, h, device=DEV)
