@@ -1,0 +1,355 @@
+// Deterministic backward of the neighbour gathers of the RandLA-Net path.
+//
+// The forward gathers rows through a neighbour graph: PointFeatureAugmentation reads
+// features[idx[b][i][k]] (reference randlanet/utils/modules.py:213-221) and the decoder's nearest-
+// neighbour interpolation reads features[nn[b][i]] (modules.py:359-364).  The reference's backward of
+// both is torch's scatter_add_ over the same index, whose order of summation is undefined; here the
+// graph is transposed once per step ("who gathered from me") and every destination row sums its
+// contributions in ascending source-row order - a fixed order, so training is bitwise reproducible.
+//
+//   rl_csr_build        : for up to 8 graphs of the same B clouds, destination (b, j) -> the list of local
+//                         source rows r = i*k + kk with idx[b][i][kk] == j, ascending.  Counting sort:
+//                         count (integer atomics: the COUNTS are order independent), per-cloud scan, fill
+//                         (arrival order), then every segment is sorted by rank - short ones (<= CAP entries)
+//                         in lane-private LDS, long ones (duplicate-heavy clouds) by a whole workgroup.
+//   rl_segment_sum_rows : dst[(b, j), :] (=|+=) sum over the segment of src[(b, r), col0 : col0 + C].
+#include "rl_common.h"
+
+namespace {
+
+constexpr int CSR_MAX_TASKS = 8;
+
+struct CsrTask {
+    const int32_t* idx;   // (B, n_src, k) destination index inside the cloud
+    int n_src, k, n_dst;
+    int32_t* offsets;     // (B, n_dst + 1) local to the cloud's entries
+    int32_t* entries;     // (B, n_src*k) local source rows, segment by segment, ascending
+    int32_t* tmp;         // (B, n_src*k) entries in arrival order
+    int32_t* cursor;      // (B, n_dst) counts, then fill cursors
+    int32_t* long_list;   // segments longer than cap: b*n_dst + j
+    int32_t* long_count;
+    int long_cap;
+    int cap;              // 32 / 64 / 128: longest segment the lane-private LDS sort takes
+};
+struct CsrMulti {
+    CsrTask t[CSR_MAX_TASKS];
+    int ntasks;
+    int B;
+};
+
+__global__ __launch_bounds__(256) void csr_zero_kernel(const CsrMulti m) {
+    const CsrTask& T = m.t[blockIdx.y];
+    const long total = (long)m.B * T.n_dst;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) T.cursor[e] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) T.long_count[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void csr_count_kernel(const CsrMulti m) {
+    const CsrTask& T = m.t[blockIdx.y];
+    const unsigned per = (unsigned)T.n_src * (unsigned)T.k;
+    const long total = (long)m.B * per;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const unsigned b = (unsigned)e / per;      // total < 2^31 (checked on the host)
+        const int j = T.idx[e];
+        if ((unsigned)j < (unsigned)T.n_dst) atomicAdd(&T.cursor[(long)b * T.n_dst + j], 1);
+    }
+}
+
+// exclusive scan of one cloud's counts -> offsets[0..n_dst], cursor := segment start; one workgroup per (task, cloud)
+__global__ __launch_bounds__(1024) void csr_scan_kernel(const CsrMulti m) {
+    __shared__ int part[1024];
+    const int task = blockIdx.x / m.B, b = blockIdx.x % m.B, t = threadIdx.x;
+    const CsrTask& T = m.t[task];
+    int* cu = T.cursor + (long)b * T.n_dst;
+    int* off = T.offsets + (long)b * (T.n_dst + 1);
+    const int chunk = (T.n_dst + 1023) / 1024;
+    const int lo = min(T.n_dst, t * chunk), hi = min(T.n_dst, lo + chunk);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += cu[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = lo; i < hi; ++i) {
+        const int c = cu[i];
+        off[i] = run;
+        cu[i] = run;
+        run += c;
+    }
+    if (t == 1023) off[T.n_dst] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(const CsrMulti m) {
+    const CsrTask& T = m.t[blockIdx.y];
+    const unsigned per = (unsigned)T.n_src * (unsigned)T.k;
+    const long total = (long)m.B * per;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const unsigned b = (unsigned)e / per;
+        const int j = T.idx[e];
+        if ((unsigned)j >= (unsigned)T.n_dst) continue;
+        const int pos = atomicAdd(&T.cursor[(long)b * T.n_dst + j], 1);
+        T.tmp[(long)b * per + pos] = (int)((unsigned)e - b * per);
+    }
+}
+
+// One lane per destination: its segment goes to a lane-private LDS row (stride CAP + 1 words: the 64 lanes of a
+// wavefront read distinct banks), every entry's rank = how many entries of the segment are smaller (they are distinct),
+// entry -> entries[start + rank].  All LDS reads are independent, nothing waits on a chain.
+template <int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void csr_sort_kernel(const CsrMulti m) {
+    __shared__ int seg[THREADS][CAP + 1];
+    const CsrTask& T = m.t[blockIdx.y];
+    if (T.cap != CAP) return;
+    const long total = (long)m.B * T.n_dst;
+    const unsigned per = (unsigned)T.n_src * (unsigned)T.k;
+    for (long d = (long)blockIdx.x * THREADS + threadIdx.x; d < total; d += (long)gridDim.x * THREADS) {
+        const unsigned b = (unsigned)d / (unsigned)T.n_dst;
+        const int j = (int)((unsigned)d - b * (unsigned)T.n_dst);
+        const int* off = T.offsets + (long)b * (T.n_dst + 1);
+        const int s0 = off[j], len = off[j + 1] - s0;
+        if (len <= 0) continue;
+        const int* src = T.tmp + (long)b * per + s0;
+        int* dst = T.entries + (long)b * per + s0;
+        if (len == 1) { dst[0] = src[0]; continue; }
+        if (len > CAP) {
+            const int slot = atomicAdd(T.long_count, 1);     // which slot a segment gets does not matter: each is sorted alone
+            if (slot < T.long_cap) T.long_list[slot] = (int)d;
+            continue;
+        }
+        int* mine = seg[threadIdx.x];
+        for (int a = 0; a < len; ++a) mine[a] = src[a];
+        for (int a = 0; a < len; ++a) {
+            const int v = mine[a];
+            int rank = 0;
+            for (int c = 0; c < len; ++c) rank += (mine[c] < v) ? 1 : 0;
+            dst[rank] = v;
+        }
+    }
+}
+
+// long segments (more than CAP gatherers of one point: duplicated coordinates): one workgroup each, rank by comparison
+// against LDS-staged chunks of the segment
+__global__ __launch_bounds__(256) void csr_sort_long_kernel(const CsrMulti m) {
+    __shared__ int chunk[1024];
+    const CsrTask& T = m.t[blockIdx.y];
+    const int nlong = min(T.long_count[0], T.long_cap);
+    const unsigned per = (unsigned)T.n_src * (unsigned)T.k;
+    for (int it = blockIdx.x; it < nlong; it += gridDim.x) {
+        const unsigned d = (unsigned)T.long_list[it];
+        const unsigned b = d / (unsigned)T.n_dst;
+        const int j = (int)(d - b * (unsigned)T.n_dst);
+        const int* off = T.offsets + (long)b * (T.n_dst + 1);
+        const int s0 = off[j], len = off[j + 1] - s0;
+        const int* src = T.tmp + (long)b * per + s0;
+        int* dst = T.entries + (long)b * per + s0;
+        for (int a0 = 0; a0 < len; a0 += 256) {
+            const int a = a0 + threadIdx.x;
+            const int v = a < len ? src[a] : 0;
+            int rank = 0;
+            for (int c0 = 0; c0 < len; c0 += 1024) {
+                __syncthreads();
+                for (int c = threadIdx.x; c < 1024; c += 256) chunk[c] = c0 + c < len ? src[c0 + c] : 0x7fffffff;
+                __syncthreads();
+                const int cn = min(1024, len - c0);
+                for (int c = 0; c < cn; ++c) rank += (chunk[c] < v) ? 1 : 0;
+            }
+            if (a < len) dst[rank] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ segment sum
+struct SegParams {
+    const float* src;
+    long lds, src_bstride;   // source row (b, r) at src + (b*src_bstride + r)*lds
+    float* dst;
+    long ldd, dst_bstride;
+    const int32_t* offsets;
+    const int32_t* entries;
+    int n_dst, C;
+    long per;                // entries per cloud
+    long total;              // B * n_dst
+    int accumulate;
+};
+
+// tpr = C/4 lanes (a power of two <= 64... or 128/256 for wider rows) share one destination row, 16 bytes each
+template <int TPR>
+__global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p) {
+    constexpr int RPW = 256 / TPR;      // destination rows in flight per workgroup
+    const int q = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
+    for (long d = (long)blockIdx.x * RPW + rsub; d < p.total; d += (long)gridDim.x * RPW) {
+        const unsigned b = (unsigned)d / (unsigned)p.n_dst;
+        const int j = (int)((unsigned)d - b * (unsigned)p.n_dst);
+        const int* off = p.offsets + (long)b * (p.n_dst + 1);
+        const int s0 = off[j], s1 = off[j + 1];
+        const int* ent = p.entries + (long)b * p.per;
+        const float* sb = p.src + (long)b * p.src_bstride * p.lds;
+        for (int c = q * 4; c < p.C; c += TPR * 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int e = s0;
+            for (; e + 4 <= s1; e += 4) {      // four rows requested before the first is added (order of the adds is fixed)
+                const int r0 = ent[e], r1 = ent[e + 1], r2 = ent[e + 2], r3 = ent[e + 3];
+                const float4 v0 = *reinterpret_cast<const float4*>(sb + (long)r0 * p.lds + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(sb + (long)r1 * p.lds + c);
+                const float4 v2 = *reinterpret_cast<const float4*>(sb + (long)r2 * p.lds + c);
+                const float4 v3 = *reinterpret_cast<const float4*>(sb + (long)r3 * p.lds + c);
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            }
+            for (; e < s1; ++e) {
+                const float4 v = *reinterpret_cast<const float4*>(sb + (long)ent[e] * p.lds + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float4* o = reinterpret_cast<float4*>(p.dst + ((long)b * p.dst_bstride + j) * p.ldd + c);
+            if (p.accumulate) {
+                const float4 old = *o;
+                acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+            }
+            *o = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void segment_sum_kernel(const SegParams p) {
+    const long elems = p.total * p.C;
+    for (long x = (long)blockIdx.x * 256 + threadIdx.x; x < elems; x += (long)gridDim.x * 256) {
+        const long d = x / p.C;
+        const int c = (int)(x - d * p.C);
+        const long b = d / p.n_dst;
+        const int j = (int)(d - b * p.n_dst);
+        const int* off = p.offsets + b * (p.n_dst + 1);
+        const int* ent = p.entries + b * p.per;
+        const float* sb = p.src + b * p.src_bstride * p.lds;
+        float acc = 0.f;
+        for (int e = off[j]; e < off[j + 1]; ++e) acc += sb[(long)ent[e] * p.lds + c];
+        float* o = p.dst + (b * p.dst_bstride + j) * p.ldd + c;
+        *o = p.accumulate ? *o + acc : acc;
+    }
+}
+
+struct Plan {
+    size_t tmp, cursor, long_list, long_count, bytes;
+    int long_cap, cap;
+};
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+Plan make_plan(int B, const rl_csr_task& t) {
+    Plan p;
+    const size_t ent = (size_t)B * t.n_src * t.k;
+    // lane-private sort capacity: at least twice the mean in-degree
+    const double mean = (double)t.n_src * t.k / (double)(t.n_dst > 0 ? t.n_dst : 1);
+    p.cap = mean * 2 <= 32 ? 32 : (mean * 2 <= 64 ? 64 : 128);
+    p.long_cap = (int)(ent / (size_t)p.cap) + 1;
+    size_t o = 0;
+    p.tmp = o;        o += up256(ent * 4);
+    p.cursor = o;     o += up256((size_t)B * t.n_dst * 4);
+    p.long_list = o;  o += up256((size_t)p.long_cap * 4);
+    p.long_count = o; o += 256;
+    p.bytes = o;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int64_t rl_csr_workspace_bytes(const rl_csr_task* tasks, int ntasks, int B) {
+    if (!tasks || ntasks <= 0 || B <= 0) return 0;
+    int64_t total = 0;
+    for (int i = 0; i < ntasks; ++i) total += (int64_t)make_plan(B, tasks[i]).bytes;
+    return total;
+}
+
+extern "C" int rl_csr_build(const rl_csr_task* tasks, int ntasks, int B, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+    RL_REQUIRE(tasks && ntasks > 0 && ntasks <= CSR_MAX_TASKS && B > 0 && (long)B * ntasks <= 65535, RL_ERR_ARGS,
+               "rl_csr_build: 1..%d tasks expected", CSR_MAX_TASKS);
+    RL_REQUIRE(workspace && ((uintptr_t)workspace & 255) == 0, RL_ERR_ARGS, "rl_csr_build: workspace must be 256-byte aligned");
+    CsrMulti m;
+    m.ntasks = ntasks;
+    m.B = B;
+    char* ws = (char*)workspace;
+    int64_t used = 0;
+    long max_ent = 1, max_dst = 1;
+    bool need[3] = {false, false, false};
+    for (int i = 0; i < ntasks; ++i) {
+        const rl_csr_task& t = tasks[i];
+        RL_REQUIRE(t.idx && t.offsets && t.entries && t.n_src > 0 && t.k > 0 && t.n_dst > 0, RL_ERR_ARGS,
+                   "rl_csr_build: bad task %d", i);
+        RL_REQUIRE((int64_t)B * t.n_src * t.k < (1l << 31) && (int64_t)B * t.n_dst < (1l << 31), RL_ERR_ARGS,
+                   "rl_csr_build: task %d is too large", i);
+        const Plan p = make_plan(B, t);
+        RL_REQUIRE(used + (int64_t)p.bytes <= workspace_bytes, RL_ERR_ARGS, "rl_csr_build: workspace too small");
+        CsrTask& T = m.t[i];
+        T.idx = t.idx; T.n_src = t.n_src; T.k = t.k; T.n_dst = t.n_dst; T.offsets = t.offsets; T.entries = t.entries;
+        T.tmp = (int32_t*)(ws + used + p.tmp);
+        T.cursor = (int32_t*)(ws + used + p.cursor);
+        T.long_list = (int32_t*)(ws + used + p.long_list);
+        T.long_count = (int32_t*)(ws + used + p.long_count);
+        T.long_cap = p.long_cap; T.cap = p.cap;
+        need[p.cap == 32 ? 0 : p.cap == 64 ? 1 : 2] = true;
+        used += (int64_t)p.bytes;
+        max_ent = max_ent > (long)B * t.n_src * t.k ? max_ent : (long)B * t.n_src * t.k;
+        max_dst = max_dst > (long)B * t.n_dst ? max_dst : (long)B * t.n_dst;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    auto gridx = [](long work, int per) { long g = (work + per - 1) / per; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); };
+    hipLaunchKernelGGL(csr_zero_kernel, dim3(gridx(max_dst, 256), ntasks), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(csr_count_kernel, dim3(gridx(max_ent, 256), ntasks), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(ntasks * B), dim3(1024), 0, st, m);
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(gridx(max_ent, 256), ntasks), dim3(256), 0, st, m);
+    if (need[0]) hipLaunchKernelGGL((csr_sort_kernel<32, 256>), dim3(gridx(max_dst, 256), ntasks), dim3(256), 0, st, m);
+    if (need[1]) hipLaunchKernelGGL((csr_sort_kernel<64, 128>), dim3(gridx(max_dst, 128), ntasks), dim3(128), 0, st, m);
+    if (need[2]) hipLaunchKernelGGL((csr_sort_kernel<128, 64>), dim3(gridx(max_dst, 64), ntasks), dim3(64), 0, st, m);
+    hipLaunchKernelGGL(csr_sort_long_kernel, dim3(128, ntasks), dim3(256), 0, st, m);
+    rl_note_kernel("csr_sort_kernel");
+    RL_LAUNCH_CHECK("rl_csr_build");
+    return RL_OK;
+}
+
+extern "C" int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream) {
+    RL_REQUIRE(d && d->src && d->dst && d->offsets && d->entries && d->B > 0 && d->n_dst > 0 && d->C > 0 && d->entries_per_cloud >= 0,
+               RL_ERR_ARGS, "rl_segment_sum_rows: bad descriptor");
+    RL_REQUIRE(d->lds >= d->C && d->ldd >= d->C && d->dst_bstride >= d->n_dst && d->src_bstride > 0, RL_ERR_ARGS,
+               "rl_segment_sum_rows: bad strides");
+    RL_REQUIRE((int64_t)d->B * d->n_dst < (1l << 31), RL_ERR_ARGS, "rl_segment_sum_rows: too many rows");
+    SegParams p;
+    p.src = d->src; p.lds = d->lds; p.src_bstride = d->src_bstride; p.dst = d->dst; p.ldd = d->ldd;
+    p.dst_bstride = d->dst_bstride; p.offsets = d->offsets; p.entries = d->entries; p.n_dst = d->n_dst; p.C = d->C;
+    p.per = d->entries_per_cloud; p.total = (long)d->B * d->n_dst; p.accumulate = d->accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (d->C % 4 == 0) && (d->lds % 4 == 0) && (d->ldd % 4 == 0) && (((uintptr_t)d->src | (uintptr_t)d->dst) & 15) == 0;
+    if (vec) {
+        const int c4 = d->C / 4;
+        int tpr = 1;
+        while (tpr < c4 && tpr < 256) tpr <<= 1;      // power of two >= C/4 (lanes beyond the row idle), at most 256
+        const long rpw = 256 / tpr;
+        long g = (p.total + rpw - 1) / rpw;
+        if (g > 8192) g = 8192;
+        if (g < 1) g = 1;
+        switch (tpr) {
+            case 1:   hipLaunchKernelGGL(segment_sum_vec_kernel<1>, dim3(g), dim3(256), 0, st, p); break;
+            case 2:   hipLaunchKernelGGL(segment_sum_vec_kernel<2>, dim3(g), dim3(256), 0, st, p); break;
+            case 4:   hipLaunchKernelGGL(segment_sum_vec_kernel<4>, dim3(g), dim3(256), 0, st, p); break;
+            case 8:   hipLaunchKernelGGL(segment_sum_vec_kernel<8>, dim3(g), dim3(256), 0, st, p); break;
+            case 16:  hipLaunchKernelGGL(segment_sum_vec_kernel<16>, dim3(g), dim3(256), 0, st, p); break;
+            case 32:  hipLaunchKernelGGL(segment_sum_vec_kernel<32>, dim3(g), dim3(256), 0, st, p); break;
+            case 64:  hipLaunchKernelGGL(segment_sum_vec_kernel<64>, dim3(g), dim3(256), 0, st, p); break;
+            case 128: hipLaunchKernelGGL(segment_sum_vec_kernel<128>, dim3(g), dim3(256), 0, st, p); break;
+            default:  hipLaunchKernelGGL(segment_sum_vec_kernel<256>, dim3(g), dim3(256), 0, st, p); break;
+        }
+        rl_note_kernel("segment_sum_vec_kernel");
+    } else {
+        long g = (p.total * p.C + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(segment_sum_kernel, dim3(g < 1 ? 1 : g), dim3(256), 0, st, p);
+        rl_note_kernel("segment_sum_kernel");
+    }
+    RL_LAUNCH_CHECK("rl_segment_sum_rows");
+    return RL_OK;
+}

@@ -1100,8 +1100,12 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                     }
                     long o2 = 0;
                     if (p.out2) {
-                        const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
-                        o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
+                        if (p.out2_index) {
+                            const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                            o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
+                        } else {
+                            o2 = R * (N - p.split_col) - p.split_col;      // dense: one row per source row
+                        }
                     }
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) {
@@ -1111,7 +1115,8 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                             if (p.bias) v += p.bias[c];
                             if (p.addend) v += p.addend[R * N + c];
                             if (p.out2 && c >= p.split_col) {
-                                atomicAdd(p.out2 + o2 + c, v);
+                                if (p.out2_index) atomicAdd(p.out2 + o2 + c, v);
+                                else p.out2[o2 + c] = v;
                             } else {
                                 if (p.accumulate) v += p.Y[yoff + c];
                                 p.Y[yoff + c] = v;
@@ -1645,7 +1650,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     p.split_col = d->out2 ? d->split_col : d->N;
     const bool split = d->addend != nullptr || d->out2 != nullptr;
     if (split) {
-        RL_REQUIRE(!d->out2 || (d->out2_index && d->split_col > 0 && d->split_col < d->N && d->out2_bstride > 0), RL_ERR_ARGS,
+        RL_REQUIRE(!d->out2 || (d->split_col > 0 && d->split_col < d->N && (!d->out2_index || d->out2_bstride > 0)), RL_ERR_ARGS,
                    "rl_gemm: bad split-scatter fields");
         RL_REQUIRE(d->ldy >= (d->out2 ? d->split_col : d->N), RL_ERR_ARGS, "rl_gemm: ldy smaller than the columns stored to Y");
         RL_REQUIRE(d->stats == nullptr, RL_ERR_UNSUPPORTED, "rl_gemm: split-scatter epilogue has no statistics");

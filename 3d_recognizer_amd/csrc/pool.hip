@@ -14,9 +14,10 @@
 // whole kernel (stride d+4 as well), read as MFMA B fragments.
 //
 // Backward, per point:  recompute X, S, A = softmax_K(S), P;  dS = A*dP*(X - P);
-//   dX = dP*A + dS.W  ->  first half to the rpe-branch gradient (plain stores), second half
-//   scatter-added to the gathered features' gradient (fp32 atomics);  dW += dS^T.X accumulates in
-//   registers over all points of the wavefront and leaves the workgroup as one partial slab.
+//   dX = dP*A + dS.W  ->  first half to the rpe-branch gradient, second half to DG, the gradient of every
+//   gathered row (both plain stores; rl_segment_sum_rows adds DG up per gathered point in a fixed order - no
+//   atomics, bitwise reproducible);  dW += dS^T.X accumulates in registers over all points of the
+//   wavefront and leaves the workgroup as one partial slab.
 #include "rl_common.h"
 
 namespace {
@@ -60,7 +61,7 @@ struct PoolParams {
     // backward outputs
     float* GU;             // (P*16) x h
     int gu_accumulate;
-    float* GG;             // same addressing as G (zeroed by the caller)
+    float* DG;             // (P*16) x h: gradient of the gathered row of every neighbourhood slot
     float* slab;           // per-workgroup partial dW: [grid][d*d]
     float* X_out;          // d = 128 backward: X and dS leave the kernel ((P*16) x d each); dW = dS^T.X is the caller's
     float* dS_out;         //   weight-gradient GEMM (64 accumulator tiles do not fit one wavefront)
@@ -340,8 +341,6 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     float4 raw[DT];
     if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
     for (; pt < p.P; pt += pstep) {
-        const int my_idx = idx_cur;
-        const long b = (unsigned)pt / (unsigned)p.n;   // points * 16 < 2^31 (checked on the host)
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
@@ -425,13 +424,11 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
                 for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dl, xh[kb], accw[nb][kb]);
             }
         }
-        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> scatter to the gathered rows
+        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rowi = lj * 4 + r;
-            const int nbr = __shfl(my_idx, rowi, 64);
             const long urow = (pt * 16 + rowi) * H;
-            const long grow = (b * p.g_bstride + nbr) * H;
 #pragma unroll
             for (int nb = 0; nb < DT; ++nb) {
                 const int col = nb * 16 + li;
@@ -440,7 +437,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
                     if (p.gu_accumulate) p.GU[urow + col] += v;
                     else p.GU[urow + col] = v;
                 } else {
-                    atomicAdd(p.GG + grow + (col - H), v);
+                    p.DG[urow + (col - H)] = v;
                 }
             }
         }
@@ -522,8 +519,6 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     float4 raw[DT];
     if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
     for (; pt < p.P; pt += pstep) {
-        const int my_idx = idx_cur;
-        const long b = (unsigned)pt / (unsigned)p.n;
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
@@ -597,13 +592,11 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                 }
             }
         }
-        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> scatter to the gathered rows
+        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rowi = lj * 4 + r;
-            const int nbr = __shfl(my_idx, rowi, 64);
             const long urow = (pt * 16 + rowi) * H;
-            const long grow = (b * p.g_bstride + nbr) * H;
 #pragma unroll
             for (int nb = 0; nb < DT; ++nb) {
                 const int col = nb * 16 + li;
@@ -612,7 +605,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                     if (p.gu_accumulate) p.GU[urow + col] += v;
                     else p.GU[urow + col] = v;
                 } else {
-                    atomicAdd(p.GG + grow + (col - H), v);
+                    p.DG[urow + (col - H)] = v;
                 }
             }
         }
@@ -668,10 +661,10 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->G = d->G; p->g_bstride = d->g_bstride;
     p->glazy.scale = d->g_scale; p->glazy.shift = d->g_shift; p->glazy.act = d->g_act; p->glazy.slope = d->g_slope;
     p->idx = d->idx; p->W = d->W; p->P = d->points; p->n = d->n; p->d = d->d;
-    p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->GG = d->GG; p->slab = d->slab;
+    p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->DG = d->DG; p->slab = d->slab;
     p->X_out = nullptr; p->dS_out = nullptr;
     if (!backward) RL_REQUIRE(d->Pout, RL_ERR_ARGS, "%s: null output", who);
-    else RL_REQUIRE(d->dP && d->GU && d->GG, RL_ERR_ARGS, "%s: null gradient buffers", who);
+    else RL_REQUIRE(d->dP && d->GU && d->DG, RL_ERR_ARGS, "%s: null gradient buffers", who);
     return RL_OK;
 }
 

@@ -191,6 +191,51 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(float* __restrict__ x, 
         x[e] = mask[e] ? x[e] * scale : 0.f;
 }
 
+// ---- Dropout(0.5) of fc_end (modules.py:528) with a counter-based generator -----------------------------------
+// Philox4x32-10 (Salmon et al., the generator behind torch's CUDA dropout): the keep decision of element e is a pure
+// function of (seed, key, e), so the backward regenerates the mask instead of storing it and a captured graph draws
+// fresh masks on every replay (the key lives in device memory and is bumped by rl_dropout_tick).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * ctr.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * ctr.z;
+        ctr = make_uint4((unsigned)(p1 >> 32) ^ ctr.y ^ key.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ ctr.w ^ key.y, (unsigned)p0);
+        key.x += 0x9E3779B9u;
+        key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+__global__ void dropout_tick_kernel(int64_t* counter, int64_t* key_out) {
+    const int64_t v = counter[0] + 1;
+    counter[0] = v;
+    key_out[0] = v;
+}
+
+// one thread per 4 consecutive elements; FWD: dst = keep ? lazy(src)*scale : 0;  !FWD: G = keep ? G*scale : 0 (in place)
+template <bool FWD>
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ src, RlLazy lazy, int C, float* __restrict__ dst,
+                                                      long quads, const int64_t* __restrict__ key, unsigned long long seed,
+                                                      unsigned threshold, float scale) {
+    const unsigned long long k = (unsigned long long)key[0];
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+        const uint4 r = philox4x32_10(make_uint4((unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)k, (unsigned)(k >> 32)),
+                                      make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+        float4 v = *reinterpret_cast<const float4*>(src + q * 4);
+        if (FWD && lazy.scale) {
+            const int c = (int)(((unsigned)q * 4u) % (unsigned)C);      // elements < 2^32 (host check); C % 4 == 0: a quad stays inside one row
+            v.x = rl_lazy(lazy, v.x, c + 0); v.y = rl_lazy(lazy, v.y, c + 1);
+            v.z = rl_lazy(lazy, v.z, c + 2); v.w = rl_lazy(lazy, v.w, c + 3);
+        }
+        v.x = r.x >= threshold ? v.x * scale : 0.f;
+        v.y = r.y >= threshold ? v.y * scale : 0.f;
+        v.z = r.z >= threshold ? v.z * scale : 0.f;
+        v.w = r.w >= threshold ? v.w * scale : 0.f;
+        *reinterpret_cast<float4*>(dst + q * 4) = v;
+    }
+}
+
 // UpSampler (modules.py:343-414) on channel-first features: out[b][f][q] = sum_j w_j feat[b][f][idx[b][q][j]],
 // w_j = (1+eps)/(dist_j^power + eps) normalised over j (power 0 -> plain nearest-neighbour copy of j = 0)
 __global__ __launch_bounds__(256) void upsample_cf_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx,
@@ -356,6 +401,54 @@ extern "C" int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t
     if (count == 0) return RL_OK;
     hipLaunchKernelGGL(scale_mask_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, x, mask, scale, (long)count);
     RL_LAUNCH_CHECK("rl_scale_mask");
+    return RL_OK;
+}
+
+extern "C" int rl_dropout_tick(int64_t* counter, int64_t* key_out, void* stream) {
+    RL_REQUIRE(counter && key_out, RL_ERR_ARGS, "rl_dropout_tick: bad arguments");
+    hipLaunchKernelGGL(dropout_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, key_out);
+    RL_LAUNCH_CHECK("rl_dropout_tick");
+    return RL_OK;
+}
+
+static int dropout_args(const float* src, float* dst, int64_t rows, int C, const int64_t* key, float p, const char* who,
+                        unsigned* threshold) {
+    RL_REQUIRE(src && dst && key && rows >= 0 && C > 0 && C % 4 == 0, RL_ERR_ARGS, "%s: bad arguments (C must be a multiple of 4)", who);
+    RL_REQUIRE(p >= 0.f && p < 1.f, RL_ERR_ARGS, "%s: p must be in [0, 1)", who);
+    RL_REQUIRE(rows * C < (1l << 32), RL_ERR_ARGS, "%s: too many elements", who);
+    RL_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, RL_ERR_ARGS, "%s: tensors must be 16-byte aligned", who);
+    const double t = (double)p * 4294967296.0;
+    *threshold = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    return RL_OK;
+}
+
+extern "C" int rl_dropout_fwd(const float* src, const float* scale, const float* shift, int act, float slope, float* dst,
+                              int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream) {
+    unsigned thr;
+    int rc = dropout_args(src, dst, rows, C, key, p, "rl_dropout_fwd", &thr);
+    if (rc) return rc;
+    RL_REQUIRE((scale == nullptr) == (shift == nullptr), RL_ERR_ARGS, "rl_dropout_fwd: scale/shift must come together");
+    if (rows == 0) return RL_OK;
+    RlLazy lz; lz.scale = scale; lz.shift = shift; lz.act = act; lz.slope = slope;
+    const long quads = (long)rows * C / 4;
+    hipLaunchKernelGGL(dropout_kernel<true>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, src, lz, C, dst, quads, key,
+                       (unsigned long long)seed, thr, 1.0f / (1.0f - p));
+    rl_note_kernel("dropout_kernel");
+    RL_LAUNCH_CHECK("rl_dropout_fwd");
+    return RL_OK;
+}
+
+extern "C" int rl_dropout_bwd(float* G, int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream) {
+    unsigned thr;
+    int rc = dropout_args(G, G, rows, C, key, p, "rl_dropout_bwd", &thr);
+    if (rc) return rc;
+    if (rows == 0) return RL_OK;
+    RlLazy lz; lz.scale = nullptr; lz.shift = nullptr; lz.act = 0; lz.slope = 0.f;
+    const long quads = (long)rows * C / 4;
+    hipLaunchKernelGGL(dropout_kernel<false>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, G, lz, C, G, quads, key,
+                       (unsigned long long)seed, thr, 1.0f / (1.0f - p));
+    rl_note_kernel("dropout_kernel");
+    RL_LAUNCH_CHECK("rl_dropout_bwd");
     return RL_OK;
 }
 

@@ -55,6 +55,10 @@ class Engine:
         self.P = params      # reference state_dict names -> tensors (parameters)
         self.Bf = buffers    # running_mean / running_var / num_batches_tracked
         self._side: Optional[torch.cuda.Stream] = None   # weight gradients run beside the dgrad chain
+        # Dropout(fc_end): Philox mask keyed by (seed, pass counter); the counter lives on the device so that captured
+        # graphs draw a new mask per replay.  The seed comes from torch's seed WITHOUT consuming its random stream.
+        self._drop_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        self._drop_counter: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------------ forward pieces
     def _w2(self, name: str) -> torch.Tensor:
@@ -93,7 +97,7 @@ class Engine:
         return self._linear(ctx, a, f"{name}.conv.weight", f"{name}.conv.bias", n_out, transposed=transposed,
                             bn=f"{name}.batch_norm" if bn else None, act=act, slope=slope, a_grad=a_grad)
 
-    def _pool(self, ctx, name: str, u: Lazy, g: Lazy, idx: torch.Tensor, n: int, d: int, n_out: int) -> Lazy:
+    def _pool(self, ctx, name: str, u: Lazy, g: Lazy, idx: torch.Tensor, csr, n: int, d: int, n_out: int) -> Lazy:
         """PointFeatureAugmentation + AttentivePooling (modules.py:213-221, 246-253)."""
         B, K, h = u.B, self.K, d // 2
         rows = B * n * K
@@ -101,7 +105,7 @@ class Engine:
         if ops.pool_supported(d, K):
             # narrow levels: one fused kernel, nothing of size rows x d touches HBM
             pooled = ops.plain(ops.pool_fwd(u, g, idx, Ws, n, d), B, n)
-            ctx.tape.append(("pool_fused", name, u, g, idx, pooled, n, d))
+            ctx.tape.append(("pool_fused", name, u, g, csr, idx, pooled, n, d))
             return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
         X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
         ops.copy_rows(u.raw, (0, h), n * K, X, (0, h), rows, n * K, lazy=u)
@@ -109,10 +113,10 @@ class Engine:
         S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None)
         Pt = ops.attpool_fwd(X, S, B * n, K)
         pooled = ops.plain(Pt, B, n)
-        ctx.tape.append(("pool", name, u, g, idx, X, S, pooled, n, d))
+        ctx.tape.append(("pool", name, u, g, csr, X, S, pooled, n, d))
         return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
 
-    def _lfa(self, ctx, l: int, xin: Lazy, xyz: torch.Tensor, n: int, d: int, idx, d2) -> Lazy:
+    def _lfa(self, ctx, l: int, xin: Lazy, xyz: torch.Tensor, n: int, d: int, idx, d2, csr=None) -> Lazy:
         """LocalFeatureAggregation (modules.py:298-325); idx / d2 = its K nearest neighbours."""
         e = f"encoder.{l}"
         B, K, h = xin.B, self.K, d // 2
@@ -124,9 +128,9 @@ class Engine:
             # read twice (forward + weight gradient): cheaper as a 48-byte row than re-gathered in both kernels
             rpe = ops.rpe_build(rpe)
         u1 = self._mlp(ctx, rpe, f"{e}.mlp_rpe1", h, H.ACT_RELU, a_grad=False)
-        q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, n, d, h)
+        q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, csr, n, d, h)
         u2 = self._mlp(ctx, u1, f"{e}.mlp_rpe2", h, H.ACT_RELU)
-        q2 = self._pool(ctx, f"{e}.pool2", u2, q1, idx, n, d, d)
+        q2 = self._pool(ctx, f"{e}.pool2", u2, q1, idx, csr, n, d, d)
         m2 = self._mlp(ctx, q2, f"{e}.mlp2", 2 * d)
         O = ops.plain(ops.add_act_fwd(m2, sc, 0.01), B, n)
         ctx.tape.append(("add_act", m2, sc, O))
@@ -138,8 +142,9 @@ class Engine:
         return max(self.K * self.dec ** (L - 1), 2 * self.dec ** L)       # modules.py:488-491
 
     def forward(self, inp: torch.Tensor, perm: torch.Tensor, training: bool, dropout_p: float = 0.5,
-                keep_mask: Optional[torch.Tensor] = None):
-        """inp (B,N,3+F) fp32 on the device, perm (N,) int64 on the device -> logits (B,C,N), ctx."""
+                keep_mask: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None):
+        """inp (B,N,3+F) fp32 on the device, perm (N,) int64 on the device -> logits (B,C,N), ctx.
+        keep_mask (B*N, 32) uint8: an explicit Dropout mask (parity tests); by default the mask is generated in the kernel."""
         B, N, cin = inp.shape
         assert cin == 3 + self.F and inp.dtype == torch.float32 and inp.is_cuda and inp.is_contiguous()
         assert perm.dtype == torch.int64 and perm.numel() == N and perm.is_cuda
@@ -169,6 +174,11 @@ class Engine:
             tasks.append((N // ratio, dec * N // ratio, 1))
             ratio //= dec
         searches = ops.knn_multi(xyz, tasks)
+        # training: the transpose of every neighbour graph ("who gathered from me"), so that the gathers' backward sums
+        # each destination row in a fixed order (bitwise reproducible steps; torch's scatter_add_ has no defined order)
+        csrs = [None] * (2 * L)
+        if training:
+            csrs = ops.csr_build([(searches[i][0], tasks[i][0]) for i in range(2 * L)])
 
         # fc_start + bn_start (modules.py:565-566)
         x = self._linear(ctx, ops.plain(inp_p, B, N), "fc_start.weight", "fc_start.bias", 8, bn="bn_start.0",
@@ -178,7 +188,7 @@ class Engine:
         ratio = 1
         for l, d in enumerate(self.layers):
             n_l = N // ratio
-            x = self._lfa(ctx, l, x.prefix(n_l), xyz, n_l, d, *searches[l])
+            x = self._lfa(ctx, l, x.prefix(n_l), xyz, n_l, d, *searches[l], csr=csrs[l])
             skips.append(x)
             ratio *= dec
         x = self._mlp(ctx, x.prefix(N // ratio), "mlp", x.C, H.ACT_RELU)        # modules.py:591
@@ -193,7 +203,7 @@ class Engine:
             ops.copy_rows(x.raw, (0, x.C), x.bstride, cat, (0, x.C), B * n_f, n_f, index=nn, lazy=x)
             ops.copy_rows(skip.raw, (0, skip.C), skip.bstride, cat, (x.C, skip.C), B * n_f, n_f)
             catl = ops.plain(cat, B, n_f)
-            ctx.tape.append(("interp_concat", x, skip, nn, catl))
+            ctx.tape.append(("interp_concat", x, skip, csrs[L + j], catl))
             n_out = 8 if j == L - 1 else 2 * self.layers[L - 2 - j]
             x = self._mlp(ctx, catl, f"decoder.{j}", n_out, H.ACT_RELU, transposed=True)
             ratio //= dec
@@ -202,16 +212,21 @@ class Engine:
         x = self._mlp(ctx, x, "fc_end.1", 32, H.ACT_RELU)
         if training and dropout_p > 0.0:
             if keep_mask is None:
-                keep_mask = (torch.rand((B * N, 32), device=dev) >= dropout_p).to(torch.uint8)
-            t = torch.empty((B * N, 32), dtype=torch.float32, device=dev)
-            ops.copy_rows(x.raw, (0, 32), N, t, (0, 32), B * N, N, lazy=x)
-            ops.scale_mask(t, keep_mask, 1.0 / (1.0 - dropout_p))
-            dropped = ops.plain(t, B, N)
-            ctx.tape.append(("dropout", x, dropped, keep_mask, 1.0 / (1.0 - dropout_p)))
+                if self._drop_counter is None or self._drop_counter.device != dev:
+                    self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+                key = ops.dropout_tick(self._drop_counter)
+                dropped = ops.plain(ops.dropout_fwd(x, key, self._drop_seed, dropout_p), B, N)
+                ctx.tape.append(("dropout_philox", x, dropped, key, dropout_p))
+            else:
+                t = torch.empty((B * N, 32), dtype=torch.float32, device=dev)
+                ops.copy_rows(x.raw, (0, 32), N, t, (0, 32), B * N, N, lazy=x)
+                ops.scale_mask(t, keep_mask, 1.0 / (1.0 - dropout_p))
+                dropped = ops.plain(t, B, N)
+                ctx.tape.append(("dropout", x, dropped, keep_mask, 1.0 / (1.0 - dropout_p)))
             x = dropped
         lp = self._mlp(ctx, x, "fc_end.3", self.C, bn=False)
         ctx.logits_perm = lp
-        logits = ops.logits_unpermute(lp.raw, perm, B, N)
+        logits = ops.logits_unpermute(lp.raw, perm, B, N, out=logits_out)
         return logits, ctx
 
     # ----------------------------------------------------------------------------- backward
@@ -248,16 +263,16 @@ class Engine:
             elif kind == "pool":
                 self._bwd_pool(ctx, grads, *rec[1:])
             elif kind == "pool_fused":
-                _, name, u, g, idx, pooled, n, d = rec
+                _, name, u, g, csr, idx, pooled, n, d = rec
                 GP, init = self._gbuf(ctx, pooled)
                 assert init
                 gu, gg = self._gbuf(ctx, u), self._gbuf(ctx, g)
-                if not gg[1]:
-                    gg[0].zero_()
-                    gg[1] = True
-                ops.pool_bwd(u, g, idx, self.P[f"{name}.score_fn.0.weight"], n, d, GP, gu[0], gu[1], gg[0],
-                             grads[f"{name}.score_fn.0.weight"], pending=ctx.pending)
+                DG = ops.pool_bwd(u, g, idx, self.P[f"{name}.score_fn.0.weight"], n, d, GP, gu[0], gu[1],
+                                  grads[f"{name}.score_fn.0.weight"], pending=ctx.pending)
                 gu[1] = True
+                # gradient of the gather: every gathered point sums its slots in a fixed order
+                ops.segment_sum_rows(DG, (0, d // 2), n * self.K, csr, gg[0], g.bstride, accumulate=gg[1])
+                gg[1] = True
             elif kind == "add_act":
                 _, m2, sc, O = rec
                 G, init = self._gbuf(ctx, O)
@@ -274,17 +289,21 @@ class Engine:
                 ctx.grads[id(m2.raw)] = [G, True]
                 ctx.grads[id(sc.raw)] = [g2, True]
             elif kind == "interp_concat":
-                _, prev, skip, nn, catl = rec
+                _, prev, skip, csr, catl = rec
                 G, init = self._gbuf(ctx, catl)
                 assert init
                 gp = self._gbuf(ctx, prev)
-                if not gp[1]:
-                    gp[0].zero_()
-                    gp[1] = True
-                ops.scatter_add_rows(G, (0, prev.C), gp[0], prev.bstride, catl.rows, catl.n, nn)
+                ops.segment_sum_rows(G, (0, prev.C), catl.n, csr, gp[0], prev.bstride, accumulate=gp[1])
+                gp[1] = True
                 gs = self._gbuf(ctx, skip)
                 ops.copy_rows(G, (prev.C, skip.C), catl.n, gs[0], (0, skip.C), catl.rows, catl.n, accumulate=gs[1])
                 gs[1] = True
+            elif kind == "dropout_philox":
+                _, src, dropped, key, p_drop = rec
+                G, init = self._gbuf(ctx, dropped)
+                assert init
+                ops.dropout_bwd(G, key, self._drop_seed, p_drop)
+                ctx.grads[id(src.raw)] = [G, True]
             elif kind == "dropout":
                 _, src, dropped, mask, scale = rec
                 G, init = self._gbuf(ctx, dropped)
@@ -330,7 +349,7 @@ class Engine:
             ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=ga[0], out_bstride=a.bstride, accumulate=ga[1])
             ga[1] = True
 
-    def _bwd_pool(self, ctx, grads, name, u: Lazy, g: Lazy, idx, X, S, pooled: Lazy, n, d):
+    def _bwd_pool(self, ctx, grads, name, u: Lazy, g: Lazy, csr, X, S, pooled: Lazy, n, d):
         B, K, h = u.B, self.K, d // 2
         rows = B * n * K
         GP, init = self._gbuf(ctx, pooled)
@@ -341,16 +360,15 @@ class Engine:
                                             grads[f"{name}.score_fn.0.weight"], 1, d, None, pending=ctx.pending), X, dS)
         gu = self._gbuf(ctx, u)
         gg = self._gbuf(ctx, g)
-        if not gg[1]:
-            gg[0].zero_()
-            gg[1] = True
         if ops.NO_SPLIT_SCATTER or d <= 64:      # the epilogue lives in the wide (LDS-tiled) kernel only
             ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
             ops.copy_rows(dX, (0, h), n * K, gu[0], (0, h), rows, n * K, accumulate=gu[1])
-            ops.scatter_add_rows(dX, (h, h), gg[0], g.bstride, rows, n * K, idx)
+            ops.segment_sum_rows(dX, (h, h), n * K, csr, gg[0], g.bstride, accumulate=gg[1])
         else:
-            # dX = dP*A + dS.W leaves the GEMM epilogue straight for its two destinations: the rpe-branch half is stored
-            # (or accumulated), the gathered half is scatter-added to the rows it came from
+            # dX = dP*A + dS.W leaves the GEMM epilogue in two pieces: the rpe-branch half is stored (or accumulated)
+            # where it belongs, the gathered half goes to a dense tensor that is then summed per gathered point
+            DG = torch.empty((rows, h), dtype=torch.float32, device=dX.device)
             ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=gu[0], out_bstride=n * K, accumulate=gu[1],
-                     addend=dX, out2=gg[0], out2_index=idx.view(-1), out2_bstride=g.bstride, split_col=h)
-        gu[1] = True
+                     addend=dX, out2=DG, split_col=h)
+            ops.segment_sum_rows(DG, (0, h), n * K, csr, gg[0], g.bstride, accumulate=gg[1])
+        gu[1] = gg[1] = True

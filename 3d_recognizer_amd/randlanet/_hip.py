@@ -108,7 +108,7 @@ class PoolDesc(C.Structure):
         ("idx", C.c_void_p), ("W", C.c_void_p), ("points", C.c_int64),
         ("n", C.c_int32), ("d", C.c_int32), ("nbr_k", C.c_int32),
         ("Pout", C.c_void_p), ("dP", C.c_void_p), ("GU", C.c_void_p), ("gu_accumulate", C.c_int32),
-        ("GG", C.c_void_p), ("dW", C.c_void_p), ("slab", C.c_void_p), ("slab_floats", C.c_int64),
+        ("DG", C.c_void_p), ("dW", C.c_void_p), ("slab", C.c_void_p), ("slab_floats", C.c_int64),
         ("X_out", C.c_void_p), ("dS_out", C.c_void_p),
     ]
 
@@ -119,6 +119,25 @@ class ResidBnBwdDesc(C.Structure):
         ("Y1", C.c_void_p), ("scale1", C.c_void_p), ("mean1", C.c_void_p), ("invstd1", C.c_void_p),
         ("Y2", C.c_void_p), ("scale2", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
         ("stats1", C.c_void_p), ("stats2", C.c_void_p), ("coef1", C.c_void_p), ("coef2", C.c_void_p),
+    ]
+
+
+class CsrTask(C.Structure):
+    _fields_ = [
+        ("idx", C.c_void_p), ("n_src", C.c_int32), ("k", C.c_int32), ("n_dst", C.c_int32),
+        ("offsets", C.c_void_p), ("entries", C.c_void_p),
+    ]
+
+
+CSR_MAX_TASKS = 8
+
+
+class SegsumDesc(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("lds", C.c_int64), ("src_bstride", C.c_int64),
+        ("dst", C.c_void_p), ("ldd", C.c_int64), ("dst_bstride", C.c_int64),
+        ("offsets", C.c_void_p), ("entries", C.c_void_p), ("entries_per_cloud", C.c_int64),
+        ("B", C.c_int32), ("n_dst", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32),
     ]
 
 
@@ -164,6 +183,9 @@ _SIGNATURES = {
     "rl_resid_bn_bwd_apply": (_i, [C.POINTER(ResidBnBwdDesc), _vp]),
     "rl_copy_rows": (_i, [C.POINTER(RowsDesc), _vp]),
     "rl_scatter_add_rows": (_i, [C.POINTER(RowsDesc), _vp]),
+    "rl_csr_workspace_bytes": (_l, [C.POINTER(CsrTask), _i, _i]),
+    "rl_csr_build": (_i, [C.POINTER(CsrTask), _i, _i, _vp, _l, _vp]),
+    "rl_segment_sum_rows": (_i, [C.POINTER(SegsumDesc), _vp]),
     "rl_pool_supported": (_i, [_i, _i]),
     "rl_pool_slab_floats": (_l, [_l, _i]),
     "rl_pool_fwd": (_i, [C.POINTER(PoolDesc), _vp]),
@@ -175,6 +197,9 @@ _SIGNATURES = {
     "rl_rpe_build": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_batch_assemble": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
+    "rl_dropout_tick": (_i, [_vp, _vp, _vp]),
+    "rl_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _l, _i, _vp, C.c_uint64, _f, _vp]),
+    "rl_dropout_bwd": (_i, [_vp, _l, _i, _vp, C.c_uint64, _f, _vp]),
     "rl_upsample_cf": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rl_logits_unpermute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_logits_permute_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -225,6 +250,11 @@ def stream_ptr(device=None) -> int:
     if _RAW_STREAM is not None and _GET_DEVICE is not None and device is None:
         return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def current_device() -> int:
+    """Index of the current HIP device (the one whose current stream stream_ptr() returns)."""
+    return _GET_DEVICE() if _GET_DEVICE is not None else torch.cuda.current_device()
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -48,11 +48,19 @@ def plain(t: torch.Tensor, B: int, n: int) -> Lazy:
 
 
 def _dev_check(*ts):
+    """Every operand of a launch must be a contiguous tensor on the CURRENT HIP device: kernels go to the current
+    device's current stream (H.stream_ptr), so a tensor living on another GPU would be dereferenced by the wrong
+    device - a memory fault on a multi-GPU node.  Raised before anything is launched."""
+    cur = H.current_device()
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise H.HipKernelError("HIP kernels need device tensors")
+        if t.get_device() != cur:
+            raise H.HipKernelError(
+                f"tensor on cuda:{t.get_device()} but the current device is cuda:{cur}: run under "
+                "`with torch.cuda.device(tensor.device)` (launches use the current device's stream)")
         if not t.is_contiguous():
             raise H.HipKernelError("HIP kernels need contiguous tensors")
 
@@ -264,9 +272,9 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
          accumulate: bool = False, stats: Optional[torch.Tensor] = None,
          addend: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
          out2_index: Optional[torch.Tensor] = None, out2_bstride: int = 0, split_col: int = 0) -> torch.Tensor:
-    """Y = A'.W (+ bias).  With `out2` (split-scatter epilogue, wide layers only): v = A'.W + addend; columns < split_col
-    go to `out` (which then has split_col columns), the others are atomically added to the rows out2_index names of
-    out2 - the gradient of a gather + concat written where it belongs in one pass."""
+    """Y = A'.W (+ bias).  With `out2` (split epilogue, wide layers only): v = A'.W + addend; columns < split_col go to
+    `out` (which then has split_col columns), the others to the dense (M, N - split_col) tensor `out2` (or, with
+    `out2_index`, atomically to the rows it names) - the two halves of a concat's gradient in one pass."""
     d = H.GemmDesc()
     M, K = _fill_a(d, a)
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
@@ -290,9 +298,12 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
         _dev_check(addend, out2, out2_index)
         assert addend is None or (addend.dtype == F32 and addend.shape == (M, N))
         if out2 is not None:
-            assert out2.dtype == F32 and out2_index is not None and out2_index.dtype == torch.int32
-            assert out2_index.numel() == M and 0 < split_col < N and out2.shape[1] == N - split_col
-            assert out2.shape[0] >= (d.B - 1) * out2_bstride + 1
+            assert out2.dtype == F32 and 0 < split_col < N and out2.shape[1] == N - split_col
+            if out2_index is None:
+                assert out2.shape[0] >= M
+            else:
+                assert out2_index.dtype == torch.int32 and out2_index.numel() == M
+                assert out2.shape[0] >= (d.B - 1) * out2_bstride + 1
         d.addend, d.out2, d.out2_index = H.ptr(addend), H.ptr(out2), H.ptr(out2_index)
         d.out2_bstride, d.split_col = out2_bstride, split_col
     kfloats = H.lib().rl_gemm_kslab_floats(M, N, K) if (N > 64 and not isinstance(a, Rpe) and out2 is None and addend is None) else 0
@@ -484,6 +495,64 @@ def scatter_add_rows(src: torch.Tensor, src_cols: Tuple[int, int], dst: torch.Te
         H.check(H.lib().rl_scatter_add_rows(C.byref(d), _st()), "rl_scatter_add_rows")
 
 
+@dataclass
+class Csr:
+    """Transpose of a neighbour graph idx (B, n_src, k) -> for destination (b, j) the local source rows i*k + kk that
+    gathered it, ascending (rl_csr_build)."""
+    offsets: torch.Tensor   # (B, n_dst + 1) int32
+    entries: torch.Tensor   # (B, n_src*k) int32
+    B: int
+    n_src: int
+    k: int
+    n_dst: int
+
+
+def csr_build(graphs):
+    """graphs: list of (idx int32 (B, n_src, k), n_dst).  One launch set for all of them."""
+    out = []
+    for c0 in range(0, len(graphs), H.CSR_MAX_TASKS):
+        chunk = graphs[c0:c0 + H.CSR_MAX_TASKS]
+        arr = (H.CsrTask * len(chunk))()
+        res = []
+        B = chunk[0][0].shape[0]
+        nent = 0
+        for t, (idx, n_dst) in zip(arr, chunk):
+            _dev_check(idx)
+            assert idx.dtype == torch.int32 and idx.dim() == 3 and idx.shape[0] == B and n_dst > 0
+            _, n_src, k = idx.shape
+            off = torch.empty((B, n_dst + 1), dtype=torch.int32, device=idx.device)
+            ent = torch.empty((B, n_src * k), dtype=torch.int32, device=idx.device)
+            t.idx, t.n_src, t.k, t.n_dst, t.offsets, t.entries = idx.data_ptr(), n_src, k, n_dst, off.data_ptr(), ent.data_ptr()
+            res.append(Csr(off, ent, B, n_src, k, n_dst))
+            nent += B * n_src * k
+        nbytes = H.lib().rl_csr_workspace_bytes(arr, len(chunk), B)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=chunk[0][0].device)
+        with _rec("csr_build", (len(chunk), nent), 16 * nent, 0):
+            H.check(H.lib().rl_csr_build(arr, len(chunk), B, ws.data_ptr(), ws.numel(), _st()), "rl_csr_build")
+        out.extend(res)
+    return out
+
+
+def segment_sum_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, csr: Csr, dst: torch.Tensor,
+                     dst_bstride: int, accumulate: bool = False) -> None:
+    """dst[b*dst_bstride + j, :] (=|+=) sum of src[b*src_bstride + r, src_cols] over the rows r that gathered (b, j), in
+    ascending r - the gather's backward in a fixed order (no atomics, first writer needs no zero fill)."""
+    _dev_check(src, dst, csr.offsets, csr.entries)
+    c0, cn = src_cols
+    assert src.dtype == F32 and dst.dtype == F32 and src.dim() == 2 and dst.dim() == 2
+    assert c0 + cn <= src.shape[1] and cn == dst.shape[1]
+    assert src.shape[0] >= (csr.B - 1) * src_bstride + csr.n_src * csr.k
+    assert dst.shape[0] >= (csr.B - 1) * dst_bstride + csr.n_dst
+    d = H.SegsumDesc()
+    d.src, d.lds, d.src_bstride = src.data_ptr() + 4 * c0, src.shape[1], src_bstride
+    d.dst, d.ldd, d.dst_bstride = dst.data_ptr(), dst.shape[1], dst_bstride
+    d.offsets, d.entries, d.entries_per_cloud = csr.offsets.data_ptr(), csr.entries.data_ptr(), csr.n_src * csr.k
+    d.B, d.n_dst, d.C, d.accumulate = csr.B, csr.n_dst, cn, int(accumulate)
+    rows = csr.B * csr.n_src * csr.k
+    with _rec("segment_sum", (rows, cn), 4 * cn * (rows + csr.B * csr.n_dst * (2 if accumulate else 1)) + 4 * rows, 0):
+        H.check(H.lib().rl_segment_sum_rows(C.byref(d), _st()), "rl_segment_sum_rows")
+
+
 # ------------------------------------------------------------------------- pooling, residual
 def pool_supported(d: int, K: int) -> bool:
     return (not NO_FUSED_POOL) and bool(H.lib().rl_pool_supported(d, K))
@@ -517,14 +586,17 @@ def pool_fwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: in
 
 
 def pool_bwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP: torch.Tensor,
-             GU: torch.Tensor, gu_accumulate: bool, GG: torch.Tensor, dW: torch.Tensor, pending: Optional[list] = None) -> None:
-    """Backward of the fused pooling block.  d <= 64: dW comes out of the kernel.  d = 128: the kernel writes X and dS
-    and the weight gradient is the ordinary wide kernel on them (queued on `pending` like every other layer's)."""
+             GU: torch.Tensor, gu_accumulate: bool, dW: torch.Tensor, pending: Optional[list] = None) -> torch.Tensor:
+    """Backward of the fused pooling block.  Returns DG ((points*16) x d/2): the gradient of the gathered row of every
+    neighbourhood slot, to be summed per gathered point with segment_sum_rows.  d <= 64: dW comes out of the kernel.
+    d = 128: the kernel writes X and dS and the weight gradient is the ordinary wide kernel on them (queued on `pending`
+    like every other layer's)."""
     pd = _pool_desc(u, g, idx, W, n, d)
-    _dev_check(dP, GU, GG, dW)
+    _dev_check(dP, GU, dW)
     P = u.B * n
-    assert dP.shape == (P, d) and GU.shape == u.raw.shape and GG.shape == g.raw.shape and dW.numel() == d * d
-    pd.dP, pd.GU, pd.gu_accumulate, pd.GG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), GG.data_ptr(), dW.data_ptr()
+    assert dP.shape == (P, d) and GU.shape == u.raw.shape and dW.numel() == d * d
+    DG = torch.empty((P * 16, d // 2), dtype=F32, device=W.device)
+    pd.dP, pd.GU, pd.gu_accumulate, pd.DG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), DG.data_ptr(), dW.data_ptr()
     nbytes = 4 * (3 * P * 16 * (d // 2) + P * 16 * (d // 2) * (1 + int(gu_accumulate)) + P * 16 + 2 * P * d)
     if d == 128:
         X = torch.empty((P * 16, d), dtype=F32, device=W.device)
@@ -533,12 +605,13 @@ def pool_bwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: in
         with _rec("pool_bwd", (P, 16, d), nbytes + 8 * P * 16 * d, 4 * P * 16 * d * d):
             H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
         wgrad(plain(X, u.B, n * 16), dS, n * 16, d, dW, 1, d, None, pending=pending)
-        return
+        return DG
     floats = H.lib().rl_pool_slab_floats(P, d)
     slab = _slab(W.device, floats)
     pd.slab, pd.slab_floats = slab.data_ptr(), slab.numel()
     with _rec("pool_bwd", (P, 16, d), nbytes, 6 * P * 16 * d * d):
         H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
+    return DG
 
 
 def attpool_fwd(X: torch.Tensor, S: torch.Tensor, P: int, K: int) -> torch.Tensor:
@@ -585,6 +658,35 @@ def scale_mask(x: torch.Tensor, mask: torch.Tensor, scale: float) -> None:
     H.check(H.lib().rl_scale_mask(x.data_ptr(), mask.data_ptr(), scale, x.numel(), _st()), "rl_scale_mask")
 
 
+def dropout_tick(counter: torch.Tensor) -> torch.Tensor:
+    """counter[0] += 1 on the device; returns a fresh device scalar holding the new value - the key of one pass's mask."""
+    _dev_check(counter)
+    assert counter.dtype == torch.int64 and counter.numel() == 1
+    key = torch.empty(1, dtype=torch.int64, device=counter.device)
+    H.check(H.lib().rl_dropout_tick(counter.data_ptr(), key.data_ptr(), _st()), "rl_dropout_tick")
+    return key
+
+
+def dropout_fwd(x: Lazy, key: torch.Tensor, seed: int, p: float) -> torch.Tensor:
+    """Dropout of the (activated) dense tensor x with the Philox mask of (seed, key): (rows, C) output."""
+    _dev_check(x.raw, x.scale, x.shift, key)
+    assert x.bstride == x.n and x.raw.shape == (x.rows, x.C) and x.C % 4 == 0
+    out = torch.empty_like(x.raw)
+    with _rec("dropout", (x.rows, x.C), 8 * x.rows * x.C, 0):
+        H.check(H.lib().rl_dropout_fwd(x.raw.data_ptr(), H.ptr(x.scale), H.ptr(x.shift), x.act, x.slope, out.data_ptr(),
+                                       x.rows, x.C, key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p, _st()), "rl_dropout_fwd")
+    return out
+
+
+def dropout_bwd(G: torch.Tensor, key: torch.Tensor, seed: int, p: float) -> None:
+    """In place: the gradient through the same mask (regenerated from (seed, key))."""
+    _dev_check(G, key)
+    assert G.dim() == 2 and G.shape[1] % 4 == 0
+    with _rec("dropout", (G.shape[0], G.shape[1]), 8 * G.numel(), 0):
+        H.check(H.lib().rl_dropout_bwd(G.data_ptr(), G.shape[0], G.shape[1], key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p,
+                                       _st()), "rl_dropout_bwd")
+
+
 def upsample_cf(feat: torch.Tensor, idx: torch.Tensor, d2: Optional[torch.Tensor], power: int) -> torch.Tensor:
     """feat (B,F,N1) channel-first, idx/d2 (B,N2,k) -> (B,F,N2)."""
     _dev_check(feat, idx, d2)
@@ -597,10 +699,14 @@ def upsample_cf(feat: torch.Tensor, idx: torch.Tensor, d2: Optional[torch.Tensor
     return out
 
 
-def logits_unpermute(lp: torch.Tensor, perm: torch.Tensor, B: int, N: int) -> torch.Tensor:
+def logits_unpermute(lp: torch.Tensor, perm: torch.Tensor, B: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     Cc = lp.shape[1]
     assert lp.shape == (B * N, Cc) and perm.dtype == torch.int64 and perm.numel() == N
-    out = torch.empty((B, Cc, N), dtype=F32, device=lp.device)
+    if out is None:
+        out = torch.empty((B, Cc, N), dtype=F32, device=lp.device)
+    else:
+        _dev_check(out)
+        assert out.shape == (B, Cc, N) and out.dtype == F32
     H.check(H.lib().rl_logits_unpermute(lp.data_ptr(), perm.data_ptr(), B, N, Cc, out.data_ptr(), _st()),
             "rl_logits_unpermute")
     return out
@@ -626,13 +732,17 @@ LOSS_KINDS = {  # reference trainer.py:244-269
 
 
 def loss_forward(logits: torch.Tensor, labels: torch.Tensor, kind: int, alpha: float, gamma: float,
-                 neglect_background: bool = True):
+                 neglect_background: bool = True, out: Optional[torch.Tensor] = None):
     """Returns (out, work): out[0] = loss, out[1:] metric counts (doubles, on device)."""
     _dev_check(logits, labels)
     B, Cc, N = logits.shape
     assert labels.shape == (B, N) and labels.dtype == torch.int64 and logits.dtype == F32
     work = torch.empty(H.lib().rl_loss_work_doubles(B * N, Cc), dtype=torch.float64, device=logits.device)
-    out = torch.empty(1 + 4 * Cc, dtype=torch.float64, device=logits.device)
+    if out is None:
+        out = torch.empty(1 + 4 * Cc, dtype=torch.float64, device=logits.device)
+    else:
+        _dev_check(out)
+        assert out.dtype == torch.float64 and out.numel() == 1 + 4 * Cc
     with _rec("loss", (B, Cc, N), 4 * B * Cc * N + 8 * B * N, 0):
         H.check(H.lib().rl_loss_forward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
                                         int(neglect_background), work.data_ptr(), out.data_ptr(), _st()),

@@ -135,10 +135,9 @@ class TrainStep:
     # -- the schedule ------------------------------------------------------------------------
     def _fwd_bwd(self):
         logits, ctx = self.engine.forward(self.inp, self.perm, True, self.p_drop)
-        out, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True)
+        _, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True, out=self.out)
         dlogits = ops.loss_backward(logits, self.labels, self.kind, self.alpha, self.gamma, True, work)
         self.engine.backward(ctx, dlogits, self.flat.grads)
-        self.out.copy_(out)
 
     def _adam(self):
         ops.adam_step(self.flat.param, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
@@ -149,6 +148,10 @@ class TrainStep:
 
     def capture(self, warmup: int = 2) -> None:
         """Run a few eager steps on a side stream (allocator warm-up), then capture."""
+        with torch.cuda.device(self.dev):       # launches go to the current device's stream
+            self._capture(warmup)
+
+    def _capture(self, warmup: int) -> None:
         self.module.train()
         if not self.use_graph:
             return
@@ -180,6 +183,10 @@ class TrainStep:
         self.labels.copy_(labels, non_blocking=True)
 
     def step(self, perm: np.ndarray) -> None:
+        with torch.cuda.device(self.dev):
+            self._step(perm)
+
+    def _step(self, perm: np.ndarray) -> None:
         slot = self._perm_slot
         self._perm_slot = (slot + 1) % len(self._perm_ring)
         if self._perm_events[slot] is not None:
@@ -240,10 +247,13 @@ class InferStep:
         self._g: Optional[torch.cuda.CUDAGraph] = None
 
     def _fwd(self):
-        logits, _ = self.engine.forward(self.inp, self.perm, False)
-        self.logits.copy_(logits)
+        self.engine.forward(self.inp, self.perm, False, logits_out=self.logits)
 
     def capture(self, warmup: int = 2) -> None:
+        with torch.cuda.device(self.dev):
+            self._capture(warmup)
+
+    def _capture(self, warmup: int) -> None:
         self.module.eval()
         if not self.use_graph:
             return
@@ -260,6 +270,10 @@ class InferStep:
         torch.cuda.synchronize(self.dev)
 
     def step(self, perm: np.ndarray) -> torch.Tensor:
+        with torch.cuda.device(self.dev):
+            return self._step(perm)
+
+    def _step(self, perm: np.ndarray) -> torch.Tensor:
         if self._copied is not None:
             self._copied.synchronize()         # the staging buffer is free again once its copy has executed
         self._staging_np[:] = perm

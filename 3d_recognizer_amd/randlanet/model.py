@@ -86,7 +86,8 @@ class Model:
     # --------------------------------------------------------------------------- inference
     def upsample(self, logits: torch.Tensor, xyz: torch.Tensor, xyz_upsampled: torch.Tensor) -> torch.Tensor:
         """Softmax confidences of `logits` (B,C,N1) carried to `xyz_upsampled` (B,N2,3) -> (B,C,N2)."""
-        conf = ops.softmax_cf(logits.to(self.device, torch.float32).contiguous())
+        with torch.cuda.device(self.device):
+            conf = ops.softmax_cf(logits.to(self.device, torch.float32).contiguous())
         return self._upsampler(conf.unsqueeze(3), xyz, xyz_upsampled).squeeze(-1)
 
     def _knn_advice(self) -> None:
@@ -134,7 +135,8 @@ class Model:
             else:
                 logits = self._model(full.to(self._model.device))
                 # (the reference returns a device tensor in this branch, against its own annotation)
-                out = ops.softmax_cf(logits.contiguous()).cpu().numpy()
+                with torch.cuda.device(logits.device):
+                    out = ops.softmax_cf(logits.contiguous()).cpu().numpy()
         return out if batched else out[0]
 
     # ---------------------------------------------------------------------------- training

@@ -31,7 +31,8 @@ def knn_exact(xyz: torch.Tensor, xyz_query: torch.Tensor, n_neighbors: int) -> T
     s = xyz.to(dev, torch.float32).contiguous()
     q = xyz_query.to(dev, torch.float32).contiguous()
     try:
-        return ops.knn_f32(s, q, int(n_neighbors))
+        with torch.cuda.device(dev):
+            return ops.knn_f32(s, q, int(n_neighbors))
     except H.HipKernelError as e:
         if "Not enough points" in str(e):
             # the reference raises c10::Error -> RuntimeError with this text (knn.cpp:15-17)

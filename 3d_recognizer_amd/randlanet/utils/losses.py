@@ -18,7 +18,8 @@ class _HipLoss(torch.autograd.Function):
             raise H.HipKernelError("losses run on the MI355X only: there is no CPU path in this build")
         lg = logits.detach().to(torch.float32).contiguous()
         lb = labels.to(lg.device, torch.int64).contiguous()
-        out, work = ops.loss_forward(lg, lb, kind, alpha, gamma, neglect_background)
+        with torch.cuda.device(lg.device):
+            out, work = ops.loss_forward(lg, lb, kind, alpha, gamma, neglect_background)
         ctx.save_for_backward(lg, lb, work)
         ctx.cfg = (kind, alpha, gamma, neglect_background)
         return out[0].to(torch.float32)
@@ -27,7 +28,8 @@ class _HipLoss(torch.autograd.Function):
     def backward(ctx, grad_out):
         lg, lb, work = ctx.saved_tensors
         kind, alpha, gamma, neglect = ctx.cfg
-        dlogits = ops.loss_backward(lg, lb, kind, alpha, gamma, neglect, work)
+        with torch.cuda.device(lg.device):
+            dlogits = ops.loss_backward(lg, lb, kind, alpha, gamma, neglect, work)
         return dlogits * grad_out, None, None, None, None, None
 
 

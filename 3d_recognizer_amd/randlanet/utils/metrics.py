@@ -26,7 +26,8 @@ def class_counts(logits: torch.Tensor, labels: torch.Tensor) -> np.ndarray:
         logits = logits.cuda()
     lg = logits.detach().to(torch.float32).contiguous()
     lb = labels.to(lg.device, torch.int64).contiguous()
-    out, _ = ops.loss_forward(lg, lb, 0, 0.0, 0.0, False)
+    with torch.cuda.device(lg.device):
+        out, _ = ops.loss_forward(lg, lb, 0, 0.0, 0.0, False)
     C = lg.shape[1]
     return out[1:1 + 3 * C].cpu().numpy().reshape(3, C)
 

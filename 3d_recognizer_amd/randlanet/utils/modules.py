@@ -210,10 +210,11 @@ class RandLANet(nn.Module):
         inp = input.to(self._device, torch.float32).contiguous()
         perm = torch.from_numpy(np.random.permutation(N)).to(self._device)
         p_drop = float(self.fc_end[2].p)
-        if self.training and torch.is_grad_enabled():
-            names = [n for n, _ in self.named_parameters()]
-            return _NetFunction.apply(self, inp, perm, p_drop, names, *self.parameters())
-        logits, _ = self.engine().forward(inp, perm, self.training, p_drop)
+        with torch.cuda.device(self._device):       # launches go to the CURRENT device's stream
+            if self.training and torch.is_grad_enabled():
+                names = [n for n, _ in self.named_parameters()]
+                return _NetFunction.apply(self, inp, perm, p_drop, names, *self.parameters())
+            logits, _ = self.engine().forward(inp, perm, self.training, p_drop)
         return logits
 
 
@@ -232,5 +233,6 @@ class _NetFunction(torch.autograd.Function):
     def backward(fctx, dlogits):
         grads: Dict[str, torch.Tensor] = {
             n: torch.empty(s, dtype=torch.float32, device=d) for n, (s, d) in zip(fctx.names, fctx.shapes)}
-        fctx.eng.backward(fctx.ectx, dlogits, grads)
+        with torch.cuda.device(dlogits.device):
+            fctx.eng.backward(fctx.ectx, dlogits, grads)
         return (None, None, None, None, None) + tuple(grads[n] for n in fctx.names)

@@ -22,6 +22,7 @@ def upsample_features(approach: str, features: torch.Tensor, xyz: torch.Tensor, 
     B, F, N1 = f.shape[0], f.shape[1], f.shape[2]
     s = xyz.to(device, torch.float32).contiguous()
     q = xyz_upsampled.to(device, torch.float32).contiguous()
-    idx, d2 = ops.knn_i32(s, q, s.shape[1], q.shape[1], k)
-    out = ops.upsample_cf(f.reshape(B, F, N1).contiguous(), idx, d2, power)
+    with torch.cuda.device(device):
+        idx, d2 = ops.knn_i32(s, q, s.shape[1], q.shape[1], k)
+        out = ops.upsample_cf(f.reshape(B, F, N1).contiguous(), idx, d2, power)
     return out.unsqueeze(-1)

@@ -4,15 +4,21 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config A of BASELINE.json / SURVEY.md 8d): N=40960 points per cloud, 2 classes,
-k=16, encoder layers [16,64,128,256], 4 clouds per GPU, synthetic clouds xyz ~ U[0,1)^3 from
-RandomState(1234+rank), labels = sphere rule, random-init weights.  One step = per-forward
+Workload (BASELINE.json `metric`: "training clouds/sec, N=40960 pts, bs=8"): N=40960 points per
+cloud, 2 classes, k=16, encoder layers [16,64,128,256], 8 clouds per GPU, synthetic clouds
+xyz ~ U[0,1)^3 from RandomState(1234+rank), labels = sphere rule, random-init weights.  One step = per-forward
 numpy permutation -> forward -> dice loss + metric counts -> backward -> (RCCL all-reduce of
 the flat gradient when N>1) -> Adam, all on hand-written HIP kernels (librandla_hip.so),
 replayed as a hipGraph.  Inputs are resident in HBM before the timed region.  Weak scaling:
 per-GPU batch is fixed, clouds are sharded over ranks, the only collective is one all-reduce.
 
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (a parent that makes
+no GPU call runs `python -m torch.distributed.run`); fewer than N visible devices is an error, never a
+silent one-GPU run.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  config_A     - the same step at BASELINE.json config A / B (4 clouds per GPU, weak scaling)
+  strong_bs8   - (N > 1) the metric's global batch of 8 split over the N ranks
   roofline     - the kernel with the largest share of the step (measured with HIP events around
                  every launch of an instrumented eager pass on the launch stream): algorithmic
                  bytes per launch / mean launch duration vs the 8 TB/s HBM peak.
@@ -34,7 +40,7 @@ sys.path.insert(0, REPO)
 
 import torch  # noqa: E402
 
-CFG = dict(n_points=40960, n_classes=2, n_neighbors=16, layer_sizes=[16, 64, 128, 256], per_gpu_batch=4)
+CFG = dict(n_points=40960, n_classes=2, n_neighbors=16, layer_sizes=[16, 64, 128, 256], per_gpu_batch=8)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # same guide: ~2.5 PF dense = 16x the fp32 matrix rate
@@ -105,6 +111,26 @@ def cpu_baseline(steps=2, B=2):
                 sample=f"{steps} timed steps (+1 warm-up) of the same train step at B={B} clouds of "
                        f"{CFG['n_points']} points; PyTorch-CPU NCHW restatement (oracle/randlanet_oracle.py) "
                        "+ single-threaded exact C KNN (oracle/knn_oracle.c)")
+
+
+METRIC = "training clouds/sec, N=40960 pts, bs=8, at 1/2/4/8 GPUs; mIoU parity"     # BASELINE.json `metric`, verbatim
+
+
+def fused_min_bytes_per_cloud(N, K, layers, C, e, dec=4):
+    """SURVEY.md 8(d) "network fused-minimum HBM bytes" of one FORWARD of one cloud with e-byte activations (A: 103 MB
+    at e = 2, 190 MB at e = 4); a training step is priced at 3x that (forward + reload in backward + gradient traffic)."""
+    tot, n_in, n = 0, 8, N
+    for d in layers:
+        tot += 12 * n + 4 * n * K + e * n_in * n + 12 * n * K + 2 * e * (d // 2) * n * K + 2 * e * (d // 2) * n + e * 2 * d * n
+        n_in, n = 2 * d, n // dec
+    L = len(layers)
+    cin = 4 * layers[-1]
+    for j in range(L):
+        n *= dec
+        cout = 8 if j == L - 1 else 2 * layers[L - 2 - j]
+        tot += e * (cin + cout) * n + 4 * n
+        cin = 2 * cout
+    return tot + 4 * C * N
 
 
 MFMA_KERNELS = ("pgemm_kernel", "pwgrad", "wgrad_kernel", "sgemm_kernel", "swgrad_kernel", "gemm_kernel", "pool_fwd_kernel",
@@ -189,8 +215,90 @@ def roofline_pass(stepper, eager_steps=3):
                      top_shapes=[dict(kernel=r["kernel"], op=f"{r['category']}{list(r['shape'])}",
                                       ms_per_step=round(r["ms_per_step"], 3), launches_per_step=r["launches_per_step"],
                                       GBps=round(r["bytes"] / max(r["ms_per_launch"], 1e-9) / 1e6, 1),
-                                      TFLOPs=round(r["flops"] / max(r["ms_per_launch"], 1e-9) / 1e9, 2)) for r in rows[:80]])
+                                      TFLOPs=round(r["flops"] / max(r["ms_per_launch"], 1e-9) / 1e9, 2)) for r in rows[:80]],
+                     # consumed by step_rooflines(), not printed
+                     all_shapes=[dict(op=f"{r['category']}{list(r['shape'])}", M=(r["shape"][0] if r["shape"] and
+                                      isinstance(r["shape"][0], int) else -1), ms_per_step=r["ms_per_step"],
+                                      launches_per_step=r["launches_per_step"], bytes=r["bytes"], flops=r["flops"]) for r in rows])
     return roof, breakdown
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh children.  This parent never touches the
+    GPU (device_count() does not create a context on this image), so nothing that has initialised HIP is re-executed."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible - refusing to measure fewer GPUs "
+              "than asked for", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(stepper, N, steps, warmup, barrier, world, dist, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.  Returns seconds."""
+    for _ in range(warmup):
+        stepper.step(np.random.permutation(N))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stepper.step(np.random.permutation(N))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    m = stepper.last_metrics()
+    if not np.isfinite(m["loss"]):
+        raise SystemExit("bench.py: the training loss is not finite - the measurement is invalid")
+    return elapsed, m
+
+
+def step_rooflines(breakdown, B, value, world):
+    """Path-level roofline figures from the instrumented pass: the whole step against the fused-minimum
+    HBM traffic, the neighbour search two ways, and the matrix work per encoder level."""
+    N, K, layers, C = CFG["n_points"], CFG["n_neighbors"], CFG["layer_sizes"], CFG["n_classes"]
+    min_bytes = 3 * fused_min_bytes_per_cloud(N, K, layers, C, 4)
+    per_gpu = value / world
+    out = {"whole_step": {"bound": "hbm", "fused_min_bytes_per_cloud": min_bytes, "storage": "f32",
+                          "achieved": round(per_gpu * min_bytes / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(per_gpu * min_bytes / 1e9 / HBM_PEAK_GBS, 4),
+                          "launches_per_step": round(sum(k["launches_per_step"] for k in breakdown["kernels"].values()), 1)}}
+    rows = breakdown["all_shapes"]
+    knn = [r for r in rows if r["op"].startswith("knn")]
+    if knn:
+        ms = sum(r["ms_per_step"] for r in knn)
+        nbytes = sum(r["bytes"] * r["launches_per_step"] for r in knn)
+        pairs = sum(r["flops"] * r["launches_per_step"] for r in knn) / 8.0
+        out["knn"] = {"ms_per_step": round(ms, 3), "io_GBps": round(nbytes / ms / 1e6, 1),
+                      "io_frac_of_hbm": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                      "brute_equivalent_pair_evals_per_s": round(pairs / ms * 1e3, 0),
+                      "note": "exact grid search: pairs are the brute-force count the answer is equivalent to"}
+    # matrix work per level: a GEMM / weight-gradient / fused-pooling launch belongs to the level whose row count it has
+    lv = []
+    n = N
+    for l, d in enumerate(layers):
+        keys = {B * n, B * n * K}
+        sel = [r for r in rows if r["flops"] > 0 and r["M"] in keys and not r["op"].startswith("knn")]
+        fl = sum(r["flops"] * r["launches_per_step"] for r in sel)
+        ms = sum(r["ms_per_step"] for r in sel)
+        if ms > 0:
+            lv.append({"level": l, "d": d, "GFLOP_per_step": round(fl / 1e9, 2), "ms_per_step": round(ms, 3),
+                       "TFLOPs": round(fl / ms / 1e9, 1), "frac_fp32_mfma_peak": round(fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
+                       "frac_bf16_mfma_peak_x3": round(3 * fl / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4)})
+        n //= 4
+    out["mfma_by_level"] = lv
+    return out
 
 
 def main():
@@ -202,18 +310,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary eval-forward measurement")
-    ap.add_argument("--batch", type=int, default=CFG["per_gpu_batch"], help="clouds per GPU")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config_A / strong_bs8 objects")
+    ap.add_argument("--batch", type=int, default=CFG["per_gpu_batch"], help="clouds per GPU (the metric's bs=8)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.set_num_threads(host_cores())        # a one-GPU box shows 256 cores but grants 16: keep host ops cheap
-    dev_index = local_rank % torch.cuda.device_count()
+    torch.set_num_threads(max(1, host_cores() // world))   # a one-GPU box shows 256 cores but grants 16: keep host ops cheap
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} device(s): one GPU per rank is required")
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -224,9 +340,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        world = dist.get_world_size()            # n_gpus in the line = what the backend reports
 
-    from randlanet._train import TrainStep
+    from randlanet._train import InferStep, TrainStep, broadcast_flat
     from randlanet import _ops as _o
     global WIDE_GEMM
     WIDE_GEMM = _o.get_wide_gemm()             # what the kernels will really do
@@ -235,9 +351,9 @@ def main():
     model.train()
     stepper = TrainStep(model, B, N, loss="dice", lr=1e-2, use_graph=not args.no_graph, world_size=world)
     xyz, labels = synthetic_batch(B, N, C, 1234 + rank)
-    stepper.set_batch(torch.from_numpy(xyz).to(dev), torch.from_numpy(labels).to(dev))
+    x_dev, y_dev = torch.from_numpy(xyz).to(dev), torch.from_numpy(labels).to(dev)
+    stepper.set_batch(x_dev, y_dev)
     np.random.seed(1234 + rank)                # rank-distinct permutation streams
-    from randlanet._train import broadcast_flat
     broadcast_flat(stepper.flat.param, world)  # replicas must start identical
     stepper.capture()
 
@@ -246,26 +362,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        stepper.step(np.random.permutation(N))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stepper.step(np.random.permutation(N))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    metrics = stepper.last_metrics()
-    if not np.isfinite(metrics["loss"]):
-        raise SystemExit("bench.py: the training loss is not finite - the measurement is invalid")
+    elapsed, metrics = timed_steps(stepper, N, args.steps, args.warmup, barrier, world, dist, dev)
+    value = B * world * args.steps / elapsed
+
+    # secondary configurations: the same model / optimiser state, other batch shapes
+    def secondary(per_gpu: int, scaling: str, what: str):
+        st = TrainStep(model, per_gpu, N, loss="dice", use_graph=not args.no_graph, state=stepper.state)
+        st.set_batch(x_dev[:per_gpu].contiguous(), y_dev[:per_gpu].contiguous())
+        st.capture()
+        el, m = timed_steps(st, N, args.steps, args.warmup, barrier, world, dist, dev)
+        return {"workload": what, "value": round(per_gpu * world * args.steps / el, 3), "unit": "clouds/s",
+                "per_gpu_batch": per_gpu, "global_batch": per_gpu * world, "scaling": scaling,
+                "ms_per_step": round(1e3 * el / args.steps, 3), "final_loss": round(m["loss"], 5)}
+    config_a = strong = None
+    if not args.no_secondary:
+        if B != 4:
+            config_a = secondary(4, "weak", "BASELINE.json config A (1 GPU) / B (8 GPUs): 4 clouds per GPU")
+        if world > 1 and 8 % world == 0 and 8 // world != B:
+            strong = secondary(8 // world, "strong", "the metric's global batch of 8 clouds split over the ranks")
 
     # secondary line: eval-mode forward clouds/s with the weights as trained so far, same batch shape
     infer = None
     if rank == 0 and not args.no_inference:
-        from randlanet._train import InferStep
         inf = InferStep(model, B, N, use_graph=not args.no_graph)
         inf.inp.copy_(stepper.inp)
         inf.capture()
@@ -288,14 +406,17 @@ def main():
         # every rank runs the instrumented eager steps (they contain the gradient all-reduce, a collective);
         # rank 0's timings are the ones reported
         roof, breakdown = roofline_pass(stepper)
+        roof.update(step_rooflines(breakdown, B, value, world))
+        breakdown.pop("all_shapes", None)
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        dist.destroy_process_group()             # every collective is done: the other ranks leave, rank 0 times the host path
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
         line = {
-            "metric": "training clouds/sec, N=40960 pts",
-            "value": round(B * world * args.steps / elapsed, 3),
+            "metric": METRIC,
+            "value": round(value, 3),
             "unit": "clouds/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -304,16 +425,19 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 storage/accumulate, bf16x3 MFMA in the wide GEMMs" if WIDE_GEMM == "bf16x3" else
+                     ("f32" if WIDE_GEMM == "fp32" else "f32 storage/accumulate, bf16 MFMA in the wide GEMMs"),
             "data": "synthetic",
-            "config": {"workload": "RandLA-Net train step: 40960 pts/cloud, 2 classes, k=16, 4 encoder layers "
+            "config": {"workload": "RandLA-Net train step: 40960 pts/cloud, bs=8 per GPU, 2 classes, k=16, 4 encoder layers "
                                    "[16,64,128,256], dice loss + Adam", "per_gpu_batch": B,
                        "global_batch": B * world, "parallelism": f"dp{world}", "graph": not args.no_graph,
                        "wide_gemm": WIDE_GEMM},
-            "final_loss": round(metrics["loss"], 5) if np.isfinite(metrics["loss"]) else None,
+            "final_loss": round(metrics["loss"], 5),
             "final_mIoU": round(metrics["mIoU"], 4),
             "roofline": roof,
             "cpu_baseline": cpu,
+            "config_A": config_a,
+            "strong_bs8": strong,
             "inference": infer,
         }
         if breakdown is not None:
@@ -322,8 +446,6 @@ def main():
                 json.dump(breakdown, f, indent=1)
             print(json.dumps(breakdown), file=sys.stderr)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

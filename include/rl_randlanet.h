@@ -29,6 +29,8 @@
  *                         PointFeatureAugmentation gather+concat (modules.py:213-221), permutation /
  *                         prefix slicing (modules.py:571-573, 608), nearest-neighbour interpolation
  *                         gather + skip concat (modules.py:359-364, 600-602) and their backward
+ *   rl_csr_build / rl_segment_sum_rows
+ *                         the backward of those gathers (torch's scatter_add_) in a fixed summation order
  *   rl_pool_fwd/_bwd      PointFeatureAugmentation + AttentivePooling fused (modules.py:213-253)
  *   rl_attpool_*          AttentivePooling softmax over K + weighted sum (modules.py:246-253)
  *   rl_add_act_*          LocalFeatureAggregation residual + LeakyReLU (modules.py:325)
@@ -150,10 +152,13 @@ typedef struct rl_gemm_desc {
     int64_t kslab_floats;
     /* optional "split-scatter" epilogue (the dX of PointFeatureAugmentation's concat, modules.py:213-221):
      *   addend  != NULL : v += addend[R*N + c] before anything else (row stride N, row R = global row)
-     *   out2    != NULL : columns c >= split_col are not stored to Y but atomically added to
-     *                     out2[(b*out2_bstride + out2_index[R])*(N - split_col) + c - split_col], b = R / rows per
-     *                     cloud - the gradient of the gathered half goes straight to the rows it was gathered from;
-     *                     columns c < split_col go to Y as usual (ldy, y_bstride, accumulate apply to them only).
+     *   out2    != NULL : columns c >= split_col are not stored to Y.  With out2_index == NULL they are stored to
+     *                     out2[R*(N - split_col) + c - split_col] (a dense (M, N - split_col) tensor: the gradient of
+     *                     every gathered row, summed per destination afterwards by rl_segment_sum_rows in a fixed
+     *                     order - the deterministic path the network uses).  With out2_index they are atomically
+     *                     added to out2[(b*out2_bstride + out2_index[R])*(N - split_col) + c - split_col], b = R / rows
+     *                     per cloud (order-dependent in the last bits; out2 zeroed by the caller).
+     *                     Columns c < split_col go to Y as usual (ldy, y_bstride, accumulate apply to them only).
      * Needs the LDS-tiled kernel (K or N > 64, 16-byte aligned operands) and no statistics; else RL_ERR_UNSUPPORTED. */
     const float* addend;
     float* out2;
@@ -322,6 +327,45 @@ int rl_copy_rows(const rl_rows_desc* d, void* stream);
 int rl_scatter_add_rows(const rl_rows_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Deterministic gather backward.  The reference's backward of `torch.gather(features, idx)`
+ * (PointFeatureAugmentation, modules.py:213-221; nearest_neighbor_interpolation, modules.py:359-364)
+ * is a scatter_add_ whose summation order is undefined.  Here the neighbour graph is transposed once
+ * per step and every destination row adds its contributions in ascending source-row order.
+ *
+ * rl_csr_build: for each task (a graph idx (B, n_src, k) int32 with values in [0, n_dst)) writes
+ *   offsets (B, n_dst + 1): segment bounds of destination j of cloud b, local to the cloud
+ *   entries (B, n_src*k)  : local source rows r = i*k + kk with idx[b][i][kk] == j, ascending per segment
+ * All tasks (<= 8, same B) run in one launch set; workspace of rl_csr_workspace_bytes bytes, 256-byte
+ * aligned.  Out-of-range indices are ignored.                                                   */
+typedef struct rl_csr_task {
+    const int32_t* idx;
+    int32_t n_src, k, n_dst;
+    int32_t* offsets;
+    int32_t* entries;
+} rl_csr_task;
+
+int64_t rl_csr_workspace_bytes(const rl_csr_task* tasks, int ntasks, int B);
+int rl_csr_build(const rl_csr_task* tasks, int ntasks, int B, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
+/* dst[(b*dst_bstride + j)*ldd + c] (=|+=) sum over e in [offsets[b][j], offsets[b][j+1]) of
+ * src[(b*src_bstride + entries[b][e])*lds + c],  c < C, added in the order of the segment.
+ * `src` may point at a column offset inside wider rows (lds is the row stride).                 */
+typedef struct rl_segsum_desc {
+    const float* src;
+    int64_t lds, src_bstride;
+    float* dst;
+    int64_t ldd, dst_bstride;
+    const int32_t* offsets;
+    const int32_t* entries;
+    int64_t entries_per_cloud;
+    int32_t B, n_dst, C;
+    int32_t accumulate;
+} rl_segsum_desc;
+
+int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Attentive pooling core (modules.py:246-253) on X, S of shape (P*K) x C (K consecutive rows
  * per point): A = softmax over the K rows of S, per channel;  Pout[p][c] = sum_k A*X.
  * Backward: dS = A * dP * (X - Pout);  dXa = dP * A  (the direct path of X).               */
@@ -337,8 +381,9 @@ int rl_attpool_bwd(const float* X, const float* S, const float* Pout, const floa
  *   (b*g_bstride + i)*(d/2), gathered through idx (points,16) int32;  W (d,d) score weight.
  * rl_pool_fwd : Pout (points, d).
  * rl_pool_bwd : given dP (points, d) recomputes the block and produces GU (gradient w.r.t. the
- *   activated U, stored or accumulated), GG += (gradient w.r.t. the activated G rows, fp32 atomics,
- *   zeroed by the caller) and dW (d,d) through per-workgroup slabs (rl_pool_slab_floats floats).  */
+ *   activated U, stored or accumulated), DG ((points*16) x d/2, plain stores: the gradient w.r.t. the
+ *   activated gathered row of every neighbourhood slot - rl_segment_sum_rows then sums it per gathered
+ *   point in a fixed order) and dW (d,d) through per-workgroup slabs (rl_pool_slab_floats floats).  */
 typedef struct rl_pool_desc {
     const float* U;
     const float* u_scale;
@@ -359,7 +404,7 @@ typedef struct rl_pool_desc {
     const float* dP;
     float* GU;
     int32_t gu_accumulate;
-    float* GG;
+    float* DG;
     float* dW;
     float* slab;
     int64_t slab_floats;
@@ -423,6 +468,16 @@ int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int F, const i
 /* Dropout (fc_end, modules.py:528) with a keep-mask drawn by the caller (uint8, 1 = keep):
  * x[i] = mask[i] ? x[i]*scale : 0, in place; the same call is its own backward.             */
 int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t count, void* stream);
+
+/* Dropout (fc_end's nn.Dropout, modules.py:528) with a counter-based generator (Philox4x32-10): element e of the
+ * (rows, C) tensor is kept iff philox(seed, key[0], e) >= p*2^32; kept values are scaled by 1/(1-p).  `key` is a
+ * device scalar, so a captured graph draws a fresh mask per replay: rl_dropout_tick does counter[0] += 1 and copies
+ * the new value to key_out[0]; forward and backward of one pass read the same key and regenerate the same mask (no
+ * mask tensor).  rl_dropout_fwd also applies the producer's lazy BatchNorm + activation; dense rows (ld = C), C % 4 == 0. */
+int rl_dropout_tick(int64_t* counter, int64_t* key_out, void* stream);
+int rl_dropout_fwd(const float* src, const float* scale, const float* shift, int act, float slope, float* dst,
+                   int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream);
+int rl_dropout_bwd(float* G, int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream);
 
 /* UpSampler (modules.py:343-456) on channel-first features feat (B,F,N1) with neighbours
  * idx/d2 (B,N2,k) from rl_knn_i32: power 0 = nearest-neighbour interpolation (k = 1),

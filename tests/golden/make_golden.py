@@ -332,6 +332,36 @@ def g6_training_run():
     print("history", np.round(np.array(hist), 4).tolist(), "final", final)
 
 
+def g6s_training_seeds(n_seeds=64):
+    """The G6 run repeated by the REFERENCE trainer over `n_seeds` (torch seed, numpy seed) pairs on the clouds of
+    train_run.npz: the distribution of the final validation mIoU (and of the whole per-epoch history) that the HIP
+    path's same-seed runs are compared with (north_star: mIoU parity; reference evaluation loop trainer.py:271-367,
+    per-batch averaging metrics.py:149-151, 10 seeded passes metrics.py:239-242)."""
+    from randlanet import AugmentationSettings, Model, RandLANetSettings, TrainingSettings
+    z = np.load(os.path.join(HERE, "train_run.npz"))
+    C, n_pts = 3, 1024
+    clouds = [(xyz, np.zeros((xyz.shape[0], 0), np.float32), lab.astype(np.int64)) for xyz, lab in zip(z["clouds"], z["labels"])]
+    train, val = clouds[:8], clouds[8:]
+    hists, finals = [], []
+    for seed in range(n_seeds):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        s = RandLANetSettings(n_classes=C, n_points=n_pts, n_neighbors=16, layer_sizes=[8, 16, 32, 32], knn="approximate")
+        model = Model(s, use_gpu=False)
+        model.module.fc_end[2].p = 0.0          # Dropout draws from torch's device RNG: not comparable
+        hist = []
+        ts = TrainingSettings(epochs=6, batch_size=4, learning_rate=1e-2, early_stopping=False)
+        model.train(train, val, ts, AugmentationSettings(), None, ["bg", "a", "b"],
+                    callbacks=[lambda e, m: hist.append([m["loss"], m["mIoU"], m["val_loss"], m["val_mIoU"]])])
+        hists.append(hist)
+        finals.append(hist[-1][3])
+        print(f"seed {seed}: val_mIoU per epoch {np.round(np.array(hist)[:, 3], 4).tolist()}", flush=True)
+    finals = np.array(finals)
+    save("train_seeds.npz", seeds=np.arange(n_seeds), histories=np.array(hists, dtype=np.float64), final_val_miou=finals)
+    print(f"final val_mIoU over {n_seeds} seeds: mean {finals.mean():.4f} std {finals.std(ddof=1):.4f} "
+          f"SE {finals.std(ddof=1) / np.sqrt(n_seeds):.4f}")
+
+
 # --------------------------------------------------------------------- G7: input pipeline
 def g7_pipeline():
     """The reference's own PointCloudPreprocessor / get_data_loader on small clouds."""
@@ -402,3 +432,5 @@ if __name__ == "__main__":
         g5_model_zip()
     if "g6" in which:
         g6_training_run()
+    if "g6s" in which:
+        g6s_training_seeds()

@@ -59,3 +59,30 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_hip, "_LIB_PATH", "/nonexistent/librandla_hip.so")
     with pytest.raises(_hip.HipKernelError, match="no fallback"):
         _hip.lib()
+
+
+def test_operands_on_another_device_are_refused_before_launch(monkeypatch):
+    """Launches go to the CURRENT device's stream: a tensor on another GPU, or on the host, must raise on the host side
+    (a kernel dereferencing another device's pointer is a memory fault on an 8-GPU node)."""
+    import torch
+
+    from randlanet import _hip, _ops
+
+    class FakeDeviceTensor:
+        is_cuda = True
+
+        def __init__(self, index):
+            self._i = index
+
+        def get_device(self):
+            return self._i
+
+        def is_contiguous(self):
+            return True
+
+    monkeypatch.setattr(_hip, "current_device", lambda: 0)
+    _ops._dev_check(FakeDeviceTensor(0), None)
+    with pytest.raises(_hip.HipKernelError, match="current device is cuda:0"):
+        _ops._dev_check(FakeDeviceTensor(0), FakeDeviceTensor(1))
+    with pytest.raises(_hip.HipKernelError, match="device tensors"):
+        _ops._dev_check(torch.zeros(3))

@@ -243,7 +243,7 @@ def test_gemm_split_scatter_epilogue(ops, d, B, n_parent, n, accumulate):
     ops.copy_rows(dX, (0, h), n * K, gu_ref, (0, h), rows, n * K, accumulate=accumulate)
     gg_ref = torch.zeros(B * n_parent, h, device=DEV)
     ops.scatter_add_rows(dX, (h, h), gg_ref, n_parent, rows, n * K, idx)
-    # fused epilogue
+    # fused epilogue, atomic form (kept in the ABI)
     gu = gu0.clone() if accumulate else torch.full_like(gu0, float("nan"))
     gg = torch.zeros(B * n_parent, h, device=DEV)
     ops.gemm(ops.plain(dS, B, n * K), W, d, 1, d, None, out=gu, out_bstride=n * K, accumulate=accumulate,
@@ -251,6 +251,19 @@ def test_gemm_split_scatter_epilogue(ops, d, B, n_parent, n, accumulate):
     # same products; the composition may have split K over workgroups (few row tiles), so the order can differ
     assert float((gu - gu_ref).abs().max()) < 1e-5 * float(gu_ref.abs().max())
     assert float((gg - gg_ref).abs().max()) < 1e-4 * float(gg_ref.abs().max())   # fp32 atomics: order differs
+    # dense form + segment sum: what the network runs; bitwise reproducible
+    (csr,) = ops.csr_build([(idx, n_parent)])
+    res = []
+    for _ in range(2):
+        gu2 = gu0.clone() if accumulate else torch.full_like(gu0, float("nan"))
+        DG = torch.full((rows, h), float("nan"), device=DEV)
+        ops.gemm(ops.plain(dS, B, n * K), W, d, 1, d, None, out=gu2, out_bstride=n * K, accumulate=accumulate,
+                 addend=addend, out2=DG, split_col=h)
+        gg2 = torch.full((B * n_parent, h), float("nan"), device=DEV)
+        ops.segment_sum_rows(DG, (0, h), n * K, csr, gg2, n_parent)
+        res.append((gu2, gg2))
+    assert torch.equal(res[0][0], gu) and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float((res[0][1] - gg_ref).abs().max()) < 1e-4 * float(gg_ref.abs().max())
     # narrow layers have no such epilogue: loud error, no silent fallback
     small = torch.randn(64, 32, device=DEV)
     with pytest.raises(Exception, match="split-scatter"):
@@ -523,17 +536,67 @@ def test_fused_pool_forward_backward(ops, d, B, n_parent, n):
     assert float((P - Pref).abs().max()) < 2e-5
     dP = torch.randn(B * n, d, device=DEV)
     Pref.backward(dP)
+    (csr,) = ops.csr_build([(idx, n)])
     GU = torch.full_like(U, 3.0)
-    GG = torch.zeros_like(Gf)
+    GG = torch.full_like(Gf, float("nan"))[: (B - 1) * n_parent + n]
     dW = torch.empty(d, d, device=DEV)
-    ops.pool_bwd(u, g, idx, W.detach(), n, d, dP, GU, False, GG, dW)
+    DG = ops.pool_bwd(u, g, idx, W.detach(), n, d, dP, GU, False, dW)
+    ops.segment_sum_rows(DG, (0, h), n * K, csr, GG, n_parent)                 # first writer: no zero fill
+    GGv = torch.stack([GG[b * n_parent: b * n_parent + n] for b in range(B)])
+    ref_gg = ga.grad.view(B, n_parent, h)[:, :n]
     assert float((GU - ua.grad).abs().max()) < 2e-5 * max(1.0, float(ua.grad.abs().max()))
-    assert float((GG - ga.grad).abs().max()) < 1e-4 * max(1.0, float(ga.grad.abs().max()))
+    assert float((GGv - ref_gg).abs().max()) < 1e-4 * max(1.0, float(ga.grad.abs().max()))
     assert float((dW - W.grad).abs().max()) < 2e-4 * max(1.0, float(W.grad.abs().max()))
     GU2 = torch.ones_like(U)
-    GG.zero_()
-    ops.pool_bwd(u, g, idx, W.detach(), n, d, dP, GU2, True, GG, dW)          # accumulate into GU
+    dW2 = torch.empty(d, d, device=DEV)
+    DG2 = ops.pool_bwd(u, g, idx, W.detach(), n, d, dP, GU2, True, dW2)       # accumulate into GU
     assert float((GU2 - 1.0 - ua.grad).abs().max()) < 2e-5 * max(1.0, float(ua.grad.abs().max()))
+    # no atomics anywhere: a second run gives the same bits
+    GG2 = torch.empty_like(GG)
+    ops.segment_sum_rows(DG2, (0, h), n * K, csr, GG2, n_parent)
+    assert torch.equal(DG, DG2) and torch.equal(dW, dW2)
+    assert torch.equal(GGv, torch.stack([GG2[b * n_parent: b * n_parent + n] for b in range(B)]))
+
+
+@pytest.mark.parametrize("B,n_src,k,n_dst,Cc,kind", [(3, 500, 16, 500, 8, "uniform"), (2, 1000, 1, 250, 512, "uniform"),
+                                                     (2, 300, 32, 300, 64, "uniform"), (1, 2500, 16, 2500, 32, "dup"),
+                                                     (2, 200, 5, 77, 10, "uniform"), (1, 4096, 16, 4096, 16, "one")])
+def test_csr_transpose_and_segment_sum(ops, B, n_src, k, n_dst, Cc, kind):
+    """rl_csr_build + rl_segment_sum_rows = the backward of torch.gather over a neighbour index, in a fixed order:
+    segments hold exactly the gatherers of each point, ascending; sums equal scatter_add_ up to fp32 ordering; two
+    runs are bitwise equal.  "dup" / "one": duplicate-heavy graphs (predict.py's warm-up cloud, modules.py ties) where
+    a few points are gathered by very many rows - the long-segment path."""
+    torch.manual_seed(n_src + k)
+    if kind == "uniform":
+        idx = torch.randint(0, n_dst, (B, n_src, k), device=DEV, dtype=torch.int32)
+    elif kind == "dup":
+        idx = torch.randint(0, 30, (B, n_src, k), device=DEV, dtype=torch.int32)        # 30 targets take everything
+    else:
+        idx = torch.zeros((B, n_src, k), device=DEV, dtype=torch.int32)
+        idx[:, :, 1:] = 7                                                            # two segments of 4096 and 61440
+    src = torch.randn(B * n_src * k, Cc + 4, device=DEV)
+    outs = []
+    for _ in range(2):
+        (csr,) = ops.csr_build([(idx, n_dst)])
+        dst = torch.full((B * n_dst + 3, Cc), float("nan"), device=DEV)
+        ops.segment_sum_rows(src, (4, Cc), n_src * k, csr, dst, n_dst)
+        outs.append((csr.offsets.clone(), csr.entries.clone(), dst[: B * n_dst].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    off, ent, dst = (t.cpu() for t in outs[0])
+    flat = idx.cpu().reshape(B, n_src * k).long()
+    for b in range(B):
+        order = torch.argsort(flat[b], stable=True)           # ascending source row inside every destination
+        assert torch.equal(ent[b].long(), order)
+        assert torch.equal(off[b].long(), torch.cat([torch.zeros(1, dtype=torch.long),
+                                                     torch.bincount(flat[b], minlength=n_dst).cumsum(0)]))
+    ref = torch.zeros(B, n_dst, Cc, dtype=torch.float64)
+    ref.scatter_add_(1, flat.view(B, -1, 1).expand(-1, -1, Cc), src[:, 4:].cpu().double().view(B, n_src * k, Cc))
+    assert float((dst.view(B, n_dst, Cc).double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    # accumulate
+    acc = torch.ones(B * n_dst, Cc, device=DEV)
+    (csr,) = ops.csr_build([(idx, n_dst)])
+    ops.segment_sum_rows(src, (4, Cc), n_src * k, csr, acc, n_dst, accumulate=True)
+    assert float((acc.cpu().view(B, n_dst, Cc).double() - 1.0 - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_add_act_and_logits_layout(ops):
