@@ -560,15 +560,19 @@ def test_fused_pool_forward_backward(ops, d, B, n_parent, n):
 
 @pytest.mark.parametrize("B,n_src,k,n_dst,Cc,kind", [(3, 500, 16, 500, 8, "uniform"), (2, 1000, 1, 250, 512, "uniform"),
                                                      (2, 300, 32, 300, 64, "uniform"), (1, 2500, 16, 2500, 32, "dup"),
-                                                     (2, 200, 5, 77, 10, "uniform"), (1, 4096, 16, 4096, 16, "one")])
+                                                     (2, 200, 5, 77, 10, "uniform"), (1, 4096, 16, 4096, 16, "one"),
+                                                     (2, 3000, 16, 3000, 8, "near"), (1, 2000, 4, 300000, 4, "uniform")])
 def test_csr_transpose_and_segment_sum(ops, B, n_src, k, n_dst, Cc, kind):
     """rl_csr_build + rl_segment_sum_rows = the backward of torch.gather over a neighbour index, in a fixed order:
     segments hold exactly the gatherers of each point, ascending; sums equal scatter_add_ up to fp32 ordering; two
-    runs are bitwise equal.  "dup" / "one": duplicate-heavy graphs (predict.py's warm-up cloud, modules.py ties) where
+    runs are bitwise equal.  The last case (300000 destinations) is beyond the two-level sort's packing and takes the
+    per-entry-atomics path.  "dup" / "one": duplicate-heavy graphs (predict.py's warm-up cloud, modules.py ties) where
     a few points are gathered by very many rows - the long-segment path."""
     torch.manual_seed(n_src + k)
     if kind == "uniform":
         idx = torch.randint(0, n_dst, (B, n_src, k), device=DEV, dtype=torch.int32)
+    elif kind == "near":       # like a K-NN graph: row i gathers from i's surroundings (buckets see their own tiles' entries)
+        idx = ((torch.arange(n_src, device=DEV).view(1, -1, 1) + torch.randint(-40, 41, (B, n_src, k), device=DEV)) % n_dst).to(torch.int32)
     elif kind == "dup":
         idx = torch.randint(0, 30, (B, n_src, k), device=DEV, dtype=torch.int32)        # 30 targets take everything
     else:
