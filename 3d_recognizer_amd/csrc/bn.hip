@@ -69,6 +69,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     }
 }
 
+// (nslots, 2, C) partials -> (2, C) totals, one wavefront per channel, fixed order: the piece a data-parallel caller
+// all-reduces between ranks in the SyncBN / equivalence mode before rl_bn_finalize / rl_bn_bwd_finalize (nslots = 1)
+__global__ __launch_bounds__(256) void bn_reduce_slots_kernel(const double* __restrict__ stats, int nslots, int C,
+                                                              double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s, q;
+    slot_sums(stats, nslots, C, c, lane, s, q);
+    if (lane == 0) {
+        out[c] = s;
+        out[C + c] = q;
+    }
+}
+
 struct BwdParams {
     float* G;
     const float* Y;
@@ -431,6 +446,13 @@ extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, in
                        (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, training,
                        scale, shift, save_mean, save_invstd);
     RL_LAUNCH_CHECK("rl_bn_finalize");
+    return RL_OK;
+}
+
+extern "C" int rl_bn_reduce_slots(const double* stats, int nslots, int C, double* out, void* stream) {
+    RL_REQUIRE(stats && out && nslots > 0 && C > 0, RL_ERR_ARGS, "rl_bn_reduce_slots: bad arguments");
+    hipLaunchKernelGGL(bn_reduce_slots_kernel, dim3(rl_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, stats, nslots, C, out);
+    RL_LAUNCH_CHECK("rl_bn_reduce_slots");
     return RL_OK;
 }
 

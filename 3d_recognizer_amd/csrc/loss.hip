@@ -81,26 +81,32 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
         work[(long)blockIdx.x * rs + e] = accw[0][e] + accw[1][e] + accw[2][e] + accw[3][e];
 }
 
-__global__ __launch_bounds__(256) void loss_finalize_kernel(double* __restrict__ work, int nslots, int B, int C, int N,
+// mode bit 0: sum the slots into the totals record; bit 1: form the loss / counts from the totals record (between the
+// two a data-parallel caller may all-reduce the totals record: the "global batch" loss of the equivalence mode)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(double* __restrict__ work, int nslots, double points, int C,
                                                             int kind, float alpha, float gamma, int neglect,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, int mode) {
     __shared__ double tot[5 * LS_MAXC + 1];
     const int rs = rec_size(C);
     // one wavefront per record entry, lanes stride over the slots (fixed order -> deterministic)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = wave; e < rs; e += 4) {
         double s = 0.0;
-        for (int i = lane; i < nslots; i += 64) s += work[(long)i * rs + e];
-        s = rl_wave_sum(s);
+        if (mode & 1) {
+            for (int i = lane; i < nslots; i += 64) s += work[(long)i * rs + e];
+            s = rl_wave_sum(s);
+        } else {
+            s = work[(long)RL_MAX_SLOTS * rs + e];
+        }
         if (lane == 0) {
             tot[e] = s;
-            work[(long)RL_MAX_SLOTS * rs + e] = s;  // totals record, read by the backward kernel
+            if (mode & 1) work[(long)RL_MAX_SLOTS * rs + e] = s;  // totals record, read by the backward kernel
         }
     }
     __syncthreads();
+    if (!(mode & 2)) return;
     if (threadIdx.x == 0) {
         double loss;
-        const double points = (double)B * (double)N;
         if (kind == 2) {
             const int c0 = neglect ? 1 : 0;
             double acc = 0.0;
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(double* __restrict__
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                        int B, int C, int N, int kind, float alpha, float gamma, int neglect,
                                                        const double* __restrict__ totals, float grad_scale,
-                                                       float* __restrict__ dlogits) {
+                                                       double norm_points, float* __restrict__ dlogits) {
     __shared__ float cu[LS_MAXC], cw[LS_MAXC];  // dL/dp_c[n] = cu[c]*y_c[n] + cw[c]
     if (threadIdx.x < LS_MAXC) {
         float u = 0.f, w = 0.f;
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     }
     __syncthreads();
     const long total = (long)B * N;
-    const float invn = 1.f / (float)total;
+    const float invn = 1.f / (float)norm_points;          // the mean is over the GLOBAL batch in the equivalence mode
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long b = e / N;
         const long i = e - b * N;
@@ -248,38 +254,78 @@ static int loss_check(const char* who, const void* logits, const void* labels, i
     return RL_OK;
 }
 
+static int loss_forward_impl(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float alpha,
+                             float gamma, int neglect_background, double* work, double* out, int mode, double points,
+                             void* stream, const char* who) {
+    RL_REQUIRE(work, RL_ERR_ARGS, "%s: null work", who);
+    RL_REQUIRE(C > 0 && C <= LS_MAXC, RL_ERR_UNSUPPORTED, "%s: C=%d outside 1..%d classes", who, C, LS_MAXC);
+    RL_REQUIRE(kind >= 0 && kind <= 2, RL_ERR_ARGS, "%s: unknown loss kind %d", who, kind);
+    RL_REQUIRE(!(kind == 2 && neglect_background && C < 2), RL_ERR_ARGS, "%s: needs a foreground class", who);
+    hipStream_t st = (hipStream_t)stream;
+    int nslots = 0;
+    if (mode & 1) {
+        int rc = loss_check(who, logits, labels, B, C, N, kind);
+        if (rc) return rc;
+        nslots = rl_row_blocks_host((long)B * N, LS_ROWS);
+        hipLaunchKernelGGL(loss_fwd_kernel, dim3(nslots), dim3(256), 0, st, logits, labels, B, C, N, kind, gamma, work);
+        rl_note_kernel("loss_fwd_kernel");
+        RL_LAUNCH_CHECK(who);
+    }
+    if (mode & 2) RL_REQUIRE(out && points > 0, RL_ERR_ARGS, "%s: null out / bad point count", who);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, work, nslots, points, C, kind, alpha, gamma,
+                       neglect_background, out, mode);
+    RL_LAUNCH_CHECK(who);
+    return RL_OK;
+}
+
 extern "C" int rl_loss_forward(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float alpha,
                                float gamma, int neglect_background, double* work, double* out, void* stream) {
-    int rc = loss_check("rl_loss_forward", logits, labels, B, C, N, kind);
+    return loss_forward_impl(logits, labels, B, C, N, kind, alpha, gamma, neglect_background, work, out, 3,
+                             (double)B * (double)N, stream, "rl_loss_forward");
+}
+
+extern "C" int rl_loss_partials(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float gamma,
+                                double* work, void* stream) {
+    return loss_forward_impl(logits, labels, B, C, N, kind, 0.5f, gamma, 0, work, nullptr, 1, 1.0, stream, "rl_loss_partials");
+}
+
+extern "C" int64_t rl_loss_totals_offset(int C) { return (int64_t)RL_MAX_SLOTS * (5 * C + 1); }
+
+extern "C" int rl_loss_from_totals(int64_t points_total, int C, int kind, float alpha, float gamma, int neglect_background,
+                                   double* work, double* out, void* stream) {
+    return loss_forward_impl(nullptr, nullptr, 0, C, 0, kind, alpha, gamma, neglect_background, work, out, 2,
+                             (double)points_total, stream, "rl_loss_from_totals");
+}
+
+static int loss_backward_impl(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float alpha,
+                              float gamma, int neglect_background, const double* work, float grad_scale,
+                              double norm_points, float* dlogits, void* stream) {
+    int rc = loss_check("rl_loss_backward", logits, labels, B, C, N, kind);
     if (rc) return rc;
-    RL_REQUIRE(work && out, RL_ERR_ARGS, "rl_loss_forward: null work/out");
-    RL_REQUIRE(!(kind == 2 && neglect_background && C < 2), RL_ERR_ARGS, "rl_loss_forward: needs a foreground class");
-    const int nslots = rl_row_blocks_host((long)B * N, LS_ROWS);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(nslots), dim3(256), 0, st, logits, labels, B, C, N, kind, gamma, work);
-    rl_note_kernel("loss_fwd_kernel");
-    RL_LAUNCH_CHECK("rl_loss_forward");
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, work, nslots, B, C, N, kind, alpha, gamma,
-                       neglect_background, out);
-    RL_LAUNCH_CHECK("rl_loss_finalize");
+    RL_REQUIRE(work && dlogits && norm_points > 0, RL_ERR_ARGS, "rl_loss_backward: null work/dlogits");
+    const long total = (long)B * N;
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    const double* totals = work + (long)RL_MAX_SLOTS * (5 * C + 1);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels, B, C, N, kind,
+                       alpha, gamma, neglect_background, totals, grad_scale, norm_points, dlogits);
+    rl_note_kernel("loss_bwd_kernel");
+    RL_LAUNCH_CHECK("rl_loss_backward");
     return RL_OK;
 }
 
 extern "C" int rl_loss_backward(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float alpha,
                                 float gamma, int neglect_background, const double* work, float grad_scale,
                                 float* dlogits, void* stream) {
-    int rc = loss_check("rl_loss_backward", logits, labels, B, C, N, kind);
-    if (rc) return rc;
-    RL_REQUIRE(work && dlogits, RL_ERR_ARGS, "rl_loss_backward: null work/dlogits");
-    const long total = (long)B * N;
-    long g = (total + 255) / 256;
-    if (g > 4096) g = 4096;
-    const double* totals = work + (long)RL_MAX_SLOTS * (5 * C + 1);
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels, B, C, N, kind,
-                       alpha, gamma, neglect_background, totals, grad_scale, dlogits);
-    rl_note_kernel("loss_bwd_kernel");
-    RL_LAUNCH_CHECK("rl_loss_backward");
-    return RL_OK;
+    return loss_backward_impl(logits, labels, B, C, N, kind, alpha, gamma, neglect_background, work, grad_scale,
+                              (double)B * (double)N, dlogits, stream);
+}
+
+extern "C" int rl_loss_backward_global(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float alpha,
+                                       float gamma, int neglect_background, const double* work, float grad_scale,
+                                       int64_t points_total, float* dlogits, void* stream) {
+    return loss_backward_impl(logits, labels, B, C, N, kind, alpha, gamma, neglect_background, work, grad_scale,
+                              (double)points_total, dlogits, stream);
 }
 
 extern "C" int rl_softmax_cf(const float* logits, int B, int C, int N, float* out, void* stream) {

@@ -57,6 +57,8 @@ class Engine:
         self._side: Optional[torch.cuda.Stream] = None   # weight gradients run beside the dgrad chain
         # Dropout(fc_end): Philox mask keyed by (seed, pass counter); the counter lives on the device so that captured
         # graphs draw a new mask per replay.  The seed comes from torch's seed WITHOUT consuming its random stream.
+        # data-parallel equivalence mode: BatchNorm statistics of the global batch (ops.SyncGroup)
+        self.sync: Optional[ops.SyncGroup] = None
         self._drop_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self._drop_counter: Optional[torch.Tensor] = None
 
@@ -70,7 +72,7 @@ class Engine:
         scale, shift, mean, invstd = ops.bn_finalize(
             stats, out.rows, 128, out.C, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
             self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
-            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training)
+            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync)
         out.scale, out.shift, out.mean, out.invstd = scale, shift, mean, invstd
         out.act, out.slope, out.bn = act, slope, bn_name
 
@@ -280,7 +282,7 @@ class Engine:
                 if not ops.NO_RESID_BN and ops.resid_bn_supported(m2, sc):
                     # the junction's derivative and both BatchNorm backwards behind it in two sweeps
                     g2 = ops.resid_bn_backward(G, O.raw, 0.01, m2, sc, grads[f"{m2.bn}.weight"], grads[f"{m2.bn}.bias"],
-                                               grads[f"{sc.bn}.weight"], grads[f"{sc.bn}.bias"])
+                                               grads[f"{sc.bn}.weight"], grads[f"{sc.bn}.bias"], sync=self.sync)
                     ctx.bn_done.update((id(m2.raw), id(sc.raw)))
                 else:
                     ops.add_act_bwd(G, O.raw, 0.01)
@@ -336,7 +338,7 @@ class Engine:
         G, init = self._gbuf(ctx, out)
         assert init, f"no gradient reached {wname}"
         if out.scale is not None and id(out.raw) not in ctx.bn_done:
-            ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True)
+            ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True, sync=self.sync)
         n_out = out.C
         self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,
                                             grads[bname] if bname else None, pending=ctx.pending), G)

@@ -174,6 +174,7 @@ _SIGNATURES = {
     "rl_wgrad_nsplit": (_i, [_l, _i, _i]),
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
     "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rl_bn_reduce_slots": (_i, [_vp, _i, _i, _vp, _vp]),
     "rl_bn_bwd_slots": (_i, [_l]),
     "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),
     "rl_bn_bwd_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp]),
@@ -206,6 +207,10 @@ _SIGNATURES = {
     "rl_loss_work_doubles": (_l, [_l, _i]),
     "rl_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp]),
     "rl_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _f, _vp, _vp]),
+    "rl_loss_partials": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "rl_loss_totals_offset": (_l, [_i]),
+    "rl_loss_from_totals": (_i, [_l, _i, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "rl_loss_backward_global": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _f, _l, _vp, _vp]),
     "rl_softmax_cf": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rl_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _f, _f, _f, _f, _vp, _vp]),
 }

@@ -371,15 +371,46 @@ def new_stats(device, C: int) -> torch.Tensor:
     return torch.empty((H.MAX_SLOTS, 2, C), dtype=torch.float64, device=device)
 
 
+class SyncGroup:
+    """Data-parallel EQUIVALENCE mode: BatchNorm batch statistics and the loss' class sums are
+    all-reduced over the ranks, so that N ranks on shards of a batch compute exactly the single-process step on the whole
+    batch (up to fp32 summation order).  Not the throughput path: ~150 small collectives per step, no hipGraph.
+    `staged=True` moves the (tiny, float64) records through host memory - for backends without device collectives
+    (gloo rehearsals on a one-GPU box)."""
+
+    def __init__(self, world: int, group=None, staged: bool = False):
+        self.world, self.group, self.staged = world, group, staged
+
+    def allreduce(self, t: torch.Tensor) -> None:
+        import torch.distributed as dist
+        if self.staged:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
+def _stats_totals(stats: torch.Tensor, nslots: int, C: int) -> torch.Tensor:
+    out = torch.empty((1, 2, C), dtype=torch.float64, device=stats.device)
+    H.check(H.lib().rl_bn_reduce_slots(stats.data_ptr(), nslots, C, out.data_ptr(), _st()), "rl_bn_reduce_slots")
+    return out
+
+
 def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, nbt, momentum: float,
-                eps: float, training: bool):
+                eps: float, training: bool, sync: Optional[SyncGroup] = None):
     dev = gamma.device
+    nslots = H.row_blocks(rows, tile)
+    if training and sync is not None:            # batch statistics of the GLOBAL batch
+        stats = _stats_totals(stats, nslots, C)
+        sync.allreduce(stats)
+        nslots, rows = 1, rows * sync.world
     scale = torch.empty(C, dtype=F32, device=dev)
     shift = torch.empty(C, dtype=F32, device=dev)
     mean = torch.empty(C, dtype=F32, device=dev) if training else None
     invstd = torch.empty(C, dtype=F32, device=dev) if training else None
     _dev_check(stats, gamma, beta, rmean, rvar, nbt)
-    H.check(H.lib().rl_bn_finalize(H.ptr(stats), H.row_blocks(rows, tile), rows, C, H.ptr(gamma), H.ptr(beta),
+    H.check(H.lib().rl_bn_finalize(H.ptr(stats), nslots, rows, C, H.ptr(gamma), H.ptr(beta),
                                    H.ptr(rmean), H.ptr(rvar), H.ptr(nbt), momentum, eps, int(training),
                                    scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), _st()),
             "rl_bn_finalize")
@@ -398,8 +429,19 @@ def _bn_bwd_desc(G: torch.Tensor, g_bstride: int, y: Lazy) -> H.BnBwdDesc:
     return d
 
 
+def _bn_bwd_finalize(stats, slots: int, rows: int, Cc: int, dgamma, dbeta, coef, sync: Optional[SyncGroup]) -> None:
+    """dgamma / dbeta = this rank's sums; coef = the means the apply pass subtracts - of the GLOBAL batch with `sync`."""
+    H.check(H.lib().rl_bn_bwd_finalize(stats.data_ptr(), slots, rows, Cc, H.ptr(dgamma), H.ptr(dbeta), coef.data_ptr(), _st()),
+            "rl_bn_bwd_finalize")
+    if sync is not None:
+        tot = _stats_totals(stats, slots, Cc)
+        sync.allreduce(tot)
+        H.check(H.lib().rl_bn_bwd_finalize(tot.data_ptr(), 1, rows * sync.world, Cc, None, None, coef.data_ptr(), _st()),
+                "rl_bn_bwd_finalize")
+
+
 def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
-                training: bool) -> None:
+                training: bool, sync: Optional[SyncGroup] = None) -> None:
     """In place: G (gradient w.r.t. the activated value of `y`) becomes the gradient w.r.t. y.raw."""
     d = _bn_bwd_desc(G, y.bstride, y)
     if training and y.mean is not None:
@@ -408,9 +450,7 @@ def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta:
         d.stats = stats.data_ptr()
         with _rec("bn_bwd_reduce", (y.rows, y.C), 8 * y.rows * y.C, 0):
             H.check(H.lib().rl_bn_bwd_reduce(C.byref(d), _st()), "rl_bn_bwd_reduce")
-        H.check(H.lib().rl_bn_bwd_finalize(stats.data_ptr(), H.lib().rl_bn_bwd_slots(y.rows), y.rows, y.C,
-                                           H.ptr(dgamma), H.ptr(dbeta), coef.data_ptr(), _st()),
-                "rl_bn_bwd_finalize")
+        _bn_bwd_finalize(stats, H.lib().rl_bn_bwd_slots(y.rows), y.rows, y.C, dgamma, dbeta, coef, sync)
         d.coef = coef.data_ptr()
     with _rec("bn_bwd_apply", (y.rows, y.C), 12 * y.rows * y.C, 0):
         H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
@@ -421,7 +461,8 @@ def resid_bn_supported(y1: Lazy, y2: Lazy) -> bool:
     return dense and y1.C == y2.C and y1.rows == y2.rows and bool(H.lib().rl_resid_bn_bwd_supported(y1.rows, y1.C))
 
 
-def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, y2: Lazy, dgamma1, dbeta1, dgamma2, dbeta2):
+def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, y2: Lazy, dgamma1, dbeta1, dgamma2, dbeta2,
+                      sync: Optional[SyncGroup] = None):
     """Backward of O = LeakyReLU(BN1(y1) + BN2(y2)) down to the two raw tensors: G (dL/dO) becomes the gradient
     w.r.t. y1.raw in place, the returned tensor is the gradient w.r.t. y2.raw (modules.py:325 + two BatchNorm2d)."""
     _dev_check(G, O, y1.raw, y2.raw)
@@ -439,8 +480,8 @@ def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, 
     with _rec("resid_bn_bwd_reduce", (rows, Cc), 16 * rows * Cc, 0):
         H.check(H.lib().rl_resid_bn_bwd_reduce(C.byref(d), _st()), "rl_resid_bn_bwd_reduce")
     slots = H.lib().rl_bn_bwd_slots(rows)
-    H.check(H.lib().rl_bn_bwd_finalize(st1.data_ptr(), slots, rows, Cc, H.ptr(dgamma1), H.ptr(dbeta1), c1.data_ptr(), _st()), "rl_bn_bwd_finalize")
-    H.check(H.lib().rl_bn_bwd_finalize(st2.data_ptr(), slots, rows, Cc, H.ptr(dgamma2), H.ptr(dbeta2), c2.data_ptr(), _st()), "rl_bn_bwd_finalize")
+    _bn_bwd_finalize(st1, slots, rows, Cc, dgamma1, dbeta1, c1, sync)
+    _bn_bwd_finalize(st2, slots, rows, Cc, dgamma2, dbeta2, c2, sync)
     with _rec("resid_bn_bwd_apply", (rows, Cc), 24 * rows * Cc, 0):
         H.check(H.lib().rl_resid_bn_bwd_apply(C.byref(d), _st()), "rl_resid_bn_bwd_apply")
     return G2
@@ -732,8 +773,9 @@ LOSS_KINDS = {  # reference trainer.py:244-269
 
 
 def loss_forward(logits: torch.Tensor, labels: torch.Tensor, kind: int, alpha: float, gamma: float,
-                 neglect_background: bool = True, out: Optional[torch.Tensor] = None):
-    """Returns (out, work): out[0] = loss, out[1:] metric counts (doubles, on device)."""
+                 neglect_background: bool = True, out: Optional[torch.Tensor] = None, sync: Optional[SyncGroup] = None):
+    """Returns (out, work): out[0] = loss, out[1:] metric counts (doubles, on device).  With `sync` the class sums are
+    all-reduced first: the loss (and the counts) of the GLOBAL batch, identical on every rank."""
     _dev_check(logits, labels)
     B, Cc, N = logits.shape
     assert labels.shape == (B, N) and labels.dtype == torch.int64 and logits.dtype == F32
@@ -743,6 +785,14 @@ def loss_forward(logits: torch.Tensor, labels: torch.Tensor, kind: int, alpha: f
     else:
         _dev_check(out)
         assert out.dtype == torch.float64 and out.numel() == 1 + 4 * Cc
+    if sync is not None:
+        H.check(H.lib().rl_loss_partials(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, gamma, work.data_ptr(), _st()),
+                "rl_loss_partials")
+        o = H.lib().rl_loss_totals_offset(Cc)
+        sync.allreduce(work[o:o + 5 * Cc + 1])
+        H.check(H.lib().rl_loss_from_totals(B * N * sync.world, Cc, kind, alpha, gamma, int(neglect_background),
+                                            work.data_ptr(), out.data_ptr(), _st()), "rl_loss_from_totals")
+        return out, work
     with _rec("loss", (B, Cc, N), 4 * B * Cc * N + 8 * B * N, 0):
         H.check(H.lib().rl_loss_forward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
                                         int(neglect_background), work.data_ptr(), out.data_ptr(), _st()),
@@ -751,9 +801,14 @@ def loss_forward(logits: torch.Tensor, labels: torch.Tensor, kind: int, alpha: f
 
 
 def loss_backward(logits, labels, kind: int, alpha: float, gamma: float, neglect_background: bool, work,
-                  grad_scale: float = 1.0) -> torch.Tensor:
+                  grad_scale: float = 1.0, sync: Optional[SyncGroup] = None) -> torch.Tensor:
     B, Cc, N = logits.shape
     dlogits = torch.empty_like(logits)
+    if sync is not None:
+        H.check(H.lib().rl_loss_backward_global(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
+                                                int(neglect_background), work.data_ptr(), grad_scale, B * N * sync.world,
+                                                dlogits.data_ptr(), _st()), "rl_loss_backward_global")
+        return dlogits
     with _rec("loss", (B, Cc, N), 8 * B * Cc * N + 8 * B * N, 0):
         H.check(H.lib().rl_loss_backward(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
                                          int(neglect_background), work.data_ptr(), grad_scale, dlogits.data_ptr(),

@@ -104,8 +104,15 @@ class TrainStep:
     packed loss/metric record in `self.out` (device) / `self.out_host` (pinned, asynchronous)."""
 
     def __init__(self, module, B: int, N: int, loss: str = "dice", lr: float = 1e-2, use_graph: bool = True,
-                 process_group=None, world_size: int = 1, state: Optional[TrainState] = None):
+                 process_group=None, world_size: int = 1, state: Optional[TrainState] = None,
+                 sync: Optional[ops.SyncGroup] = None):
+        """sync: the data-parallel EQUIVALENCE mode - BatchNorm batch statistics and the loss' class
+        sums of the GLOBAL batch (all-reduced), gradients summed instead of averaged: N ranks on shards reproduce the
+        single-process step on the whole batch.  Eager launches only (collectives between kernels)."""
         self.state = state if state is not None else TrainState(module, lr, process_group, world_size)
+        self.sync = sync
+        if sync is not None:
+            use_graph = False
         st = self.state
         self.module = module
         self.dev = st.dev
@@ -134,16 +141,25 @@ class TrainStep:
 
     # -- the schedule ------------------------------------------------------------------------
     def _fwd_bwd(self):
-        logits, ctx = self.engine.forward(self.inp, self.perm, True, self.p_drop)
-        _, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True, out=self.out)
-        dlogits = ops.loss_backward(logits, self.labels, self.kind, self.alpha, self.gamma, True, work)
-        self.engine.backward(ctx, dlogits, self.flat.grads)
+        self.engine.sync = self.sync
+        try:
+            logits, ctx = self.engine.forward(self.inp, self.perm, True, self.p_drop)
+            _, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True, out=self.out, sync=self.sync)
+            dlogits = ops.loss_backward(logits, self.labels, self.kind, self.alpha, self.gamma, True, work, sync=self.sync)
+            self.engine.backward(ctx, dlogits, self.flat.grads)
+        finally:
+            self.engine.sync = None
 
     def _adam(self):
+        # per-rank losses are averaged (grad / world); the equivalence mode's loss is already the global one (grad summed)
         ops.adam_step(self.flat.param, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
-                      grad_scale=1.0 / self.world)
+                      grad_scale=1.0 if self.sync is not None else 1.0 / self.world)
 
     def _allreduce(self):
+        if self.sync is not None:
+            if self.sync.world > 1:
+                self.sync.allreduce(self.flat.grad)
+            return
         sync_gradients(self.flat.grad, self.world, self.pg)
 
     def capture(self, warmup: int = 2) -> None:
@@ -212,7 +228,7 @@ class TrainStep:
         """Synchronises and unpacks the record of the last step (reference metrics.py:8-59).  With several
         ranks the counts are summed and the loss averaged over the ranks first."""
         from .utils.metrics import accuracy_from_counts, iou_from_counts
-        if self.world > 1:
+        if self.world > 1 and self.sync is None:
             import torch.distributed as dist
             rec_dev = self.out.clone()
             dist.all_reduce(rec_dev, op=dist.ReduceOp.SUM, group=self.pg)

@@ -74,20 +74,44 @@ class Trainer:
 
     _get_loss = staticmethod(get_loss)
 
+    # The step machinery behind train(); class attributes so that the multi-rank control flow can be exercised on CPU
+    # with stand-ins (tests/test_ddp_gloo.py).  The real ones need the MI355X.
+    @staticmethod
+    def _make_state(model, lr, world):
+        from .._train import TrainState
+        return TrainState(model, lr, None, world)
+
+    @staticmethod
+    def _make_stepper(model, B, N, loss, use_graph, state):
+        from .._train import TrainStep
+        return TrainStep(model, B, N, loss=loss, use_graph=use_graph, state=state)
+
     def train(self, model: RandLANet, settings: TrainingSettings,
               callbacks: List[Callable[[int, Dict[str, float]], None]] = []) -> RandLANet:
         """Reference semantics (trainer.py:62-168): Adam(lr) + StepLR(10, decay), per-batch forward / loss /
         backward / step / metrics, per-epoch validation, early stopping on val_mIoU, best weights returned.
         The inner step runs as the fused HIP schedule (`_train.TrainStep`): full batches replay a captured
         hipGraph, a ragged last batch runs the same schedule eagerly; parameters, gradients and Adam moments
-        live in flat buffers shared by both.  With torch.distributed initialised every rank trains on its
-        shard and gradients are all-reduced once per step."""
-        from .._train import TrainState, TrainStep
+        live in flat buffers shared by both.
+
+        With torch.distributed initialised every rank trains on its shard of every batch and the gradients are
+        all-reduced once per step.  The replicas are kept in lock-step: rank 0's parameters and BatchNorm buffers
+        are broadcast before the first step; a batch with fewer clouds than ranks is skipped on ALL ranks (a rank
+        without clouds would miss the gradient all-reduce the others wait in); before every validation the
+        BatchNorm running statistics - which each rank updates from its own shard - are averaged over the ranks,
+        so every rank validates the same model; the early-stopping decision and the choice of the best weights
+        follow rank 0's monitored metric on every rank."""
+        from .._train import broadcast_flat, shard_range
         world, rank = 1, 0
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world, rank = torch.distributed.get_world_size(), torch.distributed.get_rank()
-        state = TrainState(model, settings.learning_rate, None, world)
-        steppers: Dict[tuple, TrainStep] = {}
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(), dist.get_rank()
+        state = self._make_state(model, settings.learning_rate, world)
+        if world > 1:
+            broadcast_flat(state.flat.param, world)
+            for _, buf in model.named_buffers():
+                dist.broadcast(buf, 0)
+        steppers: Dict[tuple, object] = {}
         patience = settings.early_stopping_patience if settings.early_stopping else settings.epochs
         stopper = EarlyStopper(patience=patience, metric="val_mIoU")
         model.train()
@@ -96,17 +120,22 @@ class Trainer:
         writer = _summary_writer(self._log_dir) if rank == 0 else None
         full_batch = self._train_dataloader.batch_size
         lr = settings.learning_rate
+        warned_short = False
         for epoch in range(1, settings.epochs + 1):
             collected = MetricCollector(self._class_names)
             for batch, labels, _ in tqdm(self._train_dataloader, desc="Training", leave=False, disable=rank != 0):
                 if world > 1:           # clouds are independent: each rank takes its contiguous shard
-                    from .._train import shard_range
+                    if batch.shape[0] < world:
+                        if not warned_short and rank == 0:
+                            logger.warning(f"A batch of {batch.shape[0]} clouds cannot be shared by {world} ranks: skipped.")
+                        warned_short = True
+                        continue
                     part = shard_range(batch.shape[0], rank, world)
                     batch, labels = batch[part.start:part.stop], labels[part.start:part.stop]
                 key = (batch.shape[0], batch.shape[1])
                 if key not in steppers:
-                    steppers[key] = TrainStep(model, key[0], key[1], loss=settings.loss_function,
-                                              use_graph=(key[0] == full_batch or world > 1), state=state)
+                    steppers[key] = self._make_stepper(model, key[0], key[1], settings.loss_function,
+                                                       (key[0] == full_batch or world > 1), state)
                     steppers[key].capture()
                     model.train()
                 stepper = steppers[key]
@@ -118,10 +147,19 @@ class Trainer:
             if epoch % 10 == 0:                                  # StepLR(step_size=10, gamma) (trainer.py:81-83)
                 lr *= settings.learning_rate_decay
                 state.set_lr(lr)
+            if world > 1:               # every rank validates the same model: average the per-shard running statistics
+                for _, buf in model.named_buffers():
+                    if buf.is_floating_point():
+                        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                        buf.div_(world)
             validation = Trainer.evaluate(model, self._validation_dataloader, class_names=self._class_names,
                                           loss_function=settings.loss_function)
             metrics = collected.as_dict()
             metrics.update(validation.as_dict("val"))
+            if world > 1:               # one decision for all ranks: rank 0's monitored value
+                monitored = torch.tensor([float(metrics["val_mIoU"])], dtype=torch.float64, device=model.device)
+                dist.broadcast(monitored, 0)
+                metrics["val_mIoU"] = float(monitored.item())
             keep_going = stopper.check(metrics, model)
             if rank == 0:
                 self._log(epoch, settings.epochs, lr, collected.as_dict(), validation.as_dict(include_stdev=True), writer)

@@ -265,6 +265,10 @@ typedef struct rl_bn_bwd_desc {
     const float* coef;  /* apply: in, 2*C floats, or NULL */
 } rl_bn_bwd_desc;
 
+/* (nslots, 2, C) per-workgroup partials -> (2, C) totals in slot order.  SyncBN / equivalence mode: the caller
+ * all-reduces the totals over the ranks and passes them on as ONE slot with the global row count
+ * (rl_bn_finalize / rl_bn_bwd_finalize with nslots = 1).                                             */
+int rl_bn_reduce_slots(const double* stats, int nslots, int C, double* out, void* stream);
 int rl_bn_bwd_slots(int64_t rows);
 int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream);
 int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, float* dgamma,
@@ -510,6 +514,20 @@ int rl_loss_forward(const float* logits, const int64_t* labels, int B, int C, in
 int rl_loss_backward(const float* logits, const int64_t* labels, int B, int C, int N, int kind,
                      float alpha, float gamma, int neglect_background, const double* work,
                      float grad_scale, float* dlogits, void* stream);
+
+/* The same loss in two steps, for the data-parallel EQUIVALENCE mode (the dice ratio of the global
+ * batch is not the mean of per-rank dice ratios): rl_loss_partials runs the pass over the logits and leaves this
+ * rank's sums in the totals record, 5*C+1 doubles at work + rl_loss_totals_offset(C); the caller all-reduces that
+ * record (SUM) over the ranks; rl_loss_from_totals forms the loss and the metric counts from it with the GLOBAL
+ * point count; rl_loss_backward_global is rl_loss_backward normalised by the global point count.               */
+int rl_loss_partials(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float gamma,
+                     double* work, void* stream);
+int64_t rl_loss_totals_offset(int C);
+int rl_loss_from_totals(int64_t points_total, int C, int kind, float alpha, float gamma, int neglect_background,
+                        double* work, double* out, void* stream);
+int rl_loss_backward_global(const float* logits, const int64_t* labels, int B, int C, int N, int kind, float alpha,
+                            float gamma, int neglect_background, const double* work, float grad_scale,
+                            int64_t points_total, float* dlogits, void* stream);
 
 /* Softmax over the class axis of (B,C,N) logits -> confidences (model.py:137, 229).         */
 int rl_softmax_cf(const float* logits, int B, int C, int N, float* out, void* stream);
