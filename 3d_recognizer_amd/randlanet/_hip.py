@@ -162,6 +162,7 @@ _SIGNATURES = {
     "rl_row_blocks": (_i, [_l, _i]),
     "rl_knn_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "rl_knn_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
+    "rl_knn_f32_cpu": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "rl_knn_multi_workspace_bytes": (_l, [C.POINTER(KnnTask), _i, _i]),
     "rl_knn_multi": (_i, [C.POINTER(KnnTask), _i, _i, _vp, _l, _vp]),

@@ -86,8 +86,11 @@ class Model:
     # --------------------------------------------------------------------------- inference
     def upsample(self, logits: torch.Tensor, xyz: torch.Tensor, xyz_upsampled: torch.Tensor) -> torch.Tensor:
         """Softmax confidences of `logits` (B,C,N1) carried to `xyz_upsampled` (B,N2,3) -> (B,C,N2)."""
-        with torch.cuda.device(self.device):
-            conf = ops.softmax_cf(logits.to(self.device, torch.float32).contiguous())
+        if self.device.type != "cuda":
+            conf = torch.softmax(logits.to("cpu", torch.float32), dim=1)
+        else:
+            with torch.cuda.device(self.device):
+                conf = ops.softmax_cf(logits.to(self.device, torch.float32).contiguous())
         return self._upsampler(conf.unsqueeze(3), xyz, xyz_upsampled).squeeze(-1)
 
     def _knn_advice(self) -> None:
@@ -135,8 +138,11 @@ class Model:
             else:
                 logits = self._model(full.to(self._model.device))
                 # (the reference returns a device tensor in this branch, against its own annotation)
-                with torch.cuda.device(logits.device):
-                    out = ops.softmax_cf(logits.contiguous()).cpu().numpy()
+                if logits.is_cuda:
+                    with torch.cuda.device(logits.device):
+                        out = ops.softmax_cf(logits.contiguous()).cpu().numpy()
+                else:
+                    out = torch.softmax(logits, dim=1).numpy()
         return out if batched else out[0]
 
     # ---------------------------------------------------------------------------- training

@@ -24,9 +24,21 @@ def _device_of(*ts) -> torch.device:
     return torch.device("cuda")
 
 
-def knn_exact(xyz: torch.Tensor, xyz_query: torch.Tensor, n_neighbors: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def knn_exact(xyz: torch.Tensor, xyz_query: torch.Tensor, n_neighbors: int, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(B,N',3),(B,N,3) -> neighbours int64 (B,N,K), squared distances fp32 (B,N,K), ascending,
-    ties by lowest index; results live on the device."""
+    ties by lowest index; results live on the device.  `device` = the owning module's device: a module placed on the
+    CPU searches on the host."""
+    on_host = (device is not None and torch.device(device).type != "cuda") or \
+        (not xyz.is_cuda and not xyz_query.is_cuda and not torch.cuda.is_available())
+    if on_host:
+        # a box without a HIP device: the library's host twin (rl_knn_f32_cpu), as the reference's CPU-only knn_tpk.knn
+        from .._cpu import knn_host
+        try:
+            return knn_host(xyz, xyz_query, int(n_neighbors))
+        except H.HipKernelError as e:
+            if "Not enough points" in str(e):
+                raise RuntimeError(f"Not enough points in support to find {n_neighbors} neighboors") from e
+            raise
     dev = _device_of(xyz, xyz_query)
     s = xyz.to(dev, torch.float32).contiguous()
     q = xyz_query.to(dev, torch.float32).contiguous()

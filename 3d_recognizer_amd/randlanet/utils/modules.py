@@ -116,7 +116,7 @@ class KNN(nn.Module):
         if approach not in _KNN_CHOICES:
             raise ValueError(f"KNN approach {approach} not understood!")
         from .knn import knn_exact
-        neighbors, d2 = knn_exact(xyz.to(self._device), xyz_query.to(self._device), n_neighbors)
+        neighbors, d2 = knn_exact(xyz.to(self._device), xyz_query.to(self._device), n_neighbors, device=self._device)
         return neighbors, torch.sqrt(d2)
 
 
@@ -206,7 +206,15 @@ class RandLANet(nn.Module):
         assert N >= self._min_n_points, \
             f"Input point cloud should have at least {self._min_n_points} points!"
         if self._device.type != "cuda":
-            raise H.HipKernelError("RandLANet runs on an MI355X (HIP) device only: there is no CPU path in this build")
+            # the model was PLACED on the CPU (use_gpu=False, or a box without a HIP device - the reference's device
+            # choice, model.py:38-40): host inference path; never a fallback for a failing HIP library on a GPU
+            if self.training:
+                raise H.HipKernelError("training runs on an MI355X (HIP) device only; the CPU device does inference")
+            from .._cpu import HostForward
+            s = self._settings
+            host = HostForward(s.layer_sizes, s.n_neighbors, s.decimation,
+                               {k: v.detach() for k, v in self.named_parameters()}, dict(self.named_buffers()))
+            return host(input.to("cpu", torch.float32), np.random.permutation(N))
         inp = input.to(self._device, torch.float32).contiguous()
         perm = torch.from_numpy(np.random.permutation(N)).to(self._device)
         p_drop = float(self.fc_end[2].p)

@@ -15,7 +15,8 @@ def upsample_features(approach: str, features: torch.Tensor, xyz: torch.Tensor, 
     if approach not in _POWER:
         raise ValueError(f"Upsampling approach {approach} not understood!")
     if torch.device(device).type != "cuda":
-        raise H.HipKernelError("UpSampler needs an MI355X (HIP) device: there is no CPU path in this build")
+        from .._cpu import upsample_host          # the module lives on the CPU device (model.py:38-40): host twin
+        return upsample_host(approach, features, xyz, xyz_upsampled)
     power = _POWER[approach]
     k = 1 if power == 0 else 8                                        # modules.py:371
     f = features.to(device, torch.float32)

@@ -87,6 +87,12 @@ int rl_knn_f32(const float* support, const float* query, int B, int Ns, int Nq, 
                int64_t* idx_out, float* d2_out, void* workspace, int64_t workspace_bytes,
                void* stream);
 
+/* Host twin: the same search on the calling host, HOST pointers, no GPU involved, synchronous (queries are split over
+ * the hardware threads).  Same contract and error codes; backs the package's CPU device (reference model.py:38-40
+ * falls back to the CPU when there is no GPU: config P, predict.py on a GPU-less box).                         */
+int rl_knn_f32_cpu(const float* support, const float* query, int B, int Ns, int Nq, int k,
+                   int64_t* idx_out, float* d2_out);
+
 /* Same search with int32 indices and batch strides (in points), used inside the network:
  * cloud b of the support starts at support + b*support_bstride*3.                          */
 int rl_knn_i32(const float* support, int64_t support_bstride, const float* query,

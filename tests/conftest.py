@@ -46,3 +46,6 @@ def _build_oracle():
     src = os.path.join(REPO, "oracle", "knn_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle")])
+
+# progress bars of the trainer (tqdm, as in the reference) only clutter captured test output
+os.environ.setdefault("TQDM_DISABLE", "1")

@@ -95,9 +95,12 @@ def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step():
     off, worst = 0, 0.0
     for name, n in layout:
         a, b = g0[off:off + n], ref_grad[off:off + n]
-        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
-        worst = max(worst, err)
-        assert err < 2e-4, (name, err)
+        # (a bias in front of a BatchNorm has an exactly-zero gradient: rounding noise on both sides, hence the floor)
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        if scale > 1e-6:
+            worst = max(worst, err / scale)
+        assert err < 2e-4 * scale + 1e-7, (name, err, scale)
         off += -(-n // 4) * 4
     # BatchNorm running statistics: global-batch statistics on every rank
     for k, v in ref_bufs.items():

@@ -53,8 +53,19 @@ def test_forward_asserts_and_no_cpu_path():
         net(torch.zeros(1, 2048, 4))
     with pytest.raises(AssertionError, match="at least 1024 points"):
         net(torch.zeros(1, 100, 3))
-    with pytest.raises(_hip.HipKernelError, match="no CPU path"):
+    # a module placed on the CPU device: training is refused, eval runs the host path - which lives in the same
+    # library (rl_knn_f32_cpu): without librandla_hip.so it fails loudly, there is no pure-Python stand-in
+    with pytest.raises(_hip.HipKernelError, match="training runs on an MI355X"):
         net(torch.zeros(1, 2048, 3))
+    net.eval()
+    lib, path = _hip._LIB, _hip._LIB_PATH
+    try:
+        _hip._LIB, _hip._LIB_PATH = None, "/nonexistent/librandla_hip.so"
+        with pytest.raises(_hip.HipKernelError, match="no fallback"):
+            net(torch.rand(1, 2048, 3))
+    finally:
+        _hip._LIB, _hip._LIB_PATH = lib, path
+    assert net(torch.rand(1, 2048, 3)).shape == (1, 2, 2048)
     with pytest.raises(_hip.HipKernelError, match="parameters only"):
         net.encoder[0].mlp1(torch.zeros(1, 8, 4, 1))
 
@@ -111,3 +122,116 @@ def test_sampling_and_augmentation_consume_the_rng_like_the_reference():
     radius = np.mean(np.linalg.norm(j - j.mean(0, keepdims=True), axis=1))
     j = j + radius * np.random.uniform(-s.shift_limit, s.shift_limit, 3)
     np.testing.assert_allclose(out, j, rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The package's CPU device (reference model.py:38-40; config P = predict.py without a GPU): product-own host path.
+def test_host_knn_twin_matches_reference_golden(golden_dir):
+    """rl_knn_f32_cpu against the outputs of the COMPILED reference knn_tpk.knn (tests/golden/knn_cases.npz) under the
+    parity rule of SURVEY 8a-3 (d2 bit-equal everywhere, index equal wherever the distance is unique in its row, ties in
+    ascending index order), plus queries far outside the support's bounding box and k = Ns."""
+    import numpy as np
+    import torch
+    from knn_parity import check_knn
+    from randlanet._cpu import knn_host
+    z = np.load(f"{golden_dir}/knn_cases.npz")
+    tags = sorted({k.split("/")[0] for k in z.files if k.endswith("/idx")})
+    assert len(tags) >= 14
+    for t in tags:
+        data = str(z[f"{t}/data"])
+        sup = z[f"{data}/support"]
+        qry = z[f"{data}/query"] if f"{data}/query" in z.files else sup
+        idx, d2 = knn_host(torch.from_numpy(sup)[None], torch.from_numpy(qry)[None], int(z[f"{t}/k"]))
+        frac = check_knn(idx[0].numpy(), d2[0].numpy(), z[f"{t}/idx"], z[f"{t}/d2"], sup, qry, expect_lowest_index=True)
+        if t.startswith("uniform") or t.startswith("cross"):
+            assert frac == 1.0, t
+    rs = np.random.RandomState(3)
+    s = torch.from_numpy(rs.normal(0, 1, (2, 700, 3)).astype(np.float32))
+    q = torch.from_numpy(rs.normal(0, 4, (2, 300, 3)).astype(np.float32))        # most queries outside the support's box
+    for k in (1, 8, 700):
+        idx, d2 = knn_host(s, q, k)
+        full = ((q[:, :, None, :] - s[:, None, :, :]) ** 2)
+        ref = ((full[..., 0] + full[..., 1]) + full[..., 2])
+        rd, ri = torch.sort(ref, dim=-1, stable=True)
+        assert torch.equal(d2, rd[..., :k]) and torch.equal(idx, ri[..., :k])
+    import pytest
+    from randlanet import _hip
+    with pytest.raises(_hip.HipKernelError, match="Not enough points"):
+        knn_host(s[:, :5], q, 6)
+
+
+def test_cpu_device_predict_matches_reference_golden(golden_dir):
+    """Model.load(..., use_gpu=False).predict on the reference-written model zip: the confidences of the reference's own
+    CPU run (tests/golden/model_predict.npz), through the host path (HostForward + rl_knn_f32_cpu + upsample_host)."""
+    from pathlib import Path
+
+    import numpy as np
+    from randlanet import Model
+    from randlanet.utils.modules import UpSampler
+    z = np.load(f"{golden_dir}/model_predict.npz")
+    model = Model.load(Path(golden_dir) / "ref_model_small.zip", use_gpu=False)
+    assert model.device.type == "cpu" and model.module.device.type == "cpu"
+    cloud = z["cloud"]
+    for up in ("nni", "idw"):
+        model.settings.upsampling = up
+        model._upsampler = UpSampler(up, model.device)
+        np.random.seed(123)
+        conf = model.predict(cloud)
+        assert isinstance(conf, np.ndarray) and conf.shape == (2, 5000)
+        np.testing.assert_allclose(conf.sum(0), 1.0, atol=1e-5)
+        bad = np.abs(conf - z[f"conf_{up}"]).max(0) > 1e-3          # exact-distance ties of the real depth cloud
+        print(f"cpu device, {up}: {bad.mean():.4%} of the points differ by more than 1e-3 from the reference")
+        assert bad.mean() < 0.02, (up, bad.mean())
+    np.random.seed(123)
+    raw = model.predict(cloud[:600], prepostprocess=False)
+    assert np.mean(np.abs(np.asarray(raw) - z["conf_raw"]).max(0) > 1e-3) < 0.02
+    # training stays a GPU matter, loudly
+    import pytest
+    import torch
+    from randlanet import _hip
+    model.module.train()
+    with pytest.raises(_hip.HipKernelError, match="training runs on an MI355X"):
+        model.module(torch.zeros(1, 600, 3))
+
+
+def test_broaden_annotation_is_bit_identical_to_the_reference_loop():
+    """the vectorised broaden_annotation against the reference's loop (dataset.py:8-18) restated with `bool`
+    for the removed `np.bool` - float32 and float64 clouds, several radii, empty annotation."""
+    import numpy as np
+    from randlanet.utils.annotation import broaden_annotation
+
+    def reference_loop(point_cloud, annotation, radius=0.01):
+        output = []
+        annotation_cloud = point_cloud[annotation.astype(bool)]
+        for annotation_point in annotation_cloud:
+            ds = np.abs(np.linalg.norm(annotation_point - point_cloud, axis=1))
+            output.append(ds < radius)
+        return np.logical_or.reduce(output).astype(np.uint8)
+
+    rs = np.random.RandomState(0)
+    for dtype in (np.float32, np.float64):
+        cloud = rs.uniform(0, 0.3, (6000, 3)).astype(dtype)
+        cloud[100:140] = cloud[100]                      # duplicates
+        ann = (rs.uniform(size=6000) < 0.01).astype(np.uint8)
+        for radius in (0.01, 0.02, 0.0):
+            got, ref = broaden_annotation(cloud, ann, radius), reference_loop(cloud, ann, radius)
+            assert got.dtype == ref.dtype == np.uint8 and np.array_equal(got, ref), (dtype, radius)
+            if radius > 0:
+                assert got.sum() > ann.sum()
+    assert np.array_equal(broaden_annotation(cloud, np.zeros(6000, np.uint8)), reference_loop(cloud, np.zeros(6000, np.uint8)))
+
+
+def test_reference_loads_a_zip_written_by_this_package():
+    """SURVEY 8f-4, the reverse direction: tests/golden/ref_loads_our_zip.py (build container only: the reference tree
+    and its compiled KNN must be present; elsewhere the test is skipped, nothing here reads /root/reference at run time
+    on the GPU box)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (os.path.isdir("/root/reference/randlanet") and os.path.exists(os.path.join(repo, "oracle", "_ref", "knn_tpk.so"))):
+        pytest.skip("needs the reference tree (build container)")
+    out = subprocess.run([sys.executable, os.path.join(repo, "tests", "golden", "ref_loads_our_zip.py")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "state_dict entries identical" in out.stdout
