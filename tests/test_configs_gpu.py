@@ -44,6 +44,75 @@ def test_full_size_eval_logits_match_oracle(tag, C, N, K, layers):
     assert torch.equal(logits.argmax(1), ref.argmax(1)) or float((logits.argmax(1) != ref.argmax(1)).float().mean()) < 1e-4
 
 
+@pytest.mark.parametrize("tag,C,N,K,layers,B", [
+    ("A", 2, 40960, 16, [16, 64, 128, 256], 4),          # the workload bench.py times (config A: 4 clouds per GPU)
+    ("S", 13, 65536, 16, [16, 64, 128, 256, 512], 1),
+    ("Kt", 20, 122880, 16, [16, 64, 128, 256], 1),
+])
+def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, layers, B):
+    """The path bench.py times, at its own size: _train.TrainStep's forward + dice + backward (fused pooling incl.
+    d = 128, split-K, the deferred slab reducer, residual-junction BatchNorm fusion, the CSR gather backward) against the
+    oracle's train-mode forward + autograd - loss, every parameter gradient (5e-3 relative), train-mode logits (1e-3) -
+    in the default bf16x3 arithmetic and, for config A, once more in the fp32 mode."""
+    from oracle import randlanet_oracle as O
+    from oracle.loss_metrics_oracle import loss_by_name
+    from randlanet import _ops as ops
+    from randlanet._train import TrainStep
+    net, sd = _pair(C, N, K, layers, seed=23)
+    net.fc_end[2].p = 0.0
+    rs = np.random.RandomState(6)
+    x = rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    inside = np.linalg.norm(x - 0.5, axis=-1) < 0.3
+    y = np.where(inside, np.clip(1 + np.floor((C - 1) * x[..., 2]).astype(np.int64), 1, C - 1), 0).astype(np.int64)
+    perm = np.random.RandomState(9).permutation(N)
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+         for k, v in sd.items()}
+    ref = O.forward(P, torch.from_numpy(x), perm, layer_sizes=layers, n_neighbors=K, training=True, dropout_p=0.0)
+    ref_loss = loss_by_name("dice", ref, torch.from_numpy(y))
+    ref_loss.backward()
+    modes = ["bf16x3", "fp32"] if tag == "A" else ["bf16x3"]
+    default = ops.get_wide_gemm()
+    try:
+        for mode in modes:
+            ops.set_wide_gemm(mode)
+            net.load_state_dict(sd)
+            net.train()
+            st = TrainStep(net, B, N, loss="dice", use_graph=False)
+            st.set_batch(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV))
+            st.perm.copy_(torch.from_numpy(perm).to(DEV))
+            st._fwd_bwd()
+            torch.cuda.synchronize()
+            loss = float(st.out[0])
+            assert abs(loss - float(ref_loss)) < 2e-5, (tag, mode, loss, float(ref_loss))
+            worst = 0.0
+            for name, p in net.named_parameters():
+                r = P[name].grad
+                g = st.flat.grads[name].cpu()
+                scale = float(r.abs().max())
+                e = float((g - r).abs().max())
+                if scale > 1e-4:
+                    worst = max(worst, e / scale)
+                # conv biases in front of a BatchNorm have a zero true gradient: rounding noise on both sides
+                assert e < 5e-3 * scale + 2e-5, (tag, mode, name, e, scale)
+            # train-mode logits (batch statistics) through the module surface, same permutation
+            net.load_state_dict(sd)
+            np.random.seed(0)
+            state = np.random.get_state()
+            perm_again = np.random.permutation(N)
+            np.random.set_state(state)
+            with torch.no_grad():
+                logits = net(torch.from_numpy(x).to(DEV)).cpu()
+            ref2 = ref if np.array_equal(perm_again, perm) else \
+                O.forward({k: v.detach() for k, v in P.items()}, torch.from_numpy(x), perm_again, layer_sizes=layers,
+                          n_neighbors=K, training=True, dropout_p=0.0).detach()
+            lerr = float((logits - ref2.detach()).abs().max())
+            print(f"[train parity] config {tag} B={B} {mode}: loss {loss:.7f} vs {float(ref_loss):.7f}, worst relative "
+                  f"gradient error {worst:.2e}, train-mode logits max |diff| {lerr:.2e}")
+            assert lerr < 1e-3, (tag, mode, lerr)
+    finally:
+        ops.set_wide_gemm(default)
+
+
 def test_train_step_k32_matches_oracle_autograd():
     """train.py's settings (n_points 2500, K 32, reference train.py:50-51): K != 16 takes the unfused
     gather + score GEMM + softmax-pool kernels; all gradients against the oracle's autograd."""

@@ -29,10 +29,13 @@ def test_load_reference_zip_and_predict(golden_dir):
         # a real depth cloud has exact-distance ties: a few points may pick another
         # equally-near neighbour than the reference's kd-tree order did
         bad = np.abs(conf - z[f"conf_{up}"]).max(0) > 1e-3
-        assert bad.mean() < 0.02, (up, bad.mean())
+        print(f"[parity] Model.predict {up}: {bad.mean():.4%} of the points differ by more than 1e-3 from the reference")
+        assert bad.mean() < 0.005, (up, bad.mean())
     np.random.seed(123)
     raw = model.predict(cloud[:600], prepostprocess=False)
-    assert np.mean(np.abs(np.asarray(raw) - z["conf_raw"]).max(0) > 1e-3) < 0.02
+    frac_raw = np.mean(np.abs(np.asarray(raw) - z["conf_raw"]).max(0) > 1e-3)
+    print(f"[parity] Model.predict raw: {frac_raw:.4%} of the points differ by more than 1e-3 from the reference")
+    assert frac_raw < 0.005
     # batched input keeps the batch axis (model.py:186-190, 233-234)
     np.random.seed(123)
     assert model.predict(np.stack([cloud, cloud])).shape == (2, 2, 5000)
