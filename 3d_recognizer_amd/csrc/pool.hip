@@ -65,6 +65,16 @@ struct PoolParams {
     float* slab;           // per-workgroup partial dW: [grid][d*d]
     float* X_out;          // d = 128 backward: X and dS leave the kernel ((P*16) x d each); dW = dS^T.X is the caller's
     float* dS_out;         //   weight-gradient GEMM (64 accumulator tiles do not fit one wavefront)
+    // u_source 1 / 2: the rpe-branch half of X is not a tensor but a function of the coordinates, recomputed per point:
+    //   1: relu(bn1(rpe . W1^T + b1))                       (what mlp_rpe1 would have stored; U is ignored)
+    //   2: relu(bn2(relu(bn1(rpe . W1^T + b1)) . W2^T + b2)) (mlp_rpe2 on top of it)
+    int src;
+    const float* xyz;      // (B, xyz_bstride, 3)
+    long xyz_bstride;
+    const float* nbr_d2;   // (P, 16) squared neighbour distances
+    const float* W1; const float* b1; const float* sc1; const float* sh1;   // mlp_rpe1 (h x 10) + folded BatchNorm
+    const float* W2; const float* b2; const float* sc2; const float* sh2;   // mlp_rpe2 (h x h)
+    const float* mu1; const float* is1; const float* mu2; const float* is2; // saved mean / invstd (backward kernels)
 };
 
 template <int DT>
@@ -105,8 +115,9 @@ __device__ __forceinline__ void fetch_x(const PoolParams& p, long pt, int li, in
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
-        if (k < H) raw[c] = *reinterpret_cast<const float4*>(p.U + row * H + k);
-        else raw[c] = *reinterpret_cast<const float4*>(p.G + (b * p.g_bstride + my_idx) * H + (k - H));
+        if (k < H) {
+            if (p.src == 0) raw[c] = *reinterpret_cast<const float4*>(p.U + row * H + k);
+        } else raw[c] = *reinterpret_cast<const float4*>(p.G + (b * p.g_bstride + my_idx) * H + (k - H));
     }
 }
 template <int DT>
@@ -204,6 +215,231 @@ __device__ __forceinline__ void tile_gemm_bf(const float4 (&a)[DT], const __bf16
     }
 }
 
+
+// ===============================================================================================================
+// The rpe branch as a virtual tensor.  mlp_rpe1 / mlp_rpe2 (reference modules.py:287-291, 313-320) act on the
+// (points*K) x 10 relative position encoding - a pure function of the coordinates and the neighbour indices - with tiny
+// weights (10 x h, h x h).  Storing their outputs costs (points*K) x h floats per tensor and every consumer streams
+// them back; recomputing a point's 16 x h tile inside the consumer costs two small MFMA GEMMs and no HBM traffic.
+//   rpe tile  (A layout, K = 10 padded to 16): lane (i, j) holds channels 4j..4j+3 of neighbour slot i
+//   u1raw = rpe . W1^T + b1            (C layout)      u1 = relu(u1raw*sc1 + sh1)
+//   u2raw = u1  . W2^T + b2            (C layout)      u2 = relu(u2raw*sc2 + sh2)
+// The activated tile lands in the wavefront's X tile (columns < H), exactly where a loaded U would have gone.
+// ===============================================================================================================
+template <int DT>
+struct VT {
+    static constexpr int H = 8 * DT;                 // width of the rpe branch
+    static constexpr int DTH = (H + 15) / 16;        // its 16-column blocks
+    static constexpr int HP = 16 * DTH;
+    static constexpr int S1 = 20;                    // fp32 row stride of the staged W1 ([n][16 k] + pad, 16-byte aligned)
+    static constexpr int S1B = 24;                   // bf16 row stride of the staged W1
+};
+
+// LDS image of the two small weights: TERMS == 0 floats, else bf16 head + tail
+template <int DT, int TERMS>
+struct VWeights {
+    static constexpr int HP = VT<DT>::HP, DTH = VT<DT>::DTH;
+    static constexpr int XS2 = Tile<DTH>::XS, XSB2 = Tile<DTH>::XSB;
+    static constexpr int BYTES = TERMS == 0 ? (HP * VT<DT>::S1 + HP * XS2) * 4 : (HP * VT<DT>::S1B + HP * XSB2) * 2 * 2;
+    float* w1f; float* w2f;
+    __bf16 *w1h, *w1l, *w2h, *w2l;
+    __device__ __forceinline__ void bind(unsigned char* mem) {
+        if constexpr (TERMS == 0) {
+            w1f = reinterpret_cast<float*>(mem);
+            w2f = w1f + HP * VT<DT>::S1;
+        } else {
+            w1h = reinterpret_cast<__bf16*>(mem);
+            w1l = w1h + HP * VT<DT>::S1B;
+            w2h = w1l + HP * VT<DT>::S1B;
+            w2l = w2h + HP * XSB2;
+        }
+    }
+    // all threads of the workgroup; a barrier must follow
+    __device__ __forceinline__ void stage(const PoolParams& p, int nthreads) {
+        constexpr int H = VT<DT>::H;
+        for (int e = threadIdx.x; e < HP * 16; e += nthreads) {
+            const int n = e >> 4, k = e & 15;
+            const float w = (n < H && k < 10) ? p.W1[n * 10 + k] : 0.f;
+            if constexpr (TERMS == 0) w1f[n * VT<DT>::S1 + k] = w;
+            else {
+                const __bf16 h = (__bf16)w;
+                w1h[n * VT<DT>::S1B + k] = h;
+                w1l[n * VT<DT>::S1B + k] = (__bf16)(w - (float)h);
+            }
+        }
+        if (p.src >= 2) {
+            for (int e = threadIdx.x; e < HP * HP; e += nthreads) {
+                const int n = e / HP, k = e - n * HP;
+                const float w = (n < H && k < H) ? p.W2[n * H + k] : 0.f;
+                if constexpr (TERMS == 0) w2f[n * XS2 + k] = w;
+                else {
+                    const __bf16 h = (__bf16)w;
+                    w2h[n * XSB2 + k] = h;
+                    w2l[n * XSB2 + k] = (__bf16)(w - (float)h);
+                }
+            }
+        }
+    }
+};
+
+// per-lane constants of the C-layout epilogues: column nb*16 + li of each stage
+template <int DT>
+struct VCols {
+    static constexpr int DTH = VT<DT>::DTH;
+    float b1[DTH], s1[DTH], h1[DTH], b2[DTH], s2[DTH], h2[DTH];
+    __device__ __forceinline__ void load(const PoolParams& p, int li) {
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb) {
+            const int c = nb * 16 + li;
+            const bool in = c < VT<DT>::H;
+            b1[nb] = in ? p.b1[c] : 0.f;
+            s1[nb] = (in && p.sc1) ? p.sc1[c] : 0.f;
+            h1[nb] = (in && p.sh1) ? p.sh1[c] : 0.f;
+            b2[nb] = (in && p.src >= 2) ? p.b2[c] : 0.f;
+            s2[nb] = (in && p.src >= 2 && p.sc2) ? p.sc2[c] : 0.f;
+            h2[nb] = (in && p.src >= 2 && p.sh2) ? p.sh2[c] : 0.f;
+        }
+    }
+};
+
+// what a lane needs of one point to build the relative position encoding of its neighbour slot li
+struct RpeIn {
+    float xi[3], xj[3], dd;
+};
+__device__ __forceinline__ void fetch_rpe(const PoolParams& p, long pt, int li, int nbr, RpeIn& r) {
+    const long b = (unsigned)pt / (unsigned)p.n;
+    const long i = pt - b * p.n;
+    const float* xb = p.xyz + b * p.xyz_bstride * 3;
+    r.xi[0] = xb[i * 3 + 0]; r.xi[1] = xb[i * 3 + 1]; r.xi[2] = xb[i * 3 + 2];
+    r.xj[0] = xb[(long)nbr * 3 + 0]; r.xj[1] = xb[(long)nbr * 3 + 1]; r.xj[2] = xb[(long)nbr * 3 + 2];
+    r.dd = p.nbr_d2[pt * 16 + li];
+}
+// channels [x_i, x_nbr, x_i - x_nbr, dist, 0...] (modules.py:173-186): this lane's float4 = channels 4*lj .. 4*lj+3
+__device__ __forceinline__ float4 rpe_frag(const RpeIn& r, int lj) {
+    if (lj == 0) return make_float4(r.xi[0], r.xi[1], r.xi[2], r.xj[0]);
+    if (lj == 1) return make_float4(r.xj[1], r.xj[2], r.xi[0] - r.xj[0], r.xi[1] - r.xj[1]);
+    if (lj == 2) return make_float4(r.xi[2] - r.xj[2], __fsqrt_rn(r.dd), 0.f, 0.f);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// acc[nb] (C layout) = rpe tile (16 x 16, A layout) . W1^T
+template <int DT, int TERMS>
+__device__ __forceinline__ void rpe_gemm(const float4 a, const VWeights<DT, TERMS>& w, int li, int lj, f32x4 (&acc)[VT<DT>::DTH]) {
+#pragma unroll
+    for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
+        acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (TERMS == 0) {
+            const float4 b = *reinterpret_cast<const float4*>(w.w1f + (nb * 16 + li) * VT<DT>::S1 + 4 * lj);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nb], 0, 0, 0);
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nb], 0, 0, 0);
+        } else {
+            bf16x4 ah, al;
+            split4(a, ah, al);
+            const bf16x4 bh = *reinterpret_cast<const bf16x4*>(w.w1h + (nb * 16 + li) * VT<DT>::S1B + 4 * lj);
+            const bf16x4 bl = *reinterpret_cast<const bf16x4*>(w.w1l + (nb * 16 + li) * VT<DT>::S1B + 4 * lj);
+            acc[nb] = mfma16(ah, bh, acc[nb]);
+            acc[nb] = mfma16(ah, bl, acc[nb]);
+            acc[nb] = mfma16(al, bh, acc[nb]);
+        }
+    }
+}
+
+// The raw (pre-BatchNorm) tile of stage `stage` (1 or 2) of the rpe branch for one point, C layout, and - when
+// `Xs` is given - the ACTIVATED tile of the last stage written to columns < H of the wavefront's X tile.
+// `scratch` is a wavefront-private 16 x XS tile used to turn u1 from C into A layout for stage 2 (may alias Xs).
+template <int DT, int TERMS>
+__device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in, int stage, const VWeights<DT, TERMS>& w,
+                                           const VCols<DT>& vc, int li, int lj, float* scratch, int XS,
+                                           f32x4 (&raw)[VT<DT>::DTH], float* Xs) {
+    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH;
+    rpe_gemm<DT, TERMS>(rpe_frag(in, lj), w, li, lj, raw);
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) raw[nb][r] += vc.b1[nb];
+    if (stage == 1) {
+        if (Xs) {
+#pragma unroll
+            for (int nb = 0; nb < DTH; ++nb) {
+                const int col = nb * 16 + li;
+                if (col < H) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = fmaxf(raw[nb][r] * vc.s1[nb] + vc.h1[nb], 0.f);
+                }
+            }
+        }
+        return;
+    }
+    // stage 2: u1 (activated) through the scratch tile into A layout, then the h x h GEMM
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) {
+        const int col = nb * 16 + li;
+        if (col < H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scratch[(4 * lj + r) * XS + col] = fmaxf(raw[nb][r] * vc.s1[nb] + vc.h1[nb], 0.f);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float4 a1[DTH];
+#pragma unroll
+    for (int c = 0; c < DTH; ++c) {
+        a1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (16 * c + 4 * lj < H) a1[c] = *reinterpret_cast<const float4*>(scratch + li * XS + 16 * c + 4 * lj);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) raw[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (TERMS == 0) tile_gemm<DTH>(a1, w.w2f, li, lj, raw);
+    else tile_gemm_bf<DTH>(a1, w.w2h, w.w2l, li, lj, raw);
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) raw[nb][r] += vc.b2[nb];
+    if (Xs) {
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb) {
+            const int col = nb * 16 + li;
+            if (col < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = fmaxf(raw[nb][r] * vc.s2[nb] + vc.h2[nb], 0.f);
+            }
+        }
+    }
+}
+
+// The X tile of a point whose rpe half is virtual: the gathered half comes from `graw` (fetch_x loaded only those
+// chunks), the rpe half is computed; xa (A layout) is read back from the tile.
+template <int DT, int TERMS>
+__device__ __forceinline__ void finish_x_virtual(const PoolParams& p, int li, int lj, const float4 (&graw)[DT], const RpeIn& in,
+                                                 const float (&sc)[DT][4], const float (&sh)[DT][4], const VWeights<DT, TERMS>& w,
+                                                 const VCols<DT>& vc, float4 (&xa)[DT], float* Xs) {
+    constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
+    f32x4 rawu[VT<DT>::DTH];
+    rpe_branch<DT, TERMS>(p, in, p.src, w, vc, li, lj, Xs, XS, rawu, Xs);
+    const int gact = p.glazy.scale ? p.glazy.act : RL_ACT_NONE;
+#pragma unroll
+    for (int c = 0; c < DT; ++c) {
+        const int k = 16 * c + 4 * lj;
+        if (k >= H) {
+            float4 v = graw[c];
+            v.x = rl_act(v.x * sc[c][0] + sh[c][0], gact, p.glazy.slope);
+            v.y = rl_act(v.y * sc[c][1] + sh[c][1], gact, p.glazy.slope);
+            v.z = rl_act(v.z * sc[c][2] + sh[c][2], gact, p.glazy.slope);
+            v.w = rl_act(v.w * sc[c][3] + sh[c][3], gact, p.glazy.slope);
+            xa[c] = v;
+            *reinterpret_cast<float4*>(Xs + li * XS + k) = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < DT; ++c) {
+        const int k = 16 * c + 4 * lj;
+        if (k < H) xa[c] = *reinterpret_cast<const float4*>(Xs + li * XS + k);
+    }
+}
+
 // softmax over the 16 rows of a C-layout tile, in place: s -> A
 template <int DT>
 __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
@@ -238,11 +474,12 @@ __device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* W
     }
 }
 
-template <int DT, int TERMS, int NW = 4>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product); NW wavefronts
+template <int DT, int TERMS, int NW = 4, bool VIRT = false>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product); NW wavefronts; VIRT: rpe half recomputed (PoolParams::src)
 __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     __shared__ __attribute__((aligned(16))) unsigned char wmem[TERMS == 0 ? D * XS * 4 : 2 * D * XSB * 2];
     __shared__ __attribute__((aligned(16))) float Xt[NW][16 * XS];
+    __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
     float* Wt = reinterpret_cast<float*>(wmem);
     __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
     __bf16* Wl = Wh + D * XSB;
@@ -259,6 +496,13 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
             Wl[o * XSB + i] = (__bf16)(w - (float)h);
         }
     }
+    VWeights<DT, TERMS> vw;
+    VCols<DT> vc;
+    if constexpr (VIRT) {
+        vw.bind(vmem);
+        vw.stage(p, 64 * NW);
+        vc.load(p, li);
+    }
     __syncthreads();
     float sc[DT][4], sh[DT][4];
     lane_lazy<DT>(p, lj, sc, sh);
@@ -269,12 +513,20 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
-    if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+    RpeIn rin, rin_nxt;
+    if (pt < p.P) {
+        fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+        if constexpr (VIRT) fetch_rpe(p, pt, li, idx_cur, rin);
+    }
     for (; pt < p.P; pt += pstep) {
         float4 xa[DT];
-        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs);
+        else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+        if (pt + pstep < p.P) {
+            fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+            if constexpr (VIRT) fetch_rpe(p, pt + pstep, li, idx_nxt, rin_nxt);
+        }
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         f32x4 s[DT];
 #pragma unroll
@@ -293,12 +545,70 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
             if (lj == 0) p.Pout[pt * D + nb * 16 + li] = acc;
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (VIRT) rin = rin_nxt;
     }
 }
 
+// BatchNorm batch statistics of the raw stage-1 / stage-2 tile of the rpe branch (PoolParams::src) over all rows:
+// the reduction that mlp_rpe1 / mlp_rpe2's GEMM epilogue would have produced, without the tensor.  One partial
+// (sum, sum of squares; doubles) per workgroup and channel, [grid][2][H], for rl_bn_finalize.
 template <int DT, int TERMS>
+__global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, double* __restrict__ stats) {
+    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, XS = Tile<VT<DT>::DTH>::XS;
+    __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
+    __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
+    __shared__ double red[4][2][VT<DT>::HP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    VWeights<DT, TERMS> vw;
+    VCols<DT> vc;
+    vw.bind(vmem);
+    vw.stage(p, 256);
+    vc.load(p, li);
+    __syncthreads();
+    float ssum[DTH], ssq[DTH];
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    const long pstep = (long)gridDim.x * 4;
+    long pt = (long)blockIdx.x * 4 + wave;
+    RpeIn rin, rin_nxt;
+    if (pt < p.P) fetch_rpe(p, pt, li, p.idx[pt * 16 + li], rin);
+    for (; pt < p.P; pt += pstep) {
+        if (pt + pstep < p.P) fetch_rpe(p, pt + pstep, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        f32x4 raw[DTH];
+        rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ssum[nb] += raw[nb][r];
+                ssq[nb] += raw[nb][r] * raw[nb][r];
+            }
+        __builtin_amdgcn_wave_barrier();
+        rin = rin_nxt;
+    }
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) {
+        float sm = ssum[nb], q = ssq[nb];
+        sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        if (lane < 16) {
+            red[wave][0][nb * 16 + lane] = (double)sm;
+            red[wave][1][nb * 16 + lane] = (double)q;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < H) {
+        const int c = threadIdx.x;
+        stats[((long)blockIdx.x * 2 + 0) * H + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+        stats[((long)blockIdx.x * 2 + 1) * H + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    }
+}
+
+template <int DT, int TERMS, bool VIRT = false>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
+    __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
     // LDS: W^T, W, and per wavefront an X tile and a dS tile; after the main loop the W region is
     // reused to combine the four wavefronts' dW tiles
     __shared__ __attribute__((aligned(16))) float Wmem[TERMS == 0 ? 2 * D * XS : 2 * D * XSB];   // bf16: 4 arrays of D*XSB
@@ -322,6 +632,13 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
             Wth[i * XSB + o] = h; Wtl[i * XSB + o] = l;
         }
     }
+    VWeights<DT, TERMS> vw;
+    VCols<DT> vc;
+    if constexpr (VIRT) {
+        vw.bind(vmem);
+        vw.stage(p, 256);
+        vc.load(p, li);
+    }
     __syncthreads();
     float sc[DT][4], sh[DT][4];
     lane_lazy<DT>(p, lj, sc, sh);
@@ -339,12 +656,21 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
-    if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+    RpeIn rin, rin_nxt;
+    if (pt < p.P) {
+        fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+        if constexpr (VIRT) fetch_rpe(p, pt, li, idx_cur, rin);
+    }
     for (; pt < p.P; pt += pstep) {
         float4 xa[DT];
-        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs);
+        else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+        if (pt + pstep < p.P) {
+            fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+            if constexpr (VIRT) fetch_rpe(p, pt + pstep, li, idx_nxt, rin_nxt);
+        }
+        if constexpr (VIRT) rin = rin_nxt;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         float gp[DT];          // dP of this point: requested now, needed after the score GEMM and the softmax
 #pragma unroll
@@ -613,6 +939,307 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of a virtual rpe stage (mlp_rpe1 / mlp_rpe2 + BatchNorm + ReLU whose output was never stored).  G holds the
+// gradient w.r.t. the ACTIVATED stage output ((points*16) x H, written by the pooling backward kernels); the raw tile
+// is recomputed per point.  With g = G*[act > 0] and xhat = (raw - mean)*invstd:
+//   rpe_bn_reduce_kernel : per-workgroup partials of sum g and sum g*xhat (doubles)            -> rl_bn_bwd_finalize
+//   rpe_wgrad_kernel     : dY = scale*(g - coef0 - xhat*coef1);  dW += dY^T . input (rpe rows / activated stage 1),
+//                          db += sum dY (one partial slab per workgroup, the layout rl_wgrad_reduce_batch sums);
+//                          stage 2 also stores dY . W2 = the gradient w.r.t. the activated stage-1 output (GU1).
+// ---------------------------------------------------------------------------------------------------------------
+struct RpeBwdParams {
+    PoolParams pp;
+    const float* G;       // (P*16, H) gradient w.r.t. the activated output of stage pp.src
+    double* stats;        // reduce: [grid][2][H]
+    const float* coef;    // wgrad: 2H floats (mean g, mean g*xhat)
+    float* slab;          // wgrad: [grid][H*Kin + H]
+    float* GU1;           // wgrad stage 2: (P*16, H) out
+};
+
+template <int DT>
+struct VBwdCols {
+    static constexpr int DTH = VT<DT>::DTH;
+    float mu[DTH], is[DTH], scl[DTH], sft[DTH], k0[DTH], k1[DTH];
+    __device__ __forceinline__ void load(const PoolParams& p, const float* coef, int li) {
+        const float* mu_ = p.src == 1 ? p.mu1 : p.mu2;
+        const float* is_ = p.src == 1 ? p.is1 : p.is2;
+        const float* sc_ = p.src == 1 ? p.sc1 : p.sc2;
+        const float* sh_ = p.src == 1 ? p.sh1 : p.sh2;
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb) {
+            const int c = nb * 16 + li;
+            const bool in = c < VT<DT>::H;
+            mu[nb] = in ? mu_[c] : 0.f;
+            is[nb] = in ? is_[c] : 0.f;
+            scl[nb] = in ? sc_[c] : 0.f;
+            sft[nb] = in ? sh_[c] : 0.f;
+            k0[nb] = (in && coef) ? coef[c] : 0.f;
+            k1[nb] = (in && coef) ? coef[VT<DT>::H + c] : 0.f;
+        }
+    }
+};
+
+template <int DT, int TERMS>
+__global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q) {
+    const PoolParams& p = q.pp;
+    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, XS = Tile<VT<DT>::DTH>::XS;
+    __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
+    __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
+    __shared__ double red[4][2][VT<DT>::HP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    VWeights<DT, TERMS> vw;
+    VCols<DT> vc;
+    VBwdCols<DT> bc;
+    vw.bind(vmem);
+    vw.stage(p, 256);
+    vc.load(p, li);
+    bc.load(p, nullptr, li);
+    __syncthreads();
+    float sg[DTH], sx[DTH];
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) sg[nb] = sx[nb] = 0.f;
+    const long pstep = (long)gridDim.x * 4;
+    long pt = (long)blockIdx.x * 4 + wave;
+    RpeIn rin, rin_nxt;
+    if (pt < p.P) fetch_rpe(p, pt, li, p.idx[pt * 16 + li], rin);
+    for (; pt < p.P; pt += pstep) {
+        if (pt + pstep < p.P) fetch_rpe(p, pt + pstep, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        float gin[DTH][4];
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = nb * 16 + li;
+                gin[nb][r] = col < H ? q.G[(pt * 16 + 4 * lj + r) * H + col] : 0.f;
+            }
+        f32x4 raw[DTH];
+        rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = raw[nb][r] * bc.scl[nb] + bc.sft[nb];
+                const float g = z > 0.f ? gin[nb][r] : 0.f;
+                sg[nb] += g;
+                sx[nb] += g * ((raw[nb][r] - bc.mu[nb]) * bc.is[nb]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        rin = rin_nxt;
+    }
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) {
+        float a = sg[nb], b = sx[nb];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        if (lane < 16) {
+            red[wave][0][nb * 16 + lane] = (double)a;
+            red[wave][1][nb * 16 + lane] = (double)b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < H) {
+        const int c = threadIdx.x;
+        q.stats[((long)blockIdx.x * 2 + 0) * H + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+        q.stats[((long)blockIdx.x * 2 + 1) * H + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    }
+}
+
+template <int DT, int TERMS>
+__global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
+    const PoolParams& p = q.pp;
+    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, HP = VT<DT>::HP, XS = Tile<VT<DT>::DTH>::XS, XSB = Tile<VT<DT>::DTH>::XSB;
+    constexpr int KB = DTH;                           // k blocks of dW: stage 1 uses block 0 only (10 of its 16 columns)
+    __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char w2t_mem[TERMS == 0 ? HP * XS * 4 : HP * XSB * 2 * 2];   // W2^T image for dY . W2
+    // [0]: the stage's input rows [row][k] (rpe rows for stage 1, the activated stage-1 tile for stage 2); [1]: dY [row][n]
+    __shared__ __attribute__((aligned(16))) float Tl[2][4][16 * XS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lj = lane >> 4;
+    VWeights<DT, TERMS> vw;
+    VCols<DT> vc;
+    VBwdCols<DT> bc;
+    vw.bind(vmem);
+    vw.stage(p, 256);
+    vc.load(p, li);
+    bc.load(p, q.coef, li);
+    float* w2tf = reinterpret_cast<float*>(w2t_mem);
+    __bf16* w2th = reinterpret_cast<__bf16*>(w2t_mem);
+    __bf16* w2tl = w2th + HP * XSB;
+    if (p.src == 2) {
+        // transposed-B image of W2^T for dA[row][k] = sum_n dY[row][n] W2[n][k]:  Bt[k][n] = W2[n][k]
+        for (int e = threadIdx.x; e < HP * HP; e += 256) {
+            const int k = e / HP, n = e - k * HP;
+            const float w = (n < H && k < H) ? p.W2[n * H + k] : 0.f;
+            if constexpr (TERMS == 0) w2tf[k * XS + n] = w;
+            else {
+                const __bf16 hh = (__bf16)w;
+                w2th[k * XSB + n] = hh;
+                w2tl[k * XSB + n] = (__bf16)(w - (float)hh);
+            }
+        }
+    }
+    for (int e = threadIdx.x; e < 2 * 4 * 16 * XS; e += 256) (&Tl[0][0][0])[e] = 0.f;     // padding columns stay zero
+    __syncthreads();
+    float* Is = Tl[0][wave];
+    float* Ds = Tl[1][wave];
+    f32x4 accw[DTH][KB];
+    float bsum[DTH];
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) {
+        bsum[nb] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const long pstep = (long)gridDim.x * 4;
+    long pt = (long)blockIdx.x * 4 + wave;
+    RpeIn rin, rin_nxt;
+    if (pt < p.P) fetch_rpe(p, pt, li, p.idx[pt * 16 + li], rin);
+    for (; pt < p.P; pt += pstep) {
+        if (pt + pstep < p.P) fetch_rpe(p, pt + pstep, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        float gin[DTH][4];
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = nb * 16 + li;
+                gin[nb][r] = col < H ? q.G[(pt * 16 + 4 * lj + r) * H + col] : 0.f;
+            }
+        f32x4 raw[DTH];
+        // stage 2 leaves the activated stage-1 tile in Is (its scratch); stage 1's input is the rpe tile itself
+        rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Is, XS, raw, nullptr);
+        if (p.src == 1) *reinterpret_cast<float4*>(Is + li * XS + 4 * lj) = rpe_frag(rin, lj);
+        // dY, C layout -> Ds
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb) {
+            const int col = nb * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = raw[nb][r] * bc.scl[nb] + bc.sft[nb];
+                const float g = z > 0.f ? gin[nb][r] : 0.f;
+                const float xh = (raw[nb][r] - bc.mu[nb]) * bc.is[nb];
+                const float dy = col < H ? bc.scl[nb] * (g - bc.k0[nb] - xh * bc.k1[nb]) : 0.f;
+                bsum[nb] += dy;
+                Ds[(4 * lj + r) * XS + col] = dy;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dW[n][k] += sum_rows dY[row][n] * In[row][k]   (rows are the MFMA reduction index)
+        if constexpr (TERMS == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float bx[KB];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) bx[kb] = Is[(4 * t + lj) * XS + kb * 16 + li];
+#pragma unroll
+                for (int nb = 0; nb < DTH; ++nb) {
+                    const float ad = Ds[(4 * t + lj) * XS + nb * 16 + li];
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+                        accw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, bx[kb], accw[nb][kb], 0, 0, 0);
+                }
+            }
+        } else {
+            bf16x4 xh[KB], xl[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                float4 v;
+                v.x = Is[(4 * lj + 0) * XS + kb * 16 + li]; v.y = Is[(4 * lj + 1) * XS + kb * 16 + li];
+                v.z = Is[(4 * lj + 2) * XS + kb * 16 + li]; v.w = Is[(4 * lj + 3) * XS + kb * 16 + li];
+                split4(v, xh[kb], xl[kb]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < DTH; ++nb) {
+                float4 v;
+                v.x = Ds[(4 * lj + 0) * XS + nb * 16 + li]; v.y = Ds[(4 * lj + 1) * XS + nb * 16 + li];
+                v.z = Ds[(4 * lj + 2) * XS + nb * 16 + li]; v.w = Ds[(4 * lj + 3) * XS + nb * 16 + li];
+                bf16x4 dh, dl;
+                split4(v, dh, dl);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dh, xh[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dh, xl[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dl, xh[kb], accw[nb][kb]);
+            }
+        }
+        if (p.src == 2) {
+            // gradient w.r.t. the activated stage-1 output: dY . W2  (dY re-read in A layout)
+            float4 da[DTH];
+#pragma unroll
+            for (int c = 0; c < DTH; ++c) da[c] = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
+            f32x4 gu[DTH];
+#pragma unroll
+            for (int nb = 0; nb < DTH; ++nb) gu[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (TERMS == 0) tile_gemm<DTH>(da, w2tf, li, lj, gu);
+            else tile_gemm_bf<DTH>(da, w2th, w2tl, li, lj, gu);
+#pragma unroll
+            for (int nb = 0; nb < DTH; ++nb) {
+                const int col = nb * 16 + li;
+                if (col < H) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q.GU1[(pt * 16 + 4 * lj + r) * H + col] = gu[nb][r];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        rin = rin_nxt;
+    }
+    // combine the four wavefronts in a fixed order; slab layout: dW[n][k] (n < H, k < Kin) then db[n]
+    const int Kin = p.src == 1 ? 10 : H;
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) {
+        bsum[nb] += __shfl_xor(bsum[nb], 16, 64);
+        bsum[nb] += __shfl_xor(bsum[nb], 32, 64);
+    }
+    __syncthreads();
+    float* red = &Tl[0][0][0];       // DTH*KB*256 + DTH*64 floats <= 2 * 4*16*XS: checked by the static_assert below
+    static_assert(DTH * KB * 256 + DTH * 64 <= 2 * 4 * 16 * XS, "reduction scratch does not fit");
+    float* rb = red + DTH * KB * 256;
+    for (int wv = 1; wv < 4; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int nb = 0; nb < DTH; ++nb) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((nb * KB + kb) * 4 + r) * 64 + lane] = accw[nb][kb][r];
+                rb[nb * 64 + lane] = bsum[nb];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int nb = 0; nb < DTH; ++nb) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accw[nb][kb][r] += red[((nb * KB + kb) * 4 + r) * 64 + lane];
+                bsum[nb] += rb[nb * 64 + lane];
+            }
+        }
+    }
+    if (wave == 0) {
+        float* out = q.slab + (long)blockIdx.x * ((long)H * Kin + H);
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int k = kb * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb * 16 + lj * 4 + r;
+                    if (n < H && k < Kin) out[(long)n * Kin + k] = accw[nb][kb][r];
+                }
+            }
+            const int n = nb * 16 + li;
+            if (lj == 0 && n < H) out[(long)H * Kin + n] = bsum[nb];
+        }
+    }
+}
+
 // 64 consecutive elements (256 contiguous bytes per slab row) x 4 slab lanes per workgroup, fixed order
 __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __restrict__ slab, int nsplit, int count,
                                                              float* __restrict__ dW) {
@@ -648,13 +1275,13 @@ int pool_grid(long P, int d, bool backward) {
 }
 
 int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
-    RL_REQUIRE(d && d->U && d->G && d->idx && d->W && d->points > 0 && d->n > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
+    RL_REQUIRE(d && d->G && d->idx && d->W && d->points > 0 && d->n > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
     RL_REQUIRE(d->nbr_k == 16, RL_ERR_UNSUPPORTED, "%s: the fused kernel needs 16 neighbours (got %d)", who, d->nbr_k);
     RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64 || (d->d == 128 && rl_wide_terms() != 0), RL_ERR_UNSUPPORTED,
                "%s: d must be 16, 32 or 64, or 128 outside the fp32 arithmetic mode (got %d)", who, d->d);
     RL_REQUIRE(d->g_bstride >= d->n && d->points % d->n == 0, RL_ERR_ARGS, "%s: bad cloud geometry", who);
     RL_REQUIRE((int64_t)d->points * 16 < (1l << 31), RL_ERR_ARGS, "%s: too many neighbourhood rows", who);
-    RL_REQUIRE(((uintptr_t)d->U & 15) == 0 && ((uintptr_t)d->G & 15) == 0, RL_ERR_ARGS, "%s: U/G must be 16-byte aligned", who);
+    RL_REQUIRE((d->u_source > 0 || ((uintptr_t)d->U & 15) == 0) && ((uintptr_t)d->G & 15) == 0, RL_ERR_ARGS, "%s: U/G must be 16-byte aligned", who);
     RL_REQUIRE((d->u_scale == nullptr) == (d->u_shift == nullptr) && (d->g_scale == nullptr) == (d->g_shift == nullptr),
                RL_ERR_ARGS, "%s: scale/shift must come together", who);
     p->U = d->U; p->ulazy.scale = d->u_scale; p->ulazy.shift = d->u_shift; p->ulazy.act = d->u_act; p->ulazy.slope = d->u_slope;
@@ -663,6 +1290,19 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->idx = d->idx; p->W = d->W; p->P = d->points; p->n = d->n; p->d = d->d;
     p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->DG = d->DG; p->slab = d->slab;
     p->X_out = nullptr; p->dS_out = nullptr;
+    p->src = d->u_source;
+    RL_REQUIRE(d->u_source >= 0 && d->u_source <= 2, RL_ERR_ARGS, "%s: u_source must be 0, 1 or 2", who);
+    if (d->u_source > 0) {
+        RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64, RL_ERR_UNSUPPORTED, "%s: a virtual rpe branch needs d = 16, 32 or 64 (got %d)", who, d->d);
+        RL_REQUIRE(d->xyz && d->nbr_d2 && d->xyz_bstride >= d->n && d->W1 && d->b1, RL_ERR_ARGS, "%s: incomplete virtual rpe branch", who);
+        RL_REQUIRE(d->u_source < 2 || (d->W2 && d->b2 && d->scale1 && d->shift1), RL_ERR_ARGS, "%s: stage 2 needs W2 / b2 and BatchNorm 1", who);
+    } else {
+        RL_REQUIRE(d->U, RL_ERR_ARGS, "%s: null U", who);
+    }
+    p->xyz = d->xyz; p->xyz_bstride = d->xyz_bstride; p->nbr_d2 = d->nbr_d2;
+    p->W1 = d->W1; p->b1 = d->b1; p->sc1 = d->scale1; p->sh1 = d->shift1;
+    p->W2 = d->W2; p->b2 = d->b2; p->sc2 = d->scale2; p->sh2 = d->shift2;
+    p->mu1 = d->mean1; p->is1 = d->invstd1; p->mu2 = d->mean2; p->is2 = d->invstd2;
     if (!backward) RL_REQUIRE(d->Pout, RL_ERR_ARGS, "%s: null output", who);
     else RL_REQUIRE(d->dP && d->GU && d->DG, RL_ERR_ARGS, "%s: null gradient buffers", who);
     return RL_OK;
@@ -685,6 +1325,21 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     if (rc) return rc;
     const int g = pool_grid(p.P, p.d, false);
     hipStream_t st = (hipStream_t)stream;
+    if (p.src > 0) {
+        RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_fwd: the virtual rpe branch needs its folded BatchNorm(s)");
+        if (rl_wide_terms() == 0) {
+            if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
+            else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((pool_fwd_kernel<4, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
+        } else {
+            if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 3, 4, true>), dim3(g), dim3(256), 0, st, p);
+            else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 3, 4, true>), dim3(g), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((pool_fwd_kernel<4, 3, 4, true>), dim3(g), dim3(256), 0, st, p);
+        }
+        rl_note_kernel(p.d == 16 ? "pool_fwd_kernel<1,virtual>" : p.d == 32 ? "pool_fwd_kernel<2,virtual>" : "pool_fwd_kernel<4,virtual>");
+        RL_LAUNCH_CHECK("rl_pool_fwd(virtual)");
+        return RL_OK;
+    }
     if (rl_wide_terms() == 0) {
         if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);
@@ -719,6 +1374,23 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     RL_REQUIRE(d->dW && d->slab, RL_ERR_ARGS, "rl_pool_bwd: null gradient buffers");
     const int g = pool_grid(p.P, p.d, true);
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
+    if (p.src > 0) {
+        RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_bwd: the virtual rpe branch needs its folded BatchNorm(s)");
+        if (rl_wide_terms() == 0) {
+            if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0, true>), dim3(g), dim3(256), 0, st, p);
+            else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0, true>), dim3(g), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((pool_bwd_kernel<4, 0, true>), dim3(g), dim3(256), 0, st, p);
+        } else {
+            if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3, true>), dim3(g), dim3(256), 0, st, p);
+            else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3, true>), dim3(g), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((pool_bwd_kernel<4, 3, true>), dim3(g), dim3(256), 0, st, p);
+        }
+        rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1,virtual>" : p.d == 32 ? "pool_bwd_kernel<2,virtual>" : "pool_bwd_kernel<4,virtual>");
+        RL_LAUNCH_CHECK("rl_pool_bwd(virtual)");
+        hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 64)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
+        RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
+        return RL_OK;
+    }
     if (rl_wide_terms() == 0) {
         if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);
@@ -732,5 +1404,111 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     RL_LAUNCH_CHECK("rl_pool_bwd");
     hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 64)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
     RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
+    return RL_OK;
+}
+
+// ---- the rpe branch without its tensors: batch statistics of a virtual stage ------------------------------------
+static int rpe_grid(long P) {
+    long g = (P + 15) / 16;
+    if (g < 1) g = 1;
+    return (int)(g < RL_MAX_SLOTS ? g : RL_MAX_SLOTS);
+}
+
+extern "C" int rl_rpe_stats_slots(int64_t points) { return rpe_grid(points); }
+
+extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) {
+    RL_REQUIRE(d && stats && d->idx && d->points > 0 && d->n > 0 && d->points % d->n == 0, RL_ERR_ARGS, "rl_rpe_stats: bad descriptor");
+    RL_REQUIRE(d->nbr_k == 16, RL_ERR_UNSUPPORTED, "rl_rpe_stats: 16 neighbours expected (got %d)", d->nbr_k);
+    RL_REQUIRE(d->u_source == 1 || d->u_source == 2, RL_ERR_ARGS, "rl_rpe_stats: u_source must be 1 or 2");
+    RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64, RL_ERR_UNSUPPORTED, "rl_rpe_stats: d must be 16, 32 or 64 (got %d)", d->d);
+    RL_REQUIRE(d->xyz && d->nbr_d2 && d->xyz_bstride >= d->n && d->W1 && d->b1, RL_ERR_ARGS, "rl_rpe_stats: incomplete rpe branch");
+    RL_REQUIRE(d->u_source < 2 || (d->W2 && d->b2 && d->scale1 && d->shift1), RL_ERR_ARGS, "rl_rpe_stats: stage 2 needs W2 / b2 and BatchNorm 1");
+    RL_REQUIRE((int64_t)d->points * 16 < (1l << 31), RL_ERR_ARGS, "rl_rpe_stats: too many neighbourhood rows");
+    PoolParams p = {};
+    p.idx = d->idx; p.P = d->points; p.n = d->n; p.d = d->d; p.src = d->u_source;
+    p.xyz = d->xyz; p.xyz_bstride = d->xyz_bstride; p.nbr_d2 = d->nbr_d2;
+    p.W1 = d->W1; p.b1 = d->b1; p.sc1 = d->scale1; p.sh1 = d->shift1;
+    p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
+    const int g = rpe_grid(p.P);
+    hipStream_t st = (hipStream_t)stream;
+    if (rl_wide_terms() == 0) {
+        if (p.d == 16) hipLaunchKernelGGL((rpe_stats_kernel<1, 0>), dim3(g), dim3(256), 0, st, p, stats);
+        else if (p.d == 32) hipLaunchKernelGGL((rpe_stats_kernel<2, 0>), dim3(g), dim3(256), 0, st, p, stats);
+        else hipLaunchKernelGGL((rpe_stats_kernel<4, 0>), dim3(g), dim3(256), 0, st, p, stats);
+    } else {
+        if (p.d == 16) hipLaunchKernelGGL((rpe_stats_kernel<1, 3>), dim3(g), dim3(256), 0, st, p, stats);
+        else if (p.d == 32) hipLaunchKernelGGL((rpe_stats_kernel<2, 3>), dim3(g), dim3(256), 0, st, p, stats);
+        else hipLaunchKernelGGL((rpe_stats_kernel<4, 3>), dim3(g), dim3(256), 0, st, p, stats);
+    }
+    rl_note_kernel("rpe_stats_kernel");
+    RL_LAUNCH_CHECK("rl_rpe_stats");
+    return RL_OK;
+}
+
+static int rpe_bwd_fill(RpeBwdParams* q, const rl_pool_desc* d, const float* G, const char* who) {
+    RL_REQUIRE(d && G && d->idx && d->points > 0 && d->n > 0 && d->points % d->n == 0, RL_ERR_ARGS, "%s: bad descriptor", who);
+    RL_REQUIRE(d->nbr_k == 16, RL_ERR_UNSUPPORTED, "%s: 16 neighbours expected (got %d)", who, d->nbr_k);
+    RL_REQUIRE(d->u_source == 1 || d->u_source == 2, RL_ERR_ARGS, "%s: u_source must be 1 or 2", who);
+    RL_REQUIRE(d->d == 16 || d->d == 32 || d->d == 64, RL_ERR_UNSUPPORTED, "%s: d must be 16, 32 or 64 (got %d)", who, d->d);
+    RL_REQUIRE(d->xyz && d->nbr_d2 && d->xyz_bstride >= d->n && d->W1 && d->b1 && d->scale1 && d->shift1 && d->mean1 && d->invstd1,
+               RL_ERR_ARGS, "%s: incomplete rpe branch (stage 1 and its BatchNorm records)", who);
+    RL_REQUIRE(d->u_source < 2 || (d->W2 && d->b2 && d->scale2 && d->shift2 && d->mean2 && d->invstd2), RL_ERR_ARGS,
+               "%s: stage 2 needs W2 / b2 and its BatchNorm records", who);
+    RL_REQUIRE((int64_t)d->points * 16 < (1l << 31), RL_ERR_ARGS, "%s: too many neighbourhood rows", who);
+    PoolParams& p = q->pp;
+    p = PoolParams{};
+    p.idx = d->idx; p.P = d->points; p.n = d->n; p.d = d->d; p.src = d->u_source;
+    p.xyz = d->xyz; p.xyz_bstride = d->xyz_bstride; p.nbr_d2 = d->nbr_d2;
+    p.W1 = d->W1; p.b1 = d->b1; p.sc1 = d->scale1; p.sh1 = d->shift1;
+    p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
+    p.mu1 = d->mean1; p.is1 = d->invstd1; p.mu2 = d->mean2; p.is2 = d->invstd2;
+    q->G = G; q->stats = nullptr; q->coef = nullptr; q->slab = nullptr; q->GU1 = nullptr;
+    return RL_OK;
+}
+
+#define RPE_DISPATCH(KERNEL, grid, st, q)                                                                          \
+    do {                                                                                                           \
+        if (rl_wide_terms() == 0) {                                                                                \
+            if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 0>), dim3(grid), dim3(256), 0, st, q);               \
+            else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 0>), dim3(grid), dim3(256), 0, st, q);          \
+            else hipLaunchKernelGGL((KERNEL<4, 0>), dim3(grid), dim3(256), 0, st, q);                              \
+        } else {                                                                                                   \
+            if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 3>), dim3(grid), dim3(256), 0, st, q);               \
+            else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 3>), dim3(grid), dim3(256), 0, st, q);          \
+            else hipLaunchKernelGGL((KERNEL<4, 3>), dim3(grid), dim3(256), 0, st, q);                              \
+        }                                                                                                          \
+    } while (0)
+
+extern "C" int rl_rpe_bn_reduce(const rl_pool_desc* d, const float* G, double* stats, void* stream) {
+    RpeBwdParams q;
+    int rc = rpe_bwd_fill(&q, d, G, "rl_rpe_bn_reduce");
+    if (rc) return rc;
+    RL_REQUIRE(stats, RL_ERR_ARGS, "rl_rpe_bn_reduce: null stats");
+    q.stats = stats;
+    const int g = rpe_grid(q.pp.P);
+    RPE_DISPATCH(rpe_bn_reduce_kernel, g, (hipStream_t)stream, q);
+    rl_note_kernel("rpe_bn_reduce_kernel");
+    RL_LAUNCH_CHECK("rl_rpe_bn_reduce");
+    return RL_OK;
+}
+
+extern "C" int64_t rl_rpe_wgrad_slab_floats(int64_t points, int d, int stage) {
+    const int h = d / 2;
+    return (int64_t)rpe_grid(points) * ((int64_t)h * (stage == 1 ? 10 : h) + h);
+}
+
+extern "C" int rl_rpe_wgrad(const rl_pool_desc* d, const float* G, const float* coef, float* slab, int64_t slab_floats,
+                            float* GU1, void* stream) {
+    RpeBwdParams q;
+    int rc = rpe_bwd_fill(&q, d, G, "rl_rpe_wgrad");
+    if (rc) return rc;
+    RL_REQUIRE(coef && slab, RL_ERR_ARGS, "rl_rpe_wgrad: null coef / slab");
+    RL_REQUIRE(slab_floats >= rl_rpe_wgrad_slab_floats(d->points, d->d, d->u_source), RL_ERR_ARGS, "rl_rpe_wgrad: slab too small");
+    RL_REQUIRE(d->u_source == 1 || GU1, RL_ERR_ARGS, "rl_rpe_wgrad: stage 2 needs the stage-1 gradient output");
+    q.coef = coef; q.slab = slab; q.GU1 = GU1;
+    const int g = rpe_grid(q.pp.P);
+    RPE_DISPATCH(rpe_wgrad_kernel, g, (hipStream_t)stream, q);
+    rl_note_kernel("rpe_wgrad_kernel");
+    RL_LAUNCH_CHECK("rl_rpe_wgrad");
     return RL_OK;
 }

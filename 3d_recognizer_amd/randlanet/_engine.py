@@ -99,15 +99,15 @@ class Engine:
         return self._linear(ctx, a, f"{name}.conv.weight", f"{name}.conv.bias", n_out, transposed=transposed,
                             bn=f"{name}.batch_norm" if bn else None, act=act, slope=slope, a_grad=a_grad)
 
-    def _pool(self, ctx, name: str, u: Lazy, g: Lazy, idx: torch.Tensor, csr, n: int, d: int, n_out: int) -> Lazy:
+    def _pool(self, ctx, name: str, u, g: Lazy, idx: torch.Tensor, csr, n: int, d: int, n_out: int, stage: int = 0) -> Lazy:
         """PointFeatureAugmentation + AttentivePooling (modules.py:213-221, 246-253)."""
         B, K, h = u.B, self.K, d // 2
         rows = B * n * K
         Ws = self.P[f"{name}.score_fn.0.weight"]
         if ops.pool_supported(d, K):
             # narrow levels: one fused kernel, nothing of size rows x d touches HBM
-            pooled = ops.plain(ops.pool_fwd(u, g, idx, Ws, n, d), B, n)
-            ctx.tape.append(("pool_fused", name, u, g, csr, idx, pooled, n, d))
+            pooled = ops.plain(ops.pool_fwd(u, g, idx, Ws, n, d, stage), B, n)
+            ctx.tape.append(("pool_fused", name, u, g, csr, idx, pooled, n, d, stage))
             return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
         X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
         ops.copy_rows(u.raw, (0, h), n * K, X, (0, h), rows, n * K, lazy=u)
@@ -118,6 +118,17 @@ class Engine:
         ctx.tape.append(("pool", name, u, g, csr, X, S, pooled, n, d))
         return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
 
+    def _virtual_bn(self, ctx: Context, vr, stage: int, bn_name: str) -> Lazy:
+        """BatchNorm of a virtual rpe stage: statistics from rl_rpe_stats (training) or the running ones."""
+        stats, nslots = (ops.rpe_stats(vr, stage) if ctx.training else (None, 1))
+        nbt = self.Bf.get(f"{bn_name}.num_batches_tracked")
+        scale, shift, mean, invstd = ops.bn_finalize(
+            stats, vr.rows, 128, vr.h, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
+            self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
+            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, nslots=nslots)
+        rec = Lazy(vr.d2, vr.B, vr.n * 16, vr.n * 16, vr.h, scale, shift, H.ACT_RELU, 0.0, mean, invstd, bn_name)
+        return rec
+
     def _lfa(self, ctx, l: int, xin: Lazy, xyz: torch.Tensor, n: int, d: int, idx, d2, csr=None) -> Lazy:
         """LocalFeatureAggregation (modules.py:298-325); idx / d2 = its K nearest neighbours."""
         e = f"encoder.{l}"
@@ -125,14 +136,23 @@ class Engine:
         ctx.keep += [idx, d2]
         f0 = self._mlp(ctx, xin, f"{e}.mlp1", h, H.ACT_LRELU, 0.2)
         sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
-        rpe = Rpe(xyz, idx, d2, B, n, K)
-        if h <= 64 and not ops.NO_RPE_TENSOR:
-            # read twice (forward + weight gradient): cheaper as a 48-byte row than re-gathered in both kernels
-            rpe = ops.rpe_build(rpe)
-        u1 = self._mlp(ctx, rpe, f"{e}.mlp_rpe1", h, H.ACT_RELU, a_grad=False)
-        q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, csr, n, d, h)
-        u2 = self._mlp(ctx, u1, f"{e}.mlp_rpe2", h, H.ACT_RELU)
-        q2 = self._pool(ctx, f"{e}.pool2", u2, q1, idx, csr, n, d, d)
+        if ops.virtual_rpe_supported(d, K):
+            # the outputs of mlp_rpe1 / mlp_rpe2 are never stored: their consumers recompute them from the coordinates
+            vr = ops.VirtualRpe(xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
+                                self.P[f"{e}.mlp_rpe2.conv.weight"], self.P[f"{e}.mlp_rpe2.conv.bias"])
+            vr.bn1 = self._virtual_bn(ctx, vr, 1, f"{e}.mlp_rpe1.batch_norm")
+            q1 = self._pool(ctx, f"{e}.pool1", vr, f0, idx, csr, n, d, h, stage=1)
+            vr.bn2 = self._virtual_bn(ctx, vr, 2, f"{e}.mlp_rpe2.batch_norm")
+            q2 = self._pool(ctx, f"{e}.pool2", vr, q1, idx, csr, n, d, d, stage=2)
+        else:
+            rpe = Rpe(xyz, idx, d2, B, n, K)
+            if h <= 64 and not ops.NO_RPE_TENSOR:
+                # read twice (forward + weight gradient): cheaper as a 48-byte row than re-gathered in both kernels
+                rpe = ops.rpe_build(rpe)
+            u1 = self._mlp(ctx, rpe, f"{e}.mlp_rpe1", h, H.ACT_RELU, a_grad=False)
+            q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, csr, n, d, h)
+            u2 = self._mlp(ctx, u1, f"{e}.mlp_rpe2", h, H.ACT_RELU)
+            q2 = self._pool(ctx, f"{e}.pool2", u2, q1, idx, csr, n, d, d)
         m2 = self._mlp(ctx, q2, f"{e}.mlp2", 2 * d)
         O = ops.plain(ops.add_act_fwd(m2, sc, 0.01), B, n)
         ctx.tape.append(("add_act", m2, sc, O))
@@ -265,7 +285,10 @@ class Engine:
             elif kind == "pool":
                 self._bwd_pool(ctx, grads, *rec[1:])
             elif kind == "pool_fused":
-                _, name, u, g, csr, idx, pooled, n, d = rec
+                _, name, u, g, csr, idx, pooled, n, d, stage = rec
+                if stage:
+                    self._bwd_pool_virtual(ctx, grads, name, u, g, csr, idx, pooled, n, d, stage)
+                    continue
                 GP, init = self._gbuf(ctx, pooled)
                 assert init
                 gu, gg = self._gbuf(ctx, u), self._gbuf(ctx, g)
@@ -350,6 +373,36 @@ class Engine:
             # dA = dY . W^T : the same kernel with the weight strides swapped
             ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=ga[0], out_bstride=a.bstride, accumulate=ga[1])
             ga[1] = True
+
+    def _bwd_pool_virtual(self, ctx, grads, name, vr, g: Lazy, csr, idx, pooled: Lazy, n, d, stage):
+        """Pooling block whose rpe half is virtual, followed by the backward of that stage itself (its BatchNorm + ReLU +
+        Linear: mlp_rpe2 for stage 2, mlp_rpe1 for stage 1 - they have no tape records of their own)."""
+        h = d // 2
+        e = name.rsplit(".", 1)[0]                       # encoder.<l>
+        GP, init = self._gbuf(ctx, pooled)
+        assert init
+        key = ("vgu", id(vr))
+        if stage == 2:
+            GU = torch.empty((vr.rows, h), dtype=torch.float32, device=GP.device)
+            first = True
+        else:
+            GU, first = ctx.grads.pop(key)[0], False     # written by stage 2's Linear backward (dY2 . W2)
+        gg = self._gbuf(ctx, g)
+        DG = ops.pool_bwd(vr, g, idx, self.P[f"{name}.score_fn.0.weight"], n, d, GP, GU, not first,
+                          grads[f"{name}.score_fn.0.weight"], pending=ctx.pending, stage=stage)
+        ops.segment_sum_rows(DG, (0, h), n * self.K, csr, gg[0], g.bstride, accumulate=gg[1])
+        gg[1] = True
+        # the stage's own backward: batch-statistics terms of its BatchNorm, then weight / bias (/ input) gradients
+        layer = f"{e}.mlp_rpe{stage}"
+        pending = ctx.pending if ctx.pending is not None else []
+        coef = ops.rpe_bn_backward(vr, stage, GU, grads[f"{layer}.batch_norm.weight"], grads[f"{layer}.batch_norm.bias"],
+                                   sync=self.sync)
+        GU1 = torch.empty_like(GU) if stage == 2 else None
+        ops.rpe_wgrad(vr, stage, GU, coef, grads[f"{layer}.conv.weight"], grads[f"{layer}.conv.bias"], pending, GU1)
+        if ctx.pending is None:
+            ops.wgrad_flush(pending)
+        if stage == 2:
+            ctx.grads[key] = [GU1, True]
 
     def _bwd_pool(self, ctx, grads, name, u: Lazy, g: Lazy, csr, X, S, pooled: Lazy, n, d):
         B, K, h = u.B, self.K, d // 2

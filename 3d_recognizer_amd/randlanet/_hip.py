@@ -110,6 +110,10 @@ class PoolDesc(C.Structure):
         ("Pout", C.c_void_p), ("dP", C.c_void_p), ("GU", C.c_void_p), ("gu_accumulate", C.c_int32),
         ("DG", C.c_void_p), ("dW", C.c_void_p), ("slab", C.c_void_p), ("slab_floats", C.c_int64),
         ("X_out", C.c_void_p), ("dS_out", C.c_void_p),
+        ("u_source", C.c_int32), ("xyz", C.c_void_p), ("xyz_bstride", C.c_int64), ("nbr_d2", C.c_void_p),
+        ("W1", C.c_void_p), ("b1", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
+        ("W2", C.c_void_p), ("b2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
+        ("mean1", C.c_void_p), ("invstd1", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
     ]
 
 
@@ -191,6 +195,11 @@ _SIGNATURES = {
     "rl_pool_supported": (_i, [_i, _i]),
     "rl_pool_slab_floats": (_l, [_l, _i]),
     "rl_pool_fwd": (_i, [C.POINTER(PoolDesc), _vp]),
+    "rl_rpe_stats_slots": (_i, [_l]),
+    "rl_rpe_stats": (_i, [C.POINTER(PoolDesc), _vp, _vp]),
+    "rl_rpe_bn_reduce": (_i, [C.POINTER(PoolDesc), _vp, _vp, _vp]),
+    "rl_rpe_wgrad_slab_floats": (_l, [_l, _i, _i]),
+    "rl_rpe_wgrad": (_i, [C.POINTER(PoolDesc), _vp, _vp, _vp, _l, _vp, _vp]),
     "rl_pool_bwd": (_i, [C.POINTER(PoolDesc), _vp]),
     "rl_attpool_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
     "rl_attpool_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp]),

@@ -97,6 +97,9 @@ NO_DEFERRED_WGRAD = bool(int(__import__("os").environ.get("RL_NO_DEFERRED_WGRAD"
 NO_SPLIT_SCATTER = bool(int(__import__("os").environ.get("RL_NO_SPLIT_SCATTER", "0")))   # diagnostics only
 NO_RESID_BN = bool(int(__import__("os").environ.get("RL_NO_RESID_BN", "0")))             # diagnostics only
 NO_RPE_TENSOR = bool(int(__import__("os").environ.get("RL_NO_RPE_TENSOR", "0")))         # diagnostics only
+# the rpe branch (mlp_rpe1 / mlp_rpe2 outputs) recomputed inside its consumers instead of stored, where the fused pooling
+# kernels support it (16 neighbours, d <= 64); RL_NO_VIRTUAL_RPE=1 keeps the tensors (diagnostics / cross-checks)
+VIRTUAL_RPE = not bool(int(__import__("os").environ.get("RL_NO_VIRTUAL_RPE", "0")))
 FORCE_BRUTE_KNN = bool(int(__import__("os").environ.get("RL_KNN_BRUTE", "0")))         # diagnostics only
 DEBUG_SYNC = bool(int(__import__("os").environ.get("RL_DEBUG_SYNC", "0")))   # print + sync around every launch
 
@@ -398,9 +401,9 @@ def _stats_totals(stats: torch.Tensor, nslots: int, C: int) -> torch.Tensor:
 
 
 def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, nbt, momentum: float,
-                eps: float, training: bool, sync: Optional[SyncGroup] = None):
+                eps: float, training: bool, sync: Optional[SyncGroup] = None, nslots: Optional[int] = None):
     dev = gamma.device
-    nslots = H.row_blocks(rows, tile)
+    nslots = H.row_blocks(rows, tile) if nslots is None else nslots
     if training and sync is not None:            # batch statistics of the GLOBAL batch
         stats = _stats_totals(stats, nslots, C)
         sync.allreduce(stats)
@@ -595,47 +598,147 @@ def segment_sum_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: 
 
 
 # ------------------------------------------------------------------------- pooling, residual
+@dataclass
+class VirtualRpe:
+    """The rpe branch of one encoder level as a function of the coordinates (never stored): stage 1 =
+    relu(bn1(rpe . W1^T + b1)), stage 2 = relu(bn2(stage1 . W2^T + b2)) (reference modules.py:313-320).  bn1 / bn2 are
+    filled in by the engine once their batch statistics are known: Lazy-like records (scale, shift, mean, invstd)."""
+    xyz: torch.Tensor
+    idx: torch.Tensor
+    d2: torch.Tensor
+    B: int
+    n: int
+    h: int
+    W1: torch.Tensor
+    b1: torch.Tensor
+    W2: torch.Tensor
+    b2: torch.Tensor
+    bn1: Optional[Lazy] = None
+    bn2: Optional[Lazy] = None
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.n * 16
+
+
+def virtual_rpe_supported(d: int, K: int) -> bool:
+    return VIRTUAL_RPE and K == 16 and d in (16, 32, 64) and pool_supported(d, K)
+
+
+def _fill_virtual(pd: "H.PoolDesc", v: VirtualRpe, stage: int) -> None:
+    _dev_check(v.xyz, v.idx, v.d2, v.W1, v.b1, v.W2, v.b2)
+    assert v.idx.dtype == torch.int32 and v.idx.shape == (v.B, v.n, 16) and v.d2.shape == v.idx.shape
+    assert v.xyz.shape[0] == v.B and v.xyz.shape[1] >= v.n and v.xyz.shape[2] == 3
+    assert v.W1.numel() == v.h * 10 and v.b1.numel() == v.h and v.W2.numel() == v.h * v.h and v.b2.numel() == v.h
+    pd.u_source, pd.xyz, pd.xyz_bstride, pd.nbr_d2 = stage, v.xyz.data_ptr(), v.xyz.shape[1], v.d2.data_ptr()
+    pd.W1, pd.b1, pd.W2, pd.b2 = v.W1.data_ptr(), v.b1.data_ptr(), v.W2.data_ptr(), v.b2.data_ptr()
+    pd.idx, pd.points, pd.n, pd.d, pd.nbr_k = v.idx.data_ptr(), v.B * v.n, v.n, 2 * v.h, 16
+    for tag, bn in (("1", v.bn1), ("2", v.bn2)):
+        if bn is not None:
+            _dev_check(bn.scale, bn.shift, bn.mean, bn.invstd)
+            setattr(pd, f"scale{tag}", bn.scale.data_ptr())
+            setattr(pd, f"shift{tag}", bn.shift.data_ptr())
+            setattr(pd, f"mean{tag}", H.ptr(bn.mean))
+            setattr(pd, f"invstd{tag}", H.ptr(bn.invstd))
+
+
+def rpe_stats(v: VirtualRpe, stage: int):
+    """BatchNorm partial statistics of the raw output of stage 1 / 2 of the virtual rpe branch: (stats, nslots)."""
+    pd = H.PoolDesc()
+    _fill_virtual(pd, v, stage)
+    assert stage == 1 or v.bn1 is not None
+    nslots = H.lib().rl_rpe_stats_slots(v.B * v.n)
+    stats = torch.empty((nslots, 2, v.h), dtype=torch.float64, device=v.xyz.device)
+    with _rec("rpe_stats", (v.rows, v.h, stage), 8 * v.rows, 2 * v.rows * (16 * v.h + (v.h * v.h if stage == 2 else 0))):
+        H.check(H.lib().rl_rpe_stats(C.byref(pd), stats.data_ptr(), _st()), "rl_rpe_stats")
+    return stats, nslots
+
+
+def rpe_bn_backward(v: VirtualRpe, stage: int, G: torch.Tensor, dgamma, dbeta, sync: Optional[SyncGroup] = None) -> torch.Tensor:
+    """BatchNorm backward statistics of virtual stage `stage` from G (gradient w.r.t. its activated output): fills
+    dgamma / dbeta and returns coef (2h floats) for rpe_wgrad."""
+    pd = H.PoolDesc()
+    _fill_virtual(pd, v, stage)
+    _dev_check(G)
+    assert G.shape == (v.rows, v.h) and G.dtype == F32
+    nslots = H.lib().rl_rpe_stats_slots(v.B * v.n)
+    stats = torch.empty((nslots, 2, v.h), dtype=torch.float64, device=G.device)
+    coef = torch.empty(2 * v.h, dtype=F32, device=G.device)
+    with _rec("rpe_bn_reduce", (v.rows, v.h, stage), 4 * v.rows * v.h + 8 * v.rows, 0):
+        H.check(H.lib().rl_rpe_bn_reduce(C.byref(pd), G.data_ptr(), stats.data_ptr(), _st()), "rl_rpe_bn_reduce")
+    _bn_bwd_finalize(stats, nslots, v.rows, v.h, dgamma, dbeta, coef, sync)
+    return coef
+
+
+def rpe_wgrad(v: VirtualRpe, stage: int, G: torch.Tensor, coef: torch.Tensor, dW: torch.Tensor, dbias: torch.Tensor,
+              pending: list, GU1: Optional[torch.Tensor] = None) -> None:
+    """Weight / bias gradient of the stage's Linear (queued on `pending` for the batched slab reduction) and, for stage 2,
+    GU1 = the gradient w.r.t. the activated stage-1 output."""
+    pd = H.PoolDesc()
+    _fill_virtual(pd, v, stage)
+    _dev_check(G, coef, dW, dbias, GU1)
+    Kin = 10 if stage == 1 else v.h
+    assert dW.numel() == v.h * Kin and dbias.numel() == v.h and (stage == 1 or GU1.shape == (v.rows, v.h))
+    floats = H.lib().rl_rpe_wgrad_slab_floats(v.B * v.n, 2 * v.h, stage)
+    slab = torch.empty(floats, dtype=F32, device=G.device)
+    with _rec("rpe_wgrad", (v.rows, Kin, v.h), 4 * v.rows * v.h * (2 if stage == 2 else 1) + 8 * v.rows, 2 * v.rows * v.h * (Kin + (v.h if stage == 2 else 0))):
+        H.check(H.lib().rl_rpe_wgrad(C.byref(pd), G.data_ptr(), coef.data_ptr(), slab.data_ptr(), slab.numel(), H.ptr(GU1), _st()),
+                "rl_rpe_wgrad")
+    it = H.WgradReduceItem()
+    it.slab, it.dW, it.dbias, it.w_ks, it.w_ns = slab.data_ptr(), dW.data_ptr(), dbias.data_ptr(), 1, Kin
+    it.nsplit, it.N, it.K = H.lib().rl_rpe_stats_slots(v.B * v.n), v.h, Kin
+    pending.append((it, slab, dW, dbias))
+
+
 def pool_supported(d: int, K: int) -> bool:
     return (not NO_FUSED_POOL) and bool(H.lib().rl_pool_supported(d, K))
 
 
-def _pool_desc(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int) -> H.PoolDesc:
-    _dev_check(u.raw, g.raw, idx, W, u.scale, u.shift, g.scale, g.shift)
+def _pool_desc(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, stage: int = 0) -> H.PoolDesc:
+    """u: the rpe-branch half of X - a Lazy tensor ((points*16) x d/2), or a VirtualRpe with `stage` 1 / 2."""
+    _dev_check(g.raw, idx, W, g.scale, g.shift)
     h = d // 2
     B = u.B
     assert idx.dtype == torch.int32 and idx.shape == (B, n, 16)
-    assert u.raw.shape == (B * n * 16, h) and u.bstride == u.n == n * 16 and u.C == h
     assert g.raw.shape[1] == h and g.C == h and g.n == n and g.raw.shape[0] >= (B - 1) * g.bstride + n
     assert W.numel() == d * d
     pd = H.PoolDesc()
-    pd.U, pd.u_scale, pd.u_shift, pd.u_act, pd.u_slope = u.raw.data_ptr(), H.ptr(u.scale), H.ptr(u.shift), u.act, u.slope
+    if isinstance(u, VirtualRpe):
+        assert stage in (1, 2) and u.h == h and u.n == n and u.bn1 is not None and (stage == 1 or u.bn2 is not None)
+        _fill_virtual(pd, u, stage)
+    else:
+        _dev_check(u.raw, u.scale, u.shift)
+        assert u.raw.shape == (B * n * 16, h) and u.bstride == u.n == n * 16 and u.C == h
+        pd.U, pd.u_scale, pd.u_shift, pd.u_act, pd.u_slope = u.raw.data_ptr(), H.ptr(u.scale), H.ptr(u.shift), u.act, u.slope
     pd.G, pd.g_bstride = g.raw.data_ptr(), g.bstride
     pd.g_scale, pd.g_shift, pd.g_act, pd.g_slope = H.ptr(g.scale), H.ptr(g.shift), g.act, g.slope
     pd.idx, pd.W, pd.points, pd.n, pd.d, pd.nbr_k = idx.data_ptr(), W.data_ptr(), B * n, n, d, 16
     return pd
 
 
-def pool_fwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int) -> torch.Tensor:
+def pool_fwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, stage: int = 0) -> torch.Tensor:
     """Fused gather+concat -> score Linear -> softmax over K -> weighted sum: (B*n, d)."""
-    pd = _pool_desc(u, g, idx, W, n, d)
+    pd = _pool_desc(u, g, idx, W, n, d, stage)
     out = torch.empty((u.B * n, d), dtype=F32, device=W.device)
     pd.Pout = out.data_ptr()
     P = u.B * n
-    with _rec("pool_fwd", (P, 16, d), 4 * (P * 16 * (d // 2) + P * 16 * (d // 2) + P * 16 + P * d), 2 * P * 16 * d * d):
+    virt = isinstance(u, VirtualRpe)
+    with _rec("pool_fwd_virtual" if virt else "pool_fwd", (P, 16, d), 4 * ((0 if virt else P * 16 * (d // 2)) + P * 16 * (d // 2) + P * 16 * (2 if virt else 1) + P * d), 2 * P * 16 * d * d):
         H.check(H.lib().rl_pool_fwd(C.byref(pd), _st()), "rl_pool_fwd")
     return out
 
 
-def pool_bwd(u: Lazy, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP: torch.Tensor,
-             GU: torch.Tensor, gu_accumulate: bool, dW: torch.Tensor, pending: Optional[list] = None) -> torch.Tensor:
+def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP: torch.Tensor,
+             GU: torch.Tensor, gu_accumulate: bool, dW: torch.Tensor, pending: Optional[list] = None,
+             stage: int = 0) -> torch.Tensor:
     """Backward of the fused pooling block.  Returns DG ((points*16) x d/2): the gradient of the gathered row of every
     neighbourhood slot, to be summed per gathered point with segment_sum_rows.  d <= 64: dW comes out of the kernel.
     d = 128: the kernel writes X and dS and the weight gradient is the ordinary wide kernel on them (queued on `pending`
     like every other layer's)."""
-    pd = _pool_desc(u, g, idx, W, n, d)
+    pd = _pool_desc(u, g, idx, W, n, d, stage)
     _dev_check(dP, GU, dW)
     P = u.B * n
-    assert dP.shape == (P, d) and GU.shape == u.raw.shape and dW.numel() == d * d
+    assert dP.shape == (P, d) and GU.shape == (P * 16, d // 2) and dW.numel() == d * d
     DG = torch.empty((P * 16, d // 2), dtype=F32, device=W.device)
     pd.dP, pd.GU, pd.gu_accumulate, pd.DG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), DG.data_ptr(), dW.data_ptr()
     nbytes = 4 * (3 * P * 16 * (d // 2) + P * 16 * (d // 2) * (1 + int(gu_accumulate)) + P * 16 + 2 * P * d)

@@ -423,12 +423,56 @@ typedef struct rl_pool_desc {
      * (dY = dS_out, A = X_out).  dW / slab are ignored then. */
     float* X_out;
     float* dS_out;
+    /* u_source 1 / 2 (d = 16 / 32 / 64): the rpe-branch half of X is not read from U but RECOMPUTED per point from the
+     * coordinates - the outputs of mlp_rpe1 / mlp_rpe2 (modules.py:287-291, 313-320) never exist in memory:
+     *   1: relu(bn1(rpe . W1^T + b1))                          rpe = [x_i, x_nbr, x_i - x_nbr, sqrt(d2)] (modules.py:173-186)
+     *   2: relu(bn2(relu(bn1(rpe . W1^T + b1)) . W2^T + b2))
+     * xyz (B, xyz_bstride, 3), nbr_d2 (points,16); W1 (d/2, 10), W2 (d/2, d/2) reference conv layouts [out][in];
+     * scale / shift = the folded BatchNorms (rl_bn_finalize on rl_rpe_stats' partials), mean / invstd = their saved
+     * batch statistics (backward entry points only).  U is ignored.                                         */
+    int32_t u_source;
+    const float* xyz;
+    int64_t xyz_bstride;
+    const float* nbr_d2;
+    const float* W1;
+    const float* b1;
+    const float* scale1;
+    const float* shift1;
+    const float* W2;
+    const float* b2;
+    const float* scale2;
+    const float* shift2;
+    const float* mean1;
+    const float* invstd1;
+    const float* mean2;
+    const float* invstd2;
 } rl_pool_desc;
 
 int rl_pool_supported(int d, int nbr_k);
 int64_t rl_pool_slab_floats(int64_t points, int d);
 int rl_pool_fwd(const rl_pool_desc* d, void* stream);
 int rl_pool_bwd(const rl_pool_desc* d, void* stream);
+
+/* BatchNorm batch statistics of the RAW output of stage u_source (1: mlp_rpe1, 2: mlp_rpe2) of the virtual rpe branch
+ * described by d (xyz, idx, nbr_d2, W1, b1 [, scale1, shift1, W2, b2]): per-workgroup partials (sum, sum of squares;
+ * doubles) stats[slot][2][d/2], slot < rl_rpe_stats_slots(points) - what the GEMM epilogue of that layer would have left
+ * for rl_bn_finalize, without the (points*16) x d/2 tensor.                                                    */
+int rl_rpe_stats_slots(int64_t points);
+int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream);
+
+/* Backward of virtual stage u_source (BatchNorm + ReLU + the stage's Linear).  G (points*16, d/2) is the gradient w.r.t.
+ * the ACTIVATED stage output, as rl_pool_bwd writes it to GU; the raw tile is recomputed (scale / shift / mean / invstd
+ * of the stage's BatchNorm - and of stage 1 for stage 2 - must be set in d).
+ *   rl_rpe_bn_reduce : partials of sum g and sum g*xhat, g = G*[output > 0]: stats[slot][2][d/2], slot <
+ *                      rl_rpe_stats_slots(points), for rl_bn_bwd_finalize (-> dgamma, dbeta, coef).
+ *   rl_rpe_wgrad     : dY = scale*(g - coef[c] - xhat*coef[d/2 + c]); per-workgroup partial slabs [slot][h*Kin + h]
+ *                      (dW[n][k], then db[n]; Kin = 10 for stage 1, d/2 for stage 2), nsplit = rl_rpe_stats_slots(points),
+ *                      to be summed by rl_wgrad_reduce_batch; stage 2 also writes GU1 (points*16, d/2) = dY . W2, the
+ *                      gradient w.r.t. the activated stage-1 output.                                                  */
+int rl_rpe_bn_reduce(const rl_pool_desc* d, const float* G, double* stats, void* stream);
+int64_t rl_rpe_wgrad_slab_floats(int64_t points, int d, int stage);
+int rl_rpe_wgrad(const rl_pool_desc* d, const float* G, const float* coef, float* slab, int64_t slab_floats,
+                 float* GU1, void* stream);
 
 /* Residual sum of two lazy tensors + LeakyReLU (modules.py:325):
  *   O = lrelu(Y1*s1+b1 + Y2*s2+b2);  backward (in place): G <- G * (O > 0 ? 1 : slope)       */

@@ -666,3 +666,56 @@ def test_adam_matches_torch(ops):
         ops.adam_step(p, g, m, v, lr, step)
     assert int(step) == 4
     assert float((p - ref.detach()).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("d,B,n_parent,n", [(16, 2, 900, 500), (32, 1, 300, 300), (64, 2, 400, 257)])
+def test_virtual_rpe_branch_forward(ops, d, B, n_parent, n):
+    """The rpe branch recomputed inside its consumers (rl_rpe_stats + rl_pool_fwd with u_source 1 / 2) against the
+    same computation with the mlp_rpe1 / mlp_rpe2 outputs stored: BatchNorm batch statistics and pooled features."""
+    from randlanet import _hip as H
+    torch.manual_seed(d + n)
+    K, h = 16, d // 2
+    xyz = torch.rand(B, n_parent, 3, device=DEV)
+    idx, d2 = ops.knn_i32(xyz, xyz, n, n, K)
+    W1, b1 = torch.randn(h, 10, device=DEV) * 0.5, torch.randn(h, device=DEV) * 0.1
+    W2, b2 = torch.randn(h, h, device=DEV) / h ** 0.5, torch.randn(h, device=DEV) * 0.1
+    g1w, g1b = torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.2
+    g2w, g2b = torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.2
+    Gf = torch.randn(B * n_parent, h, device=DEV)
+    g = ops.Lazy(Gf, B, n, n_parent, h, torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.3, 2, 0.2)
+    Ws = torch.randn(d, d, device=DEV) / d ** 0.5
+    rows = B * n * K
+
+    def bn(stats, nslots, gamma, beta, c):
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        return ops.bn_finalize(stats, rows, 128, c, gamma, beta, rm, rv, None, 0.99, 1e-6, True, nslots=nslots)
+
+    # stored path
+    rpe = ops.rpe_build(ops.Rpe(xyz, idx, d2, B, n, K))
+    st1 = ops.new_stats(DEV, h)
+    Y1 = ops.gemm(rpe, W1, 1, 10, h, b1, stats=st1)
+    s1 = bn(st1, H.row_blocks(rows, 128), g1w, g1b, h)
+    u1 = ops.Lazy(Y1, B, n * K, n * K, h, s1[0], s1[1], 1, 0.0, s1[2], s1[3])
+    P1 = ops.pool_fwd(u1, g, idx, Ws, n, d)
+    st2 = ops.new_stats(DEV, h)
+    Y2 = ops.gemm(u1, W2, 1, h, h, b2, stats=st2)
+    s2 = bn(st2, H.row_blocks(rows, 128), g2w, g2b, h)
+    u2 = ops.Lazy(Y2, B, n * K, n * K, h, s2[0], s2[1], 1, 0.0, s2[2], s2[3])
+    P2 = ops.pool_fwd(u2, g, idx, Ws, n, d)
+    # virtual path
+    vr = ops.VirtualRpe(xyz, idx, d2, B, n, h, W1, b1, W2, b2)
+    vs1, ns = ops.rpe_stats(vr, 1)
+    t1 = bn(vs1, ns, g1w, g1b, h)
+    vr.bn1 = ops.Lazy(d2, B, n * K, n * K, h, t1[0], t1[1], 1, 0.0, t1[2], t1[3])
+    V1 = ops.pool_fwd(vr, g, idx, Ws, n, d, stage=1)
+    vs2, ns = ops.rpe_stats(vr, 2)
+    t2 = bn(vs2, ns, g2w, g2b, h)
+    vr.bn2 = ops.Lazy(d2, B, n * K, n * K, h, t2[0], t2[1], 1, 0.0, t2[2], t2[3])
+    V2 = ops.pool_fwd(vr, g, idx, Ws, n, d, stage=2)
+    tol = 2e-6 if ops.get_wide_gemm() == "fp32" else 5e-5      # the stored path's narrow GEMMs are exact fp32 MFMA chains
+    for a, b_, what in ((t1[2], s1[2], "mean1"), (t1[3], s1[3], "invstd1"), (t2[2], s2[2], "mean2"), (t2[3], s2[3], "invstd2")):
+        assert float((a - b_).abs().max()) < tol * max(1.0, float(b_.abs().max())), what
+    assert float((V1 - P1).abs().max()) < 10 * tol * max(1.0, float(P1.abs().max()))
+    assert float((V2 - P2).abs().max()) < 10 * tol * max(1.0, float(P2.abs().max()))
+    # the virtual path is a pure function of its inputs: same bits on a second run
+    assert torch.equal(V2, ops.pool_fwd(vr, g, idx, Ws, n, d, stage=2))
