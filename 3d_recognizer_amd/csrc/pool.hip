@@ -69,12 +69,14 @@ struct PoolParams {
     //   1: relu(bn1(rpe . W1^T + b1))                       (what mlp_rpe1 would have stored; U is ignored)
     //   2: relu(bn2(relu(bn1(rpe . W1^T + b1)) . W2^T + b2)) (mlp_rpe2 on top of it)
     int src;
-    const float* xyz;      // (B, xyz_bstride, 3)
+    const float* xyz;      // (B, xyz_bstride, xyz_w): xyz_w = 3, or 4 (x, y, z, unused; 16-byte aligned)
     long xyz_bstride;
+    int xyz_w;
     const float* nbr_d2;   // (P, 16) squared neighbour distances
     const float* W1; const float* b1; const float* sc1; const float* sh1;   // mlp_rpe1 (h x 10) + folded BatchNorm
     const float* W2; const float* b2; const float* sc2; const float* sh2;   // mlp_rpe2 (h x h)
     const float* mu1; const float* is1; const float* mu2; const float* is2; // saved mean / invstd (backward kernels)
+    double* bstats;        // pool_bwd with a virtual stage: [grid][2][H] partial sums of g and g*xhat of that stage's BatchNorm
 };
 
 template <int DT>
@@ -309,9 +311,18 @@ struct RpeIn {
 __device__ __forceinline__ void fetch_rpe(const PoolParams& p, long pt, int li, int nbr, RpeIn& r) {
     const long b = (unsigned)pt / (unsigned)p.n;
     const long i = pt - b * p.n;
-    const float* xb = p.xyz + b * p.xyz_bstride * 3;
-    r.xi[0] = xb[i * 3 + 0]; r.xi[1] = xb[i * 3 + 1]; r.xi[2] = xb[i * 3 + 2];
-    r.xj[0] = xb[(long)nbr * 3 + 0]; r.xj[1] = xb[(long)nbr * 3 + 1]; r.xj[2] = xb[(long)nbr * 3 + 2];
+    if (p.xyz_w == 4) {
+        // padded coordinates: one 16-byte gather per point instead of three 4-byte ones (the texture path pays per
+        // distinct line and per instruction)
+        const float4* xb = reinterpret_cast<const float4*>(p.xyz) + b * p.xyz_bstride;
+        const float4 a = xb[i], c = xb[nbr];
+        r.xi[0] = a.x; r.xi[1] = a.y; r.xi[2] = a.z;
+        r.xj[0] = c.x; r.xj[1] = c.y; r.xj[2] = c.z;
+    } else {
+        const float* xb = p.xyz + b * p.xyz_bstride * 3;
+        r.xi[0] = xb[i * 3 + 0]; r.xi[1] = xb[i * 3 + 1]; r.xi[2] = xb[i * 3 + 2];
+        r.xj[0] = xb[(long)nbr * 3 + 0]; r.xj[1] = xb[(long)nbr * 3 + 1]; r.xj[2] = xb[(long)nbr * 3 + 2];
+    }
     r.dd = p.nbr_d2[pt * 16 + li];
 }
 // channels [x_i, x_nbr, x_i - x_nbr, dist, 0...] (modules.py:173-186): this lane's float4 = channels 4*lj .. 4*lj+3
@@ -414,9 +425,8 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
 template <int DT, int TERMS>
 __device__ __forceinline__ void finish_x_virtual(const PoolParams& p, int li, int lj, const float4 (&graw)[DT], const RpeIn& in,
                                                  const float (&sc)[DT][4], const float (&sh)[DT][4], const VWeights<DT, TERMS>& w,
-                                                 const VCols<DT>& vc, float4 (&xa)[DT], float* Xs) {
+                                                 const VCols<DT>& vc, float4 (&xa)[DT], float* Xs, f32x4 (&rawu)[VT<DT>::DTH]) {
     constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
-    f32x4 rawu[VT<DT>::DTH];
     rpe_branch<DT, TERMS>(p, in, p.src, w, vc, li, lj, Xs, XS, rawu, Xs);
     const int gact = p.glazy.scale ? p.glazy.act : RL_ACT_NONE;
 #pragma unroll
@@ -463,10 +473,10 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
 }
 
 template <int DT>
-__device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* Wn) {
+__device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* Wn, int nthreads = 256) {
     constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS;
     // tile_gemm wants B transposed ([n][k]):  S = X.W^T has B^T = W itself -> Wn;  dX = dS.W has B^T = W^T -> Wt
-    for (int e = threadIdx.x; e < D * D; e += 256) {
+    for (int e = threadIdx.x; e < D * D; e += nthreads) {
         const int o = e / D, i = e - o * D;
         const float w = p.W[e];
         Wn[o * XS + i] = w;
@@ -520,8 +530,10 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     }
     for (; pt < p.P; pt += pstep) {
         float4 xa[DT];
-        if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs);
-        else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        if constexpr (VIRT) {
+            f32x4 rawu[VT<DT>::DTH];
+            finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs, rawu);
+        } else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) {
             fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
@@ -605,14 +617,14 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
     }
 }
 
-template <int DT, int TERMS, bool VIRT = false>
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
+template <int DT, int TERMS, bool VIRT = false, int NW = 4>   // NW wavefronts share the staged weights
+__global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
     // LDS: W^T, W, and per wavefront an X tile and a dS tile; after the main loop the W region is
     // reused to combine the four wavefronts' dW tiles
     __shared__ __attribute__((aligned(16))) float Wmem[TERMS == 0 ? 2 * D * XS : 2 * D * XSB];   // bf16: 4 arrays of D*XSB
-    __shared__ __attribute__((aligned(16))) float Tiles[4][2][16 * XS];
+    __shared__ __attribute__((aligned(16))) float Tiles[NW][2][16 * XS];
     float* Wt = Wmem;
     float* Wn = Wmem + D * XS;
     __bf16* Wnh = reinterpret_cast<__bf16*>(Wmem);      // [n][k] head / tail: S = X.W^T
@@ -622,9 +634,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lj = lane >> 4;
     if constexpr (TERMS == 0) {
-        stage_w<DT>(p, Wt, Wn);
+        stage_w<DT>(p, Wt, Wn, 64 * NW);
     } else {
-        for (int e = threadIdx.x; e < D * D; e += 256) {
+        for (int e = threadIdx.x; e < D * D; e += 64 * NW) {
             const int o = e / D, i = e - o * D;
             const float w = p.W[e];
             const __bf16 h = (__bf16)w, l = (__bf16)(w - (float)h);
@@ -634,10 +646,22 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     }
     VWeights<DT, TERMS> vw;
     VCols<DT> vc;
+    constexpr int BDTH = VIRT ? VT<DT>::DTH : 1;
+    float bsg[BDTH], bsx[BDTH], bstat_sc[BDTH], bstat_sh[BDTH], bstat_mu[BDTH], bstat_is[BDTH];
     if constexpr (VIRT) {
         vw.bind(vmem);
-        vw.stage(p, 256);
+        vw.stage(p, 64 * NW);
         vc.load(p, li);
+#pragma unroll
+        for (int nb = 0; nb < BDTH; ++nb) {
+            const int c = nb * 16 + li;
+            const bool in = c < H && p.bstats != nullptr;
+            bsg[nb] = bsx[nb] = 0.f;
+            bstat_sc[nb] = in ? (p.src == 1 ? p.sc1[c] : p.sc2[c]) : 0.f;
+            bstat_sh[nb] = in ? (p.src == 1 ? p.sh1[c] : p.sh2[c]) : 0.f;
+            bstat_mu[nb] = in ? (p.src == 1 ? p.mu1[c] : p.mu2[c]) : 0.f;
+            bstat_is[nb] = in ? (p.src == 1 ? p.is1[c] : p.is2[c]) : 0.f;
+        }
     }
     __syncthreads();
     float sc[DT][4], sh[DT][4];
@@ -651,8 +675,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
         for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
-    const long pstep = (long)gridDim.x * 4;
-    long pt = (long)blockIdx.x * 4 + wave;
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
@@ -663,7 +687,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
     }
     for (; pt < p.P; pt += pstep) {
         float4 xa[DT];
-        if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs);
+        f32x4 rawu[VIRT ? VT<DT>::DTH : 1];
+        if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs, rawu);
         else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) {
@@ -758,10 +783,20 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
 #pragma unroll
             for (int nb = 0; nb < DT; ++nb) {
                 const int col = nb * 16 + li;
-                const float v = dx[nb][r];
+                float v = dx[nb][r];
                 if (col < H) {
-                    if (p.gu_accumulate) p.GU[urow + col] += v;
-                    else p.GU[urow + col] = v;
+                    if (p.gu_accumulate) v += p.GU[urow + col];
+                    p.GU[urow + col] = v;
+                    if constexpr (VIRT) {
+                        // this launch completes the gradient of the stage's activated output: the batch-statistics sums
+                        // of its BatchNorm backward come for free (the raw tile is in registers)
+                        if (p.bstats && nb < VT<DT>::DTH) {
+                            const float z = rawu[nb][r] * bstat_sc[nb] + bstat_sh[nb];
+                            const float g = z > 0.f ? v : 0.f;
+                            bsg[nb] += g;
+                            bsx[nb] += g * ((rawu[nb][r] - bstat_mu[nb]) * bstat_is[nb]);
+                        }
+                    }
                 } else {
                     p.DG[urow + (col - H)] = v;
                 }
@@ -769,10 +804,39 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolParams p) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (VIRT) {
+        if (p.bstats) {
+            // (Tiles is free: every wavefront is past its last point once the barrier below is reached)
+            __syncthreads();
+            double* redd = reinterpret_cast<double*>(&Tiles[0][0][0]);      // [NW][2][HP] doubles
+            constexpr int HP = VT<DT>::HP;
+#pragma unroll
+            for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
+                float a = bsg[nb], b = bsx[nb];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (lane < 16) {
+                    redd[(wave * 2 + 0) * HP + nb * 16 + lane] = (double)a;
+                    redd[(wave * 2 + 1) * HP + nb * 16 + lane] = (double)b;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < H) {
+                const int c = threadIdx.x;
+                double a0 = 0.0, a1 = 0.0;
+                for (int wv = 0; wv < NW; ++wv) {
+                    a0 += redd[(wv * 2 + 0) * HP + c];
+                    a1 += redd[(wv * 2 + 1) * HP + c];
+                }
+                p.bstats[((long)blockIdx.x * 2 + 0) * H + c] = a0;
+                p.bstats[((long)blockIdx.x * 2 + 1) * H + c] = a1;
+            }
+        }
+    }
     // combine the four wavefronts' dW tiles in a fixed order (W region is free now)
     __syncthreads();
     float* red = Wmem;  // needs DT*DT*256 floats <= 2*D*XS: 16*DT*DT*16 <= 2*16*DT*(16*DT+4) always holds
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
         __syncthreads();
         if (wave == w) {
 #pragma unroll
@@ -1266,7 +1330,13 @@ __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __rest
 // workgroups of a fused pooling launch: each stages W into LDS first and (backward) leaves a d x d slab, so more
 // than 1024 only pays for the narrow forward kernel (measured: d = 16 forward 174 -> 144 us at 2048; every
 // backward and the 64-channel forward get slower)
-int pool_grid(long P, int d, bool backward) {
+int pool_grid(long P, int d, bool backward, bool virt = false) {
+    if (backward && virt && d == 64) {
+        // 8 wavefronts per workgroup (the staged weights + the small rpe weights leave room for one workgroup per CU only)
+        long g8 = (P + 31) / 32;
+        if (g8 < 1) g8 = 1;
+        return (int)(g8 < 512 ? g8 : 512);
+    }
     const long cap = (!backward && d <= 16) ? 2048 : 1024;
     long g = (P + 15) / 16;  // >= 4 points per wavefront
     if (d == 128) g = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;   // 8 wavefronts per workgroup, one workgroup per CU
@@ -1300,9 +1370,19 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
         RL_REQUIRE(d->U, RL_ERR_ARGS, "%s: null U", who);
     }
     p->xyz = d->xyz; p->xyz_bstride = d->xyz_bstride; p->nbr_d2 = d->nbr_d2;
+    p->xyz_w = d->xyz_width == 4 ? 4 : 3;
+    if (d->u_source > 0) {
+        RL_REQUIRE(d->xyz_width == 0 || d->xyz_width == 3 || d->xyz_width == 4, RL_ERR_ARGS, "%s: xyz_width must be 3 or 4", who);
+        RL_REQUIRE(d->xyz_width != 4 || ((uintptr_t)d->xyz & 15) == 0, RL_ERR_ARGS, "%s: padded xyz must be 16-byte aligned", who);
+    }
     p->W1 = d->W1; p->b1 = d->b1; p->sc1 = d->scale1; p->sh1 = d->shift1;
     p->W2 = d->W2; p->b2 = d->b2; p->sc2 = d->scale2; p->sh2 = d->shift2;
     p->mu1 = d->mean1; p->is1 = d->invstd1; p->mu2 = d->mean2; p->is2 = d->invstd2;
+    p->bstats = backward ? d->bn_bwd_stats : nullptr;
+    if (p->bstats) {
+        RL_REQUIRE(d->u_source > 0, RL_ERR_ARGS, "%s: bn_bwd_stats needs a virtual rpe stage", who);
+        RL_REQUIRE(d->u_source == 1 ? (d->mean1 && d->invstd1) : (d->mean2 && d->invstd2), RL_ERR_ARGS, "%s: bn_bwd_stats needs the stage's saved mean / invstd", who);
+    }
     if (!backward) RL_REQUIRE(d->Pout, RL_ERR_ARGS, "%s: null output", who);
     else RL_REQUIRE(d->dP && d->GU && d->DG, RL_ERR_ARGS, "%s: null gradient buffers", who);
     return RL_OK;
@@ -1318,6 +1398,7 @@ extern "C" int rl_pool_supported(int d, int nbr_k) {
 }
 
 extern "C" int64_t rl_pool_slab_floats(int64_t points, int d) { return (int64_t)pool_grid(points, d, true) * d * d; }
+extern "C" int rl_pool_bwd_slots(int64_t points, int d) { return pool_grid(points, d, true, true); }
 
 extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     PoolParams p;
@@ -1372,18 +1453,18 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
         return RL_OK;
     }
     RL_REQUIRE(d->dW && d->slab, RL_ERR_ARGS, "rl_pool_bwd: null gradient buffers");
-    const int g = pool_grid(p.P, p.d, true);
+    const int g = pool_grid(p.P, p.d, true, p.src > 0);
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
     if (p.src > 0) {
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_bwd: the virtual rpe branch needs its folded BatchNorm(s)");
         if (rl_wide_terms() == 0) {
             if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0, true>), dim3(g), dim3(256), 0, st, p);
             else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0, true>), dim3(g), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((pool_bwd_kernel<4, 0, true>), dim3(g), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((pool_bwd_kernel<4, 0, true, 8>), dim3(g), dim3(512), 0, st, p);
         } else {
             if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3, true>), dim3(g), dim3(256), 0, st, p);
             else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3, true>), dim3(g), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((pool_bwd_kernel<4, 3, true>), dim3(g), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((pool_bwd_kernel<4, 3, true, 8>), dim3(g), dim3(512), 0, st, p);
         }
         rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1,virtual>" : p.d == 32 ? "pool_bwd_kernel<2,virtual>" : "pool_bwd_kernel<4,virtual>");
         RL_LAUNCH_CHECK("rl_pool_bwd(virtual)");
@@ -1427,6 +1508,8 @@ extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) 
     PoolParams p = {};
     p.idx = d->idx; p.P = d->points; p.n = d->n; p.d = d->d; p.src = d->u_source;
     p.xyz = d->xyz; p.xyz_bstride = d->xyz_bstride; p.nbr_d2 = d->nbr_d2;
+    p.xyz_w = d->xyz_width == 4 ? 4 : 3;
+    RL_REQUIRE(d->xyz_width != 4 || ((uintptr_t)d->xyz & 15) == 0, RL_ERR_ARGS, "rl_rpe_stats: padded xyz must be 16-byte aligned");
     p.W1 = d->W1; p.b1 = d->b1; p.sc1 = d->scale1; p.sh1 = d->shift1;
     p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
     const int g = rpe_grid(p.P);
@@ -1459,6 +1542,8 @@ static int rpe_bwd_fill(RpeBwdParams* q, const rl_pool_desc* d, const float* G, 
     p = PoolParams{};
     p.idx = d->idx; p.P = d->points; p.n = d->n; p.d = d->d; p.src = d->u_source;
     p.xyz = d->xyz; p.xyz_bstride = d->xyz_bstride; p.nbr_d2 = d->nbr_d2;
+    p.xyz_w = d->xyz_width == 4 ? 4 : 3;
+    RL_REQUIRE(d->xyz_width != 4 || ((uintptr_t)d->xyz & 15) == 0, RL_ERR_ARGS, "%s: padded xyz must be 16-byte aligned", who);
     p.W1 = d->W1; p.b1 = d->b1; p.sc1 = d->scale1; p.sh1 = d->shift1;
     p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
     p.mu1 = d->mean1; p.is1 = d->invstd1; p.mu2 = d->mean2; p.is2 = d->invstd2;

@@ -138,7 +138,7 @@ class Engine:
         sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
         if ops.virtual_rpe_supported(d, K):
             # the outputs of mlp_rpe1 / mlp_rpe2 are never stored: their consumers recompute them from the coordinates
-            vr = ops.VirtualRpe(xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
+            vr = ops.VirtualRpe(ctx.xyz4 if getattr(ctx, "xyz4", None) is not None else xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
                                 self.P[f"{e}.mlp_rpe2.conv.weight"], self.P[f"{e}.mlp_rpe2.conv.bias"])
             vr.bn1 = self._virtual_bn(ctx, vr, 1, f"{e}.mlp_rpe1.batch_norm")
             q1 = self._pool(ctx, f"{e}.pool1", vr, f0, idx, csr, n, d, h, stage=1)
@@ -196,6 +196,13 @@ class Engine:
             tasks.append((N // ratio, dec * N // ratio, 1))
             ratio //= dec
         searches = ops.knn_multi(xyz, tasks)
+        # coordinates padded to 16 bytes for the kernels that gather them per neighbour (virtual rpe branch)
+        xyz4 = None
+        if any(ops.virtual_rpe_supported(d, self.K) for d in self.layers):
+            xyz4 = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+            ops.copy_rows(xyz.view(B * N, 3), (0, 3), N, xyz4.view(B * N, 4), (0, 3), B * N, N)
+            ctx.keep.append(xyz4)
+        ctx.xyz4 = xyz4
         # training: the transpose of every neighbour graph ("who gathered from me"), so that the gathers' backward sums
         # each destination row in a fixed order (bitwise reproducible steps; torch's scatter_add_ has no defined order)
         csrs = [None] * (2 * L)
@@ -388,15 +395,19 @@ class Engine:
         else:
             GU, first = ctx.grads.pop(key)[0], False     # written by stage 2's Linear backward (dY2 . W2)
         gg = self._gbuf(ctx, g)
+        # this launch completes GU (stage 2: its only writer; stage 1: it adds the pooling path to dY2 . W2), so it can
+        # leave the batch-statistics sums of the stage's BatchNorm backward as well
+        nslots = H.lib().rl_pool_bwd_slots(vr.B * n, d)
+        bstats = torch.empty((nslots, 2, h), dtype=torch.float64, device=GP.device)
         DG = ops.pool_bwd(vr, g, idx, self.P[f"{name}.score_fn.0.weight"], n, d, GP, GU, not first,
-                          grads[f"{name}.score_fn.0.weight"], pending=ctx.pending, stage=stage)
+                          grads[f"{name}.score_fn.0.weight"], pending=ctx.pending, stage=stage, bn_bwd_stats=bstats)
         ops.segment_sum_rows(DG, (0, h), n * self.K, csr, gg[0], g.bstride, accumulate=gg[1])
         gg[1] = True
         # the stage's own backward: batch-statistics terms of its BatchNorm, then weight / bias (/ input) gradients
         layer = f"{e}.mlp_rpe{stage}"
         pending = ctx.pending if ctx.pending is not None else []
         coef = ops.rpe_bn_backward(vr, stage, GU, grads[f"{layer}.batch_norm.weight"], grads[f"{layer}.batch_norm.bias"],
-                                   sync=self.sync)
+                                   sync=self.sync, stats=bstats, nslots=nslots)
         GU1 = torch.empty_like(GU) if stage == 2 else None
         ops.rpe_wgrad(vr, stage, GU, coef, grads[f"{layer}.conv.weight"], grads[f"{layer}.conv.bias"], pending, GU1)
         if ctx.pending is None:

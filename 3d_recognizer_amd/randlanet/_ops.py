@@ -628,7 +628,8 @@ def virtual_rpe_supported(d: int, K: int) -> bool:
 def _fill_virtual(pd: "H.PoolDesc", v: VirtualRpe, stage: int) -> None:
     _dev_check(v.xyz, v.idx, v.d2, v.W1, v.b1, v.W2, v.b2)
     assert v.idx.dtype == torch.int32 and v.idx.shape == (v.B, v.n, 16) and v.d2.shape == v.idx.shape
-    assert v.xyz.shape[0] == v.B and v.xyz.shape[1] >= v.n and v.xyz.shape[2] == 3
+    assert v.xyz.shape[0] == v.B and v.xyz.shape[1] >= v.n and v.xyz.shape[2] in (3, 4)
+    pd.xyz_width = v.xyz.shape[2]
     assert v.W1.numel() == v.h * 10 and v.b1.numel() == v.h and v.W2.numel() == v.h * v.h and v.b2.numel() == v.h
     pd.u_source, pd.xyz, pd.xyz_bstride, pd.nbr_d2 = stage, v.xyz.data_ptr(), v.xyz.shape[1], v.d2.data_ptr()
     pd.W1, pd.b1, pd.W2, pd.b2 = v.W1.data_ptr(), v.b1.data_ptr(), v.W2.data_ptr(), v.b2.data_ptr()
@@ -654,18 +655,21 @@ def rpe_stats(v: VirtualRpe, stage: int):
     return stats, nslots
 
 
-def rpe_bn_backward(v: VirtualRpe, stage: int, G: torch.Tensor, dgamma, dbeta, sync: Optional[SyncGroup] = None) -> torch.Tensor:
+def rpe_bn_backward(v: VirtualRpe, stage: int, G: torch.Tensor, dgamma, dbeta, sync: Optional[SyncGroup] = None,
+                    stats: Optional[torch.Tensor] = None, nslots: int = 0) -> torch.Tensor:
     """BatchNorm backward statistics of virtual stage `stage` from G (gradient w.r.t. its activated output): fills
-    dgamma / dbeta and returns coef (2h floats) for rpe_wgrad."""
-    pd = H.PoolDesc()
-    _fill_virtual(pd, v, stage)
-    _dev_check(G)
-    assert G.shape == (v.rows, v.h) and G.dtype == F32
-    nslots = H.lib().rl_rpe_stats_slots(v.B * v.n)
-    stats = torch.empty((nslots, 2, v.h), dtype=torch.float64, device=G.device)
+    dgamma / dbeta and returns coef (2h floats) for rpe_wgrad.  `stats` / `nslots`: partials already produced by the
+    pooling backward kernel that completed G (pool_bwd's bn_bwd_stats) - then no pass over G is made here."""
+    if stats is None:
+        pd = H.PoolDesc()
+        _fill_virtual(pd, v, stage)
+        _dev_check(G)
+        assert G.shape == (v.rows, v.h) and G.dtype == F32
+        nslots = H.lib().rl_rpe_stats_slots(v.B * v.n)
+        stats = torch.empty((nslots, 2, v.h), dtype=torch.float64, device=G.device)
+        with _rec("rpe_bn_reduce", (v.rows, v.h, stage), 4 * v.rows * v.h + 8 * v.rows, 0):
+            H.check(H.lib().rl_rpe_bn_reduce(C.byref(pd), G.data_ptr(), stats.data_ptr(), _st()), "rl_rpe_bn_reduce")
     coef = torch.empty(2 * v.h, dtype=F32, device=G.device)
-    with _rec("rpe_bn_reduce", (v.rows, v.h, stage), 4 * v.rows * v.h + 8 * v.rows, 0):
-        H.check(H.lib().rl_rpe_bn_reduce(C.byref(pd), G.data_ptr(), stats.data_ptr(), _st()), "rl_rpe_bn_reduce")
     _bn_bwd_finalize(stats, nslots, v.rows, v.h, dgamma, dbeta, coef, sync)
     return coef
 
@@ -730,7 +734,7 @@ def pool_fwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, sta
 
 def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP: torch.Tensor,
              GU: torch.Tensor, gu_accumulate: bool, dW: torch.Tensor, pending: Optional[list] = None,
-             stage: int = 0) -> torch.Tensor:
+             stage: int = 0, bn_bwd_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Backward of the fused pooling block.  Returns DG ((points*16) x d/2): the gradient of the gathered row of every
     neighbourhood slot, to be summed per gathered point with segment_sum_rows.  d <= 64: dW comes out of the kernel.
     d = 128: the kernel writes X and dS and the weight gradient is the ordinary wide kernel on them (queued on `pending`
@@ -740,6 +744,11 @@ def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP:
     P = u.B * n
     assert dP.shape == (P, d) and GU.shape == (P * 16, d // 2) and dW.numel() == d * d
     DG = torch.empty((P * 16, d // 2), dtype=F32, device=W.device)
+    if bn_bwd_stats is not None:
+        _dev_check(bn_bwd_stats)
+        assert stage > 0 and bn_bwd_stats.dtype == torch.float64
+        assert bn_bwd_stats.numel() >= H.lib().rl_pool_bwd_slots(P, d) * d
+        pd.bn_bwd_stats = bn_bwd_stats.data_ptr()
     pd.dP, pd.GU, pd.gu_accumulate, pd.DG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), DG.data_ptr(), dW.data_ptr()
     nbytes = 4 * (3 * P * 16 * (d // 2) + P * 16 * (d // 2) * (1 + int(gu_accumulate)) + P * 16 + 2 * P * d)
     if d == 128:

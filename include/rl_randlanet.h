@@ -427,7 +427,9 @@ typedef struct rl_pool_desc {
      * coordinates - the outputs of mlp_rpe1 / mlp_rpe2 (modules.py:287-291, 313-320) never exist in memory:
      *   1: relu(bn1(rpe . W1^T + b1))                          rpe = [x_i, x_nbr, x_i - x_nbr, sqrt(d2)] (modules.py:173-186)
      *   2: relu(bn2(relu(bn1(rpe . W1^T + b1)) . W2^T + b2))
-     * xyz (B, xyz_bstride, 3), nbr_d2 (points,16); W1 (d/2, 10), W2 (d/2, d/2) reference conv layouts [out][in];
+     * xyz (B, xyz_bstride, xyz_width) with xyz_width 3 (0 means 3) or 4 (x, y, z and one unused float per point,
+     * 16-byte aligned: one gather per neighbour instead of three); nbr_d2 (points,16); W1 (d/2, 10), W2 (d/2, d/2)
+     * reference conv layouts [out][in];
      * scale / shift = the folded BatchNorms (rl_bn_finalize on rl_rpe_stats' partials), mean / invstd = their saved
      * batch statistics (backward entry points only).  U is ignored.                                         */
     int32_t u_source;
@@ -446,10 +448,17 @@ typedef struct rl_pool_desc {
     const float* invstd1;
     const float* mean2;
     const float* invstd2;
+    int32_t xyz_width;
+    /* rl_pool_bwd with a virtual stage, optional: when this launch COMPLETES the gradient of the stage's activated
+     * output (GU after it holds the total), it also leaves the batch-statistics partials of that stage's BatchNorm
+     * backward - what rl_rpe_bn_reduce would compute from GU - in bn_bwd_stats[slot][2][d/2], slot <
+     * rl_pool_bwd_slots(points, d), saving that pass. */
+    double* bn_bwd_stats;
 } rl_pool_desc;
 
 int rl_pool_supported(int d, int nbr_k);
 int64_t rl_pool_slab_floats(int64_t points, int d);
+int rl_pool_bwd_slots(int64_t points, int d);   /* workgroups (= partial slots) of an rl_pool_bwd launch */
 int rl_pool_fwd(const rl_pool_desc* d, void* stream);
 int rl_pool_bwd(const rl_pool_desc* d, void* stream);
 
