@@ -12,8 +12,27 @@
 
 namespace {
 
-// Sum of the per-workgroup partials of channel c over all slots, by one wavefront, in a fixed order.  Four
-// independent chains keep 8 loads in flight per lane: these kernels are pure latency (a few KB of doubles).
+// Sum of the per-workgroup partials of channel c over all slots by a whole workgroup (256 lanes: at most four slots per
+// lane, i.e. ONE round of memory latency for up to 1024 slots - these kernels are pure latency), in a fixed order:
+// lane t adds slots t, t+256, ... ; the lanes are then combined by a fixed butterfly + a fixed sum over the wavefronts.
+__device__ __forceinline__ void slot_sums_wg(const double* __restrict__ stats, int nslots, int C, int c,
+                                             double (*red)[2], double& s_out, double& q_out) {
+    const int t = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    const double* base = stats + c;
+    for (int i = t; i < nslots; i += 256) {
+        s += base[((long)i * 2 + 0) * C];
+        q += base[((long)i * 2 + 1) * C];
+    }
+    s = rl_wave_sum(s);
+    q = rl_wave_sum(q);
+    if ((t & 63) == 0) { red[t >> 6][0] = s; red[t >> 6][1] = q; }
+    __syncthreads();
+    s_out = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    q_out = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+}
+
+// one wavefront's worth of the same sum (kept for rl_bn_reduce_slots)
 __device__ __forceinline__ void slot_sums(const double* __restrict__ stats, int nslots, int C, int c, int lane,
                                           double& s_out, double& q_out) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
@@ -33,19 +52,18 @@ __device__ __forceinline__ void slot_sums(const double* __restrict__ stats, int 
     q_out = rl_wave_sum((q0 + q1) + (q2 + q3));
 }
 
-// one wavefront per channel
+// one workgroup per channel
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const double* __restrict__ stats, int nslots, double count, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double red[4][2];
+    const int c = blockIdx.x;          // one workgroup per channel
     double mean, var;
     if (training) {
         double s, q;
-        slot_sums(stats, nslots, C, c, lane, s, q);
+        slot_sums_wg(stats, nslots, C, c, red, s, q);
         mean = s / count;
         var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -53,7 +71,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         mean = (double)rmean[c];
         var = (double)rvar[c];
     }
-    if (lane != 0) return;
+    if (threadIdx.x != 0) return;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = g * invstd;
@@ -172,12 +190,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nslots,
                                                               double count, int C, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double red[4][2];
+    const int c = blockIdx.x;          // one workgroup per channel
     double s, q;
-    slot_sums(stats, nslots, C, c, lane, s, q);
-    if (lane != 0) return;
+    slot_sums_wg(stats, nslots, C, c, red, s, q);
+    if (threadIdx.x != 0) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
     coef[c] = (float)(s / count);
@@ -442,7 +459,7 @@ extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, in
     RL_REQUIRE(C > 0 && scale && shift, RL_ERR_ARGS, "rl_bn_finalize: bad arguments");
     if (training) RL_REQUIRE(stats && nslots > 0 && count > 0, RL_ERR_ARGS, "rl_bn_finalize: training needs partial statistics");
     else RL_REQUIRE(running_mean && running_var, RL_ERR_ARGS, "rl_bn_finalize: eval needs running statistics");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rl_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, stats, nslots,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslots,
                        (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, training,
                        scale, shift, save_mean, save_invstd);
     RL_LAUNCH_CHECK("rl_bn_finalize");
@@ -477,7 +494,7 @@ extern "C" int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream) {
 extern "C" int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, float* dgamma,
                                   float* dbeta, float* coef, void* stream) {
     RL_REQUIRE(stats && nslots > 0 && count > 0 && C > 0 && coef, RL_ERR_ARGS, "rl_bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(rl_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, stats,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats,
                        nslots, (double)count, C, dgamma, dbeta, coef);
     RL_LAUNCH_CHECK("rl_bn_bwd_finalize");
     return RL_OK;

@@ -19,6 +19,7 @@
 //   atomics, bitwise reproducible);  dW += dS^T.X accumulates in registers over all points of the
 //   wavefront and leaves the workgroup as one partial slab.
 #include "rl_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -76,6 +77,7 @@ struct PoolParams {
     const float* W1; const float* b1; const float* sc1; const float* sh1;   // mlp_rpe1 (h x 10) + folded BatchNorm
     const float* W2; const float* b2; const float* sc2; const float* sh2;   // mlp_rpe2 (h x h)
     const float* mu1; const float* is1; const float* mu2; const float* is2; // saved mean / invstd (backward kernels)
+    double* fstats2;       // pool_fwd with virtual stage 1: [grid][2][H] partial (sum, sum of squares) of the RAW stage-2 output
     double* bstats;        // pool_bwd with a virtual stage: [grid][2][H] partial sums of g and g*xhat of that stage's BatchNorm
 };
 
@@ -269,7 +271,7 @@ struct VWeights {
                 w1l[n * VT<DT>::S1B + k] = (__bf16)(w - (float)h);
             }
         }
-        if (p.src >= 2) {
+        if (p.src >= 2 || p.fstats2) {
             for (int e = threadIdx.x; e < HP * HP; e += nthreads) {
                 const int n = e / HP, k = e - n * HP;
                 const float w = (n < H && k < H) ? p.W2[n * H + k] : 0.f;
@@ -297,7 +299,7 @@ struct VCols {
             b1[nb] = in ? p.b1[c] : 0.f;
             s1[nb] = (in && p.sc1) ? p.sc1[c] : 0.f;
             h1[nb] = (in && p.sh1) ? p.sh1[c] : 0.f;
-            b2[nb] = (in && p.src >= 2) ? p.b2[c] : 0.f;
+            b2[nb] = (in && (p.src >= 2 || p.fstats2)) ? p.b2[c] : 0.f;
             s2[nb] = (in && p.src >= 2 && p.sc2) ? p.sc2[c] : 0.f;
             h2[nb] = (in && p.src >= 2 && p.sh2) ? p.sh2[c] : 0.f;
         }
@@ -508,10 +510,13 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     }
     VWeights<DT, TERMS> vw;
     VCols<DT> vc;
+    float fs2[VIRT ? VT<DT>::DTH : 1], fq2[VIRT ? VT<DT>::DTH : 1];
     if constexpr (VIRT) {
         vw.bind(vmem);
         vw.stage(p, 64 * NW);
         vc.load(p, li);
+#pragma unroll
+        for (int nb = 0; nb < VT<DT>::DTH; ++nb) fs2[nb] = fq2[nb] = 0.f;
     }
     __syncthreads();
     float sc[DT][4], sh[DT][4];
@@ -533,6 +538,27 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
         if constexpr (VIRT) {
             f32x4 rawu[VT<DT>::DTH];
             finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs, rawu);
+            if (p.fstats2) {
+                // the next stage's raw output (mlp_rpe2 on this tile) only for its BatchNorm batch statistics
+                constexpr int DTH = VT<DT>::DTH, H = VT<DT>::H;
+                float4 a1[DTH];
+                f32x4 r2[DTH];
+#pragma unroll
+                for (int c = 0; c < DTH; ++c) {
+                    a1[c] = (16 * c + 4 * lj < H) ? xa[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    r2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if constexpr (TERMS == 0) tile_gemm<DTH>(a1, vw.w2f, li, lj, r2);
+                else tile_gemm_bf<DTH>(a1, vw.w2h, vw.w2l, li, lj, r2);
+#pragma unroll
+                for (int nb = 0; nb < DTH; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = r2[nb][r] + vc.b2[nb];
+                        fs2[nb] += v;
+                        fq2[nb] += v * v;
+                    }
+            }
         } else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) {
@@ -558,6 +584,35 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
         }
         __builtin_amdgcn_wave_barrier();
         if constexpr (VIRT) rin = rin_nxt;
+    }
+    if constexpr (VIRT) {
+        if (p.fstats2) {
+            constexpr int H = VT<DT>::H, HP = VT<DT>::HP;
+            __syncthreads();                                                    // the X tiles are free now
+            double* redd = reinterpret_cast<double*>(&Xt[0][0]);                // [NW][2][HP] doubles
+            static_assert(NW * 2 * VT<DT>::HP * 2 <= NW * 16 * XS, "statistics scratch does not fit the X tiles");
+#pragma unroll
+            for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
+                float a = fs2[nb], b = fq2[nb];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+                if (lane < 16) {
+                    redd[(wave * 2 + 0) * HP + nb * 16 + lane] = (double)a;
+                    redd[(wave * 2 + 1) * HP + nb * 16 + lane] = (double)b;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < H) {
+                const int c = threadIdx.x;
+                double a0 = 0.0, a1 = 0.0;
+                for (int wv = 0; wv < NW; ++wv) {
+                    a0 += redd[(wv * 2 + 0) * HP + c];
+                    a1 += redd[(wv * 2 + 1) * HP + c];
+                }
+                p.fstats2[((long)blockIdx.x * 2 + 0) * H + c] = a0;
+                p.fstats2[((long)blockIdx.x * 2 + 1) * H + c] = a1;
+            }
+        }
     }
 }
 
@@ -1344,6 +1399,19 @@ int pool_grid(long P, int d, bool backward, bool virt = false) {
     return (int)(g < cap ? g : cap);
 }
 
+// Arithmetic of the tile kernels for a level of width d: the narrow levels are bound by vector-instruction issue, not by
+// the matrix pipe - the head/tail split of every operand costs more than the exact fp32 MFMA it avoids - so d <=
+// RL_POOL_FP32_MAX_D (default 0: measured no gain at d = 16 / 32) would run v_mfma_f32_16x16x4_f32 (exact fp32 products, whatever the wide-GEMM mode).
+static int pool_terms(int d) {
+    static int max_d = -1;
+    if (max_d < 0) {
+        const char* e = getenv("RL_POOL_FP32_MAX_D");
+        max_d = e ? atoi(e) : 0;
+    }
+    if (d <= max_d) return 0;
+    return rl_wide_terms();
+}
+
 int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     RL_REQUIRE(d && d->G && d->idx && d->W && d->points > 0 && d->n > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
     RL_REQUIRE(d->nbr_k == 16, RL_ERR_UNSUPPORTED, "%s: the fused kernel needs 16 neighbours (got %d)", who, d->nbr_k);
@@ -1378,6 +1446,8 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->W1 = d->W1; p->b1 = d->b1; p->sc1 = d->scale1; p->sh1 = d->shift1;
     p->W2 = d->W2; p->b2 = d->b2; p->sc2 = d->scale2; p->sh2 = d->shift2;
     p->mu1 = d->mean1; p->is1 = d->invstd1; p->mu2 = d->mean2; p->is2 = d->invstd2;
+    p->fstats2 = backward ? nullptr : d->bn_fwd_stats2;
+    if (p->fstats2) RL_REQUIRE(d->u_source == 1 && d->W2 && d->b2, RL_ERR_ARGS, "%s: bn_fwd_stats2 needs virtual stage 1 and W2 / b2", who);
     p->bstats = backward ? d->bn_bwd_stats : nullptr;
     if (p->bstats) {
         RL_REQUIRE(d->u_source > 0, RL_ERR_ARGS, "%s: bn_bwd_stats needs a virtual rpe stage", who);
@@ -1399,6 +1469,7 @@ extern "C" int rl_pool_supported(int d, int nbr_k) {
 
 extern "C" int64_t rl_pool_slab_floats(int64_t points, int d) { return (int64_t)pool_grid(points, d, true) * d * d; }
 extern "C" int rl_pool_bwd_slots(int64_t points, int d) { return pool_grid(points, d, true, true); }
+extern "C" int rl_pool_fwd_slots(int64_t points, int d) { return pool_grid(points, d, false); }
 
 extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     PoolParams p;
@@ -1408,7 +1479,7 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (p.src > 0) {
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_fwd: the virtual rpe branch needs its folded BatchNorm(s)");
-        if (rl_wide_terms() == 0) {
+        if (pool_terms(p.d) == 0) {
             if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
             else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((pool_fwd_kernel<4, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
@@ -1421,7 +1492,7 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
         RL_LAUNCH_CHECK("rl_pool_fwd(virtual)");
         return RL_OK;
     }
-    if (rl_wide_terms() == 0) {
+    if (pool_terms(p.d) == 0) {
         if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((pool_fwd_kernel<4, 0>), dim3(g), dim3(256), 0, st, p);
@@ -1457,7 +1528,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
     if (p.src > 0) {
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_bwd: the virtual rpe branch needs its folded BatchNorm(s)");
-        if (rl_wide_terms() == 0) {
+        if (pool_terms(p.d) == 0) {
             if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0, true>), dim3(g), dim3(256), 0, st, p);
             else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0, true>), dim3(g), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((pool_bwd_kernel<4, 0, true, 8>), dim3(g), dim3(512), 0, st, p);
@@ -1472,7 +1543,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
         RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
         return RL_OK;
     }
-    if (rl_wide_terms() == 0) {
+    if (pool_terms(p.d) == 0) {
         if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((pool_bwd_kernel<4, 0>), dim3(g), dim3(256), 0, st, p);
@@ -1514,7 +1585,7 @@ extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) 
     p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
     const int g = rpe_grid(p.P);
     hipStream_t st = (hipStream_t)stream;
-    if (rl_wide_terms() == 0) {
+    if (pool_terms(p.d) == 0) {
         if (p.d == 16) hipLaunchKernelGGL((rpe_stats_kernel<1, 0>), dim3(g), dim3(256), 0, st, p, stats);
         else if (p.d == 32) hipLaunchKernelGGL((rpe_stats_kernel<2, 0>), dim3(g), dim3(256), 0, st, p, stats);
         else hipLaunchKernelGGL((rpe_stats_kernel<4, 0>), dim3(g), dim3(256), 0, st, p, stats);
@@ -1553,7 +1624,7 @@ static int rpe_bwd_fill(RpeBwdParams* q, const rl_pool_desc* d, const float* G, 
 
 #define RPE_DISPATCH(KERNEL, grid, st, q)                                                                          \
     do {                                                                                                           \
-        if (rl_wide_terms() == 0) {                                                                                \
+        if (pool_terms((q).pp.d) == 0) {                                                                                \
             if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 0>), dim3(grid), dim3(256), 0, st, q);               \
             else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 0>), dim3(grid), dim3(256), 0, st, q);          \
             else hipLaunchKernelGGL((KERNEL<4, 0>), dim3(grid), dim3(256), 0, st, q);                              \

@@ -99,14 +99,20 @@ class Engine:
         return self._linear(ctx, a, f"{name}.conv.weight", f"{name}.conv.bias", n_out, transposed=transposed,
                             bn=f"{name}.batch_norm" if bn else None, act=act, slope=slope, a_grad=a_grad)
 
-    def _pool(self, ctx, name: str, u, g: Lazy, idx: torch.Tensor, csr, n: int, d: int, n_out: int, stage: int = 0) -> Lazy:
+    def _pool(self, ctx, name: str, u, g: Lazy, idx: torch.Tensor, csr, n: int, d: int, n_out: int, stage: int = 0,
+              next_stats: bool = False) -> Lazy:
         """PointFeatureAugmentation + AttentivePooling (modules.py:213-221, 246-253)."""
         B, K, h = u.B, self.K, d // 2
         rows = B * n * K
         Ws = self.P[f"{name}.score_fn.0.weight"]
         if ops.pool_supported(d, K):
             # narrow levels: one fused kernel, nothing of size rows x d touches HBM
-            pooled = ops.plain(ops.pool_fwd(u, g, idx, Ws, n, d, stage), B, n)
+            if next_stats:
+                res, st2, ns2 = ops.pool_fwd(u, g, idx, Ws, n, d, stage, next_stats=True)
+                ctx.next_stats = (st2, ns2)
+            else:
+                res = ops.pool_fwd(u, g, idx, Ws, n, d, stage)
+            pooled = ops.plain(res, B, n)
             ctx.tape.append(("pool_fused", name, u, g, csr, idx, pooled, n, d, stage))
             return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
         X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
@@ -118,9 +124,11 @@ class Engine:
         ctx.tape.append(("pool", name, u, g, csr, X, S, pooled, n, d))
         return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
 
-    def _virtual_bn(self, ctx: Context, vr, stage: int, bn_name: str) -> Lazy:
-        """BatchNorm of a virtual rpe stage: statistics from rl_rpe_stats (training) or the running ones."""
-        stats, nslots = (ops.rpe_stats(vr, stage) if ctx.training else (None, 1))
+    def _virtual_bn(self, ctx: Context, vr, stage: int, bn_name: str, stats=None, nslots: int = 1) -> Lazy:
+        """BatchNorm of a virtual rpe stage: statistics from rl_rpe_stats / the previous pooling kernel (training) or the
+        running ones."""
+        if ctx.training and stats is None:
+            stats, nslots = ops.rpe_stats(vr, stage)
         nbt = self.Bf.get(f"{bn_name}.num_batches_tracked")
         scale, shift, mean, invstd = ops.bn_finalize(
             stats, vr.rows, 128, vr.h, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
@@ -141,8 +149,10 @@ class Engine:
             vr = ops.VirtualRpe(ctx.xyz4 if getattr(ctx, "xyz4", None) is not None else xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
                                 self.P[f"{e}.mlp_rpe2.conv.weight"], self.P[f"{e}.mlp_rpe2.conv.bias"])
             vr.bn1 = self._virtual_bn(ctx, vr, 1, f"{e}.mlp_rpe1.batch_norm")
-            q1 = self._pool(ctx, f"{e}.pool1", vr, f0, idx, csr, n, d, h, stage=1)
-            vr.bn2 = self._virtual_bn(ctx, vr, 2, f"{e}.mlp_rpe2.batch_norm")
+            # in training pool1's kernel also leaves the batch statistics of mlp_rpe2's raw output (it has the tile)
+            q1 = self._pool(ctx, f"{e}.pool1", vr, f0, idx, csr, n, d, h, stage=1, next_stats=ctx.training)
+            vr.bn2 = self._virtual_bn(ctx, vr, 2, f"{e}.mlp_rpe2.batch_norm", *getattr(ctx, "next_stats", (None, 1)))
+            ctx.next_stats = (None, 1)
             q2 = self._pool(ctx, f"{e}.pool2", vr, q1, idx, csr, n, d, d, stage=2)
         else:
             rpe = Rpe(xyz, idx, d2, B, n, K)

@@ -114,7 +114,7 @@ class PoolDesc(C.Structure):
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
         ("W2", C.c_void_p), ("b2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("mean1", C.c_void_p), ("invstd1", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
-        ("xyz_width", C.c_int32), ("bn_bwd_stats", C.c_void_p),
+        ("xyz_width", C.c_int32), ("bn_bwd_stats", C.c_void_p), ("bn_fwd_stats2", C.c_void_p),
     ]
 
 
@@ -196,6 +196,7 @@ _SIGNATURES = {
     "rl_pool_supported": (_i, [_i, _i]),
     "rl_pool_slab_floats": (_l, [_l, _i]),
     "rl_pool_bwd_slots": (_i, [_l, _i]),
+    "rl_pool_fwd_slots": (_i, [_l, _i]),
     "rl_pool_fwd": (_i, [C.POINTER(PoolDesc), _vp]),
     "rl_rpe_stats_slots": (_i, [_l]),
     "rl_rpe_stats": (_i, [C.POINTER(PoolDesc), _vp, _vp]),

@@ -720,15 +720,24 @@ def _pool_desc(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, s
     return pd
 
 
-def pool_fwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, stage: int = 0) -> torch.Tensor:
-    """Fused gather+concat -> score Linear -> softmax over K -> weighted sum: (B*n, d)."""
+def pool_fwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, stage: int = 0, next_stats: bool = False):
+    """Fused gather+concat -> score Linear -> softmax over K -> weighted sum: (B*n, d).  next_stats (virtual stage 1 only):
+    also returns the BatchNorm partial statistics of the raw stage-2 output as (pooled, stats, nslots)."""
     pd = _pool_desc(u, g, idx, W, n, d, stage)
+    stats2 = None
+    if next_stats:
+        assert stage == 1
+        ns = H.lib().rl_pool_fwd_slots(u.B * n, d)
+        stats2 = torch.empty((ns, 2, d // 2), dtype=torch.float64, device=W.device)
+        pd.bn_fwd_stats2 = stats2.data_ptr()
     out = torch.empty((u.B * n, d), dtype=F32, device=W.device)
     pd.Pout = out.data_ptr()
     P = u.B * n
     virt = isinstance(u, VirtualRpe)
     with _rec("pool_fwd_virtual" if virt else "pool_fwd", (P, 16, d), 4 * ((0 if virt else P * 16 * (d // 2)) + P * 16 * (d // 2) + P * 16 * (2 if virt else 1) + P * d), 2 * P * 16 * d * d):
         H.check(H.lib().rl_pool_fwd(C.byref(pd), _st()), "rl_pool_fwd")
+    if next_stats:
+        return out, stats2, ns
     return out
 
 

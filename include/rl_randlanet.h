@@ -454,11 +454,16 @@ typedef struct rl_pool_desc {
      * backward - what rl_rpe_bn_reduce would compute from GU - in bn_bwd_stats[slot][2][d/2], slot <
      * rl_pool_bwd_slots(points, d), saving that pass. */
     double* bn_bwd_stats;
+    /* rl_pool_fwd with u_source 1, optional: the batch statistics of the NEXT stage's raw output (mlp_rpe2 applied to the
+     * tile this launch has in registers) - what rl_rpe_stats with u_source 2 would compute - as partials
+     * bn_fwd_stats2[slot][2][d/2], slot < rl_pool_fwd_slots(points, d).  Needs W2 / b2. */
+    double* bn_fwd_stats2;
 } rl_pool_desc;
 
 int rl_pool_supported(int d, int nbr_k);
 int64_t rl_pool_slab_floats(int64_t points, int d);
-int rl_pool_bwd_slots(int64_t points, int d);   /* workgroups (= partial slots) of an rl_pool_bwd launch */
+int rl_pool_bwd_slots(int64_t points, int d);   /* workgroups (= partial slots) of an rl_pool_bwd launch with a virtual stage */
+int rl_pool_fwd_slots(int64_t points, int d);   /* workgroups (= partial slots) of an rl_pool_fwd launch */
 int rl_pool_fwd(const rl_pool_desc* d, void* stream);
 int rl_pool_bwd(const rl_pool_desc* d, void* stream);
 

@@ -719,3 +719,9 @@ def test_virtual_rpe_branch_forward(ops, d, B, n_parent, n):
     assert float((V2 - P2).abs().max()) < 10 * tol * max(1.0, float(P2.abs().max()))
     # the virtual path is a pure function of its inputs: same bits on a second run
     assert torch.equal(V2, ops.pool_fwd(vr, g, idx, Ws, n, d, stage=2))
+    # pool1's kernel can leave the stage-2 batch statistics itself (it has the stage-1 tile): same moments as rl_rpe_stats
+    V1b, st2b, nsb = ops.pool_fwd(vr, g, idx, Ws, n, d, stage=1, next_stats=True)
+    t2b = bn(st2b, nsb, g2w, g2b, h)
+    assert torch.equal(V1b, V1)
+    assert float((t2b[2] - t2[2]).abs().max()) < 1e-6 * max(1.0, float(t2[2].abs().max()))
+    assert float((t2b[3] - t2[3]).abs().max()) < 1e-5 * max(1.0, float(t2[3].abs().max()))
