@@ -170,7 +170,8 @@ __global__ __launch_bounds__(256) void add_act_bwd_kernel(float* __restrict__ G,
 // one lane per neighbourhood row: 2 gathers of 12 B from the (L2-resident) coordinates, 48 B written
 __global__ __launch_bounds__(256) void rpe_build_kernel(const float* __restrict__ xyz, long xyz_bstride,
                                                         const int32_t* __restrict__ idx, const float* __restrict__ d2,
-                                                        unsigned n, unsigned k, long rows, float* __restrict__ out) {
+                                                        unsigned n, unsigned k, long rows, float* __restrict__ out,
+                                                        int is_distance) {
     for (long R = (long)blockIdx.x * 256 + threadIdx.x; R < rows; R += (long)gridDim.x * 256) {
         const unsigned pt = (unsigned)R / k;          // rows < 2^31 (checked on the host)
         const unsigned b = pt / n, i = pt - b * n;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void rpe_build_kernel(const float* __restrict_
         float4* o = reinterpret_cast<float4*>(out + R * 12);
         o[0] = make_float4(xi, yi, zi, xj);
         o[1] = make_float4(yj, zj, xi - xj, yi - yj);
-        o[2] = make_float4(zi - zj, __fsqrt_rn(d2[R]), 0.f, 0.f);
+        o[2] = make_float4(zi - zj, is_distance ? d2[R] : __fsqrt_rn(d2[R]), 0.f, 0.f);
     }
 }
 
@@ -382,18 +383,28 @@ extern "C" int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, flo
     return RL_OK;
 }
 
-extern "C" int rl_rpe_build(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_d2, int B,
-                            int n, int k, float* out, void* stream) {
+static int rpe_build_impl(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_d2, int B,
+                          int n, int k, float* out, int is_distance, void* stream) {
     RL_REQUIRE(xyz && nbr_idx && nbr_d2 && out && B > 0 && n > 0 && k > 0 && xyz_bstride >= n, RL_ERR_ARGS,
                "rl_rpe_build: bad arguments");
     RL_REQUIRE((((uintptr_t)out) & 15) == 0, RL_ERR_ARGS, "rl_rpe_build: out must be 16-byte aligned");
     const long rows = (long)B * n * k;
     RL_REQUIRE(rows < (1l << 31), RL_ERR_ARGS, "rl_rpe_build: too many rows");
     hipLaunchKernelGGL(rpe_build_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, xyz, (long)xyz_bstride,
-                       nbr_idx, nbr_d2, (unsigned)n, (unsigned)k, rows, out);
+                       nbr_idx, nbr_d2, (unsigned)n, (unsigned)k, rows, out, is_distance);
     rl_note_kernel("rpe_build_kernel");
     RL_LAUNCH_CHECK("rl_rpe_build");
     return RL_OK;
+}
+
+extern "C" int rl_rpe_build(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_d2, int B,
+                            int n, int k, float* out, void* stream) {
+    return rpe_build_impl(xyz, xyz_bstride, nbr_idx, nbr_d2, B, n, k, out, 0, stream);
+}
+
+extern "C" int rl_rpe_build_dist(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_dist, int B,
+                                 int n, int k, float* out, void* stream) {
+    return rpe_build_impl(xyz, xyz_bstride, nbr_idx, nbr_dist, B, n, k, out, 1, stream);
 }
 
 extern "C" int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t count, void* stream) {

@@ -209,6 +209,7 @@ _SIGNATURES = {
     "rl_add_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp, _vp]),
     "rl_add_act_bwd": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "rl_rpe_build": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rl_rpe_build_dist": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_batch_assemble": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
     "rl_dropout_tick": (_i, [_vp, _vp, _vp]),

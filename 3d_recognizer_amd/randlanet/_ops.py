@@ -225,7 +225,7 @@ def get_wide_gemm() -> str:
     return H.lib().rl_get_wide_gemm().decode()
 
 
-def rpe_build(a: "Rpe") -> Lazy:
+def rpe_build(a: "Rpe", distances: bool = False) -> Lazy:
     """The relative position encoding of every neighbourhood row, written out once (rows x 12 floats: 10 channels +
     2 of padding) so that mlp_rpe1's forward and weight gradient read a plain tensor (modules.py:173-186)."""
     _dev_check(a.xyz, a.idx, a.d2)
@@ -233,8 +233,9 @@ def rpe_build(a: "Rpe") -> Lazy:
     assert a.xyz.shape[0] == a.B and a.xyz.shape[1] >= a.n and a.xyz.shape[2] == 3
     out = torch.empty((a.rows, 12), dtype=F32, device=a.xyz.device)
     with _rec("rpe_build", (a.rows,), (48 + 8) * a.rows, 0):
-        H.check(H.lib().rl_rpe_build(a.xyz.data_ptr(), a.xyz.shape[1], a.idx.data_ptr(), a.d2.data_ptr(), a.B, a.n, a.K,
-                                     out.data_ptr(), _st()), "rl_rpe_build")
+        fn = H.lib().rl_rpe_build_dist if distances else H.lib().rl_rpe_build     # a.d2 holds distances, not squares
+        H.check(fn(a.xyz.data_ptr(), a.xyz.shape[1], a.idx.data_ptr(), a.d2.data_ptr(), a.B, a.n, a.K,
+                   out.data_ptr(), _st()), "rl_rpe_build")
     return Lazy(out, a.B, a.n * a.K, a.n * a.K, 10)
 
 

@@ -52,14 +52,40 @@ class RandLANetSettings:
                 setattr(self, key, value)
 
 
-def _no_forward(self, *a, **k):
-    raise H.HipKernelError(
-        f"{type(self).__name__} holds parameters only; RandLANet.forward runs the fused HIP schedule")
+# ---------------------------------------------------------------------------------------------------------------
+# Stand-alone forwards of the sub-modules (reference modules.py:93-104, 159-186, 199-221, 246-253, 298-325).  Inside
+# RandLANet.forward the blocks run as one fused launch schedule (_engine.py); called on their own they take and return the
+# reference's (B, C, N, K) tensors and run the same HIP kernels one block at a time.  Forward only: the result carries no
+# autograd graph (training goes through RandLANet / TrainStep).  Layout changes are views / copies; all arithmetic is in
+# librandla_hip.so.
+def _act_code(activation) -> tuple:
+    if activation is None:
+        return H.ACT_NONE, 0.0
+    if isinstance(activation, nn.LeakyReLU):
+        return H.ACT_LRELU, float(activation.negative_slope)
+    if isinstance(activation, nn.ReLU):
+        return H.ACT_RELU, 0.0
+    raise H.HipKernelError(f"activation {type(activation).__name__} has no HIP implementation")
+
+
+def _to_rows(x: torch.Tensor) -> torch.Tensor:
+    """(B, C, N, K) -> (B*N*K, C) fp32 contiguous"""
+    B, Cc, N, K = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * N * K, Cc).to(torch.float32).contiguous()
+
+
+def _from_rows(rows: torch.Tensor, B: int, N: int, K: int) -> torch.Tensor:
+    return rows.view(B, N, K, rows.shape[1]).permute(0, 3, 1, 2)
+
+
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise H.HipKernelError(f"{what} runs on an MI355X (HIP) device: move the module and its input there")
 
 
 class SharedMLP(nn.Module):
-    """Parameters of one shared MLP (reference modules.py:60-91): 1x1 conv or transposed conv,
-    optional BatchNorm2d(eps=1e-6, momentum=0.99), optional activation (kept for printing)."""
+    """Shared MLP (reference modules.py:60-104): 1x1 conv or transposed conv, optional BatchNorm2d(eps=1e-6,
+    momentum=0.99), optional activation.  forward: (B, n_in, N, K) -> (B, n_out, N, K)."""
 
     def __init__(self, n_in: int, n_out: int, transpose: bool = False, bn: bool = True,
                  activation: Optional[nn.Module] = None):
@@ -69,38 +95,124 @@ class SharedMLP(nn.Module):
         self.batch_norm = nn.BatchNorm2d(n_out, eps=1e-6, momentum=0.99) if bn else None
         self.activation = activation
 
-    forward = _no_forward
+    def _rows_forward(self, rows: torch.Tensor) -> torch.Tensor:
+        """(M, n_in) rows -> (M, n_out) rows: GEMM + (batch-statistics or running) BatchNorm + activation."""
+        M = rows.shape[0]
+        W = self.conv.weight.detach()
+        transposed = isinstance(self.conv, nn.ConvTranspose2d)
+        n_in, n_out = (W.shape[0], W.shape[1]) if transposed else (W.shape[1], W.shape[0])
+        W2 = W.view(W.shape[0], W.shape[1])
+        ks, ns = ops.weight_strides(W2, transposed, n_in, n_out)
+        bn = self.batch_norm
+        train_stats = bn is not None and self.training
+        stats = ops.new_stats(rows.device, n_out) if train_stats else None
+        Y = ops.gemm(ops.plain(rows, 1, M), W2, ks, ns, n_out, self.conv.bias.detach(), stats=stats)
+        act, slope = _act_code(self.activation)
+        if bn is not None:
+            scale, shift, _, _ = ops.bn_finalize(stats, M, 128, n_out, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                                 bn.running_var, bn.num_batches_tracked if train_stats else None,
+                                                 0.99, 1e-6, train_stats)
+        elif act != H.ACT_NONE:
+            scale, shift = torch.ones(n_out, device=rows.device), torch.zeros(n_out, device=rows.device)
+        else:
+            return Y
+        out = torch.empty_like(Y)
+        ops.copy_rows(Y, (0, n_out), M, out, (0, n_out), M, M, lazy=ops.Lazy(Y, 1, M, M, n_out, scale, shift, act, slope))
+        return out
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        _require_device(input, "SharedMLP")
+        B, _, N, K = input.shape
+        with torch.cuda.device(input.device), torch.no_grad():
+            return _from_rows(self._rows_forward(_to_rows(input)), B, N, K)
+
+
+class RelativePositionEncoding(nn.Module):
+    """[x_i, x_nbr, x_i - x_nbr, dist] per neighbour (reference modules.py:156-186): (B, 10, N, K)."""
+
+    def forward(self, xyz: torch.Tensor, neighbors: torch.Tensor, distances: torch.Tensor) -> torch.Tensor:
+        _require_device(xyz, "RelativePositionEncoding")
+        B, N, K = neighbors.shape
+        with torch.cuda.device(xyz.device), torch.no_grad():
+            rpe = ops.rpe_build(ops.Rpe(xyz.to(torch.float32).contiguous(), neighbors.to(torch.int32).contiguous(),
+                                        distances.to(torch.float32).contiguous(), B, N, K), distances=True)
+            return rpe.raw.view(B, N, K, 12)[..., :10].permute(0, 3, 1, 2)
+
+
+class PointFeatureAugmentation(nn.Module):
+    """cat[relative position encoding, gathered neighbour features] (reference modules.py:194-221): (B, 2h, N, K)."""
+
+    def forward(self, relative_position_encoding: torch.Tensor, features: torch.Tensor, neighbors: torch.Tensor) -> torch.Tensor:
+        _require_device(features, "PointFeatureAugmentation")
+        B, N, K = neighbors.shape
+        h = features.shape[1]
+        with torch.cuda.device(features.device), torch.no_grad():
+            r = _to_rows(relative_position_encoding)
+            f = _to_rows(features)                                      # (B*N, h)
+            X = torch.empty((B * N * K, r.shape[1] + h), dtype=torch.float32, device=f.device)
+            ops.copy_rows(r, (0, r.shape[1]), N * K, X, (0, r.shape[1]), B * N * K, N * K)
+            ops.copy_rows(f, (0, h), N, X, (r.shape[1], h), B * N * K, N * K, index=neighbors.to(torch.int32).contiguous())
+            return _from_rows(X, B, N, K)
 
 
 class AttentivePooling(nn.Module):
-    """Parameters of attentive pooling (reference modules.py:227-237)."""
+    """Attentive pooling (reference modules.py:224-253): (B, n_in, N, K) -> (B, n_out, N, 1)."""
 
     def __init__(self, n_in: int, n_out: int):
         super().__init__()
         self.score_fn = nn.Sequential(nn.Linear(n_in, n_in, bias=False), nn.Softmax(dim=-2))
         self.mlp = SharedMLP(n_in, n_out, activation=nn.ReLU())
 
-    forward = _no_forward
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        _require_device(input, "AttentivePooling")
+        B, d, N, K = input.shape
+        with torch.cuda.device(input.device), torch.no_grad():
+            X = _to_rows(input)
+            S = ops.gemm(ops.plain(X, B, N * K), self.score_fn[0].weight.detach(), 1, d, d, None)
+            pooled = ops.attpool_fwd(X, S, B * N, K)
+            return _from_rows(self.mlp._rows_forward(pooled), B, N, 1)
 
 
 class LocalFeatureAggregation(nn.Module):
-    """Parameters of one encoder block, registered in the reference's order (modules.py:275-296)
-    so that state_dict() enumerates identically."""
+    """One encoder block (reference modules.py:256-325); parameters registered in the reference's order so that
+    state_dict() enumerates identically.  forward(xyz (B,N,3), input (B,n_in,N,1), knn_approach) -> (B, 2*n_out, N, 1)."""
 
     def __init__(self, n_in: int, n_out: int, n_neighbors: int, device: torch.device):
         super().__init__()
         self._n_neighbors = n_neighbors
         self._device = device
+        self._n_out = n_out
         self.mlp1 = SharedMLP(n_in, n_out // 2, activation=nn.LeakyReLU(0.2))
         self.mlp2 = SharedMLP(n_out, 2 * n_out)
         self.shortcut = SharedMLP(n_in, 2 * n_out)
+        self.knn = KNN(device)
+        self.rpe = RelativePositionEncoding()
+        self.pfa = PointFeatureAugmentation()
         self.mlp_rpe1 = SharedMLP(10, n_out // 2, activation=nn.ReLU())
         self.mlp_rpe2 = SharedMLP(n_out // 2, n_out // 2, activation=nn.ReLU())
         self.pool1 = AttentivePooling(n_out, n_out // 2)
         self.pool2 = AttentivePooling(n_out, n_out)
         self.lrelu = nn.LeakyReLU()
 
-    forward = _no_forward
+    def forward(self, xyz: torch.Tensor, input: torch.Tensor, knn_approach: str = "approximate") -> torch.Tensor:
+        if knn_approach not in _KNN_CHOICES:
+            raise ValueError(f"KNN approach {knn_approach} not understood!")
+        dev = torch.device(self._device)
+        if dev.type != "cuda":
+            raise H.HipKernelError("LocalFeatureAggregation runs on an MI355X (HIP) device")
+        from .._engine import Context
+        B, n_in, N, _ = input.shape
+        d, K = self._n_out, self._n_neighbors
+        with torch.cuda.device(dev), torch.no_grad():
+            pts = xyz.to(dev, torch.float32).contiguous()
+            rows = _to_rows(input.to(dev))
+            idx, d2 = ops.knn_i32(pts, pts, N, N, K)
+            eng = Engine([d], K, 4, 2, 0, {f"encoder.0.{k}": v.detach() for k, v in self.named_parameters()},
+                         {f"encoder.0.{k}": v for k, v in self.named_buffers()})
+            ctx = Context()
+            ctx.training, ctx.B, ctx.N = self.training, B, N
+            out = eng._lfa(ctx, 0, ops.plain(rows, B, N), pts, N, d, idx, d2)
+            return _from_rows(out.raw, B, N, 1)
 
 
 class KNN(nn.Module):

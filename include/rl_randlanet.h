@@ -502,6 +502,9 @@ int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, v
  * when it is read more than once (forward + weight gradient).  xyz (B, xyz_bstride, 3), idx/d2 (B,n,k).   */
 int rl_rpe_build(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_d2, int B,
                  int n, int k, float* out, void* stream);
+/* the same with the DISTANCES given (RelativePositionEncoding.forward's own signature, modules.py:159-186) */
+int rl_rpe_build_dist(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_idx, const float* nbr_dist, int B,
+                      int n, int k, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Input pipeline on the device: PointCloudPreprocessor.preprocess

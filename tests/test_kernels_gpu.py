@@ -725,3 +725,38 @@ def test_virtual_rpe_branch_forward(ops, d, B, n_parent, n):
     assert torch.equal(V1b, V1)
     assert float((t2b[2] - t2[2]).abs().max()) < 1e-6 * max(1.0, float(t2[2].abs().max()))
     assert float((t2b[3] - t2[3]).abs().max()) < 1e-5 * max(1.0, float(t2[3].abs().max()))
+
+
+def test_knn_multi_and_csr_replay_from_a_captured_graph(ops):
+    """The neighbour searches of a forward (rl_knn_multi: grid reset, bounding box, counting sort, ring walk) and the
+    graph transposes (rl_csr_build) captured into ONE hipGraph and replayed on new coordinates give exactly the eager
+    answer - their scratch is reset by kernels of their own (no memset nodes, no allocation inside the region), and the
+    per-call workspaces come from the capture's private pool, so their addresses are stable across replays."""
+    torch.manual_seed(5)
+    B, N = 2, 4096
+    xyz = torch.rand(B, N, 3, device=DEV)
+    tasks = [(N, N, 16), (N // 4, N // 4, 16), (N // 16, N // 4, 1), (N // 4, N, 1)]
+
+    def run():
+        res = ops.knn_multi(xyz, tasks)
+        csr = ops.csr_build([(res[i][0], tasks[i][0]) for i in range(len(tasks))])
+        return res, csr
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()                                              # allocator warm-up
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        res_g, csr_g = run()
+    for trial in range(3):
+        xyz.copy_(torch.rand(B, N, 3, device=DEV))         # new clouds, same buffers
+        g.replay()
+        torch.cuda.synchronize()
+        res_e, csr_e = run()
+        for (ig, dg), (ie, de) in zip(res_g, res_e):
+            assert torch.equal(ig, ie) and torch.equal(dg, de), trial
+        for a, b in zip(csr_g, csr_e):
+            assert torch.equal(a.offsets, b.offsets) and torch.equal(a.entries, b.entries), trial

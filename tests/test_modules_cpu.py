@@ -66,7 +66,7 @@ def test_forward_asserts_and_no_cpu_path():
     finally:
         _hip._LIB, _hip._LIB_PATH = lib, path
     assert net(torch.rand(1, 2048, 3)).shape == (1, 2, 2048)
-    with pytest.raises(_hip.HipKernelError, match="parameters only"):
+    with pytest.raises(_hip.HipKernelError, match="runs on an MI355X"):
         net.encoder[0].mlp1(torch.zeros(1, 8, 4, 1))
 
 
