@@ -136,6 +136,7 @@ struct GemmParams {
     const int32_t* out2_index;
     long out2_bstride;
     int split_col;
+    const __bf16* wsplit;      // wgemm: head plane [N][K] (k contiguous), tail plane follows at + N*K
 };
 
 template <int NT>
@@ -1152,6 +1153,277 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
     }
 }
 
+
+// ===========================================================================================
+// wgemm_kernel: the wide GEMM again for the bf16 arithmetic modes, re-cut for memory latency.
+// pgemm_kernel<8,3> runs two 4-wavefront workgroups per CU at 256 VGPRs: two wavefronts per SIMD, one 32-deep chunk
+// of prefetch each - rocprofv3 shows its wavefronts parked on memory 58 % of their life (SQ_WAIT_ANY) while the matrix
+// pipe is 15 % busy.  Here:
+//   * the weight arrives already split into bf16 head / tail planes, [n][k] k-contiguous (rl_split_weights, once per
+//     step for all wide layers): its staging is a 16-byte copy, no conversion, no transposed scalar LDS writes for the
+//     dgrad orientation, and half the staging registers;
+//   * eight wavefronts of 16 rows x 128 columns share a 128 x 128 tile (32 accumulator registers each instead of 64),
+//     which fits 128 VGPRs: two workgroups per CU = FOUR wavefronts per SIMD, twice the loads in flight.
+// Everything else (lazy BatchNorm on the A operand, statistics epilogue, split-K, split epilogue, XCD-aware tile order)
+// is pgemm_kernel's.
+// ===========================================================================================
+template <int TERMS, bool STATS>   // TERMS 3: bf16x3, 1: bf16; STATS: BatchNorm partial statistics in the epilogue
+__global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
+    constexpr int BN = 128, BS = 40, NT = 8;
+    constexpr int NSPL = TERMS == 3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[GM_BM * BS * NSPL];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_w[BN * BS * NSPL];
+    __bf16* Ah = lds_a;
+    __bf16* Al = lds_a + GM_BM * BS;       // only touched when TERMS == 3
+    __bf16* Wh = lds_w;
+    __bf16* Wl = lds_w + BN * BS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    int bx = blockIdx.x, by = 0;
+    if (p.ny > 1) {
+        const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+        by = s % p.ny;
+        bx = (s / p.ny) * 8 + xcd;
+        if (bx >= p.gx) return;      // padding of the last group of eight
+    }
+    const int col0 = by * BN;
+    const int K = p.a.K, N = p.N;
+    const long M = p.a.M;
+    const long ntiles = (M + GM_BM - 1) / GM_BM;
+    const bool lazy = p.a.lazy.scale != nullptr;
+    const bool relu = p.a.lazy.act == RL_ACT_RELU;
+    const float nslope = p.a.lazy.act == RL_ACT_NONE ? 1.f : p.a.lazy.slope;
+    const int aq = tid & 7;            // this lane's k-quad inside a chunk (same for its 2 rows)
+    const int arow = tid >> 3;         // 0..63, +64 for the second row
+    // weight staging: per plane 128 rows x 4 pieces of 16 bytes; 256 lanes per plane, two pieces each
+    const int wplane = tid >> 8;       // 0 head, 1 tail
+    const int wpiece = (tid & 255) * 2;
+    const __bf16* wsrc = p.wsplit + (wplane ? (long)N * K : 0);
+    const bool w_active = wplane < NSPL;
+
+    float ssum[STATS ? NT : 1], ssq[STATS ? NT : 1];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    }
+
+    for (long tile = bx; tile < ntiles; tile += p.gx) {
+        const long row0 = tile * GM_BM;
+        long aoff[2];
+        bool aval[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long R = row0 + arow + 64 * i;
+            aval[i] = R < M;
+            aoff[i] = aval[i] ? a_row_offset(p.a, R) : 0;
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        float4 ra[2];
+        bf16x8 rw[2];
+        auto fetch = [&](int k0) {
+            const int ka = k0 + aq * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (aval[i] && ka < K) ra[i] = *reinterpret_cast<const float4*>(p.a.A + aoff[i] + ka);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int piece = wpiece + j, n = piece >> 2, q = piece & 3;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rw[j][e] = (__bf16)0.f;
+                if (w_active && col0 + n < N && k0 + q * 8 < K)
+                    rw[j] = *reinterpret_cast<const bf16x8*>(wsrc + (long)(col0 + n) * K + k0 + q * 8);
+            }
+        };
+        auto actf = [&](float z) {
+            const float neg = relu ? 0.f : z * nslope;
+            return z > 0.f ? z : neg;
+        };
+        auto commit = [&](int k0) {
+            const int ka = k0 + aq * 4;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lazy && ka < K) {
+                sc = *reinterpret_cast<const float4*>(p.a.lazy.scale + ka);
+                sh = *reinterpret_cast<const float4*>(p.a.lazy.shift + ka);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float4 v = ra[i];
+                if (lazy && aval[i] && ka < K) {
+                    v.x = actf(v.x * sc.x + sh.x);
+                    v.y = actf(v.y * sc.y + sh.y);
+                    v.z = actf(v.z * sc.z + sh.z);
+                    v.w = actf(v.w * sc.w + sh.w);
+                }
+                bf16x4 hi, lo;
+                split_bf16(v, hi, lo);
+                *reinterpret_cast<bf16x4*>(Ah + (arow + 64 * i) * BS + aq * 4) = hi;
+                if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(Al + (arow + 64 * i) * BS + aq * 4) = lo;
+            }
+            if (w_active) {
+                __bf16* dstp = wplane ? Wl : Wh;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int piece = wpiece + j, n = piece >> 2, q = piece & 3;
+                    *reinterpret_cast<bf16x8*>(dstp + n * BS + q * 8) = rw[j];
+                }
+            }
+        };
+
+        const int k_begin = (p.ksplit > 1) ? blockIdx.z * p.kchunk : 0;
+        const int k_end = (p.ksplit > 1) ? min(K, k_begin + p.kchunk) : K;
+        const __bf16* ah_frag = Ah + (wave * 16 + lr) * BS + lq * 8;
+        const __bf16* wh_frag = Wh + lr * BS + lq * 8;
+        constexpr int LO_A = GM_BM * BS, LO_W = BN * BS;
+        fetch(k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += PG_BK) {
+            __syncthreads();
+            commit(k0);
+            __syncthreads();
+            if (k0 + PG_BK < k_end) fetch(k0 + PG_BK);
+            // four wavefronts per SIMD hide the LDS latency between them: the B fragments are not double-buffered
+            // (16 registers instead of 32 keep the kernel inside its 128-VGPR budget)
+            bf16x8 a_h, a_l;
+            a_h = *reinterpret_cast<const bf16x8*>(ah_frag);
+            if constexpr (TERMS == 3) a_l = *reinterpret_cast<const bf16x8*>(ah_frag + LO_A);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb0 = g * 2;
+                bf16x8 b_h[2], b_l[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    b_h[j] = *reinterpret_cast<const bf16x8*>(wh_frag + (nb0 + j) * 16 * BS);
+                    if constexpr (TERMS == 3) b_l[j] = *reinterpret_cast<const bf16x8*>(wh_frag + LO_W + (nb0 + j) * 16 * BS);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[j], acc[nb0 + j], 0, 0, 0);
+                if constexpr (TERMS == 3) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l[j], acc[nb0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h[j], acc[nb0 + j], 0, 0, 0);
+                }
+            }
+        }
+        if (p.ksplit > 1) {
+            float* slab = p.kslab + (long)blockIdx.z * M * N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long R = row0 + wave * 16 + lq * 4 + r;
+                if (R < M) {
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        const int c = col0 + nb * 16 + lr;
+                        if (c < N) slab[R * N + c] = acc[nb][r];
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long R = row0 + wave * 16 + lq * 4 + r;
+            if (R < M) {
+                long yoff;
+                if (p.y_contig) yoff = R * p.ldy;
+                else {
+                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                    const int i = (int)(R - (long)b * p.rows_per_batch);
+                    yoff = ((long)b * p.y_bstride + i) * p.ldy;
+                }
+                long o2 = 0;
+                if (p.out2) {
+                    if (p.out2_index) {
+                        const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                        o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
+                    } else {
+                        o2 = R * (N - p.split_col) - p.split_col;
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) {
+                    const int c = col0 + nb * 16 + lr;
+                    if (c < N) {
+                        float v = acc[nb][r];
+                        if (p.bias) v += p.bias[c];
+                        if (p.addend) v += p.addend[R * N + c];
+                        if (p.out2 && c >= p.split_col) {
+                            if (p.out2_index) atomicAdd(p.out2 + o2 + c, v);
+                            else p.out2[o2 + c] = v;
+                        } else {
+                            if (p.accumulate) v += p.Y[yoff + c];
+                            p.Y[yoff + c] = v;
+                            if constexpr (STATS) {
+                                ssum[nb] += v;
+                                ssq[nb] += v * v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (STATS) if (p.stats && p.ksplit <= 1) {
+        __syncthreads();                                        // the operand tiles are free: reuse them for the reduction
+        double* red = reinterpret_cast<double*>(lds_a);         // [8][2][128] doubles = 16 KB <= 20 KB (10 KB in bf16 mode: use both)
+        static_assert(sizeof(lds_a) + sizeof(lds_w) >= 8 * 2 * BN * sizeof(double), "statistics scratch");
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            float s = ssum[nb], q = ssq[nb];
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (lane < 16) {
+                red[(wave * 2 + 0) * BN + nb * 16 + lane] = (double)s;
+                red[(wave * 2 + 1) * BN + nb * 16 + lane] = (double)q;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && col0 + tid < N) {
+            double s = 0.0, q = 0.0;
+            for (int w = 0; w < 8; ++w) {
+                s += red[(w * 2 + 0) * BN + tid];
+                q += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((long)bx * 2 + 0) * N + col0 + tid] = s;
+            p.stats[((long)bx * 2 + 1) * N + col0 + tid] = q;
+            for (long slot = bx + p.gx; slot < p.stat_slots; slot += p.gx) {
+                p.stats[(slot * 2 + 0) * N + col0 + tid] = 0.0;
+                p.stats[(slot * 2 + 1) * N + col0 + tid] = 0.0;
+            }
+        }
+    }
+}
+
+// bf16 head / tail planes of a weight in the orientation a GEMM reads it: out[n*K + k] = head(W[k*w_ks + n*w_ns]),
+// tails N*K elements further.  All wide layers of a step in one launch.
+constexpr int WS_MAX = 64;
+struct SplitBatch {
+    rl_wsplit_item item[WS_MAX];
+    int first_block[WS_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void split_weights_kernel(const SplitBatch b) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.first_block[i + 1]) ++i;
+    const rl_wsplit_item& it = b.item[i];
+    const long total = (long)it.N * it.K;
+    const long e = ((long)blockIdx.x - b.first_block[i]) * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int n = (int)(e / it.K), k = (int)(e - (long)n * it.K);
+    const float w = it.W[(long)k * it.w_ks + (long)n * it.w_ns];
+    __bf16* out = reinterpret_cast<__bf16*>(it.out);
+    const __bf16 h = (__bf16)w;
+    out[e] = h;
+    out[total + e] = (__bf16)(w - (float)h);
+}
+
 // Split-K reducer: Y = sum over splits (fixed order) + bias (+ Y when accumulating), plus the BatchNorm
 // partial statistics, one slot per workgroup exactly like the single-pass kernels (rl_row_blocks(M,128)).
 // Needs N % 4 == 0.
@@ -1250,6 +1522,23 @@ void launch_pgemm(dim3 logical, hipStream_t st, GemmParams p) {
     if (t == 0)      hipLaunchKernelGGL((pgemm_kernel<NT, 0>), grid, dim3(256), 0, st, p);
     else if (t == 1) hipLaunchKernelGGL((pgemm_kernel<NT, 1>), grid, dim3(256), 0, st, p);
     else             hipLaunchKernelGGL((pgemm_kernel<NT, 3>), grid, dim3(256), 0, st, p);
+}
+
+// the 8-wavefront kernel: bf16 arithmetic modes, pre-split weight, K a multiple of 8 (16-byte pieces of a weight row)
+inline bool wgemm_ok(const GemmParams& p) {
+    return p.wsplit != nullptr && wide_gemm_terms() != 0 && (p.a.K % 8 == 0) && (((uintptr_t)p.wsplit & 15) == 0);
+}
+void launch_wgemm(dim3 logical, hipStream_t st, GemmParams p) {
+    p.gx = (int)logical.x; p.ny = (int)logical.y;
+    const dim3 grid(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : logical.x, 1, logical.z);
+    const bool stats = p.stats != nullptr && p.ksplit <= 1;
+    if (wide_gemm_terms() == 1) {
+        if (stats) hipLaunchKernelGGL((wgemm_kernel<1, true>), grid, dim3(512), 0, st, p);
+        else       hipLaunchKernelGGL((wgemm_kernel<1, false>), grid, dim3(512), 0, st, p);
+    } else {
+        if (stats) hipLaunchKernelGGL((wgemm_kernel<3, true>), grid, dim3(512), 0, st, p);
+        else       hipLaunchKernelGGL((wgemm_kernel<3, false>), grid, dim3(512), 0, st, p);
+    }
 }
 
 inline bool pgemm_ok(const GemmParams& p) {
@@ -1648,6 +1937,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     p.accumulate = d->accumulate; p.stats = d->stats;
     p.addend = d->addend; p.out2 = d->out2; p.out2_index = d->out2_index; p.out2_bstride = d->out2_bstride;
     p.split_col = d->out2 ? d->split_col : d->N;
+    p.wsplit = reinterpret_cast<const __bf16*>(d->W_split);
     const bool split = d->addend != nullptr || d->out2 != nullptr;
     if (split) {
         RL_REQUIRE(!d->out2 || (d->split_col > 0 && d->split_col < d->N && (!d->out2_index || d->out2_bstride > 0)), RL_ERR_ARGS,
@@ -1668,8 +1958,9 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         if (d->N <= 16)      launch_pgemm<1>(dim3(gx, 1), st, p);
         else if (d->N <= 32) launch_pgemm<2>(dim3(gx, 1), st, p);
         else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
+        else if (wgemm_ok(p)) launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
         else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
-        rl_note_kernel("pgemm_kernel<8>");
+        rl_note_kernel(d->N > 64 && wgemm_ok(p) ? "wgemm_kernel" : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(split-scatter)");
         return RL_OK;
     }
@@ -1693,8 +1984,9 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
             p.kchunk = ((d->K + ks - 1) / ks + 31) / 32 * 32;
             p.ksplit = (d->K + p.kchunk - 1) / p.kchunk;
             p.kslab = d->kslab;
-            launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p);
-            rl_note_kernel("pgemm_kernel<8>+splitk");
+            if (wgemm_ok(p)) launch_wgemm(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p);
+            else launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p);
+            rl_note_kernel(wgemm_ok(p) ? "wgemm_kernel+splitk" : "pgemm_kernel<8>+splitk");
             RL_LAUNCH_CHECK("rl_gemm(split-K)");
             if ((long)gx * rl_cdiv(d->N, 64) >= 256)
                 hipLaunchKernelGGL(gemm_splitk_reduce_kernel<64>, dim3(gx, rl_cdiv(d->N, 64)), dim3(256), 0, st, p);
@@ -1708,8 +2000,9 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         if (d->N <= 16)      launch_pgemm<1>(dim3(gx, 1), st, p);
         else if (d->N <= 32) launch_pgemm<2>(dim3(gx, 1), st, p);
         else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
+        else if (wgemm_ok(p)) launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
         else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
-        rl_note_kernel(d->N <= 16 ? "pgemm_kernel<1>" : d->N <= 32 ? "pgemm_kernel<2>" : d->N <= 64 ? "pgemm_kernel<4>" : "pgemm_kernel<8>");
+        rl_note_kernel(d->N <= 16 ? "pgemm_kernel<1>" : d->N <= 32 ? "pgemm_kernel<2>" : d->N <= 64 ? "pgemm_kernel<4>" : wgemm_ok(p) ? "wgemm_kernel" : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(pipelined)");
         return RL_OK;
     }
@@ -1719,6 +2012,29 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     else                 hipLaunchKernelGGL((gemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128)), dim3(256), 0, st, p);
     rl_note_kernel("gemm_kernel");
     RL_LAUNCH_CHECK("rl_gemm");
+    return RL_OK;
+}
+
+extern "C" int rl_split_weights(const rl_wsplit_item* items, int count, void* stream) {
+    RL_REQUIRE(items != nullptr && count >= 0, RL_ERR_ARGS, "rl_split_weights: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < count; base += WS_MAX) {
+        SplitBatch b;
+        b.count = count - base < WS_MAX ? count - base : WS_MAX;
+        long blocks = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const rl_wsplit_item& it = items[base + i];
+            RL_REQUIRE(it.W && it.out && it.K > 0 && it.N > 0, RL_ERR_ARGS, "rl_split_weights: bad item %d", base + i);
+            RL_REQUIRE(((uintptr_t)it.out & 15) == 0, RL_ERR_ARGS, "rl_split_weights: item %d: out must be 16-byte aligned", base + i);
+            b.item[i] = it;
+            b.first_block[i] = (int)blocks;
+            blocks += rl_cdiv((long)it.N * it.K, 256);
+        }
+        b.first_block[b.count] = (int)blocks;
+        if (blocks > 0) hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+        RL_LAUNCH_CHECK("rl_split_weights");
+    }
+    rl_note_kernel("split_weights_kernel");
     return RL_OK;
 }
 

@@ -83,7 +83,7 @@ class Engine:
         K = 10 if isinstance(a, Rpe) else a.C
         ks, ns = ops.weight_strides(W, transposed, K, n_out)
         stats = ops.new_stats(W.device, n_out) if (bn and ctx.training) else None
-        Y = ops.gemm(a, W, ks, ns, n_out, self.P[bname] if bname else None, stats=stats)
+        Y = ops.gemm(a, W, ks, ns, n_out, self.P[bname] if bname else None, stats=stats, wsplit=getattr(ctx, "wsplit", None))
         rpb = a.n * a.K if isinstance(a, Rpe) else a.n
         out = Lazy(Y, a.B, rpb, rpb, n_out)
         if bn:
@@ -118,7 +118,7 @@ class Engine:
         X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
         ops.copy_rows(u.raw, (0, h), n * K, X, (0, h), rows, n * K, lazy=u)
         ops.copy_rows(g.raw, (0, h), g.bstride, X, (h, h), rows, n * K, index=idx, lazy=g)
-        S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None)
+        S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None, wsplit=getattr(ctx, "wsplit", None))
         Pt = ops.attpool_fwd(X, S, B * n, K)
         pooled = ops.plain(Pt, B, n)
         ctx.tape.append(("pool", name, u, g, csr, X, S, pooled, n, d))
@@ -168,6 +168,25 @@ class Engine:
         ctx.tape.append(("add_act", m2, sc, O))
         return O
 
+    def _wide_weight_uses(self, training: bool):
+        """(W, w_ks, w_ns, K, N) of every product the LDS-tiled wide GEMM will run this pass: forward orientation, and the
+        dgrad orientation (strides swapped, K and N exchanged) when training."""
+        uses = []
+        for name, W in self.P.items():
+            if not name.endswith(("conv.weight", "score_fn.0.weight")) or W.dim() < 2:
+                continue
+            a, b = int(W.shape[0]), int(W.shape[1])
+            if max(a, b) <= 64:
+                continue
+            transposed = name.startswith("decoder.")                 # ConvTranspose2d weights are (in, out)
+            K, N = (a, b) if transposed else (b, a)
+            ks, ns = (N, 1) if transposed else (1, K)
+            W2 = W.view(a, b)
+            uses.append((W2, ks, ns, K, N))
+            if training:
+                uses.append((W2, ns, ks, N, K))                      # dA = dY . W^T
+        return uses
+
     # ------------------------------------------------------------------------------ forward
     def min_points(self) -> int:
         L = len(self.layers)
@@ -186,6 +205,8 @@ class Engine:
         ctx.training, ctx.B, ctx.N, ctx.perm = training, B, N, perm
         L, dec = len(self.layers), self.dec
 
+        # wide layers: bf16 head / tail planes of their weights, both orientations, in one launch (the weights change every step)
+        ctx.wsplit = ops.split_weights(self._wide_weight_uses(training))
         # random permutation of the rows (modules.py:571-573), once, on the input
         inp_p = torch.empty((B * N, cin), dtype=torch.float32, device=dev)
         ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=perm, index_shared=True)
@@ -388,7 +409,8 @@ class Engine:
                 assert a.n == a.bstride and a.raw.shape[0] == a.B * a.n, "first writer must cover the tensor"
             gl = Lazy(G, out.B, out.n, out.bstride, n_out)
             # dA = dY . W^T : the same kernel with the weight strides swapped
-            ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=ga[0], out_bstride=a.bstride, accumulate=ga[1])
+            ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=ga[0], out_bstride=a.bstride, accumulate=ga[1],
+                     wsplit=getattr(ctx, "wsplit", None))
             ga[1] = True
 
     def _bwd_pool_virtual(self, ctx, grads, name, vr, g: Lazy, csr, idx, pooled: Lazy, n, d, stage):
@@ -437,7 +459,8 @@ class Engine:
         gu = self._gbuf(ctx, u)
         gg = self._gbuf(ctx, g)
         if ops.NO_SPLIT_SCATTER or d <= 64:      # the epilogue lives in the wide (LDS-tiled) kernel only
-            ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True)
+            ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=dX, out_bstride=n * K, accumulate=True,
+                     wsplit=getattr(ctx, "wsplit", None))
             ops.copy_rows(dX, (0, h), n * K, gu[0], (0, h), rows, n * K, accumulate=gu[1])
             ops.segment_sum_rows(dX, (h, h), n * K, csr, gg[0], g.bstride, accumulate=gg[1])
         else:
@@ -445,6 +468,6 @@ class Engine:
             # where it belongs, the gathered half goes to a dense tensor that is then summed per gathered point
             DG = torch.empty((rows, h), dtype=torch.float32, device=dX.device)
             ops.gemm(ops.plain(dS, B, n * K), Ws, d, 1, d, None, out=gu[0], out_bstride=n * K, accumulate=gu[1],
-                     addend=dX, out2=DG, split_col=h)
+                     addend=dX, out2=DG, split_col=h, wsplit=getattr(ctx, "wsplit", None))
             ops.segment_sum_rows(DG, (0, h), n * K, csr, gg[0], g.bstride, accumulate=gg[1])
         gu[1] = gg[1] = True

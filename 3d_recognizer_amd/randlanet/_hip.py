@@ -42,7 +42,13 @@ class GemmDesc(C.Structure):
         ("kslab", C.c_void_p), ("kslab_floats", C.c_int64),
         ("addend", C.c_void_p), ("out2", C.c_void_p), ("out2_index", C.c_void_p), ("out2_bstride", C.c_int64),
         ("split_col", C.c_int32),
+        ("W_split", C.c_void_p),
     ]
+
+
+class WsplitItem(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("w_ks", C.c_int64), ("w_ns", C.c_int64), ("K", C.c_int32), ("N", C.c_int32),
+                ("out", C.c_void_p)]
 
 
 class WgradDesc(C.Structure):
@@ -173,6 +179,7 @@ _SIGNATURES = {
     "rl_knn_multi": (_i, [C.POINTER(KnnTask), _i, _i, _vp, _l, _vp]),
     "rl_gemm_kslab_floats": (_l, [_l, _i, _i]),
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "rl_split_weights": (_i, [C.POINTER(WsplitItem), _i, _vp]),
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_set_wide_gemm": (_i, [C.c_char_p]),
     "rl_get_wide_gemm": (C.c_char_p, []),

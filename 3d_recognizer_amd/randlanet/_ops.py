@@ -271,11 +271,41 @@ def weight_strides(W: torch.Tensor, transposed: bool, K: int, N: int) -> Tuple[i
     return 1, K
 
 
+# weights of the wide layers pre-split into bf16 head / tail planes, per orientation: split_weights() returns a dict
+# (data_ptr, w_ks, w_ns, K, N) -> planes that the engine hands to gemm(wsplit=...) for the products of that pass only
+NO_WSPLIT = bool(int(__import__("os").environ.get("RL_NO_WSPLIT", "0")))     # diagnostics: keep the 4-wavefront wide GEMM
+
+
+def split_weights(entries) -> dict:
+    """entries: list of (W, w_ks, w_ns, K, N).  One launch; returns {(data_ptr, w_ks, w_ns, K, N): planes}."""
+    out_map = {}
+    if NO_WSPLIT or get_wide_gemm() == "fp32" or not entries:
+        return out_map
+    entries = [e for e in entries if e[3] % 8 == 0 and e[4] > 64]
+    if not entries:
+        return out_map
+    total = sum(2 * K * N + 8 for _, _, _, K, N in entries)
+    buf = torch.empty(total, dtype=torch.bfloat16, device=entries[0][0].device)
+    arr = (H.WsplitItem * len(entries))()
+    off = 0
+    for it, (W, ks, ns, K, N) in zip(arr, entries):
+        _dev_check(W)
+        assert W.dtype == F32 and W.numel() == K * N
+        out = buf[off:off + 2 * K * N]
+        it.W, it.w_ks, it.w_ns, it.K, it.N, it.out = W.data_ptr(), ks, ns, K, N, out.data_ptr()
+        out_map[(W.data_ptr(), ks, ns, K, N)] = out
+        off += (2 * K * N + 7) // 8 * 8           # 16-byte aligned planes
+    with _rec("split_weights", (len(entries),), 6 * sum(K * N for _, _, _, K, N in entries), 0):
+        H.check(H.lib().rl_split_weights(arr, len(entries), _st()), "rl_split_weights")
+    return out_map
+
+
 def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, out_bstride: Optional[int] = None,
          accumulate: bool = False, stats: Optional[torch.Tensor] = None,
          addend: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-         out2_index: Optional[torch.Tensor] = None, out2_bstride: int = 0, split_col: int = 0) -> torch.Tensor:
+         out2_index: Optional[torch.Tensor] = None, out2_bstride: int = 0, split_col: int = 0,
+         wsplit: Optional[dict] = None) -> torch.Tensor:
     """Y = A'.W (+ bias).  With `out2` (split epilogue, wide layers only): v = A'.W + addend; columns < split_col go to
     `out` (which then has split_col columns), the others to the dense (M, N - split_col) tensor `out2` (or, with
     `out2_index`, atomically to the rows it names) - the two halves of a concat's gradient in one pass."""
@@ -296,6 +326,9 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.numel() >= H.row_blocks(M, 128) * 2 * N
     d.N, d.W, d.w_ks, d.w_ns, d.bias = N, W.data_ptr(), w_ks, w_ns, H.ptr(bias)
+    planes = wsplit.get((W.data_ptr(), w_ks, w_ns, K, N)) if wsplit else None
+    if planes is not None:
+        d.W_split = planes.data_ptr()
     d.Y, d.ldy, d.y_bstride, d.accumulate = out.data_ptr(), out.shape[1], out_bstride, int(accumulate)
     d.stats = H.ptr(stats)
     if addend is not None or out2 is not None:

@@ -171,7 +171,23 @@ typedef struct rl_gemm_desc {
     const int32_t* out2_index;
     int64_t out2_bstride;
     int32_t split_col;
+    /* optional, wide layers in the bf16 arithmetic modes: the weight already split into bf16 head / tail planes in the
+     * orientation THIS product reads it - plane[n*K + k] = W(k, n), tails N*K elements after the heads (rl_split_weights;
+     * 16-byte aligned, K % 8 == 0).  Selects the 8-wavefront kernel: no conversion of the weight per tile, four
+     * wavefronts per SIMD instead of two.  Same arithmetic, same results as without it. */
+    const void* W_split;
 } rl_gemm_desc;
+
+/* Splits weights for rl_gemm_desc.W_split: out (2*N*K bf16) <- heads, then tails, of W(k, n) = W[k*w_ks + n*w_ns].
+ * One launch for all items (every wide layer of a step, in both orientations: forward and dgrad). */
+typedef struct rl_wsplit_item {
+    const float* W;
+    int64_t w_ks, w_ns;
+    int32_t K, N;
+    void* out;
+} rl_wsplit_item;
+
+int rl_split_weights(const rl_wsplit_item* items, int count, void* stream);
 
 int64_t rl_gemm_kslab_floats(int64_t M, int N, int K);
 

@@ -760,3 +760,47 @@ def test_knn_multi_and_csr_replay_from_a_captured_graph(ops):
             assert torch.equal(ig, ie) and torch.equal(dg, de), trial
         for a, b in zip(csr_g, csr_e):
             assert torch.equal(a.offsets, b.offsets) and torch.equal(a.entries, b.entries), trial
+
+
+@pytest.mark.parametrize("M,K,N,orient", [(5000, 256, 256, "fwd"), (3000, 128, 512, "bwd"), (700, 512, 128, "fwd"), (4096, 64, 256, "bwd")])
+def test_wide_gemm_with_presplit_weights(ops, M, K, N, orient):
+    """rl_gemm with W_split (rl_split_weights: bf16 head / tail planes in the product's orientation) runs the 8-wavefront
+    kernel; same operands, same MFMA sequence per accumulator -> the SAME BITS as the 4-wavefront kernel, with the lazy
+    BatchNorm operand, bias, accumulate, the split epilogue and split-K; statistics agree to rounding."""
+    if ops.get_wide_gemm() == "fp32":
+        pytest.skip("the pre-split path exists in the bf16 arithmetic modes")
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K, device=DEV)
+    a = ops.plain(A, 1, M)
+    a.scale, a.shift, a.act, a.slope = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.3, 2, 0.2
+    if orient == "fwd":
+        W = torch.randn(N, K, device=DEV) / K ** 0.5            # (out, in): k contiguous
+        ks, ns = 1, K
+    else:
+        W = torch.randn(K, N, device=DEV) / K ** 0.5            # n contiguous: the dgrad orientation
+        ks, ns = N, 1
+    bias = torch.randn(N, device=DEV)
+    ws = ops.split_weights([(W, ks, ns, K, N)])
+    assert len(ws) == 1
+    st0, st1 = ops.new_stats(DEV, N), ops.new_stats(DEV, N)
+    Y0 = ops.gemm(a, W, ks, ns, N, bias, stats=st0)
+    Y1 = ops.gemm(a, W, ks, ns, N, bias, stats=st1, wsplit=ws)
+    assert torch.equal(Y0, Y1)
+    ref = torch.nn.functional.leaky_relu(A * a.scale + a.shift, 0.2).double() @ (W.double().t() if orient == "fwd" else W.double()) + bias.double()
+    assert float((Y1.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    from randlanet import _hip as H
+    nsl = H.row_blocks(M, 128)
+    assert torch.allclose(st0[:nsl].sum(0), st1[:nsl].sum(0), rtol=2e-6, atol=1e-4)      # per-lane fp32 partial sums, other row grouping
+    # accumulate + split epilogue (addend, two destinations)
+    acc0 = torch.randn(M, N, device=DEV)
+    acc1 = acc0.clone()
+    ops.gemm(a, W, ks, ns, N, None, out=acc0, out_bstride=M, accumulate=True)
+    ops.gemm(a, W, ks, ns, N, None, out=acc1, out_bstride=M, accumulate=True, wsplit=ws)
+    assert torch.equal(acc0, acc1)
+    addend = torch.randn(M, N, device=DEV)
+    h = N // 2
+    o0, o1 = torch.empty(M, h, device=DEV), torch.empty(M, h, device=DEV)
+    d0, d1 = torch.empty(M, N - h, device=DEV), torch.empty(M, N - h, device=DEV)
+    ops.gemm(a, W, ks, ns, N, None, out=o0, out_bstride=M, addend=addend, out2=d0, split_col=h)
+    ops.gemm(a, W, ks, ns, N, None, out=o1, out_bstride=M, addend=addend, out2=d1, split_col=h, wsplit=ws)
+    assert torch.equal(o0, o1) and torch.equal(d0, d1)
