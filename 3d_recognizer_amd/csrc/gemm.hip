@@ -1899,6 +1899,164 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
     if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
 }
 
+// The same weight-gradient tile cut for memory latency like wgemm_kernel: eight wavefronts of 16 (n) x 128 (k) share the
+// 128 x 128 tile of dW (32 accumulator registers each instead of 64), which fits 128 VGPRs: two workgroups per CU = four
+// wavefronts per SIMD, twice the loads in flight (pwgrad128_kernel<3>: 240 VGPRs, two per SIMD, 39 % of its wavefront
+// cycles parked on memory).  bf16 arithmetic modes only; same operands and MFMA sequence per accumulator -> same bits.
+template <int TERMS>   // 3: bf16x3; 1: bf16
+__global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p) {
+    constexpr int BS = 40;
+    constexpr int NSPL = TERMS == 3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 lds_d[PW2_T * BS * NSPL];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[PW2_T * BS * NSPL];
+    __bf16* Dh = lds_d;
+    __bf16* Dl = Dh + PW2_T * BS;
+    __bf16* Xh = lds_a;
+    __bf16* Xl = Xh + PW2_T * BS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int N = p.N, K = p.a.K;
+    const int n0 = blockIdx.y * PW2_T, k0 = blockIdx.z * PW2_T;
+    const int nvalid = min(PW2_T, N - n0), kvalid = min(PW2_T, K - k0);
+    const long r_begin = (long)blockIdx.x * p.rows_per_block;
+    const long r_end = min(p.a.M, r_begin + p.rows_per_block);
+    const bool lazy = p.a.lazy.scale != nullptr;
+    const bool relu = p.a.lazy.act == RL_ACT_RELU;
+    const float nslope = p.a.lazy.act == RL_ACT_NONE ? 1.f : p.a.lazy.slope;
+    auto actf = [&](float z) {
+        const float neg = relu ? 0.f : z * nslope;
+        return z > 0.f ? z : neg;
+    };
+    // staging units of this lane: u = i*8 + wave -> columns (u%8)*16 + 4*(l&3), rows (u/8)*16 + (l>>2)
+    int ucol[2], urow[2];
+    float4 sc[2], sh[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = i * 8 + wave;
+        ucol[i] = (u & 7) * 16 + (lane & 3) * 4;
+        urow[i] = (u >> 3) * 16 + (lane >> 2);
+        sc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lazy && ucol[i] < kvalid) {
+            sc[i] = *reinterpret_cast<const float4*>(p.a.lazy.scale + k0 + ucol[i]);
+            sh[i] = *reinterpret_cast<const float4*>(p.a.lazy.shift + k0 + ucol[i]);
+        }
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    float4 rd[2], ra[2];
+
+    auto fetch = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long R = r0 + urow[i];
+            rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (R < r_end) {
+                if (ucol[i] < nvalid) {
+                    long off;
+                    if (p.dy_contig) off = R * p.lddy;
+                    else {
+                        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                        const int ii = (int)(R - (long)b * p.rows_per_batch);
+                        off = ((long)b * p.dy_bstride + ii) * p.lddy;
+                    }
+                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + ucol[i]);
+                }
+                if (ucol[i] < kvalid) ra[i] = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + ucol[i]);
+            }
+        }
+    };
+    auto commit = [&](long r0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 v = ra[i];
+            if (lazy && r0 + urow[i] < r_end && ucol[i] < kvalid) {
+                v.x = actf(v.x * sc[i].x + sh[i].x);
+                v.y = actf(v.y * sc[i].y + sh[i].y);
+                v.z = actf(v.z * sc[i].z + sh[i].z);
+                v.w = actf(v.w * sc[i].w + sh[i].w);
+            }
+            bf16x4 dh, dl, xh, xl;
+            split_bf16(rd[i], dh, dl);
+            split_bf16(v, xh, xl);
+            const int o = ucol[i] * BS + urow[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Dh[o + j * BS] = dh[j];
+                Xh[o + j * BS] = xh[j];
+                if constexpr (TERMS == 3) {
+                    Dl[o + j * BS] = dl[j];
+                    Xl[o + j * BS] = xl[j];
+                }
+            }
+        }
+    };
+
+    const __bf16* dh_frag = Dh + (wave * 16 + lr) * BS + lq * 8;
+    const __bf16* xh_frag = Xh + lr * BS + lq * 8;
+    constexpr int LO = PW2_T * BS;
+    if (r_begin < r_end) fetch(r_begin);
+    for (long r0 = r_begin; r0 < r_end; r0 += PW2_RB) {
+        __syncthreads();
+        commit(r0);
+        __syncthreads();
+        if (r0 + PW2_RB < r_end) fetch(r0 + PW2_RB);
+        if (p.has_bias && blockIdx.z == 0 && tid < PW2_T) {
+#pragma unroll
+            for (int j = 0; j < PW2_RB / 8; ++j) {
+                const bf16x8 h = *reinterpret_cast<const bf16x8*>(Dh + tid * BS + j * 8);
+                float t = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t += (float)h[e];
+                if constexpr (TERMS == 3) {
+                    const bf16x8 l = *reinterpret_cast<const bf16x8*>(Dl + tid * BS + j * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t += (float)l[e];
+                }
+                bsum += t;
+            }
+        }
+        bf16x8 a_h, a_l;
+        a_h = *reinterpret_cast<const bf16x8*>(dh_frag);
+        if constexpr (TERMS == 3) a_l = *reinterpret_cast<const bf16x8*>(dh_frag + LO);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kb0 = g * 2;
+            bf16x8 b_h[2], b_l[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b_h[j] = *reinterpret_cast<const bf16x8*>(xh_frag + (kb0 + j) * 16 * BS);
+                if constexpr (TERMS == 3) b_l[j] = *reinterpret_cast<const bf16x8*>(xh_frag + LO + (kb0 + j) * 16 * BS);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[j], acc[kb0 + j], 0, 0, 0);
+            if constexpr (TERMS == 3) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l[j], acc[kb0 + j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h[j], acc[kb0 + j], 0, 0, 0);
+            }
+        }
+    }
+    float* out = p.slab + (long)blockIdx.x * ((long)N * K + N);
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const int k = k0 + kb * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wave * 16 + lq * 4 + r;
+            if (n < N && k < K) out[(long)n * K + k] = acc[kb][r];
+        }
+    }
+    if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
+}
+
 inline bool pwgrad_ok(const WgradParams& p) {
     if (p.a.a_mode != 0 || !p.a.vec4) return false;
     if ((p.N % 4) || (p.lddy % 4) || (((uintptr_t)p.dY) & 15)) return false;
@@ -2082,9 +2240,12 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         dim3 grid(nsplit, rl_cdiv(d->N, T), rl_cdiv(d->K, T));
         if (pipelined && T == 128) {
             const int t = wide_gemm_terms();
+            static const bool narrow_wg = getenv("RL_WGRAD_4WAVE") != nullptr;      // diagnostics: the 4-wavefront kernel
             if (t == 0)      hipLaunchKernelGGL(pwgrad128_kernel<0>, grid, dim3(256), 0, st, p);
-            else if (t == 1) hipLaunchKernelGGL(pwgrad128_kernel<1>, grid, dim3(256), 0, st, p);
-            else             hipLaunchKernelGGL(pwgrad128_kernel<3>, grid, dim3(256), 0, st, p);
+            else if (narrow_wg && t == 1) hipLaunchKernelGGL(pwgrad128_kernel<1>, grid, dim3(256), 0, st, p);
+            else if (narrow_wg)           hipLaunchKernelGGL(pwgrad128_kernel<3>, grid, dim3(256), 0, st, p);
+            else if (t == 1) hipLaunchKernelGGL(pwgrad128w_kernel<1>, grid, dim3(512), 0, st, p);
+            else             hipLaunchKernelGGL(pwgrad128w_kernel<3>, grid, dim3(512), 0, st, p);
         }
         else if (pipelined) hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
