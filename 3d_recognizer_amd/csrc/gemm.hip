@@ -2249,7 +2249,8 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         }
         else if (pipelined) hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, st, p);
-        rl_note_kernel(pipelined && T == 128 ? "pwgrad128_kernel" : pipelined ? "pwgrad_kernel" : "wgrad_kernel");
+        rl_note_kernel(pipelined && T == 128 ? (wide_gemm_terms() != 0 && getenv("RL_WGRAD_4WAVE") == nullptr ? "pwgrad128w_kernel" : "pwgrad128_kernel")
+                                             : pipelined ? "pwgrad_kernel" : "wgrad_kernel");
     }
     RL_LAUNCH_CHECK("rl_wgrad");
     if (d->defer_reduce) return RL_OK;

@@ -18,10 +18,12 @@ stats = ops.new_stats(dev, N)
 dY = torch.randn(M, N, device=dev)
 dW = torch.empty_like(W)
 big = torch.empty(1 << 28, dtype=torch.float32, device=dev)      # 1 GiB: evicts the 256 MiB Infinity Cache between launches
+ws = ops.split_weights([(W, 1, K, K, N)])      # the 8-wavefront kernel, as inside a step (empty in the fp32 mode)
+use_stats = len(sys.argv) > 6 and sys.argv[6] == "stats"
 for _ in range(reps):
     big.fill_(1.0)
     if kind == "gemm":
-        ops.gemm(a, W, 1, K, N, None, stats=stats)
+        ops.gemm(a, W, 1, K, N, None, stats=stats if use_stats else None, wsplit=ws)
     else:
         ops.wgrad(a, dY, M, N, dW, 1, K, None)
 torch.cuda.synchronize()
