@@ -236,25 +236,25 @@ struct VT {
     static constexpr int DTH = (H + 15) / 16;        // its 16-column blocks
     static constexpr int HP = 16 * DTH;
     static constexpr int S1 = 20;                    // fp32 row stride of the staged W1 ([n][16 k] + pad, 16-byte aligned)
-    static constexpr int S1B = 24;                   // bf16 row stride of the staged W1
 };
 
-// LDS image of the two small weights: TERMS == 0 floats, else bf16 head + tail
+// LDS image of the two small weights.  W1 (10 x h, applied to raw coordinates) is ALWAYS kept in fp32 and multiplied with
+// the exact fp32 MFMA: its inputs are coordinates of magnitude ~1 whose differences carry the signal, a bf16x3 product
+// error of 2^-16 relative to the LARGEST term would be felt in the logits (train-mode logits error 1.4e-4 -> 3e-4 when it
+// was bf16x3), and the matrix pipe is idle in these kernels anyway.  W2 (h x h): TERMS == 0 floats, else bf16 head + tail.
 template <int DT, int TERMS>
 struct VWeights {
     static constexpr int HP = VT<DT>::HP, DTH = VT<DT>::DTH;
     static constexpr int XS2 = Tile<DTH>::XS, XSB2 = Tile<DTH>::XSB;
-    static constexpr int BYTES = TERMS == 0 ? (HP * VT<DT>::S1 + HP * XS2) * 4 : (HP * VT<DT>::S1B + HP * XSB2) * 2 * 2;
+    static constexpr int BYTES = HP * VT<DT>::S1 * 4 + (TERMS == 0 ? HP * XS2 * 4 : HP * XSB2 * 2 * 2);
     float* w1f; float* w2f;
-    __bf16 *w1h, *w1l, *w2h, *w2l;
+    __bf16 *w2h, *w2l;
     __device__ __forceinline__ void bind(unsigned char* mem) {
+        w1f = reinterpret_cast<float*>(mem);
         if constexpr (TERMS == 0) {
-            w1f = reinterpret_cast<float*>(mem);
             w2f = w1f + HP * VT<DT>::S1;
         } else {
-            w1h = reinterpret_cast<__bf16*>(mem);
-            w1l = w1h + HP * VT<DT>::S1B;
-            w2h = w1l + HP * VT<DT>::S1B;
+            w2h = reinterpret_cast<__bf16*>(w1f + HP * VT<DT>::S1);
             w2l = w2h + HP * XSB2;
         }
     }
@@ -263,13 +263,7 @@ struct VWeights {
         constexpr int H = VT<DT>::H;
         for (int e = threadIdx.x; e < HP * 16; e += nthreads) {
             const int n = e >> 4, k = e & 15;
-            const float w = (n < H && k < 10) ? p.W1[n * 10 + k] : 0.f;
-            if constexpr (TERMS == 0) w1f[n * VT<DT>::S1 + k] = w;
-            else {
-                const __bf16 h = (__bf16)w;
-                w1h[n * VT<DT>::S1B + k] = h;
-                w1l[n * VT<DT>::S1B + k] = (__bf16)(w - (float)h);
-            }
+            w1f[n * VT<DT>::S1 + k] = (n < H && k < 10) ? p.W1[n * 10 + k] : 0.f;
         }
         if (p.src >= 2 || p.fstats2) {
             for (int e = threadIdx.x; e < HP * HP; e += nthreads) {
@@ -335,27 +329,17 @@ __device__ __forceinline__ float4 rpe_frag(const RpeIn& r, int lj) {
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// acc[nb] (C layout) = rpe tile (16 x 16, A layout) . W1^T
+// acc[nb] (C layout) = rpe tile (16 x 16, A layout) . W1^T, exact fp32 products in every arithmetic mode
 template <int DT, int TERMS>
 __device__ __forceinline__ void rpe_gemm(const float4 a, const VWeights<DT, TERMS>& w, int li, int lj, f32x4 (&acc)[VT<DT>::DTH]) {
 #pragma unroll
     for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
         acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (TERMS == 0) {
-            const float4 b = *reinterpret_cast<const float4*>(w.w1f + (nb * 16 + li) * VT<DT>::S1 + 4 * lj);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nb], 0, 0, 0);
-        } else {
-            bf16x4 ah, al;
-            split4(a, ah, al);
-            const bf16x4 bh = *reinterpret_cast<const bf16x4*>(w.w1h + (nb * 16 + li) * VT<DT>::S1B + 4 * lj);
-            const bf16x4 bl = *reinterpret_cast<const bf16x4*>(w.w1l + (nb * 16 + li) * VT<DT>::S1B + 4 * lj);
-            acc[nb] = mfma16(ah, bh, acc[nb]);
-            acc[nb] = mfma16(ah, bl, acc[nb]);
-            acc[nb] = mfma16(al, bh, acc[nb]);
-        }
+        const float4 b = *reinterpret_cast<const float4*>(w.w1f + (nb * 16 + li) * VT<DT>::S1 + 4 * lj);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nb], 0, 0, 0);
     }
 }
 
