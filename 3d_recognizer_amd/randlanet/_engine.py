@@ -31,11 +31,28 @@ BN_EPS = 1e-6       # modules.py:87, :497
 BN_MOMENTUM = 0.99
 
 
+class _Tape(list):
+    """The forward's records; each remembers the encoder level it was appended under (ops.LEVEL), so that the backward's
+    launches carry the same tag in the kernel timer."""
+
+    def __init__(self):
+        super().__init__()
+        self.levels: List[int] = []
+
+    def append(self, rec) -> None:
+        super().append(rec)
+        self.levels.append(ops.LEVEL)
+
+    def clear(self) -> None:
+        super().clear()
+        self.levels.clear()
+
+
 class Context:
     """What one forward leaves behind for its backward."""
 
     def __init__(self):
-        self.tape: List[tuple] = []
+        self.tape: "_Tape" = _Tape()
         self.grads: Dict[int, list] = {}     # id(raw tensor) -> [gradient tensor, initialised]
         self.keep: List[torch.Tensor] = []
         self.training = False
@@ -248,7 +265,9 @@ class Engine:
         ratio = 1
         for l, d in enumerate(self.layers):
             n_l = N // ratio
+            ops.LEVEL = l
             x = self._lfa(ctx, l, x.prefix(n_l), xyz, n_l, d, *searches[l], csr=csrs[l])
+            ops.LEVEL = -1
             skips.append(x)
             ratio *= dec
         x = self._mlp(ctx, x.prefix(N // ratio), "mlp", x.C, H.ACT_RELU)        # modules.py:591
@@ -316,7 +335,8 @@ class Engine:
         ctx.bn_done = set()       # raw tensors whose BatchNorm backward already happened (fused at the residual junction)
         # weight-gradient slabs are summed by ONE launch after the last layer (they are only needed by the optimiser)
         ctx.pending = None if (ops.SIDE_STREAM_WGRAD or ops.NO_DEFERRED_WGRAD) else []
-        for rec in reversed(ctx.tape):
+        for rec, lvl in zip(reversed(ctx.tape), reversed(ctx.tape.levels)):
+            ops.LEVEL = lvl
             kind = rec[0]
             if kind == "linear":
                 self._bwd_linear(ctx, grads, *rec[1:])
@@ -375,6 +395,7 @@ class Engine:
                 ctx.grads[id(src.raw)] = [G, True]
             else:
                 raise AssertionError(kind)
+        ops.LEVEL = -1
         self._main.wait_stream(self._side)
         if ctx.pending is not None:
             ops.wgrad_flush(ctx.pending)

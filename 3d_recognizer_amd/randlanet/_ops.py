@@ -79,7 +79,7 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for cat, key, nbytes, flops, e0, e1, _kern in self.records:
+        for cat, key, nbytes, flops, e0, e1, _kern, _lvl in self.records:
             a = agg.setdefault((cat, key), dict(category=cat, shape=key, launches=0, ms=0.0, bytes=0, flops=0))
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
@@ -89,6 +89,7 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+LEVEL = -1      # encoder level the engine is working on (-1: outside the encoder) - a tag on the timer's records only
 # Weight gradients on a second stream beside the dY->dX chain: measured 11.2 -> 19-21 ms per step under
 # hipGraph replay (every fork/join becomes a cross-branch dependency in the graph), so OFF by default.
 SIDE_STREAM_WGRAD = bool(int(__import__("os").environ.get("RL_SIDE_STREAM", "0")))
@@ -125,7 +126,7 @@ class _rec:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             kern = H.lib().rl_last_kernel().decode()
-            TIMER.records.append(self.args + (self.e0, e1, kern))
+            TIMER.records.append(self.args + (self.e0, e1, kern, LEVEL))
         return False
 
 

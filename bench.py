@@ -160,14 +160,14 @@ def roofline_pass(stepper, eager_steps=3):
         ops.TIMER = None
         stepper._g_main, stepper._g_adam = g_main, g_adam
     shapes = {}
-    for cat, key, nbytes, flops, e0, e1, kern in records:
-        a = shapes.setdefault((kern, cat, key), dict(kernel=kern, category=cat, shape=key, times=[], bytes=nbytes, flops=flops))
+    for cat, key, nbytes, flops, e0, e1, kern, lvl in records:
+        a = shapes.setdefault((kern, cat, key, lvl), dict(kernel=kern, category=cat, shape=key, times=[], bytes=nbytes, flops=flops, level=lvl))
         a["times"].append(e0.elapsed_time(e1))
     rows = []
     for a in shapes.values():
         per_launch = float(np.median(a["times"]))
         launches = len(a["times"]) / eager_steps
-        rows.append(dict(kernel=a["kernel"], category=a["category"], shape=a["shape"], ms_per_launch=per_launch,
+        rows.append(dict(kernel=a["kernel"], category=a["category"], shape=a["shape"], level=a["level"], ms_per_launch=per_launch,
                          launches_per_step=launches, ms_per_step=per_launch * launches, bytes=a["bytes"], flops=a["flops"]))
     rows.sort(key=lambda r: -r["ms_per_step"])
     total_ms = sum(r["ms_per_step"] for r in rows)
@@ -217,8 +217,7 @@ def roofline_pass(stepper, eager_steps=3):
                                       GBps=round(r["bytes"] / max(r["ms_per_launch"], 1e-9) / 1e6, 1),
                                       TFLOPs=round(r["flops"] / max(r["ms_per_launch"], 1e-9) / 1e9, 2)) for r in rows[:80]],
                      # consumed by step_rooflines(), not printed
-                     all_shapes=[dict(op=f"{r['category']}{list(r['shape'])}", M=(r["shape"][0] if r["shape"] and
-                                      isinstance(r["shape"][0], int) else -1), ms_per_step=r["ms_per_step"],
+                     all_shapes=[dict(op=f"{r['category']}{list(r['shape'])}", level=r["level"], ms_per_step=r["ms_per_step"],
                                       launches_per_step=r["launches_per_step"], bytes=r["bytes"], flops=r["flops"]) for r in rows])
     return roof, breakdown
 
@@ -284,19 +283,17 @@ def step_rooflines(breakdown, B, value, world):
                       "io_frac_of_hbm": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                       "brute_equivalent_pair_evals_per_s": round(pairs / ms * 1e3, 0),
                       "note": "exact grid search: pairs are the brute-force count the answer is equivalent to"}
-    # matrix work per level: a GEMM / weight-gradient / fused-pooling launch belongs to the level whose row count it has
+    # matrix work per encoder level (the engine tags every launch with the level it works on)
     lv = []
-    n = N
     for l, d in enumerate(layers):
-        keys = {B * n, B * n * K}
-        sel = [r for r in rows if r["flops"] > 0 and r["M"] in keys and not r["op"].startswith("knn")]
+        sel = [r for r in rows if r["flops"] > 0 and r["level"] == l]
         fl = sum(r["flops"] * r["launches_per_step"] for r in sel)
         ms = sum(r["ms_per_step"] for r in sel)
         if ms > 0:
             lv.append({"level": l, "d": d, "GFLOP_per_step": round(fl / 1e9, 2), "ms_per_step": round(ms, 3),
                        "TFLOPs": round(fl / ms / 1e9, 1), "frac_fp32_mfma_peak": round(fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4),
-                       "frac_bf16_mfma_peak_x3": round(3 * fl / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4)})
-        n //= 4
+                       "frac_bf16_mfma_peak_x3": round(3 * fl / ms / 1e9 / BF16_MFMA_PEAK_TFLOPS, 4),
+                       "level_ms_all_kernels": round(sum(r["ms_per_step"] for r in rows if r["level"] == l), 3)})
     out["mfma_by_level"] = lv
     return out
 
