@@ -45,6 +45,25 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x4 a, const bf16x4 b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
 
+// The tile kernels of this file are bound by vector-instruction issue (profiles/r02_pmc_sq_step.md), so their elementwise
+// passes are written on 4-vectors: the compiler turns those into v_pk_{add,mul,fma}_f32 (two floats per lane and
+// instruction) where the scalar loops became four separate instructions.
+__device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
+__device__ __forceinline__ f32x4 v4(const float4 a) { return (f32x4){a.x, a.y, a.z, a.w}; }
+__device__ __forceinline__ float4 f4(const f32x4 a) { return make_float4(a[0], a[1], a[2], a[3]); }
+__device__ __forceinline__ float sum4(const f32x4 a) { return (a[0] + a[1]) + (a[2] + a[3]); }
+// BatchNorm of a VIRTUAL rpe stage: one fused multiply-add per element, and the same expression in every kernel that
+// needs the activation or its sign (forward, statistics, the three backward kernels) so that they agree bit for bit
+__device__ __forceinline__ f32x4 vbn(const f32x4 raw, float s, float h) { return __builtin_elementwise_fma(raw, splat(s), splat(h)); }
+__device__ __forceinline__ f32x4 vrelu(const f32x4 z) { return __builtin_elementwise_max(z, splat(0.f)); }
+// activation of a lazily normalised tensor without a branch: act(z) = max(z, z*e) with e = 1 (none), 0 (ReLU) or the
+// LeakyReLU slope (0 <= slope <= 1); equal in value to rl_act (a negative input of ReLU yields -0 instead of +0)
+__device__ __forceinline__ float eff_slope(const RlLazy& t) {
+    if (t.scale == nullptr || t.act == RL_ACT_NONE) return 1.f;
+    return t.act == RL_ACT_RELU ? 0.f : t.slope;
+}
+__device__ __forceinline__ f32x4 vact(const f32x4 z, float e) { return __builtin_elementwise_max(z, z * splat(e)); }
+
 struct PoolParams {
     const float* U;        // (P*16) x h raw rpe-branch features
     RlLazy ulazy;
@@ -91,7 +110,7 @@ struct Tile {
 
 // lane-constant lazy parameters for the float4 this lane loads in chunk c
 template <int DT>
-__device__ __forceinline__ void lane_lazy(const PoolParams& p, int lj, float (&sc)[DT][4], float (&sh)[DT][4]) {
+__device__ __forceinline__ void lane_lazy(const PoolParams& p, int lj, f32x4 (&sc)[DT], f32x4 (&sh)[DT]) {
     constexpr int H = Tile<DT>::H;
 #pragma unroll
     for (int c = 0; c < DT; ++c)
@@ -107,15 +126,42 @@ __device__ __forceinline__ void lane_lazy(const PoolParams& p, int lj, float (&s
             }
         }
 }
+// effective activation slope (eff_slope) of the half of X that chunk c of this lane belongs to
+template <int DT>
+__device__ __forceinline__ float chunk_slope(int c, int lj, float es_u, float es_g) {
+    if constexpr (DT == 1) return lj < 2 ? es_u : es_g;
+    else return 16 * c < Tile<DT>::H ? es_u : es_g;
+}
+
+// Position of a wavefront in its sequence of points: the point, its cloud and its index inside the cloud.  All three are
+// wavefront-uniform (the wave number is read through readfirstlane), so this arithmetic - and every address built from
+// it - runs on the scalar unit; the cloud is tracked incrementally instead of dividing by n per point.
+struct Cursor {
+    long pt;
+    int b, i;
+    __device__ __forceinline__ void start(long pt0, int n) {
+        pt = pt0;
+        b = (int)((unsigned)pt0 / (unsigned)n);   // points * 16 < 2^31 (checked on the host)
+        i = (int)(pt0 - (long)b * n);
+    }
+    __device__ __forceinline__ Cursor next(long pstep, int n) const {
+        Cursor c;
+        c.pt = pt + pstep;
+        c.b = b;
+        c.i = i + (int)pstep;
+        while (c.i >= n) { c.i -= n; ++c.b; }
+        return c;
+    }
+};
 
 // The 16 x d tile of X for point pt in A layout, in two steps so that the loads of the NEXT point can be in flight
 // while the current one is computed: fetch_x issues the raw loads (rpe-branch rows + gathered rows),
 // finish_x applies the lazy BatchNorm / activation and parks the tile in LDS.
 template <int DT>
-__device__ __forceinline__ void fetch_x(const PoolParams& p, long pt, int li, int lj, int my_idx, float4 (&raw)[DT]) {
+__device__ __forceinline__ void fetch_x(const PoolParams& p, const Cursor& cu, int li, int lj, int my_idx, float4 (&raw)[DT]) {
     constexpr int H = Tile<DT>::H;
-    const long row = pt * 16 + li;
-    const long b = (unsigned)pt / (unsigned)p.n;   // points * 16 < 2^31 (checked on the host)
+    const long row = cu.pt * 16 + li;
+    const long b = cu.b;
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
@@ -126,25 +172,13 @@ __device__ __forceinline__ void fetch_x(const PoolParams& p, long pt, int li, in
 }
 template <int DT>
 __device__ __forceinline__ void finish_x(const PoolParams& p, int li, int lj, const float4 (&raw)[DT],
-                                         const float (&sc)[DT][4], const float (&sh)[DT][4], float4 (&xa)[DT], float* Xs) {
-    constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
+                                         const f32x4 (&sc)[DT], const f32x4 (&sh)[DT], float4 (&xa)[DT], float* Xs) {
+    constexpr int XS = Tile<DT>::XS;
+    const float es_u = eff_slope(p.ulazy), es_g = eff_slope(p.glazy);
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
-        float4 v = raw[c];
-        int act;
-        float slope;
-        if (k < H) {
-            act = p.ulazy.scale ? p.ulazy.act : RL_ACT_NONE;
-            slope = p.ulazy.slope;
-        } else {
-            act = p.glazy.scale ? p.glazy.act : RL_ACT_NONE;
-            slope = p.glazy.slope;
-        }
-        v.x = rl_act(v.x * sc[c][0] + sh[c][0], act, slope);
-        v.y = rl_act(v.y * sc[c][1] + sh[c][1], act, slope);
-        v.z = rl_act(v.z * sc[c][2] + sh[c][2], act, slope);
-        v.w = rl_act(v.w * sc[c][3] + sh[c][3], act, slope);
+        const float4 v = f4(vact(v4(raw[c]) * sc[c] + sh[c], chunk_slope<DT>(c, lj, es_u, es_g)));
         xa[c] = v;
         *reinterpret_cast<float4*>(Xs + li * XS + k) = v;
     }
@@ -304,9 +338,8 @@ struct VCols {
 struct RpeIn {
     float xi[3], xj[3], dd;
 };
-__device__ __forceinline__ void fetch_rpe(const PoolParams& p, long pt, int li, int nbr, RpeIn& r) {
-    const long b = (unsigned)pt / (unsigned)p.n;
-    const long i = pt - b * p.n;
+__device__ __forceinline__ void fetch_rpe(const PoolParams& p, const Cursor& cu, int li, int nbr, RpeIn& r) {
+    const long pt = cu.pt, b = cu.b, i = cu.i;
     if (p.xyz_w == 4) {
         // padded coordinates: one 16-byte gather per point instead of three 4-byte ones (the texture path pays per
         // distinct line and per instruction)
@@ -323,10 +356,15 @@ __device__ __forceinline__ void fetch_rpe(const PoolParams& p, long pt, int li, 
 }
 // channels [x_i, x_nbr, x_i - x_nbr, dist, 0...] (modules.py:173-186): this lane's float4 = channels 4*lj .. 4*lj+3
 __device__ __forceinline__ float4 rpe_frag(const RpeIn& r, int lj) {
-    if (lj == 0) return make_float4(r.xi[0], r.xi[1], r.xi[2], r.xj[0]);
-    if (lj == 1) return make_float4(r.xj[1], r.xj[2], r.xi[0] - r.xj[0], r.xi[1] - r.xj[1]);
-    if (lj == 2) return make_float4(r.xi[2] - r.xj[2], __fsqrt_rn(r.dd), 0.f, 0.f);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    // every lane computes all ten channels and selects its four (lane-constant masks): no divergent branches in the loops
+    const float dx = r.xi[0] - r.xj[0], dy = r.xi[1] - r.xj[1], dz = r.xi[2] - r.xj[2], dist = __fsqrt_rn(r.dd);
+    const bool l0 = lj == 0, l1 = lj == 1, l2 = lj == 2;
+    float4 o;
+    o.x = l0 ? r.xi[0] : l1 ? r.xj[1] : l2 ? dz : 0.f;
+    o.y = l0 ? r.xi[1] : l1 ? r.xj[2] : l2 ? dist : 0.f;
+    o.z = l0 ? r.xi[2] : l1 ? dx : 0.f;
+    o.w = l0 ? r.xj[0] : l1 ? dy : 0.f;
+    return o;
 }
 
 // acc[nb] (C layout) = rpe tile (16 x 16, A layout) . W1^T, exact fp32 products in every arithmetic mode
@@ -353,17 +391,16 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH;
     rpe_gemm<DT, TERMS>(rpe_frag(in, lj), w, li, lj, raw);
 #pragma unroll
-    for (int nb = 0; nb < DTH; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) raw[nb][r] += vc.b1[nb];
+    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b1[nb]);
     if (stage == 1) {
         if (Xs) {
 #pragma unroll
             for (int nb = 0; nb < DTH; ++nb) {
                 const int col = nb * 16 + li;
+                const f32x4 u = vrelu(vbn(raw[nb], vc.s1[nb], vc.h1[nb]));
                 if (col < H) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = fmaxf(raw[nb][r] * vc.s1[nb] + vc.h1[nb], 0.f);
+                    for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = u[r];
                 }
             }
         }
@@ -373,9 +410,10 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) {
         const int col = nb * 16 + li;
+        const f32x4 u = vrelu(vbn(raw[nb], vc.s1[nb], vc.h1[nb]));
         if (col < H) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scratch[(4 * lj + r) * XS + col] = fmaxf(raw[nb][r] * vc.s1[nb] + vc.h1[nb], 0.f);
+            for (int r = 0; r < 4; ++r) scratch[(4 * lj + r) * XS + col] = u[r];
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -391,16 +429,15 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
     if constexpr (TERMS == 0) tile_gemm<DTH>(a1, w.w2f, li, lj, raw);
     else tile_gemm_bf<DTH>(a1, w.w2h, w.w2l, li, lj, raw);
 #pragma unroll
-    for (int nb = 0; nb < DTH; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) raw[nb][r] += vc.b2[nb];
+    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b2[nb]);
     if (Xs) {
 #pragma unroll
         for (int nb = 0; nb < DTH; ++nb) {
             const int col = nb * 16 + li;
+            const f32x4 u = vrelu(vbn(raw[nb], vc.s2[nb], vc.h2[nb]));
             if (col < H) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = fmaxf(raw[nb][r] * vc.s2[nb] + vc.h2[nb], 0.f);
+                for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = u[r];
             }
         }
     }
@@ -410,20 +447,16 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
 // chunks), the rpe half is computed; xa (A layout) is read back from the tile.
 template <int DT, int TERMS>
 __device__ __forceinline__ void finish_x_virtual(const PoolParams& p, int li, int lj, const float4 (&graw)[DT], const RpeIn& in,
-                                                 const float (&sc)[DT][4], const float (&sh)[DT][4], const VWeights<DT, TERMS>& w,
+                                                 const f32x4 (&sc)[DT], const f32x4 (&sh)[DT], const VWeights<DT, TERMS>& w,
                                                  const VCols<DT>& vc, float4 (&xa)[DT], float* Xs, f32x4 (&rawu)[VT<DT>::DTH]) {
     constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
     rpe_branch<DT, TERMS>(p, in, p.src, w, vc, li, lj, Xs, XS, rawu, Xs);
-    const int gact = p.glazy.scale ? p.glazy.act : RL_ACT_NONE;
+    const float es_g = eff_slope(p.glazy);
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
         if (k >= H) {
-            float4 v = graw[c];
-            v.x = rl_act(v.x * sc[c][0] + sh[c][0], gact, p.glazy.slope);
-            v.y = rl_act(v.y * sc[c][1] + sh[c][1], gact, p.glazy.slope);
-            v.z = rl_act(v.z * sc[c][2] + sh[c][2], gact, p.glazy.slope);
-            v.w = rl_act(v.w * sc[c][3] + sh[c][3], gact, p.glazy.slope);
+            const float4 v = f4(vact(v4(graw[c]) * sc[c] + sh[c], es_g));
             xa[c] = v;
             *reinterpret_cast<float4*>(Xs + li * XS + k) = v;
         }
@@ -439,6 +472,11 @@ __device__ __forceinline__ void finish_x_virtual(const PoolParams& p, int li, in
 // softmax over the 16 rows of a C-layout tile, in place: s -> A
 template <int DT>
 __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
+    // exp(x) = 2^(x*log2 e) on the hardware exponential, 1/den on the hardware reciprocal (1 ulp each; the argument's
+    // rounding adds |x|*2^-24 relative - 1e-6 at the largest score differences that still matter): an accurate expf and an
+    // IEEE division are ~12 instructions each, a tenth of these kernels' instruction stream.  Forward and backward share
+    // this function, so the backward differentiates exactly the attention weights the forward used.
+    constexpr float LOG2E = 1.44269504088896340736f;
 #pragma unroll
     for (int nb = 0; nb < DT; ++nb) {
         float m = fmaxf(fmaxf(s[nb][0], s[nb][1]), fmaxf(s[nb][2], s[nb][3]));
@@ -447,12 +485,12 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
         float den = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            s[nb][r] = expf(s[nb][r] - m);
+            s[nb][r] = __builtin_amdgcn_exp2f((s[nb][r] - m) * LOG2E);
             den += s[nb][r];
         }
         den += __shfl_xor(den, 16, 64);
         den += __shfl_xor(den, 32, 64);
-        const float inv = 1.f / den;
+        const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[nb][r] *= inv;
     }
@@ -479,7 +517,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     float* Wt = reinterpret_cast<float*>(wmem);
     __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
     __bf16* Wl = Wh + D * XSB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
     const int li = lane & 15, lj = lane >> 4;
     for (int e = threadIdx.x; e < D * D; e += 64 * NW) {
         const int o = e / D, i = e - o * D;
@@ -494,16 +532,16 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     }
     VWeights<DT, TERMS> vw;
     VCols<DT> vc;
-    float fs2[VIRT ? VT<DT>::DTH : 1], fq2[VIRT ? VT<DT>::DTH : 1];
+    f32x4 fs2[VIRT ? VT<DT>::DTH : 1], fq2[VIRT ? VT<DT>::DTH : 1];   // per-lane partials of its four rows
     if constexpr (VIRT) {
         vw.bind(vmem);
         vw.stage(p, 64 * NW);
         vc.load(p, li);
 #pragma unroll
-        for (int nb = 0; nb < VT<DT>::DTH; ++nb) fs2[nb] = fq2[nb] = 0.f;
+        for (int nb = 0; nb < VT<DT>::DTH; ++nb) fs2[nb] = fq2[nb] = splat(0.f);
     }
     __syncthreads();
-    float sc[DT][4], sh[DT][4];
+    f32x4 sc[DT], sh[DT];
     lane_lazy<DT>(p, lj, sc, sh);
     float* Xs = Xt[wave];
     // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
@@ -513,11 +551,14 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
     RpeIn rin, rin_nxt;
+    Cursor cu;
+    cu.start(pt, p.n);
     if (pt < p.P) {
-        fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
-        if constexpr (VIRT) fetch_rpe(p, pt, li, idx_cur, rin);
+        fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
+        if constexpr (VIRT) fetch_rpe(p, cu, li, idx_cur, rin);
     }
     for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         if constexpr (VIRT) {
             f32x4 rawu[VT<DT>::DTH];
@@ -535,20 +576,19 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
                 if constexpr (TERMS == 0) tile_gemm<DTH>(a1, vw.w2f, li, lj, r2);
                 else tile_gemm_bf<DTH>(a1, vw.w2h, vw.w2l, li, lj, r2);
 #pragma unroll
-                for (int nb = 0; nb < DTH; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = r2[nb][r] + vc.b2[nb];
-                        fs2[nb] += v;
-                        fq2[nb] += v * v;
-                    }
+                for (int nb = 0; nb < DTH; ++nb) {
+                    const f32x4 v = r2[nb] + splat(vc.b2[nb]);
+                    fs2[nb] += v;
+                    fq2[nb] = __builtin_elementwise_fma(v, v, fq2[nb]);
+                }
             }
         } else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) {
-            fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
-            if constexpr (VIRT) fetch_rpe(p, pt + pstep, li, idx_nxt, rin_nxt);
+            fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
+            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
         }
+        cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         f32x4 s[DT];
 #pragma unroll
@@ -559,9 +599,10 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) {
-            float acc = 0.f;
+            f32x4 xc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc += s[nb][r] * Xs[(lj * 4 + r) * XS + nb * 16 + li];
+            for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + nb * 16 + li];
+            float acc = sum4(s[nb] * xc);
             acc += __shfl_xor(acc, 16, 64);
             acc += __shfl_xor(acc, 32, 64);
             if (lj == 0) p.Pout[pt * D + nb * 16 + li] = acc;
@@ -577,7 +618,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
             static_assert(NW * 2 * VT<DT>::HP * 2 <= NW * 16 * XS, "statistics scratch does not fit the X tiles");
 #pragma unroll
             for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
-                float a = fs2[nb], b = fq2[nb];
+                float a = sum4(fs2[nb]), b = sum4(fq2[nb]);
                 a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
                 b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
                 if (lane < 16) {
@@ -609,7 +650,7 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
     __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
     __shared__ double red[4][2][VT<DT>::HP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
     const int li = lane & 15, lj = lane >> 4;
     VWeights<DT, TERMS> vw;
     VCols<DT> vc;
@@ -617,30 +658,32 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
     vw.stage(p, 256);
     vc.load(p, li);
     __syncthreads();
-    float ssum[DTH], ssq[DTH];
+    f32x4 ssum[DTH], ssq[DTH];
 #pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    for (int nb = 0; nb < DTH; ++nb) ssum[nb] = ssq[nb] = splat(0.f);
     const long pstep = (long)gridDim.x * 4;
     long pt = (long)blockIdx.x * 4 + wave;
     RpeIn rin, rin_nxt;
-    if (pt < p.P) fetch_rpe(p, pt, li, p.idx[pt * 16 + li], rin);
+    Cursor cu;
+    cu.start(pt, p.n);
+    if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
     for (; pt < p.P; pt += pstep) {
-        if (pt + pstep < p.P) fetch_rpe(p, pt + pstep, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        const Cursor cn = cu.next(pstep, p.n);
+        if (pt + pstep < p.P) fetch_rpe(p, cn, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        cu = cn;
         f32x4 raw[DTH];
         rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
 #pragma unroll
-        for (int nb = 0; nb < DTH; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ssum[nb] += raw[nb][r];
-                ssq[nb] += raw[nb][r] * raw[nb][r];
-            }
+        for (int nb = 0; nb < DTH; ++nb) {
+            ssum[nb] += raw[nb];
+            ssq[nb] = __builtin_elementwise_fma(raw[nb], raw[nb], ssq[nb]);
+        }
         __builtin_amdgcn_wave_barrier();
         rin = rin_nxt;
     }
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) {
-        float sm = ssum[nb], q = ssq[nb];
+        float sm = sum4(ssum[nb]), q = sum4(ssq[nb]);
         sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
         q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
         if (lane < 16) {
@@ -670,7 +713,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     __bf16* Wnl = Wnh + D * XSB;
     __bf16* Wth = Wnl + D * XSB;                          // [n'][k'] = W[k'][n'] head / tail: dX = dS.W
     __bf16* Wtl = Wth + D * XSB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
     const int li = lane & 15, lj = lane >> 4;
     if constexpr (TERMS == 0) {
         stage_w<DT>(p, Wt, Wn, 64 * NW);
@@ -703,7 +746,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         }
     }
     __syncthreads();
-    float sc[DT][4], sh[DT][4];
+    f32x4 sc[DT], sh[DT];
     lane_lazy<DT>(p, lj, sc, sh);
     float* Xs = Tiles[wave][0];
     float* Ds = Tiles[wave][1];
@@ -720,20 +763,24 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
     RpeIn rin, rin_nxt;
+    Cursor cu;
+    cu.start(pt, p.n);
     if (pt < p.P) {
-        fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
-        if constexpr (VIRT) fetch_rpe(p, pt, li, idx_cur, rin);
+        fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
+        if constexpr (VIRT) fetch_rpe(p, cu, li, idx_cur, rin);
     }
     for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         f32x4 rawu[VIRT ? VT<DT>::DTH : 1];
         if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs, rawu);
         else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) {
-            fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
-            if constexpr (VIRT) fetch_rpe(p, pt + pstep, li, idx_nxt, rin_nxt);
+            fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
+            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
         }
+        cu = cn;
         if constexpr (VIRT) rin = rin_nxt;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         float gp[DT];          // dP of this point: requested now, needed after the score GEMM and the softmax
@@ -751,23 +798,16 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) {
             const int col = nb * 16 + li;
-            float xc[4];
-            float pool = 0.f;
+            f32x4 xc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xc[r] = Xs[(lj * 4 + r) * XS + col];
-                pool += a[nb][r] * xc[r];
-            }
+            for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + col];
+            float pool = sum4(a[nb] * xc);
             pool += __shfl_xor(pool, 16, 64);
             pool += __shfl_xor(pool, 32, 64);
-            const float g = gp[nb];
+            dx[nb] = a[nb] * splat(gp[nb]);                          // direct path dP*A
+            dsr[nb] = dx[nb] * (xc - splat(pool));                   // dS = A*dP*(X-P)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ag = a[nb][r] * g;
-                dx[nb][r] = ag;                                   // direct path dP*A
-                dsr[nb][r] = ag * (xc[r] - pool);                   // dS = A*dP*(X-P)
-                Ds[(lj * 4 + r) * XS + col] = dsr[nb][r];
-            }
+            for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + col] = dsr[nb][r];
         }
         __builtin_amdgcn_wave_barrier();
         // dX += dS . W   (dS re-read in A layout)
@@ -805,7 +845,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
 #pragma unroll
             for (int nb = 0; nb < DT; ++nb) {
                 bf16x4 dh, dl;
-                split4(make_float4(dsr[nb][0], dsr[nb][1], dsr[nb][2], dsr[nb][3]), dh, dl);
+                split4(f4(dsr[nb]), dh, dl);
 #pragma unroll
                 for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dh, xh[kb], accw[nb][kb]);
 #pragma unroll
@@ -830,7 +870,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                         // this launch completes the gradient of the stage's activated output: the batch-statistics sums
                         // of its BatchNorm backward come for free (the raw tile is in registers)
                         if (p.bstats && nb < VT<DT>::DTH) {
-                            const float z = rawu[nb][r] * bstat_sc[nb] + bstat_sh[nb];
+                            const float z = __builtin_fmaf(rawu[nb][r], bstat_sc[nb], bstat_sh[nb]);   // = vbn
                             const float g = z > 0.f ? v : 0.f;
                             bsg[nb] += g;
                             bsx[nb] += g * ((rawu[nb][r] - bstat_mu[nb]) * bstat_is[nb]);
@@ -924,7 +964,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     __shared__ __attribute__((aligned(16))) __bf16 Wh[D * XSB];
     __shared__ __attribute__((aligned(16))) __bf16 Wl[D * XSB];
     __shared__ __attribute__((aligned(16))) float Tiles[NW][16 * XS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
     const int li = lane & 15, lj = lane >> 4;
     for (int e = threadIdx.x; e < D * D; e += 64 * NW) {
         const int o = e / D, i = e - o * D;
@@ -934,7 +974,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
         if constexpr (TERMS == 3) Wl[o * XSB + i] = (__bf16)(w - (float)h);
     }
     __syncthreads();
-    float sc[DT][4], sh[DT][4];
+    f32x4 sc[DT], sh[DT];
     lane_lazy<DT>(p, lj, sc, sh);
     // one tile per wavefront: X in C layout is read and dS written by the SAME lane at the same element, so dS
     // replaces X in place (nothing needs X afterwards - the weight gradient is external)
@@ -946,12 +986,16 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
-    if (pt < p.P) fetch_x<DT>(p, pt, li, lj, idx_cur, raw);
+    Cursor cu;
+    cu.start(pt, p.n);
+    if (pt < p.P) fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
     for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) fetch_x<DT>(p, pt + pstep, li, lj, idx_nxt, raw);
+        if (pt + pstep < p.P) fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
+        cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         float gp[DT];
 #pragma unroll
@@ -969,22 +1013,16 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) {
             const int col = nb * 16 + li;
-            float xc[4];
-            float pool = 0.f;
+            f32x4 xc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xc[r] = Xs[(lj * 4 + r) * XS + col];
-                pool += a[nb][r] * xc[r];
-            }
+            for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + col];
+            float pool = sum4(a[nb] * xc);
             pool += __shfl_xor(pool, 16, 64);
             pool += __shfl_xor(pool, 32, 64);
-            const float g = gp[nb];
+            dx[nb] = a[nb] * splat(gp[nb]);                          // direct path dP*A
+            const f32x4 ds = dx[nb] * (xc - splat(pool));            // dS = A*dP*(X-P)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ag = a[nb][r] * g;
-                dx[nb][r] = ag;                                      // direct path dP*A
-                Ds[(lj * 4 + r) * XS + col] = ag * (xc[r] - pool);   // dS = A*dP*(X-P)
-            }
+            for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + col] = ds[r];
         }
         __builtin_amdgcn_wave_barrier();
         // dS in A layout: out to HBM for the weight gradient, and the A operand of dX += dS.W
@@ -1090,7 +1128,7 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
     __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
     __shared__ double red[4][2][VT<DT>::HP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
     const int li = lane & 15, lj = lane >> 4;
     VWeights<DT, TERMS> vw;
     VCols<DT> vc;
@@ -1100,15 +1138,19 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
     vc.load(p, li);
     bc.load(p, nullptr, li);
     __syncthreads();
-    float sg[DTH], sx[DTH];
+    f32x4 sg[DTH], sx[DTH];
 #pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) sg[nb] = sx[nb] = 0.f;
+    for (int nb = 0; nb < DTH; ++nb) sg[nb] = sx[nb] = splat(0.f);
     const long pstep = (long)gridDim.x * 4;
     long pt = (long)blockIdx.x * 4 + wave;
     RpeIn rin, rin_nxt;
-    if (pt < p.P) fetch_rpe(p, pt, li, p.idx[pt * 16 + li], rin);
+    Cursor cu;
+    cu.start(pt, p.n);
+    if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
     for (; pt < p.P; pt += pstep) {
-        if (pt + pstep < p.P) fetch_rpe(p, pt + pstep, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        const Cursor cn = cu.next(pstep, p.n);
+        if (pt + pstep < p.P) fetch_rpe(p, cn, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        cu = cn;
         float gin[DTH][4];
 #pragma unroll
         for (int nb = 0; nb < DTH; ++nb)
@@ -1120,20 +1162,20 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
         f32x4 raw[DTH];
         rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
 #pragma unroll
-        for (int nb = 0; nb < DTH; ++nb)
+        for (int nb = 0; nb < DTH; ++nb) {
+            const f32x4 z = vbn(raw[nb], bc.scl[nb], bc.sft[nb]);
+            f32x4 g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = raw[nb][r] * bc.scl[nb] + bc.sft[nb];
-                const float g = z > 0.f ? gin[nb][r] : 0.f;
-                sg[nb] += g;
-                sx[nb] += g * ((raw[nb][r] - bc.mu[nb]) * bc.is[nb]);
-            }
+            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? gin[nb][r] : 0.f;
+            sg[nb] += g;
+            sx[nb] = __builtin_elementwise_fma(g, (raw[nb] - splat(bc.mu[nb])) * splat(bc.is[nb]), sx[nb]);
+        }
         __builtin_amdgcn_wave_barrier();
         rin = rin_nxt;
     }
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) {
-        float a = sg[nb], b = sx[nb];
+        float a = sum4(sg[nb]), b = sum4(sx[nb]);
         a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
         b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
         if (lane < 16) {
@@ -1158,7 +1200,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     __shared__ __attribute__((aligned(16))) unsigned char w2t_mem[TERMS == 0 ? HP * XS * 4 : HP * XSB * 2 * 2];   // W2^T image for dY . W2
     // [0]: the stage's input rows [row][k] (rpe rows for stage 1, the activated stage-1 tile for stage 2); [1]: dY [row][n]
     __shared__ __attribute__((aligned(16))) float Tl[2][4][16 * XS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
     const int li = lane & 15, lj = lane >> 4;
     VWeights<DT, TERMS> vw;
     VCols<DT> vc;
@@ -1188,19 +1230,23 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     float* Is = Tl[0][wave];
     float* Ds = Tl[1][wave];
     f32x4 accw[DTH][KB];
-    float bsum[DTH];
+    f32x4 bsum4[DTH];
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) {
-        bsum[nb] = 0.f;
+        bsum4[nb] = splat(0.f);
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const long pstep = (long)gridDim.x * 4;
     long pt = (long)blockIdx.x * 4 + wave;
     RpeIn rin, rin_nxt;
-    if (pt < p.P) fetch_rpe(p, pt, li, p.idx[pt * 16 + li], rin);
+    Cursor cu;
+    cu.start(pt, p.n);
+    if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
     for (; pt < p.P; pt += pstep) {
-        if (pt + pstep < p.P) fetch_rpe(p, pt + pstep, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        const Cursor cn = cu.next(pstep, p.n);
+        if (pt + pstep < p.P) fetch_rpe(p, cn, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        cu = cn;
         float gin[DTH][4];
 #pragma unroll
         for (int nb = 0; nb < DTH; ++nb)
@@ -1217,15 +1263,16 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
 #pragma unroll
         for (int nb = 0; nb < DTH; ++nb) {
             const int col = nb * 16 + li;
+            const f32x4 z = vbn(raw[nb], bc.scl[nb], bc.sft[nb]);
+            f32x4 g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z = raw[nb][r] * bc.scl[nb] + bc.sft[nb];
-                const float g = z > 0.f ? gin[nb][r] : 0.f;
-                const float xh = (raw[nb][r] - bc.mu[nb]) * bc.is[nb];
-                const float dy = col < H ? bc.scl[nb] * (g - bc.k0[nb] - xh * bc.k1[nb]) : 0.f;
-                bsum[nb] += dy;
-                Ds[(4 * lj + r) * XS + col] = dy;
-            }
+            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? gin[nb][r] : 0.f;
+            const f32x4 xh = (raw[nb] - splat(bc.mu[nb])) * splat(bc.is[nb]);
+            // padding columns (col >= H): scale, the coefficients and the incoming gradient are all zero there -> dy = 0
+            const f32x4 dy = splat(bc.scl[nb]) * (g - splat(bc.k0[nb]) - xh * splat(bc.k1[nb]));
+            bsum4[nb] += dy;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ds[(4 * lj + r) * XS + col] = dy[r];
         }
         __builtin_amdgcn_wave_barrier();
         // dW[n][k] += sum_rows dY[row][n] * In[row][k]   (rows are the MFMA reduction index)
@@ -1291,8 +1338,10 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     }
     // combine the four wavefronts in a fixed order; slab layout: dW[n][k] (n < H, k < Kin) then db[n]
     const int Kin = p.src == 1 ? 10 : H;
+    float bsum[DTH];
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) {
+        bsum[nb] = sum4(bsum4[nb]);
         bsum[nb] += __shfl_xor(bsum[nb], 16, 64);
         bsum[nb] += __shfl_xor(bsum[nb], 32, 64);
     }
