@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     __shared__ float Ws[GM_BK * WS];
     __shared__ double red[4][2][BN];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int lr = lane & 15, lq = lane >> 4;
     const int col0 = blockIdx.y * BN;
     const int K = p.a.K, N = p.N;
@@ -265,7 +265,7 @@ struct WgradParams {
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) float dYs[WG_RB * WG_S];
     __shared__ __attribute__((aligned(16))) float As[WG_RB * WG_S];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int lr = lane & 15, lq = lane >> 4;
     const int N = p.N, K = p.a.K;
     const int n0 = blockIdx.y * WG_T, k0 = blockIdx.z * WG_T;
@@ -471,7 +471,7 @@ int fill_a(AOperand* a, const char* who, const float* A, long lda, long a_bstrid
 template <int KC, int NT>
 __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
     __shared__ double red[4][2][16 * NT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int li = lane & 15, lj = lane >> 4;
     const int K = p.a.K, N = p.N;
     const long M = p.a.M;
@@ -592,7 +592,7 @@ constexpr int SW_U = 4;  // row groups (of 4 rows) in flight per wavefront
 template <int KT, int NT>
 __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
     __shared__ float red[KT * NT * 4 * 64 + NT * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int lc = lane & 15, lr = lane >> 4;
     const int N = p.N, K = p.a.K;
     const AOperand& a = p.a;
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
     __bf16* Al = lds_a + GM_BM * BS;       // only touched when TERMS == 3
     __bf16* Wh = lds_w;
     __bf16* Wl = lds_w + BN * BS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int lr = lane & 15, lq = lane >> 4;
     int bx = blockIdx.x, by = 0;
     if (p.ny > 1) {
@@ -1558,7 +1558,7 @@ constexpr int PW_RB = 64;
 __global__ __launch_bounds__(256) void pwgrad_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) float dYs[PW_RB * WG_S];
     __shared__ __attribute__((aligned(16))) float As[PW_RB * WG_S];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int lr = lane & 15, lq = lane >> 4;
     const int N = p.N, K = p.a.K;
     const int n0 = blockIdx.y * WG_T, k0 = blockIdx.z * WG_T;
