@@ -48,6 +48,11 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x4 a, const bf16x4 b, const f3
 // The tile kernels of this file are bound by vector-instruction issue (profiles/r02_pmc_sq_step.md), so their elementwise
 // passes are written on 4-vectors: the compiler turns those into v_pk_{add,mul,fma}_f32 (two floats per lane and
 // instruction) where the scalar loops became four separate instructions.
+// vmcnt counts loads AND stores in issue order, so the wait for a prefetched operand at the top of the next iteration would
+// also wait for every store issued after it (the compiler emits vmcnt(0) there): a full store round trip exposed per
+// point.  Calling this right BEFORE an iteration's stores retires the (long since issued) prefetch loads instead; the
+// stores then drain in the background.
+__device__ __forceinline__ void loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), lgkmcnt/expcnt free
 __device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
 __device__ __forceinline__ f32x4 v4(const float4 a) { return (f32x4){a.x, a.y, a.z, a.w}; }
 __device__ __forceinline__ float4 f4(const f32x4 a) { return make_float4(a[0], a[1], a[2], a[3]); }
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
-    RpeIn rin, rin_nxt;
+    RpeIn rin;      // consumed at the top of an iteration, refilled for the next point right after
     Cursor cu;
     cu.start(pt, p.n);
     if (pt < p.P) {
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) {
             fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
-            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
+            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin);
         }
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
@@ -597,6 +602,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
         else tile_gemm_bf<DT>(xa, Wh, Wl, li, lj, s);
         softmax_rows<DT>(s);
         __builtin_amdgcn_wave_barrier();
+        loads_landed();
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) {
             f32x4 xc;
@@ -608,7 +614,6 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
             if (lj == 0) p.Pout[pt * D + nb * 16 + li] = acc;
         }
         __builtin_amdgcn_wave_barrier();
-        if constexpr (VIRT) rin = rin_nxt;
     }
     if constexpr (VIRT) {
         if (p.fstats2) {
@@ -762,13 +767,23 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
-    RpeIn rin, rin_nxt;
+    RpeIn rin;      // consumed at the top of an iteration, refilled for the next point right after
     Cursor cu;
     cu.start(pt, p.n);
+    // Every load of an iteration belongs to ONE group issued at its top - the next point's rows, coordinates and dP, the
+    // index two points ahead, and this point's GU when accumulating - and the only vector-memory wait is loads_landed()
+    // before the iteration's stores, a whole iteration of arithmetic later (vmcnt is in-order: a wait for a young load in
+    // the middle of the iteration would also wait for the prefetches issued just before it).
+    float gp[DT], gp_nxt[DT];          // dP of the current / next point
+#pragma unroll
+    for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb] = 0.f;
     if (pt < p.P) {
         fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
         if constexpr (VIRT) fetch_rpe(p, cu, li, idx_cur, rin);
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
     }
+    constexpr int NGU = DT == 1 ? 1 : DT / 2;     // column blocks that hold rpe-branch (GU) columns
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
@@ -778,14 +793,21 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         if (pt + pstep < p.P) {
             fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
-            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
+            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin);
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[(pt + pstep) * D + nb * 16 + li];
+        }
+        f32x4 gacc[NGU];                 // GU of this point when this launch adds to it
+#pragma unroll
+        for (int nb = 0; nb < NGU; ++nb) {
+            gacc[nb] = splat(0.f);
+            if (p.gu_accumulate && nb * 16 + li < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[nb][r] = p.GU[(pt * 16 + lj * 4 + r) * H + nb * 16 + li];
+            }
         }
         cu = cn;
-        if constexpr (VIRT) rin = rin_nxt;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
-        float gp[DT];          // dP of this point: requested now, needed after the score GEMM and the softmax
-#pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -855,6 +877,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
             }
         }
         // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row
+        loads_landed();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rowi = lj * 4 + r;
@@ -864,7 +887,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 const int col = nb * 16 + li;
                 float v = dx[nb][r];
                 if (col < H) {
-                    if (p.gu_accumulate) v += p.GU[urow + col];
+                    if (nb < NGU) v += gacc[nb][r];
                     p.GU[urow + col] = v;
                     if constexpr (VIRT) {
                         // this launch completes the gradient of the stage's activated output: the batch-statistics sums
@@ -881,6 +904,8 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 }
             }
         }
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb];
         __builtin_amdgcn_wave_barrier();
     }
     if constexpr (VIRT) {
