@@ -668,13 +668,18 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
     for (int nb = 0; nb < DTH; ++nb) ssum[nb] = ssq[nb] = splat(0.f);
     const long pstep = (long)gridDim.x * 4;
     long pt = (long)blockIdx.x * 4 + wave;
+    // software pipeline as in the pooling kernels: neighbour index two points ahead, coordinates (and G) one point ahead,
+    // every load of an iteration issued in one group at its top
     RpeIn rin, rin_nxt;
     Cursor cu;
     cu.start(pt, p.n);
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
-        if (pt + pstep < p.P) fetch_rpe(p, cn, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        if (pt + pstep < p.P) fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
+        idx_nxt = idx_n2;
         cu = cn;
         f32x4 raw[DTH];
         rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
@@ -1106,6 +1111,21 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// the lane's C-layout elements of G for one point (zero in the padding columns)
+template <int DT>
+__device__ __forceinline__ void load_gin(const float* __restrict__ G, long pt, int li, int lj, f32x4 (&g)[VT<DT>::DTH]) {
+    constexpr int H = VT<DT>::H;
+#pragma unroll
+    for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
+        const int col = nb * 16 + li;
+        g[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (col < H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[nb][r] = G[(pt * 16 + 4 * lj + r) * H + col];
+        }
+    }
+}
+
 // Backward of a virtual rpe stage (mlp_rpe1 / mlp_rpe2 + BatchNorm + ReLU whose output was never stored).  G holds the
 // gradient w.r.t. the ACTIVATED stage output ((points*16) x H, written by the pooling backward kernels); the raw tile
 // is recomputed per point.  With g = G*[act > 0] and xhat = (raw - mean)*invstd:
@@ -1168,22 +1188,28 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
     for (int nb = 0; nb < DTH; ++nb) sg[nb] = sx[nb] = splat(0.f);
     const long pstep = (long)gridDim.x * 4;
     long pt = (long)blockIdx.x * 4 + wave;
+    // software pipeline as in the pooling kernels: neighbour index two points ahead, coordinates (and G) one point ahead,
+    // every load of an iteration issued in one group at its top
     RpeIn rin, rin_nxt;
     Cursor cu;
     cu.start(pt, p.n);
-    if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    f32x4 gin[DTH], gin_nxt[DTH];
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb] = splat(0.f);
+    if (pt < p.P) {
+        fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
+        load_gin<DT>(q.G, pt, li, lj, gin);
+    }
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
-        if (pt + pstep < p.P) fetch_rpe(p, cn, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        if (pt + pstep < p.P) {
+            fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
+            load_gin<DT>(q.G, pt + pstep, li, lj, gin_nxt);
+        }
+        idx_nxt = idx_n2;
         cu = cn;
-        float gin[DTH][4];
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = nb * 16 + li;
-                gin[nb][r] = col < H ? q.G[(pt * 16 + 4 * lj + r) * H + col] : 0.f;
-            }
         f32x4 raw[DTH];
         rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
 #pragma unroll
@@ -1197,6 +1223,8 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
         }
         __builtin_amdgcn_wave_barrier();
         rin = rin_nxt;
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb];
     }
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) {
@@ -1264,22 +1292,28 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     }
     const long pstep = (long)gridDim.x * 4;
     long pt = (long)blockIdx.x * 4 + wave;
+    // software pipeline as in the pooling kernels: neighbour index two points ahead, coordinates (and G) one point ahead,
+    // every load of an iteration issued in one group at its top
     RpeIn rin, rin_nxt;
     Cursor cu;
     cu.start(pt, p.n);
-    if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    f32x4 gin[DTH], gin_nxt[DTH];
+#pragma unroll
+    for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb] = splat(0.f);
+    if (pt < p.P) {
+        fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
+        load_gin<DT>(q.G, pt, li, lj, gin);
+    }
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
-        if (pt + pstep < p.P) fetch_rpe(p, cn, li, p.idx[(pt + pstep) * 16 + li], rin_nxt);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        if (pt + pstep < p.P) {
+            fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
+            load_gin<DT>(q.G, pt + pstep, li, lj, gin_nxt);
+        }
+        idx_nxt = idx_n2;
         cu = cn;
-        float gin[DTH][4];
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = nb * 16 + li;
-                gin[nb][r] = col < H ? q.G[(pt * 16 + 4 * lj + r) * H + col] : 0.f;
-            }
         f32x4 raw[DTH];
         // stage 2 leaves the activated stage-1 tile in Is (its scratch); stage 1's input is the rpe tile itself
         rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Is, XS, raw, nullptr);
@@ -1349,6 +1383,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
             for (int nb = 0; nb < DTH; ++nb) gu[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if constexpr (TERMS == 0) tile_gemm<DTH>(da, w2tf, li, lj, gu);
             else tile_gemm_bf<DTH>(da, w2th, w2tl, li, lj, gu);
+            loads_landed();
 #pragma unroll
             for (int nb = 0; nb < DTH; ++nb) {
                 const int col = nb * 16 + li;
@@ -1360,6 +1395,8 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
         }
         __builtin_amdgcn_wave_barrier();
         rin = rin_nxt;
+#pragma unroll
+        for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb];
     }
     // combine the four wavefronts in a fixed order; slab layout: dW[n][k] (n < H, k < Kin) then db[n]
     const int Kin = p.src == 1 ? 10 : H;
