@@ -537,6 +537,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, wf[c][s][nb], acc[nb], 0, 0, 0);
             }
         }
+        // the next block's rows (requested above) are waited for HERE, before this block's stores: vmcnt is in-order, so the
+        // wait the compiler would place at the top of the next iteration would also sit out these stores' round trip
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long R = blk * 16 + lj * 4 + r;

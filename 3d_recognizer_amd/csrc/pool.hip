@@ -1018,18 +1018,26 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     float4 raw[DT];
     Cursor cu;
     cu.start(pt, p.n);
-    if (pt < p.P) fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
+    float gp[DT], gp_nxt[DT];      // dP of the current / next point (one load group per iteration, as in pool_bwd_kernel)
+#pragma unroll
+    for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb] = 0.f;
+    if (pt < p.P) {
+        fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
+    }
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
+        if (pt + pstep < p.P) {
+            fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[(pt + pstep) * D + nb * 16 + li];
+        }
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
-        float gp[DT];
-#pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
         // X leaves the kernel for the weight-gradient GEMM: row li, 16 bytes per 16-column chunk
 #pragma unroll
         for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(p.X_out + (pt * 16 + li) * D + 16 * c + 4 * lj) = xa[c];
@@ -1090,6 +1098,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
             }
         }
         // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row
+        loads_landed();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rowi = lj * 4 + r;
@@ -1106,6 +1115,8 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                 }
             }
         }
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb];
         __builtin_amdgcn_wave_barrier();
     }
 }
