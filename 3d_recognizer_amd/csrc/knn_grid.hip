@@ -237,15 +237,26 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const KMulti m) {
 // ~8 points per cell one cell costs one memory round trip instead of eight (at small clouds there
 // is a single wavefront per SIMD and nothing else hides that latency).
 // sorted insertion of one key (ascending (d2, index) order; a key that is not smaller than the last entry falls out)
+// A key is (float bits of d2) << 32 | index.  d2 >= 0 is finite, so the high word is below 0x7f800000 and the 64 bits,
+// read as an IEEE double, are a non-negative finite number (or a denormal / zero) whose floating-point order IS the
+// unsigned integer order of the keys.  One step of the network is then v_min_f64 + v_max_f64 (full rate, two
+// instructions) instead of a 64-bit compare and four selects - the network is most of this kernel's instruction stream.
+// Empty slots hold +infinity as a double (above every key in both orders; the all-ones pattern would be a NaN, which
+// min / max drop).  Inline asm: the builtins canonicalise their inputs first (a third instruction per step); these
+// inputs are never NaNs and fp64 denormals are always preserved on this target, so the raw instructions return one
+// of their operands bit for bit.
+constexpr unsigned long long KEY_EMPTY = 0x7FF0000000000000ull;
 template <int KMAX>
 __device__ __forceinline__ void insert_key(unsigned long long key, unsigned long long (&best)[KMAX]) {
+    double kd = __builtin_bit_cast(double, key);
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
-        const bool lt = key < best[s];
-        const unsigned long long lo = lt ? key : best[s];
-        const unsigned long long hi = lt ? best[s] : key;
-        best[s] = lo;
-        key = hi;
+        const double bs = __builtin_bit_cast(double, best[s]);
+        double lo, hi;
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(kd), "v"(bs));
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(kd), "v"(bs));
+        best[s] = __builtin_bit_cast(unsigned long long, lo);
+        kd = hi;
     }
 }
 
@@ -332,7 +343,7 @@ __device__ __forceinline__ void query_one_lane(const KTask& T, int b) {
     cell_coords(g, qx, qy, qz, c);
     unsigned long long best[KMAX];
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
+    for (int s = 0; s < KMAX; ++s) best[s] = KEY_EMPTY;
 
     const float q3[3] = {qx, qy, qz};
     for (int r = 0;; ++r) {
@@ -355,7 +366,7 @@ __device__ __forceinline__ void query_one_lane(const KTask& T, int b) {
                         if (s == k - 1) kth = best[s];
                 }
                 // strict test with a rounding margin: ties must be looked at
-                const bool have = kth != ~0ull;
+                const bool have = kth != KEY_EMPTY;
                 const float lim = have ? __uint_as_float((unsigned)(kth >> 32)) * 1.00001f + 1e-30f : INFINITY;
                 if (dyz > lim) continue;            // nothing in this row of cells can be closer than the K-th
                 if (full_row) {
@@ -392,7 +403,7 @@ __device__ __forceinline__ void query_one_lane(const KTask& T, int b) {
 #pragma unroll
         for (int s = 0; s < KMAX; ++s)
             if (s == k - 1) kth = best[s];
-        if (kth != ~0ull) {
+        if (kth != KEY_EMPTY) {
             float bound = INFINITY;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -408,10 +419,11 @@ __device__ __forceinline__ void query_one_lane(const KTask& T, int b) {
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
         if (s < k) {
-            const unsigned id = (unsigned)(best[s] & 0xffffffffull);
+            const bool empty = best[s] == KEY_EMPTY;        // fewer than k support points: index -1, distance NaN
+            const unsigned id = empty ? 0xffffffffu : (unsigned)(best[s] & 0xffffffffull);
             if (idx32) idx32[o + s] = (int32_t)id;
             if (idx64) idx64[o + s] = (int64_t)id;
-            d2out[o + s] = __uint_as_float((unsigned)(best[s] >> 32));
+            d2out[o + s] = __uint_as_float(empty ? 0xffffffffu : (unsigned)(best[s] >> 32));
         }
     }
 }
@@ -490,7 +502,7 @@ __device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned lo
     const bool active = t < Nq;                // same for the four lanes of a query; every lane reaches the barrier
     unsigned long long best[KMAX];
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
+    for (int s = 0; s < KMAX; ++s) best[s] = KEY_EMPTY;
     int qi = 0;
     if (active) {
         const GridGeom g = T.geom[b];
@@ -522,7 +534,7 @@ __device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned lo
                     const float dyz = dy * dy + dz * dz;
                     const int row = (z * g.n[1] + y) * g.n[0];
                     const unsigned long long kth = group_bound<KMAX, LANES>(best, k);
-                    const float lim = kth != ~0ull ? __uint_as_float((unsigned)(kth >> 32)) * 1.00001f + 1e-30f : INFINITY;
+                    const float lim = kth != KEY_EMPTY ? __uint_as_float((unsigned)(kth >> 32)) * 1.00001f + 1e-30f : INFINITY;
                     if (dyz > lim) continue;
                     if (full_row) {
                         int xa = x0, xb = x1;
@@ -551,7 +563,7 @@ __device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned lo
                                 (c[2] - r <= 0) && (c[2] + r >= g.n[2] - 1);
             if (covers) break;
             const unsigned long long kth = group_bound<KMAX, LANES>(best, k);
-            if (kth != ~0ull) {
+            if (kth != KEY_EMPTY) {
                 float bound = INFINITY;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -573,7 +585,7 @@ __device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned lo
 #pragma unroll
         for (int s = 0; s < KMAX; ++s) {
             const unsigned long long key = best[s];
-            if (key == ~0ull) continue;
+            if (key == KEY_EMPTY) continue;
             int rank = s;
 #pragma unroll
             for (int j = 1; j < LANES; ++j) {
