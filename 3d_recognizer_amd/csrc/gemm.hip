@@ -1204,11 +1204,10 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
     const __bf16* wsrc = p.wsplit + (wplane ? (long)N * K : 0);
     const bool w_active = wplane < NSPL;
 
-    float ssum[STATS ? NT : 1], ssq[STATS ? NT : 1];
-    if constexpr (STATS) {
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
-    }
+    // BatchNorm partial statistics: a tile's column sums exist only during its epilogue (16 registers that would
+    // otherwise be alive through the K loop and push the kernel over its 128-VGPR budget into scratch); the workgroup's
+    // running totals are two doubles in the first 128 lanes.
+    double tot_s = 0.0, tot_q = 0.0;
 
     for (long tile = bx; tile < ntiles; tile += p.gx) {
         const long row0 = tile * GM_BM;
@@ -1330,6 +1329,11 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
             }
             continue;
         }
+        float ssum[STATS ? NT : 1], ssq[STATS ? NT : 1];
+        if constexpr (STATS) {
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long R = row0 + wave * 16 + lq * 4 + r;
@@ -1372,30 +1376,34 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
                 }
             }
         }
+        if constexpr (STATS) if (p.stats && p.ksplit <= 1) {
+            __syncthreads();                                        // the operand tiles are free: reuse them for the reduction
+            double* red = reinterpret_cast<double*>(lds_a);         // [8][2][128] doubles = 16 KB <= 20 KB (10 KB in bf16 mode: use both)
+            static_assert(sizeof(lds_a) + sizeof(lds_w) >= 8 * 2 * BN * sizeof(double), "statistics scratch");
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                float sv = ssum[nb], qv = ssq[nb];
+                sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+                qv += __shfl_xor(qv, 16, 64); qv += __shfl_xor(qv, 32, 64);
+                if (lane < 16) {
+                    red[(wave * 2 + 0) * BN + nb * 16 + lane] = (double)sv;
+                    red[(wave * 2 + 1) * BN + nb * 16 + lane] = (double)qv;
+                }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                for (int w = 0; w < 8; ++w) {
+                    tot_s += red[(w * 2 + 0) * BN + tid];
+                    tot_q += red[(w * 2 + 1) * BN + tid];
+                }
+            }
+            // (the next tile's first staging write is behind the barrier at the top of its K loop)
+        }
     }
     if constexpr (STATS) if (p.stats && p.ksplit <= 1) {
-        __syncthreads();                                        // the operand tiles are free: reuse them for the reduction
-        double* red = reinterpret_cast<double*>(lds_a);         // [8][2][128] doubles = 16 KB <= 20 KB (10 KB in bf16 mode: use both)
-        static_assert(sizeof(lds_a) + sizeof(lds_w) >= 8 * 2 * BN * sizeof(double), "statistics scratch");
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-            float s = ssum[nb], q = ssq[nb];
-            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-            if (lane < 16) {
-                red[(wave * 2 + 0) * BN + nb * 16 + lane] = (double)s;
-                red[(wave * 2 + 1) * BN + nb * 16 + lane] = (double)q;
-            }
-        }
-        __syncthreads();
         if (tid < BN && col0 + tid < N) {
-            double s = 0.0, q = 0.0;
-            for (int w = 0; w < 8; ++w) {
-                s += red[(w * 2 + 0) * BN + tid];
-                q += red[(w * 2 + 1) * BN + tid];
-            }
-            p.stats[((long)bx * 2 + 0) * N + col0 + tid] = s;
-            p.stats[((long)bx * 2 + 1) * N + col0 + tid] = q;
+            p.stats[((long)bx * 2 + 0) * N + col0 + tid] = tot_s;
+            p.stats[((long)bx * 2 + 1) * N + col0 + tid] = tot_q;
             for (long slot = bx + p.gx; slot < p.stat_slots; slot += p.gx) {
                 p.stats[(slot * 2 + 0) * N + col0 + tid] = 0.0;
                 p.stats[(slot * 2 + 1) * N + col0 + tid] = 0.0;
