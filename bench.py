@@ -19,6 +19,8 @@ silent one-GPU run.
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   config_A     - the same step at BASELINE.json config A / B (4 clouds per GPU, weak scaling)
   strong_bs8   - (N > 1) the metric's global batch of 8 split over the N ranks
+  bf16_operands- the metric's configuration with plain bf16 operands in the wide kernels (BASELINE config A says "bf16");
+                 storage stays fp32 and its logits leave the 1e-3 parity bound, so it is never `value`
   roofline     - the kernel with the largest share of the step (measured with HIP events around
                  every launch of an instrumented eager pass on the launch stream): algorithmic
                  bytes per launch / mean launch duration vs the 8 TB/s HBM peak.
@@ -307,7 +309,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary eval-forward measurement")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the config_A / strong_bs8 objects")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config_A / strong_bs8 / bf16_operands objects")
     ap.add_argument("--batch", type=int, default=CFG["per_gpu_batch"], help="clouds per GPU (the metric's bs=8)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box)")
@@ -377,6 +379,17 @@ def main():
             config_a = secondary(4, "weak", "BASELINE.json config A (1 GPU) / B (8 GPUs): 4 clouds per GPU")
         if world > 1 and 8 % world == 0 and 8 // world != B:
             strong = secondary(8 // world, "strong", "the metric's global batch of 8 clouds split over the ranks")
+    # BASELINE config A names "bf16": the same step with plain bf16 operands in the wide GEMMs / weight gradients
+    # (rl_set_wide_gemm("bf16"); storage and accumulation stay fp32).  Outside the 1e-3 logit bound (0.7e-3 ... 1.1e-3,
+    # DESIGN.md section 5), so it is reported beside the parity mode, never as `value`.
+    bf16_ops = None
+    if not args.no_secondary and WIDE_GEMM == "bf16x3":
+        _o.set_wide_gemm("bf16")
+        try:
+            bf16_ops = secondary(B, "weak", "the metric's configuration with bf16 (1-term) operands in the wide kernels, fp32 storage")
+            bf16_ops["dtype"] = "f32 storage/accumulate, bf16 MFMA operands in the wide GEMMs (not the parity mode)"
+        finally:
+            _o.set_wide_gemm("bf16x3")
 
     # secondary line: eval-mode forward clouds/s with the weights as trained so far, same batch shape
     infer = None
@@ -434,6 +447,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "config_A": config_a,
+            "bf16_operands": bf16_ops,
             "strong_bs8": strong,
             "inference": infer,
         }
