@@ -539,7 +539,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
         }
         // the next block's rows (requested above) are waited for HERE, before this block's stores: vmcnt is in-order, so the
         // wait the compiler would place at the top of the next iteration would also sit out these stores' round trip
+        asm volatile("" ::: "memory");          // (pins the loads above / stores below at the IR level; see pool.hip loads_landed)
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long R = blk * 16 + lj * 4 + r;

@@ -52,7 +52,17 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x4 a, const bf16x4 b, const f3
 // also wait for every store issued after it (the compiler emits vmcnt(0) there): a full store round trip exposed per
 // point.  Calling this right BEFORE an iteration's stores retires the (long since issued) prefetch loads instead; the
 // stores then drain in the background.
-__device__ __forceinline__ void loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), lgkmcnt/expcnt free
+// The builtin (not inline asm: the waitcnt-insertion pass must SEE the wait, or it adds its own vmcnt(0) at the next use)
+// between two empty asm statements with memory clobbers: to the optimiser the builtin alone touches no memory, so a
+// prefetch could be sunk below it - one build did exactly that and the d = 16 kernels lost 18 %.
+// After an iteration's load group: nothing may be scheduled across this point.  The prefetched values have no consumer
+// inside the iteration, so the scheduler otherwise sinks the loads down to the wait (shortest live ranges).
+__device__ __forceinline__ void loads_issued() { __builtin_amdgcn_sched_barrier(0); }
+__device__ __forceinline__ void loads_landed() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0); lgkmcnt / expcnt unconstrained
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
 __device__ __forceinline__ f32x4 v4(const float4 a) { return (f32x4){a.x, a.y, a.z, a.w}; }
 __device__ __forceinline__ float4 f4(const f32x4 a) { return make_float4(a[0], a[1], a[2], a[3]); }
@@ -319,29 +329,67 @@ struct VWeights {
     }
 };
 
-// per-lane constants of the C-layout epilogues: column nb*16 + li of each stage
+// per-lane constants of the C-layout epilogues: column nb*16 + li of each stage.  d >= 64 (two column blocks): the twelve
+// values live in LDS and are read where they are used - the 64-channel backward kernel has no registers to spare (it ran
+// 33 dwords into scratch with them).  `lds` = NCONST * HP floats of the kernel's LDS; the caller's barrier after the
+// staging makes them visible.
 template <int DT>
 struct VCols {
-    static constexpr int DTH = VT<DT>::DTH;
-    float b1[DTH], s1[DTH], h1[DTH], b2[DTH], s2[DTH], h2[DTH];
-    __device__ __forceinline__ void load(const PoolParams& p, int li) {
+    static constexpr int DTH = VT<DT>::DTH, HP = VT<DT>::HP;
+    static constexpr bool INLDS = DT >= 4;
+    static constexpr int NCONST = 10;            // b1 s1 h1 b2 s2 h2 + the four BatchNorm-backward constants of pool_bwd
+    float rb1[INLDS ? 1 : DTH], rs1[INLDS ? 1 : DTH], rh1[INLDS ? 1 : DTH], rb2[INLDS ? 1 : DTH], rs2[INLDS ? 1 : DTH], rh2[INLDS ? 1 : DTH];
+    const float* lc;                               // lds + li
+    __device__ __forceinline__ void load(const PoolParams& p, int li, float* lds) {
+        lc = lds + li;
+        if constexpr (INLDS) {
+            for (int c = threadIdx.x; c < HP; c += blockDim.x) {
+                const bool in = c < VT<DT>::H;
+                lds[0 * HP + c] = in ? p.b1[c] : 0.f;
+                lds[1 * HP + c] = (in && p.sc1) ? p.sc1[c] : 0.f;
+                lds[2 * HP + c] = (in && p.sh1) ? p.sh1[c] : 0.f;
+                lds[3 * HP + c] = (in && (p.src >= 2 || p.fstats2)) ? p.b2[c] : 0.f;
+                lds[4 * HP + c] = (in && p.src >= 2 && p.sc2) ? p.sc2[c] : 0.f;
+                lds[5 * HP + c] = (in && p.src >= 2 && p.sh2) ? p.sh2[c] : 0.f;
+            }
+        } else {
 #pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) {
-            const int c = nb * 16 + li;
-            const bool in = c < VT<DT>::H;
-            b1[nb] = in ? p.b1[c] : 0.f;
-            s1[nb] = (in && p.sc1) ? p.sc1[c] : 0.f;
-            h1[nb] = (in && p.sh1) ? p.sh1[c] : 0.f;
-            b2[nb] = (in && (p.src >= 2 || p.fstats2)) ? p.b2[c] : 0.f;
-            s2[nb] = (in && p.src >= 2 && p.sc2) ? p.sc2[c] : 0.f;
-            h2[nb] = (in && p.src >= 2 && p.sh2) ? p.sh2[c] : 0.f;
+            for (int nb = 0; nb < DTH; ++nb) {
+                const int c = nb * 16 + li;
+                const bool in = c < VT<DT>::H;
+                rb1[nb] = in ? p.b1[c] : 0.f;
+                rs1[nb] = (in && p.sc1) ? p.sc1[c] : 0.f;
+                rh1[nb] = (in && p.sh1) ? p.sh1[c] : 0.f;
+                rb2[nb] = (in && (p.src >= 2 || p.fstats2)) ? p.b2[c] : 0.f;
+                rs2[nb] = (in && p.src >= 2 && p.sc2) ? p.sc2[c] : 0.f;
+                rh2[nb] = (in && p.src >= 2 && p.sh2) ? p.sh2[c] : 0.f;
+            }
         }
     }
+    __device__ __forceinline__ float cst(int which, int nb, const float (&r)[INLDS ? 1 : DTH]) const {
+        if constexpr (INLDS) return lc[which * HP + nb * 16];
+        else return r[nb];
+    }
+    __device__ __forceinline__ float b1(int nb) const { return cst(0, nb, rb1); }
+    __device__ __forceinline__ float s1(int nb) const { return cst(1, nb, rs1); }
+    __device__ __forceinline__ float h1(int nb) const { return cst(2, nb, rh1); }
+    __device__ __forceinline__ float b2(int nb) const { return cst(3, nb, rb2); }
+    __device__ __forceinline__ float s2(int nb) const { return cst(4, nb, rs2); }
+    __device__ __forceinline__ float h2(int nb) const { return cst(5, nb, rh2); }
 };
 
 // what a lane needs of one point to build the relative position encoding of its neighbour slot li
+// (the two coordinate loads stay whole 4-vectors: a loop-carried value that is the load's own register tuple needs no
+// copy - with separate floats the compiler copied them out right behind the load, i.e. waited for it on the spot)
 struct RpeIn {
-    float xi[3], xj[3], dd;
+    float4 a, c;      // the point, its neighbour (w unused; three-float coordinates are widened on load)
+    float dd;
+    // Called right after loads_landed() by the kernels that refill `rin` in place: the loop-carried copies of the
+    // loaded registers are made HERE (an empty asm "redefines" every field), not right behind the loads - where the
+    // compiler otherwise puts them, with a wait for the loads it has just issued.
+    __device__ __forceinline__ void pin() {
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(dd));
+    }
 };
 __device__ __forceinline__ void fetch_rpe(const PoolParams& p, const Cursor& cu, int li, int nbr, RpeIn& r) {
     const long pt = cu.pt, b = cu.b, i = cu.i;
@@ -349,26 +397,25 @@ __device__ __forceinline__ void fetch_rpe(const PoolParams& p, const Cursor& cu,
         // padded coordinates: one 16-byte gather per point instead of three 4-byte ones (the texture path pays per
         // distinct line and per instruction)
         const float4* xb = reinterpret_cast<const float4*>(p.xyz) + b * p.xyz_bstride;
-        const float4 a = xb[i], c = xb[nbr];
-        r.xi[0] = a.x; r.xi[1] = a.y; r.xi[2] = a.z;
-        r.xj[0] = c.x; r.xj[1] = c.y; r.xj[2] = c.z;
+        r.a = xb[i];
+        r.c = xb[nbr];
     } else {
         const float* xb = p.xyz + b * p.xyz_bstride * 3;
-        r.xi[0] = xb[i * 3 + 0]; r.xi[1] = xb[i * 3 + 1]; r.xi[2] = xb[i * 3 + 2];
-        r.xj[0] = xb[(long)nbr * 3 + 0]; r.xj[1] = xb[(long)nbr * 3 + 1]; r.xj[2] = xb[(long)nbr * 3 + 2];
+        r.a = make_float4(xb[i * 3 + 0], xb[i * 3 + 1], xb[i * 3 + 2], 0.f);
+        r.c = make_float4(xb[(long)nbr * 3 + 0], xb[(long)nbr * 3 + 1], xb[(long)nbr * 3 + 2], 0.f);
     }
     r.dd = p.nbr_d2[pt * 16 + li];
 }
 // channels [x_i, x_nbr, x_i - x_nbr, dist, 0...] (modules.py:173-186): this lane's float4 = channels 4*lj .. 4*lj+3
 __device__ __forceinline__ float4 rpe_frag(const RpeIn& r, int lj) {
     // every lane computes all ten channels and selects its four (lane-constant masks): no divergent branches in the loops
-    const float dx = r.xi[0] - r.xj[0], dy = r.xi[1] - r.xj[1], dz = r.xi[2] - r.xj[2], dist = __fsqrt_rn(r.dd);
+    const float dx = r.a.x - r.c.x, dy = r.a.y - r.c.y, dz = r.a.z - r.c.z, dist = __fsqrt_rn(r.dd);
     const bool l0 = lj == 0, l1 = lj == 1, l2 = lj == 2;
     float4 o;
-    o.x = l0 ? r.xi[0] : l1 ? r.xj[1] : l2 ? dz : 0.f;
-    o.y = l0 ? r.xi[1] : l1 ? r.xj[2] : l2 ? dist : 0.f;
-    o.z = l0 ? r.xi[2] : l1 ? dx : 0.f;
-    o.w = l0 ? r.xj[0] : l1 ? dy : 0.f;
+    o.x = l0 ? r.a.x : l1 ? r.c.y : l2 ? dz : 0.f;
+    o.y = l0 ? r.a.y : l1 ? r.c.z : l2 ? dist : 0.f;
+    o.z = l0 ? r.a.z : l1 ? dx : 0.f;
+    o.w = l0 ? r.c.x : l1 ? dy : 0.f;
     return o;
 }
 
@@ -396,13 +443,13 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH;
     rpe_gemm<DT, TERMS>(rpe_frag(in, lj), w, li, lj, raw);
 #pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b1[nb]);
+    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b1(nb));
     if (stage == 1) {
         if (Xs) {
 #pragma unroll
             for (int nb = 0; nb < DTH; ++nb) {
                 const int col = nb * 16 + li;
-                const f32x4 u = vrelu(vbn(raw[nb], vc.s1[nb], vc.h1[nb]));
+                const f32x4 u = vrelu(vbn(raw[nb], vc.s1(nb), vc.h1(nb)));
                 if (col < H) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = u[r];
@@ -415,7 +462,7 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) {
         const int col = nb * 16 + li;
-        const f32x4 u = vrelu(vbn(raw[nb], vc.s1[nb], vc.h1[nb]));
+        const f32x4 u = vrelu(vbn(raw[nb], vc.s1(nb), vc.h1(nb)));
         if (col < H) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) scratch[(4 * lj + r) * XS + col] = u[r];
@@ -434,12 +481,12 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
     if constexpr (TERMS == 0) tile_gemm<DTH>(a1, w.w2f, li, lj, raw);
     else tile_gemm_bf<DTH>(a1, w.w2h, w.w2l, li, lj, raw);
 #pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b2[nb]);
+    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b2(nb));
     if (Xs) {
 #pragma unroll
         for (int nb = 0; nb < DTH; ++nb) {
             const int col = nb * 16 + li;
-            const f32x4 u = vrelu(vbn(raw[nb], vc.s2[nb], vc.h2[nb]));
+            const f32x4 u = vrelu(vbn(raw[nb], vc.s2(nb), vc.h2(nb)));
             if (col < H) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = u[r];
@@ -519,6 +566,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char wmem[TERMS == 0 ? D * XS * 4 : 2 * D * XSB * 2];
     __shared__ __attribute__((aligned(16))) float Xt[NW][16 * XS];
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
+    __shared__ float vcl[(VIRT && VCols<DT>::INLDS) ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
     float* Wt = reinterpret_cast<float*>(wmem);
     __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
     __bf16* Wl = Wh + D * XSB;
@@ -541,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     if constexpr (VIRT) {
         vw.bind(vmem);
         vw.stage(p, 64 * NW);
-        vc.load(p, li);
+        vc.load(p, li, vcl);
 #pragma unroll
         for (int nb = 0; nb < VT<DT>::DTH; ++nb) fs2[nb] = fq2[nb] = splat(0.f);
     }
@@ -562,6 +610,8 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
         fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
         if constexpr (VIRT) fetch_rpe(p, cu, li, idx_cur, rin);
     }
+    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
+                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
@@ -582,17 +632,19 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
                 else tile_gemm_bf<DTH>(a1, vw.w2h, vw.w2l, li, lj, r2);
 #pragma unroll
                 for (int nb = 0; nb < DTH; ++nb) {
-                    const f32x4 v = r2[nb] + splat(vc.b2[nb]);
+                    const f32x4 v = r2[nb] + splat(vc.b2(nb));
                     fs2[nb] += v;
                     fq2[nb] = __builtin_elementwise_fma(v, v, fq2[nb]);
                 }
             }
         } else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) {
-            fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
-            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin);
-        }
+        // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
+        // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
+        const Cursor cf = pt + pstep < p.P ? cn : cu;
+        fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
+        if constexpr (VIRT) fetch_rpe(p, cf, li, pt + pstep < p.P ? idx_nxt : idx_cur, rin);
+        loads_issued();
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         f32x4 s[DT];
@@ -653,6 +705,7 @@ template <int DT, int TERMS>
 __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, double* __restrict__ stats) {
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, XS = Tile<VT<DT>::DTH>::XS;
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
+    __shared__ float vcl[VCols<DT>::INLDS ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
     __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
     __shared__ double red[4][2][VT<DT>::HP];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
@@ -661,7 +714,7 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
     VCols<DT> vc;
     vw.bind(vmem);
     vw.stage(p, 256);
-    vc.load(p, li);
+    vc.load(p, li, vcl);
     __syncthreads();
     f32x4 ssum[DTH], ssq[DTH];
 #pragma unroll
@@ -675,10 +728,13 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
     cu.start(pt, p.n);
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
+    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
+                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
+        fetch_rpe(p, pt + pstep < p.P ? cn : cu, li, idx_nxt, rin_nxt);      // (no branch: see pool_fwd_kernel)
+        loads_issued();
         idx_nxt = idx_n2;
         cu = cn;
         f32x4 raw[DTH];
@@ -713,6 +769,7 @@ template <int DT, int TERMS, bool VIRT = false, int NW = 4>   // NW wavefronts s
 __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
+    __shared__ float vcl[(VIRT && VCols<DT>::INLDS) ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
     // LDS: W^T, W, and per wavefront an X tile and a dS tile; after the main loop the W region is
     // reused to combine the four wavefronts' dW tiles
     __shared__ __attribute__((aligned(16))) float Wmem[TERMS == 0 ? 2 * D * XS : 2 * D * XSB];   // bf16: 4 arrays of D*XSB
@@ -739,22 +796,40 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     VWeights<DT, TERMS> vw;
     VCols<DT> vc;
     constexpr int BDTH = VIRT ? VT<DT>::DTH : 1;
-    float bsg[BDTH], bsx[BDTH], bstat_sc[BDTH], bstat_sh[BDTH], bstat_mu[BDTH], bstat_is[BDTH];
+    constexpr bool CL = VIRT && VCols<DT>::INLDS;       // BatchNorm-backward constants in LDS beside vc's (rows 6..9)
+    constexpr int BREG = CL ? 1 : BDTH;
+    float bsg[BDTH], bsx[BDTH], bstat_sc[BREG], bstat_sh[BREG], bstat_mu[BREG], bstat_is[BREG];
     if constexpr (VIRT) {
         vw.bind(vmem);
         vw.stage(p, 64 * NW);
-        vc.load(p, li);
+        vc.load(p, li, vcl);
 #pragma unroll
-        for (int nb = 0; nb < BDTH; ++nb) {
-            const int c = nb * 16 + li;
-            const bool in = c < H && p.bstats != nullptr;
-            bsg[nb] = bsx[nb] = 0.f;
-            bstat_sc[nb] = in ? (p.src == 1 ? p.sc1[c] : p.sc2[c]) : 0.f;
-            bstat_sh[nb] = in ? (p.src == 1 ? p.sh1[c] : p.sh2[c]) : 0.f;
-            bstat_mu[nb] = in ? (p.src == 1 ? p.mu1[c] : p.mu2[c]) : 0.f;
-            bstat_is[nb] = in ? (p.src == 1 ? p.is1[c] : p.is2[c]) : 0.f;
+        for (int nb = 0; nb < BDTH; ++nb) bsg[nb] = bsx[nb] = 0.f;
+        if constexpr (CL) {
+            constexpr int HP = VCols<DT>::HP;
+            for (int c = threadIdx.x; c < HP; c += 64 * NW) {
+                const bool in = c < H && p.bstats != nullptr;
+                vcl[6 * HP + c] = in ? (p.src == 1 ? p.sc1[c] : p.sc2[c]) : 0.f;
+                vcl[7 * HP + c] = in ? (p.src == 1 ? p.sh1[c] : p.sh2[c]) : 0.f;
+                vcl[8 * HP + c] = in ? (p.src == 1 ? p.mu1[c] : p.mu2[c]) : 0.f;
+                vcl[9 * HP + c] = in ? (p.src == 1 ? p.is1[c] : p.is2[c]) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < BDTH; ++nb) {
+                const int c = nb * 16 + li;
+                const bool in = c < H && p.bstats != nullptr;
+                bstat_sc[nb] = in ? (p.src == 1 ? p.sc1[c] : p.sc2[c]) : 0.f;
+                bstat_sh[nb] = in ? (p.src == 1 ? p.sh1[c] : p.sh2[c]) : 0.f;
+                bstat_mu[nb] = in ? (p.src == 1 ? p.mu1[c] : p.mu2[c]) : 0.f;
+                bstat_is[nb] = in ? (p.src == 1 ? p.is1[c] : p.is2[c]) : 0.f;
+            }
         }
     }
+    auto bcst = [&](int which, int nb, const float (&r)[BREG]) -> float {
+        if constexpr (CL) return vcl[(6 + which) * VCols<DT>::HP + nb * 16 + li];
+        else return r[nb];
+    };
     __syncthreads();
     f32x4 sc[DT], sh[DT];
     lane_lazy<DT>(p, lj, sc, sh);
@@ -789,6 +864,8 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
     }
     constexpr int NGU = DT == 1 ? 1 : DT / 2;     // column blocks that hold rpe-branch (GU) columns
+    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
+                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
@@ -796,12 +873,13 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs, rawu);
         else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) {
-            fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
-            if constexpr (VIRT) fetch_rpe(p, cn, li, idx_nxt, rin);
+        // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
+        // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
+        const Cursor cf = pt + pstep < p.P ? cn : cu;
+        fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
+        if constexpr (VIRT) fetch_rpe(p, cf, li, pt + pstep < p.P ? idx_nxt : idx_cur, rin);
 #pragma unroll
-            for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[(pt + pstep) * D + nb * 16 + li];
-        }
+        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
         f32x4 gacc[NGU];                 // GU of this point when this launch adds to it
 #pragma unroll
         for (int nb = 0; nb < NGU; ++nb) {
@@ -811,6 +889,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 for (int r = 0; r < 4; ++r) gacc[nb][r] = p.GU[(pt * 16 + lj * 4 + r) * H + nb * 16 + li];
             }
         }
+        loads_issued();
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         f32x4 a[DT];
@@ -898,10 +977,10 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                         // this launch completes the gradient of the stage's activated output: the batch-statistics sums
                         // of its BatchNorm backward come for free (the raw tile is in registers)
                         if (p.bstats && nb < VT<DT>::DTH) {
-                            const float z = __builtin_fmaf(rawu[nb][r], bstat_sc[nb], bstat_sh[nb]);   // = vbn
+                            const float z = __builtin_fmaf(rawu[nb][r], bcst(0, nb, bstat_sc), bcst(1, nb, bstat_sh));   // = vbn
                             const float g = z > 0.f ? v : 0.f;
                             bsg[nb] += g;
-                            bsx[nb] += g * ((rawu[nb][r] - bstat_mu[nb]) * bstat_is[nb]);
+                            bsx[nb] += g * ((rawu[nb][r] - bcst(2, nb, bstat_mu)) * bcst(3, nb, bstat_is));
                         }
                     }
                 } else {
@@ -1026,16 +1105,20 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
     }
+    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
+                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) {
-            fetch_x<DT>(p, cn, li, lj, idx_nxt, raw);
+        // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
+        // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
+        const Cursor cf = pt + pstep < p.P ? cn : cu;
+        fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
 #pragma unroll
-            for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[(pt + pstep) * D + nb * 16 + li];
-        }
+        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
+        loads_issued();
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         // X leaves the kernel for the weight-gradient GEMM: row li, 16 bytes per 16-column chunk
@@ -1182,6 +1265,7 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
     const PoolParams& p = q.pp;
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, XS = Tile<VT<DT>::DTH>::XS;
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
+    __shared__ float vcl[VCols<DT>::INLDS ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
     __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
     __shared__ double red[4][2][VT<DT>::HP];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
@@ -1191,7 +1275,7 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
     VBwdCols<DT> bc;
     vw.bind(vmem);
     vw.stage(p, 256);
-    vc.load(p, li);
+    vc.load(p, li, vcl);
     bc.load(p, nullptr, li);
     __syncthreads();
     f32x4 sg[DTH], sx[DTH];
@@ -1212,13 +1296,17 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
         fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
         load_gin<DT>(q.G, pt, li, lj, gin);
     }
+    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
+                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) {
-            fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
-            load_gin<DT>(q.G, pt + pstep, li, lj, gin_nxt);
+        {
+            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
+            fetch_rpe(p, cf, li, idx_nxt, rin_nxt);
+            load_gin<DT>(q.G, cf.pt, li, lj, gin_nxt);
         }
+        loads_issued();
         idx_nxt = idx_n2;
         cu = cn;
         f32x4 raw[DTH];
@@ -1261,6 +1349,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, HP = VT<DT>::HP, XS = Tile<VT<DT>::DTH>::XS, XSB = Tile<VT<DT>::DTH>::XSB;
     constexpr int KB = DTH;                           // k blocks of dW: stage 1 uses block 0 only (10 of its 16 columns)
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
+    __shared__ float vcl[VCols<DT>::INLDS ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
     __shared__ __attribute__((aligned(16))) unsigned char w2t_mem[TERMS == 0 ? HP * XS * 4 : HP * XSB * 2 * 2];   // W2^T image for dY . W2
     // [0]: the stage's input rows [row][k] (rpe rows for stage 1, the activated stage-1 tile for stage 2); [1]: dY [row][n]
     __shared__ __attribute__((aligned(16))) float Tl[2][4][16 * XS];
@@ -1271,7 +1360,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     VBwdCols<DT> bc;
     vw.bind(vmem);
     vw.stage(p, 256);
-    vc.load(p, li);
+    vc.load(p, li, vcl);
     bc.load(p, q.coef, li);
     float* w2tf = reinterpret_cast<float*>(w2t_mem);
     __bf16* w2th = reinterpret_cast<__bf16*>(w2t_mem);
@@ -1316,13 +1405,17 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
         fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
         load_gin<DT>(q.G, pt, li, lj, gin);
     }
+    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
+                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        if (pt + pstep < p.P) {
-            fetch_rpe(p, cn, li, idx_nxt, rin_nxt);
-            load_gin<DT>(q.G, pt + pstep, li, lj, gin_nxt);
+        {
+            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
+            fetch_rpe(p, cf, li, idx_nxt, rin_nxt);
+            load_gin<DT>(q.G, cf.pt, li, lj, gin_nxt);
         }
+        loads_issued();
         idx_nxt = idx_n2;
         cu = cn;
         f32x4 raw[DTH];
