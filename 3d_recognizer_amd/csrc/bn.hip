@@ -228,21 +228,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
 
 // ---- float4 variants: C % 4 == 0, C/4 a power of two <= 256, 16-byte aligned rows ----------
 // tpr = min(C/4, 256) lanes sweep one row (16 B each), 256/tpr rows in flight per workgroup
-__device__ __forceinline__ void bn_row_math(const BwdParams& p, const float4 y, const float4 gin, int c,
-                                            float4* g, float4* xh) {
-    const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 sh = p.shift ? *reinterpret_cast<const float4*>(p.shift + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    g->x = gin.x * rl_act_grad(y.x * sc.x + sh.x, p.act, p.slope);
-    g->y = gin.y * rl_act_grad(y.y * sc.y + sh.y, p.act, p.slope);
-    g->z = gin.z * rl_act_grad(y.z * sc.z + sh.z, p.act, p.slope);
-    g->w = gin.w * rl_act_grad(y.w * sc.w + sh.w, p.act, p.slope);
-    if (xh) {
-        const float4 mu = *reinterpret_cast<const float4*>(p.mean + c);
-        const float4 is = *reinterpret_cast<const float4*>(p.invstd + c);
-        xh->x = (y.x - mu.x) * is.x; xh->y = (y.y - mu.y) * is.y;
-        xh->z = (y.z - mu.z) * is.z; xh->w = (y.w - mu.w) * is.w;
+typedef float bnf4 __attribute__((ext_vector_type(4)));
+// Per-thread constants of its channel quad, loaded ONCE (the row loops used to re-load them per row - G is written through
+// a plain pointer, so the compiler could not hoist them - and to pass results through pointers to locals, which put them
+// in scratch): BatchNorm affine, saved mean / invstd, and the activation derivative as "z > 0 ? 1 : neg".
+struct BnQuad {
+    bnf4 sc, sh, mu, is;
+    float neg;
+    __device__ __forceinline__ void load(const BwdParams& p, int c, bool want_xhat) {
+        sc = p.scale ? *reinterpret_cast<const bnf4*>(p.scale + c) : (bnf4){1.f, 1.f, 1.f, 1.f};
+        sh = p.shift ? *reinterpret_cast<const bnf4*>(p.shift + c) : (bnf4){0.f, 0.f, 0.f, 0.f};
+        mu = (bnf4){0.f, 0.f, 0.f, 0.f};
+        is = mu;
+        if (want_xhat) {
+            mu = *reinterpret_cast<const bnf4*>(p.mean + c);
+            is = *reinterpret_cast<const bnf4*>(p.invstd + c);
+        }
+        neg = p.act == RL_ACT_RELU ? 0.f : (p.act == RL_ACT_LRELU ? p.slope : 1.f);     // rl_act_grad: z > 0 ? 1 : neg
     }
-}
+    // g = gin * act'(y*sc + sh)      xhat = (y - mean) * invstd
+    __device__ __forceinline__ bnf4 grad(const bnf4 y, const bnf4 gin) const {
+        const bnf4 z = y * sc + sh;
+        bnf4 d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = z[j] > 0.f ? 1.f : neg;
+        return gin * d;
+    }
+    __device__ __forceinline__ bnf4 xhat(const bnf4 y) const { return (y - mu) * is; }
+};
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BwdParams p) {
     __shared__ float red[256][9];
@@ -252,19 +265,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BwdParams 
     const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
     const int c = q * 4;
     const long ntiles = (p.M + p.tile - 1) / p.tile;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    BnQuad k;
+    k.load(p, c, true);
+    bnf4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long rend = min(p.M, (tile + 1) * p.tile);
-        for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
-            const long off = row_off(p, R) + c;
-            const float4 y = *reinterpret_cast<const float4*>(p.Y + off);
-            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
-            float4 g, xh;
-            bn_row_math(p, y, gi, c, &g, &xh);
-            acc[0] += g.x; acc[1] += g.y; acc[2] += g.z; acc[3] += g.w;
-            acc[4] += g.x * xh.x; acc[5] += g.y * xh.y; acc[6] += g.z * xh.z; acc[7] += g.w * xh.w;
+        long R = tile * p.tile + rsub;
+        for (; R + rpar < rend; R += 2 * rpar) {          // two rows per trip: four loads in flight per lane
+            const long o0 = row_off(p, R) + c, o1 = row_off(p, R + rpar) + c;
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
+            const bnf4 y1 = *reinterpret_cast<const bnf4*>(p.Y + o1), g1 = *reinterpret_cast<const bnf4*>(p.G + o1);
+            const bnf4 d0 = k.grad(y0, g0), d1 = k.grad(y1, g1);
+            a0 += d0; a1 += d0 * k.xhat(y0);
+            a0 += d1; a1 += d1 * k.xhat(y1);
+        }
+        if (R < rend) {
+            const long o0 = row_off(p, R) + c;
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
+            const bnf4 d0 = k.grad(y0, g0);
+            a0 += d0; a1 += d0 * k.xhat(y0);
         }
     }
+    float acc[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
     // lanes of one wavefront that share a channel quad (tpr < 64) combine by butterfly
     for (int o = 32; o >= tpr && o >= 1; o >>= 1) {
 #pragma unroll
@@ -294,27 +316,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BwdParams p
     const int rpar = 256 / tpr;
     const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
     const int c = q * 4;
-    const float4 sc = p.scale ? *reinterpret_cast<const float4*>(p.scale + c) : make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0;
-    if (p.coef) {
-        k0 = *reinterpret_cast<const float4*>(p.coef + c);
-        k1 = *reinterpret_cast<const float4*>(p.coef + C + c);
+    const bool full = p.coef != nullptr;       // BatchNorm backward (else only the activation derivative and the scale)
+    BnQuad k;
+    k.load(p, c, full);
+    bnf4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
+    if (full) {
+        k0 = *reinterpret_cast<const bnf4*>(p.coef + c);
+        k1 = *reinterpret_cast<const bnf4*>(p.coef + C + c);
     }
+    const bnf4 osc = p.scale ? k.sc : (bnf4){1.f, 1.f, 1.f, 1.f};
+    auto row = [&](const bnf4 y, const bnf4 gi) {
+        bnf4 g = k.grad(y, gi);
+        if (full) g = g - k0 - k.xhat(y) * k1;
+        return g * osc;
+    };
     const long ntiles = (p.M + p.tile - 1) / p.tile;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long rend = min(p.M, (tile + 1) * p.tile);
-        for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
-            const long off = row_off(p, R) + c;
-            const float4 y = *reinterpret_cast<const float4*>(p.Y + off);
-            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
-            float4 g, xh;
-            bn_row_math(p, y, gi, c, &g, p.coef ? &xh : nullptr);
-            if (p.coef) {
-                g.x = g.x - k0.x - xh.x * k1.x; g.y = g.y - k0.y - xh.y * k1.y;
-                g.z = g.z - k0.z - xh.z * k1.z; g.w = g.w - k0.w - xh.w * k1.w;
-            }
-            g.x *= sc.x; g.y *= sc.y; g.z *= sc.z; g.w *= sc.w;
-            *reinterpret_cast<float4*>(p.G + off) = g;
+        long R = tile * p.tile + rsub;
+        for (; R + rpar < rend; R += 2 * rpar) {          // two rows per trip: four loads in flight per lane
+            const long o0 = row_off(p, R) + c, o1 = row_off(p, R + rpar) + c;
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
+            const bnf4 y1 = *reinterpret_cast<const bnf4*>(p.Y + o1), g1 = *reinterpret_cast<const bnf4*>(p.G + o1);
+            *reinterpret_cast<bnf4*>(p.G + o0) = row(y0, g0);
+            *reinterpret_cast<bnf4*>(p.G + o1) = row(y1, g1);
+        }
+        if (R < rend) {
+            const long o0 = row_off(p, R) + c;
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
+            *reinterpret_cast<bnf4*>(p.G + o0) = row(y0, g0);
         }
     }
 }
