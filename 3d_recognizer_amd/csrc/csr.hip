@@ -408,6 +408,24 @@ __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p)
         for (int c = q * 4; c < p.C; c += TPR * 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = s0;
+            // Eight rows per trip, their indices requested one trip ahead: a segment of 16 entries is 1 + 2 dependent
+            // round trips instead of 8 (index -> row, four times over).  The adds keep the entry order.
+            if (e + 8 <= s1) {
+                int r[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) r[t] = ent[e + t];
+                for (; e + 8 <= s1; e += 8) {
+                    float4 v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = *reinterpret_cast<const float4*>(sb + (long)r[t] * p.lds + c);
+                    if (e + 16 <= s1) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) r[t] = ent[e + 8 + t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { acc.x += v[t].x; acc.y += v[t].y; acc.z += v[t].z; acc.w += v[t].w; }
+                }
+            }
             for (; e + 4 <= s1; e += 4) {      // four rows requested before the first is added (order of the adds is fixed)
                 const int r0 = ent[e], r1 = ent[e + 1], r2 = ent[e + 2], r3 = ent[e + 3];
                 const float4 v0 = *reinterpret_cast<const float4*>(sb + (long)r0 * p.lds + c);
