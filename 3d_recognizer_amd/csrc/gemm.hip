@@ -1926,6 +1926,9 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
     __bf16* Dl = Dh + PW2_T * BS;
     __bf16* Xh = lds_a;
     __bf16* Xl = Xh + PW2_T * BS;
+    // the lazy BatchNorm scale / shift of this workgroup's 128 k-columns: 1 KB of LDS read in the staging step instead of
+    // 16 registers per lane (the kernel sat 2 dwords over its 128-VGPR budget, i.e. in scratch)
+    __shared__ __attribute__((aligned(16))) float lz[2][PW2_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int N = p.N, K = p.a.K;
@@ -1942,19 +1945,18 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
     };
     // staging units of this lane: u = i*8 + wave -> columns (u%8)*16 + 4*(l&3), rows (u/8)*16 + (l>>2)
     int ucol[2], urow[2];
-    float4 sc[2], sh[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int u = i * 8 + wave;
         ucol[i] = (u & 7) * 16 + (lane & 3) * 4;
         urow[i] = (u >> 3) * 16 + (lane >> 2);
-        sc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-        sh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lazy && ucol[i] < kvalid) {
-            sc[i] = *reinterpret_cast<const float4*>(p.a.lazy.scale + k0 + ucol[i]);
-            sh[i] = *reinterpret_cast<const float4*>(p.a.lazy.shift + k0 + ucol[i]);
-        }
     }
+    if (tid < PW2_T) {
+        const bool in = lazy && tid < kvalid;
+        lz[0][tid] = in ? p.a.lazy.scale[k0 + tid] : 1.f;
+        lz[1][tid] = in ? p.a.lazy.shift[k0 + tid] : 0.f;
+    }
+    // (the first barrier of the row loop makes lz visible before its first use in commit)
     f32x4 acc[8];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1987,10 +1989,12 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
         for (int i = 0; i < 2; ++i) {
             float4 v = ra[i];
             if (lazy && r0 + urow[i] < r_end && ucol[i] < kvalid) {
-                v.x = actf(v.x * sc[i].x + sh[i].x);
-                v.y = actf(v.y * sc[i].y + sh[i].y);
-                v.z = actf(v.z * sc[i].z + sh[i].z);
-                v.w = actf(v.w * sc[i].w + sh[i].w);
+                const float4 sc = *reinterpret_cast<const float4*>(&lz[0][ucol[i]]);
+                const float4 sh = *reinterpret_cast<const float4*>(&lz[1][ucol[i]]);
+                v.x = actf(v.x * sc.x + sh.x);
+                v.y = actf(v.y * sc.y + sh.y);
+                v.z = actf(v.z * sc.z + sh.z);
+                v.w = actf(v.w * sc.w + sh.w);
             }
             bf16x4 dh, dl, xh, xl;
             split_bf16(rd[i], dh, dl);
