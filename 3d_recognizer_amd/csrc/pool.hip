@@ -1584,14 +1584,18 @@ __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __rest
 // workgroups of a fused pooling launch: each stages W into LDS first and (backward) leaves a d x d slab, so more
 // than 1024 only pays for the narrow forward kernel (measured: d = 16 forward 174 -> 144 us at 2048; every
 // backward and the 64-channel forward get slower)
+// Grid caps = what is resident at once on the 256 CUs (measured, not derived: a second partial round of workgroups costs
+// a second weight staging and a tail): d = 64 backward, virtual: one 8-wavefront workgroup per CU (LDS) -> 256
+// (512: 498 -> 462 us per step); d = 64 forward: three 4-wavefront workgroups per CU (146 VGPRs) -> 768 (1024: 253 ->
+// 232 us); d = 16 forward: five per CU (96 VGPRs) -> 1280 (2048: 347 -> 336 us).  The others measured best as they are.
 int pool_grid(long P, int d, bool backward, bool virt = false) {
     if (backward && virt && d == 64) {
         // 8 wavefronts per workgroup (the staged weights + the small rpe weights leave room for one workgroup per CU only)
         long g8 = (P + 31) / 32;
         if (g8 < 1) g8 = 1;
-        return (int)(g8 < 512 ? g8 : 512);
+        return (int)(g8 < 256 ? g8 : 256);
     }
-    const long cap = (!backward && d <= 16) ? 2048 : 1024;
+    const long cap = (!backward && d <= 16) ? 1280 : (!backward && d == 64) ? 768 : 1024;
     long g = (P + 15) / 16;  // >= 4 points per wavefront
     if (d == 128) g = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;   // 8 wavefronts per workgroup, one workgroup per CU
     if (g < 1) g = 1;
