@@ -39,31 +39,62 @@ __device__ __forceinline__ long src_row(const RowsParams& p, I r) {
     return (long)b * p.src_bstride + j;
 }
 
-// one thread per (row, channel quad) when C % 4 == 0 and pointers allow, else per element
+// one thread per (row, channel quad) when C % 4 == 0 and pointers allow, else per element.
+// The quad path handles FOUR chunks per trip: their row indices are requested together, then their rows, then (when
+// accumulating) the old destinations - four independent chains in flight per lane instead of one index -> row -> store
+// chain at a time; the lazy scale / shift come as two 16-byte loads (they were eight scalar ones) and the activation is
+// max(z, z*e) (e = 1 none, 0 ReLU, slope LeakyReLU) instead of a switch per element.
 template <int VEC, typename I>
 __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
     const int cpr = p.C / VEC;  // chunks per row
     const long total = p.rows * cpr;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const I r = (I)e / (I)cpr;
-        const int c = (int)((I)e - r * (I)cpr) * VEC;
-        const long so = src_row<I>(p, r) * p.lds + c;
-        const long dofs = (long)r * p.ldd + c;
-        if (VEC == 4) {
-            float4 v = *reinterpret_cast<const float4*>(p.src + so);
-            if (p.lazy.scale) {
-                v.x = rl_lazy(p.lazy, v.x, c + 0);
-                v.y = rl_lazy(p.lazy, v.y, c + 1);
-                v.z = rl_lazy(p.lazy, v.z, c + 2);
-                v.w = rl_lazy(p.lazy, v.w, c + 3);
+    if constexpr (VEC == 4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const bool lazy = p.lazy.scale != nullptr;
+        const float es = (!lazy || p.lazy.act == RL_ACT_NONE) ? 1.f : (p.lazy.act == RL_ACT_RELU ? 0.f : p.lazy.slope);
+        const long stride = (long)gridDim.x * 256;
+        for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += 4 * stride) {
+            long so[4], dofs[4];
+            int cc[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long e = e0 + u * stride;
+                ok[u] = e < total;
+                const I ee = (I)(ok[u] ? e : e0);
+                const I r = ee / (I)cpr;
+                cc[u] = (int)(ee - r * (I)cpr) * 4;
+                so[u] = src_row<I>(p, r) * p.lds + cc[u];
+                dofs[u] = (long)r * p.ldd + cc[u];
             }
-            float4* d = reinterpret_cast<float4*>(p.dst + dofs);
+            v4f v[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f*>(p.src + so[u]);
             if (p.accumulate) {
-                const float4 o = *d;
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const v4f*>(p.dst + dofs[u]);
             }
-            *d = v;
-        } else {
+            if (lazy) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const v4f sc = *reinterpret_cast<const v4f*>(p.lazy.scale + cc[u]);
+                    const v4f sh = *reinterpret_cast<const v4f*>(p.lazy.shift + cc[u]);
+                    const v4f z = v[u] * sc + sh;
+                    v[u] = __builtin_elementwise_max(z, z * es);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p.accumulate) v[u] += o[u];
+                if (ok[u]) *reinterpret_cast<v4f*>(p.dst + dofs[u]) = v[u];
+            }
+        }
+    } else {
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const I r = (I)e / (I)cpr;
+            const int c = (int)((I)e - r * (I)cpr) * VEC;
+            const long so = src_row<I>(p, r) * p.lds + c;
+            const long dofs = (long)r * p.ldd + c;
             float v = rl_lazy(p.lazy, p.src[so], c);
             if (p.accumulate) v += p.dst[dofs];
             p.dst[dofs] = v;
@@ -368,11 +399,13 @@ extern "C" int rl_copy_rows(const rl_rows_desc* d, void* stream) {
     if (rc) return rc;
     if (p.rows == 0) return RL_OK;
     const bool v4 = (p.C % 4 == 0) && (p.lds % 4 == 0) && (p.ldd % 4 == 0) &&
-                    (((uintptr_t)p.src & 15) == 0) && (((uintptr_t)p.dst & 15) == 0);
+                    (((uintptr_t)p.src & 15) == 0) && (((uintptr_t)p.dst & 15) == 0) &&
+                    (!p.lazy.scale || ((((uintptr_t)p.lazy.scale) | ((uintptr_t)p.lazy.shift)) & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     const bool small = fits32(p.rows * p.C) && fits32(p.rows_per_batch);
-    if (v4 && small)  hipLaunchKernelGGL((copy_rows_kernel<4, uint32_t>), dim3(grid_for(p.rows * (p.C / 4))), dim3(256), 0, st, p);
-    else if (v4)      hipLaunchKernelGGL((copy_rows_kernel<4, int64_t>), dim3(grid_for(p.rows * (p.C / 4))), dim3(256), 0, st, p);
+    const long quads4 = (p.rows * (p.C / 4) + 3) / 4;      // the quad path moves four chunks per lane and trip
+    if (v4 && small)  hipLaunchKernelGGL((copy_rows_kernel<4, uint32_t>), dim3(grid_for(quads4)), dim3(256), 0, st, p);
+    else if (v4)      hipLaunchKernelGGL((copy_rows_kernel<4, int64_t>), dim3(grid_for(quads4)), dim3(256), 0, st, p);
     else if (small)   hipLaunchKernelGGL((copy_rows_kernel<1, uint32_t>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
     else              hipLaunchKernelGGL((copy_rows_kernel<1, int64_t>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
     rl_note_kernel("copy_rows_kernel");
