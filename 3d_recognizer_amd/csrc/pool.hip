@@ -1558,27 +1558,34 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     }
 }
 
-// 64 consecutive elements (256 contiguous bytes per slab row) x 4 slab lanes per workgroup, fixed order
+// Sum of the per-workgroup partial dW slabs ([nsplit][count]) in a fixed order:
 __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __restrict__ slab, int nsplit, int count,
                                                              float* __restrict__ dW) {
-    __shared__ float red[4][65];
-    const int ex = threadIdx.x & 63, sy = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + ex;
+    // 16 consecutive elements x 16 slab lanes per workgroup (was 64 x 4: d = 16 is then 16 workgroups of short chains
+    // instead of 4 of long ones); lane sy adds slabs sy, sy+16, ... with four loads in flight, fixed order throughout
+    __shared__ float red[16][17];
+    const int ex = threadIdx.x & 15, sy = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + ex;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < count) {
         const float* src = slab + e;
         int i = sy;
-        for (; i + 12 < nsplit; i += 16) {
+        for (; i + 48 < nsplit; i += 64) {
             s0 += src[(long)i * count];
-            s1 += src[(long)(i + 4) * count];
-            s2 += src[(long)(i + 8) * count];
-            s3 += src[(long)(i + 12) * count];
+            s1 += src[(long)(i + 16) * count];
+            s2 += src[(long)(i + 32) * count];
+            s3 += src[(long)(i + 48) * count];
         }
-        for (; i < nsplit; i += 4) s0 += src[(long)i * count];
+        for (; i < nsplit; i += 16) s0 += src[(long)i * count];
     }
     red[sy][ex] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sy == 0 && e < count) dW[e] = (red[0][ex] + red[1][ex]) + (red[2][ex] + red[3][ex]);
+    if (sy == 0 && e < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][ex];
+        dW[e] = t;
+    }
 }
 
 // workgroups of a fused pooling launch: each stages W into LDS first and (backward) leaves a d x d slab, so more
@@ -1742,7 +1749,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
         }
         rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1,virtual>" : p.d == 32 ? "pool_bwd_kernel<2,virtual>" : "pool_bwd_kernel<4,virtual>");
         RL_LAUNCH_CHECK("rl_pool_bwd(virtual)");
-        hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 64)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
+        hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
         RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
         return RL_OK;
     }
@@ -1757,7 +1764,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     }
     rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1>" : p.d == 32 ? "pool_bwd_kernel<2>" : "pool_bwd_kernel<4>");
     RL_LAUNCH_CHECK("rl_pool_bwd");
-    hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 64)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
+    hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
     RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
     return RL_OK;
 }

@@ -245,6 +245,31 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restric
     }
 }
 
+// four channels per lane, two quads per trip (C % 4 == 0, 16-byte aligned operands): the scalar kernel below moved 4 bytes
+// per lane and load
+__global__ __launch_bounds__(256) void add_act_fwd_vec_kernel(const float* __restrict__ Y1, const float* __restrict__ s1,
+                                                              const float* __restrict__ b1, const float* __restrict__ Y2,
+                                                              const float* __restrict__ s2, const float* __restrict__ b2,
+                                                              long quads, int C, float slope, float* __restrict__ O) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const unsigned cq = (unsigned)C >> 2;
+    const long stride = (long)gridDim.x * 256;
+    auto one = [&](long q) {
+        const int c = (int)((unsigned long)q % cq) * 4;
+        const v4f y1 = *reinterpret_cast<const v4f*>(Y1 + q * 4), y2 = *reinterpret_cast<const v4f*>(Y2 + q * 4);
+        const v4f a1 = *reinterpret_cast<const v4f*>(s1 + c), c1 = *reinterpret_cast<const v4f*>(b1 + c);
+        const v4f a2 = *reinterpret_cast<const v4f*>(s2 + c), c2 = *reinterpret_cast<const v4f*>(b2 + c);
+        const v4f z = (y1 * a1 + c1) + (y2 * a2 + c2);
+        v4f o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = z[j] > 0.f ? z[j] : z[j] * slope;
+        *reinterpret_cast<v4f*>(O + q * 4) = o;
+    };
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; q + stride < quads; q += 2 * stride) { one(q); one(q + stride); }
+    if (q < quads) one(q);
+}
+
 template <typename I>
 __global__ __launch_bounds__(256) void add_act_fwd_kernel(const float* __restrict__ Y1, const float* __restrict__ s1,
                                                           const float* __restrict__ b1, const float* __restrict__ Y2,
@@ -465,7 +490,13 @@ extern "C" int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1,
                               const float* b2, int64_t rows, int C, float slope, float* O, void* stream) {
     RL_REQUIRE(Y1 && s1 && b1 && Y2 && s2 && b2 && O && rows >= 0 && C > 0, RL_ERR_ARGS, "rl_add_act_fwd: bad arguments");
     if (rows == 0) return RL_OK;
-    if (fits32(rows * C))
+    const bool vec = C % 4 == 0 && ((((uintptr_t)Y1) | ((uintptr_t)Y2) | ((uintptr_t)O) | ((uintptr_t)s1) | ((uintptr_t)b1) |
+                                      ((uintptr_t)s2) | ((uintptr_t)b2)) & 15) == 0;
+    if (vec) {
+        const long quads = (long)rows * (C / 4);
+        hipLaunchKernelGGL(add_act_fwd_vec_kernel, dim3(grid_for((quads + 1) / 2)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
+                           s2, b2, quads, C, slope, O);
+    } else if (fits32(rows * C))
         hipLaunchKernelGGL(add_act_fwd_kernel<uint32_t>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
                            s2, b2, (long)rows * C, C, slope, O);
     else
