@@ -499,8 +499,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
         ssum[nb] = ssq[nb] = 0.f;
     }
     const bool lazy = p.a.lazy.scale != nullptr;
-    const int act = p.a.lazy.act;
-    const float slope = p.a.lazy.slope;
+    const float es = (!lazy || p.a.lazy.act == RL_ACT_NONE) ? 1.f : (p.a.lazy.act == RL_ACT_RELU ? 0.f : p.a.lazy.slope);
 
     const long nblk = (M + 15) >> 4;
     const long bstep = (long)gridDim.x * 4;
@@ -530,7 +529,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float v = av[s];
-                if (lazy) v = rl_act(v * sc[c][s] + sh[c][s], act, slope);
+                if (lazy) {      // lazy BatchNorm + activation without a switch: act(z) = max(z, z*e), e = 1 (none) / 0 (ReLU) / slope
+                    const float z = v * sc[c][s] + sh[c][s];
+                    v = fmaxf(z, z * es);
+                }
                 if (!rvalid || 16 * c + 4 * lj + s >= K) v = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb)
@@ -612,6 +614,7 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
         sh[kb] = (a.lazy.scale && k < K) ? a.lazy.shift[k] : 0.f;
     }
     const bool lazy = a.lazy.scale != nullptr;
+    const float es = (!lazy || a.lazy.act == RL_ACT_NONE) ? 1.f : (a.lazy.act == RL_ACT_RELU ? 0.f : a.lazy.slope);
     f32x4 acc[NT][KT];
     float bsum[NT];
 #pragma unroll
@@ -681,8 +684,10 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
                 const bool valid = base + u * 4 + lr < r_end;
 #pragma unroll
                 for (int kb = 0; kb < KT; ++kb)
-                    if (valid && kb * 16 + lc < K)
-                        av[u][kb] = rl_act(av[u][kb] * sc[kb] + sh[kb], a.lazy.act, a.lazy.slope);
+                    if (valid && kb * 16 + lc < K) {
+                        const float z = av[u][kb] * sc[kb] + sh[kb];
+                        av[u][kb] = fmaxf(z, z * es);       // act(z) = max(z, z*e): no switch per element
+                    }
             }
         }
 #pragma unroll

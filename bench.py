@@ -303,8 +303,10 @@ def step_rooflines(breakdown, B, value, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: ~1.7 s timed after ~0.2 s of warm-up - a 30-step (0.25 s) window right after a cold start was seen 8 % low
+    # once (clocks still ramping); the whole default run stays well under a minute
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
