@@ -490,6 +490,18 @@ def test_copy_rows_gather_concat_scatter(ops):
     acc = torch.ones(B * n * K, Cc, device=DEV)
     ops.copy_rows(dX, (0, Cc), n * K, acc, (0, Cc), B * n * K, n * K, accumulate=True)
     assert torch.equal(acc, 1 + dX[:, :Cc])
+    # the quad path moves four chunks per lane and trip: odd sizes (tails of every length), ReLU / no activation, gather +
+    # lazy + accumulate at once
+    for rows_n, Cw, act in ((1, 4, 1), (3, 8, 0), (257, 12, 1), (1031, 64, 2)):
+        srcw = torch.randn(B * n_src, Cw, device=DEV)
+        ix = torch.randint(0, n_src, (B, rows_n), device=DEV, dtype=torch.int32)
+        lzw = ops.Lazy(srcw, B, rows_n, n_src, Cw, torch.rand(Cw, device=DEV) + 0.5, torch.randn(Cw, device=DEV), act, 0.1)
+        outw = torch.full((B * rows_n, Cw), 2.0, device=DEV)
+        ops.copy_rows(srcw, (0, Cw), n_src, outw, (0, Cw), B * rows_n, rows_n, index=ix, lazy=lzw, accumulate=True)
+        z = srcw * lzw.scale + lzw.shift
+        a = z if act == 0 else (torch.relu(z) if act == 1 else torch.nn.functional.leaky_relu(z, 0.1))
+        refw = 2.0 + torch.gather(a.view(B, n_src, Cw), 1, ix.long().view(B, rows_n, 1).expand(-1, -1, Cw)).reshape(B * rows_n, Cw)
+        assert float((outw - refw).abs().max()) < 1e-6, (rows_n, Cw, act)
 
 
 @pytest.mark.parametrize("P,K,Cc", [(1000, 16, 16), (300, 32, 64), (77, 16, 256), (50, 5, 10)])
@@ -616,6 +628,14 @@ def test_add_act_and_logits_layout(ops):
     g = G.clone()
     ops.add_act_bwd(g, O, 0.01)
     assert torch.equal(g, torch.where(O > 0, G, G * 0.01))
+    # a channel count that is not a multiple of four takes the scalar kernel; an odd number of quads the vector tail
+    for rr, cw in ((77, 6), (3, 4), (1001, 20)):
+        a1, a2 = torch.randn(rr, cw, device=DEV), torch.randn(rr, cw, device=DEV)
+        m1 = ops.Lazy(a1, 1, rr, rr, cw, torch.rand(cw, device=DEV) + .5, torch.randn(cw, device=DEV))
+        m2 = ops.Lazy(a2, 1, rr, rr, cw, torch.rand(cw, device=DEV) + .5, torch.randn(cw, device=DEV))
+        o = ops.add_act_fwd(m1, m2, 0.2)
+        r = torch.nn.functional.leaky_relu((a1 * m1.scale + m1.shift) + (a2 * m2.scale + m2.shift), 0.2)
+        assert float((o - r).abs().max()) < 1e-6, (rr, cw)
     B, N, C = 2, 500, 3
     lp = torch.randn(B * N, C, device=DEV)
     perm = torch.randperm(N, device=DEV)
