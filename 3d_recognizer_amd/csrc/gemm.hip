@@ -780,19 +780,22 @@ void swgrad_split(long M, int* nsplit, long* rows_per_block) {
     if (*nsplit < 1) *nsplit = 1;
 }
 
-inline bool stream_wgrad_ok(int N, int K) { return N <= 64 && K <= 64; }
+// (K <= 16 also with up to 128 output columns: mlp_rpe1 of the 128-wide level, 10 -> 128)
+inline bool stream_wgrad_ok(int N, int K) { return (N <= 64 && K <= 64) || (K <= 16 && N <= 128); }
 
 template <int KC>
 void launch_sgemm(int N, int gx, hipStream_t st, const GemmParams& p) {
     if (N <= 16)      hipLaunchKernelGGL((sgemm_kernel<KC, 1>), dim3(gx), dim3(256), 0, st, p);
     else if (N <= 32) hipLaunchKernelGGL((sgemm_kernel<KC, 2>), dim3(gx), dim3(256), 0, st, p);
-    else              hipLaunchKernelGGL((sgemm_kernel<KC, 4>), dim3(gx), dim3(256), 0, st, p);
+    else if (N <= 64) hipLaunchKernelGGL((sgemm_kernel<KC, 4>), dim3(gx), dim3(256), 0, st, p);
+    else if constexpr (KC == 1) hipLaunchKernelGGL((sgemm_kernel<1, 8>), dim3(gx), dim3(256), 0, st, p);   // K <= 16 only
 }
 template <int KT>
 void launch_swgrad(int N, dim3 grid, hipStream_t st, const WgradParams& p) {
     if (N <= 16)      hipLaunchKernelGGL((swgrad_kernel<KT, 1>), grid, dim3(256), 0, st, p);
     else if (N <= 32) hipLaunchKernelGGL((swgrad_kernel<KT, 2>), grid, dim3(256), 0, st, p);
-    else              hipLaunchKernelGGL((swgrad_kernel<KT, 4>), grid, dim3(256), 0, st, p);
+    else if (N <= 64) hipLaunchKernelGGL((swgrad_kernel<KT, 4>), grid, dim3(256), 0, st, p);
+    else if constexpr (KT == 1) hipLaunchKernelGGL((swgrad_kernel<1, 8>), grid, dim3(256), 0, st, p);       // K <= 16 only
 }
 
 // ===========================================================================================
@@ -2144,7 +2147,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         RL_LAUNCH_CHECK("rl_gemm(split-scatter)");
         return RL_OK;
     }
-    if (d->a_mode == 0 && p.a.vec4p && d->K <= 64 && d->N <= 64) {
+    if (d->a_mode == 0 && p.a.vec4p && ((d->K <= 64 && d->N <= 64) || (d->K <= 16 && d->N <= 128))) {
         // every wavefront first loads the whole weight matrix into registers: with >= 2048 weights per
         // wavefront, fewer and longer-lived workgroups (two per CU) beat one 128-row tile per workgroup
         int sg = gx;

@@ -173,8 +173,9 @@ class Engine:
             q2 = self._pool(ctx, f"{e}.pool2", vr, q1, idx, csr, n, d, d, stage=2)
         else:
             rpe = Rpe(xyz, idx, d2, B, n, K)
-            if h <= 64 and not ops.NO_RPE_TENSOR:
-                # read twice (forward + weight gradient): cheaper as a 48-byte row than re-gathered in both kernels
+            if h <= 128 and not ops.NO_RPE_TENSOR:
+                # read twice (forward + weight gradient): cheaper as a 48-byte row than re-gathered in both kernels, and
+                # a plain 12-float row lets mlp_rpe1 run on the streaming GEMM / weight-gradient kernels (up to 128 columns)
                 rpe = ops.rpe_build(rpe)
             u1 = self._mlp(ctx, rpe, f"{e}.mlp_rpe1", h, H.ACT_RELU, a_grad=False)
             q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, csr, n, d, h)
