@@ -304,6 +304,11 @@ __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int b
     }
 }
 
+// Centre-out enumeration of the 2r+1 offsets of a ring axis: 0, -1, +1, -2, +2, ...  Rows of cells near the query are
+// scanned first, so the k-th distance falls early and later candidates enter the insertion network less often (the order
+// does not change the result: every cell the stopping rule requires is still visited).
+__device__ __forceinline__ int centre_out(int t) { return (t & 1) ? -((t + 1) >> 1) : (t >> 1); }
+
 // distance from coordinate q to the slab of cells `ci` along axis a (0 inside), shrunk by the
 // rounding slack so that it never over-estimates the distance to a point binned into that cell
 __device__ __forceinline__ float axis_gap(const GridGeom& g, int a, int ci, float q) {
@@ -350,10 +355,14 @@ __device__ __forceinline__ void query_one_lane(const KTask& T, int b) {
         const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.n[2] - 1);
         const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
         const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.n[0] - 1);
-        for (int z = z0; z <= z1; ++z) {
+        for (int tz = 0; tz <= 2 * r; ++tz) {
+            const int z = c[2] + centre_out(tz);
+            if (z < z0 || z > z1) continue;
             const bool zedge = (z == c[2] - r) || (z == c[2] + r);
             const float dz = axis_gap(g, 2, z, qz);
-            for (int y = y0; y <= y1; ++y) {
+            for (int ty = 0; ty <= 2 * r; ++ty) {
+                const int y = c[1] + centre_out(ty);
+                if (y < y0 || y > y1) continue;
                 const bool full_row = zedge || y == c[1] - r || y == c[1] + r;
                 const float dy = axis_gap(g, 1, y, qy);
                 const float dyz = dy * dy + dz * dz;
@@ -525,10 +534,14 @@ __device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned lo
             const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.n[2] - 1);
             const int y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.n[1] - 1);
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.n[0] - 1);
-            for (int z = z0; z <= z1; ++z) {
+            for (int tz = 0; tz <= 2 * r; ++tz) {
+                const int z = c[2] + centre_out(tz);
+                if (z < z0 || z > z1) continue;
                 const bool zedge = (z == c[2] - r) || (z == c[2] + r);
                 const float dz = axis_gap(g, 2, z, qz);
-                for (int y = y0; y <= y1; ++y) {
+                for (int ty = 0; ty <= 2 * r; ++ty) {
+                    const int y = c[1] + centre_out(ty);
+                    if (y < y0 || y > y1) continue;
                     const bool full_row = zedge || y == c[1] - r || y == c[1] + r;
                     const float dy = axis_gap(g, 1, y, qy);
                     const float dyz = dy * dy + dz * dz;
