@@ -960,19 +960,20 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dl, xh[kb], accw[nb][kb]);
             }
         }
-        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row
+        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row.
+        // d <= 32: the finished tile (C layout: a lane holds four ROWS of one column) goes through the wavefront's dS
+        // tile - free by now - and leaves in A layout: one 16-byte store per lane and 16-column chunk, 512 contiguous
+        // bytes per point and tensor, instead of a 4-byte store per element (pool_bwd<1>: 515 -> 493 us per step).
         loads_landed();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rowi = lj * 4 + r;
-            const long urow = (pt * 16 + rowi) * H;
 #pragma unroll
             for (int nb = 0; nb < DT; ++nb) {
                 const int col = nb * 16 + li;
                 float v = dx[nb][r];
                 if (col < H) {
                     if (nb < NGU) v += gacc[nb][r];
-                    p.GU[urow + col] = v;
                     if constexpr (VIRT) {
                         // this launch completes the gradient of the stage's activated output: the batch-statistics sums
                         // of its BatchNorm backward come for free (the raw tile is in registers)
@@ -983,9 +984,24 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                             bsx[nb] += g * ((rawu[nb][r] - bcst(2, nb, bstat_mu)) * bcst(3, nb, bstat_is));
                         }
                     }
-                } else {
-                    p.DG[urow + (col - H)] = v;
                 }
+                if constexpr (DT <= 2) Ds[rowi * XS + col] = v;
+                else {                      // d = 64: measured better with the element stores (11 us per step)
+                    const long urow = (pt * 16 + rowi) * H;
+                    if (col < H) p.GU[urow + col] = v;
+                    else p.DG[urow + (col - H)] = v;
+                }
+            }
+        }
+        if constexpr (DT <= 2) {
+            __builtin_amdgcn_wave_barrier();
+            const long orow = (pt * 16 + li) * H;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                const int k = 16 * c + 4 * lj;
+                const float4 v = *reinterpret_cast<const float4*>(Ds + li * XS + k);
+                if (k < H) *reinterpret_cast<float4*>(p.GU + orow + k) = v;
+                else *reinterpret_cast<float4*>(p.DG + orow + (k - H)) = v;
             }
         }
 #pragma unroll
