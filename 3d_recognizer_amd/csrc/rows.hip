@@ -339,10 +339,11 @@ __global__ void dropout_tick_kernel(int64_t* counter, int64_t* key_out) {
 template <bool FWD>
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ src, RlLazy lazy, int C, float* __restrict__ dst,
                                                       long quads, const int64_t* __restrict__ key, unsigned long long seed,
-                                                      unsigned threshold, float scale) {
+                                                      unsigned threshold, float scale, unsigned long long first_quad) {
     const unsigned long long k = (unsigned long long)key[0];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
-        const uint4 r = philox4x32_10(make_uint4((unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)k, (unsigned)(k >> 32)),
+        const unsigned long long gq = first_quad + (unsigned long long)q;     // index in the WHOLE batch's tensor (shards of one batch)
+        const uint4 r = philox4x32_10(make_uint4((unsigned)gq, (unsigned)(gq >> 32), (unsigned)k, (unsigned)(k >> 32)),
                                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
         float4 v = *reinterpret_cast<const float4*>(src + q * 4);
         if (FWD && lazy.scale) {
@@ -556,9 +557,10 @@ extern "C" int rl_dropout_tick(int64_t* counter, int64_t* key_out, void* stream)
     return RL_OK;
 }
 
-static int dropout_args(const float* src, float* dst, int64_t rows, int C, const int64_t* key, float p, const char* who,
-                        unsigned* threshold) {
-    RL_REQUIRE(src && dst && key && rows >= 0 && C > 0 && C % 4 == 0, RL_ERR_ARGS, "%s: bad arguments (C must be a multiple of 4)", who);
+static int dropout_args(const float* src, float* dst, int64_t rows, int64_t first_row, int C, const int64_t* key, float p,
+                        const char* who, unsigned* threshold) {
+    RL_REQUIRE(src && dst && key && rows >= 0 && first_row >= 0 && C > 0 && C % 4 == 0, RL_ERR_ARGS,
+               "%s: bad arguments (C must be a multiple of 4)", who);
     RL_REQUIRE(p >= 0.f && p < 1.f, RL_ERR_ARGS, "%s: p must be in [0, 1)", who);
     RL_REQUIRE(rows * C < (1l << 32), RL_ERR_ARGS, "%s: too many elements", who);
     RL_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, RL_ERR_ARGS, "%s: tensors must be 16-byte aligned", who);
@@ -568,30 +570,31 @@ static int dropout_args(const float* src, float* dst, int64_t rows, int C, const
 }
 
 extern "C" int rl_dropout_fwd(const float* src, const float* scale, const float* shift, int act, float slope, float* dst,
-                              int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream) {
+                              int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, void* stream) {
     unsigned thr;
-    int rc = dropout_args(src, dst, rows, C, key, p, "rl_dropout_fwd", &thr);
+    int rc = dropout_args(src, dst, rows, first_row, C, key, p, "rl_dropout_fwd", &thr);
     if (rc) return rc;
     RL_REQUIRE((scale == nullptr) == (shift == nullptr), RL_ERR_ARGS, "rl_dropout_fwd: scale/shift must come together");
     if (rows == 0) return RL_OK;
     RlLazy lz; lz.scale = scale; lz.shift = shift; lz.act = act; lz.slope = slope;
     const long quads = (long)rows * C / 4;
     hipLaunchKernelGGL(dropout_kernel<true>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, src, lz, C, dst, quads, key,
-                       (unsigned long long)seed, thr, 1.0f / (1.0f - p));
+                       (unsigned long long)seed, thr, 1.0f / (1.0f - p), (unsigned long long)first_row * (unsigned)C / 4u);
     rl_note_kernel("dropout_kernel");
     RL_LAUNCH_CHECK("rl_dropout_fwd");
     return RL_OK;
 }
 
-extern "C" int rl_dropout_bwd(float* G, int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream) {
+extern "C" int rl_dropout_bwd(float* G, int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p,
+                              void* stream) {
     unsigned thr;
-    int rc = dropout_args(G, G, rows, C, key, p, "rl_dropout_bwd", &thr);
+    int rc = dropout_args(G, G, rows, first_row, C, key, p, "rl_dropout_bwd", &thr);
     if (rc) return rc;
     if (rows == 0) return RL_OK;
     RlLazy lz; lz.scale = nullptr; lz.shift = nullptr; lz.act = 0; lz.slope = 0.f;
     const long quads = (long)rows * C / 4;
     hipLaunchKernelGGL(dropout_kernel<false>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, G, lz, C, G, quads, key,
-                       (unsigned long long)seed, thr, 1.0f / (1.0f - p));
+                       (unsigned long long)seed, thr, 1.0f / (1.0f - p), (unsigned long long)first_row * (unsigned)C / 4u);
     rl_note_kernel("dropout_kernel");
     RL_LAUNCH_CHECK("rl_dropout_bwd");
     return RL_OK;

@@ -77,7 +77,13 @@ class Engine:
         # data-parallel equivalence mode: BatchNorm statistics of the global batch (ops.SyncGroup)
         self.sync: Optional[ops.SyncGroup] = None
         self._drop_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-        self._drop_counter: Optional[torch.Tensor] = None
+        # allocated (and zeroed) HERE, eagerly: a lazy torch.zeros inside a captured forward would become a memset node
+        # of the graph and reset the counter - the same mask - on every replay
+        dev = next(iter(params.values())).device
+        self._drop_counter: Optional[torch.Tensor] = torch.zeros(1, dtype=torch.int64, device=dev) if dev.type == "cuda" else None
+        # data-parallel runs: `drop_stream` decorrelates the masks of ranks that train on DIFFERENT batches (plain DDP:
+        # the rank); `sync.first_row(N)` places a shard inside the whole batch's mask in the equivalence mode
+        self.drop_stream = 0
 
     # ------------------------------------------------------------------------ forward pieces
     def _w2(self, name: str) -> torch.Tensor:
@@ -293,10 +299,14 @@ class Engine:
         if training and dropout_p > 0.0:
             if keep_mask is None:
                 if self._drop_counter is None or self._drop_counter.device != dev:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise H.HipKernelError("the Dropout counter must exist before a forward is captured")
                     self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
                 key = ops.dropout_tick(self._drop_counter)
-                dropped = ops.plain(ops.dropout_fwd(x, key, self._drop_seed, dropout_p), B, N)
-                ctx.tape.append(("dropout_philox", x, dropped, key, dropout_p))
+                seed = (self._drop_seed + 0x9E3779B97F4A7C15 * self.drop_stream) & 0x7FFFFFFFFFFFFFFF
+                first_row = self.sync.cloud_offset * N if self.sync is not None else 0
+                dropped = ops.plain(ops.dropout_fwd(x, key, seed, dropout_p, first_row), B, N)
+                ctx.tape.append(("dropout_philox", x, dropped, key, dropout_p, seed, first_row))
             else:
                 t = torch.empty((B * N, 32), dtype=torch.float32, device=dev)
                 ops.copy_rows(x.raw, (0, 32), N, t, (0, 32), B * N, N, lazy=x)
@@ -383,10 +393,10 @@ class Engine:
                 ops.copy_rows(G, (prev.C, skip.C), catl.n, gs[0], (0, skip.C), catl.rows, catl.n, accumulate=gs[1])
                 gs[1] = True
             elif kind == "dropout_philox":
-                _, src, dropped, key, p_drop = rec
+                _, src, dropped, key, p_drop, seed, first_row = rec
                 G, init = self._gbuf(ctx, dropped)
                 assert init
-                ops.dropout_bwd(G, key, self._drop_seed, p_drop)
+                ops.dropout_bwd(G, key, seed, p_drop, first_row)
                 ctx.grads[id(src.raw)] = [G, True]
             elif kind == "dropout":
                 _, src, dropped, mask, scale = rec

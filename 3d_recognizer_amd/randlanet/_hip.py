@@ -220,8 +220,8 @@ _SIGNATURES = {
     "rl_batch_assemble": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
     "rl_dropout_tick": (_i, [_vp, _vp, _vp]),
-    "rl_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _l, _i, _vp, C.c_uint64, _f, _vp]),
-    "rl_dropout_bwd": (_i, [_vp, _l, _i, _vp, C.c_uint64, _f, _vp]),
+    "rl_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _l, _l, _i, _vp, C.c_uint64, _f, _vp]),
+    "rl_dropout_bwd": (_i, [_vp, _l, _l, _i, _vp, C.c_uint64, _f, _vp]),
     "rl_upsample_cf": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rl_logits_unpermute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_logits_permute_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -418,6 +418,34 @@ class SyncGroup:
 
     def __init__(self, world: int, group=None, staged: bool = False):
         self.world, self.group, self.staged = world, group, staged
+        # where this rank's shard sits in the global batch (set_shard); until then: `world` equal shards, rank unknown
+        self.local_clouds, self.global_clouds, self.cloud_offset = 1, world, 0
+
+    def set_shard(self, local_clouds: int, rank: Optional[int] = None) -> None:
+        """Tell the group how many clouds this rank holds; the ranks exchange their counts (one tiny host all-reduce), so
+        that shards of DIFFERENT sizes (a batch the world size does not divide) still normalise by the global row count
+        and know their offset in the batch (Dropout mask slices)."""
+        import torch.distributed as dist
+        if self.world <= 1 or not (dist.is_available() and dist.is_initialized()):
+            self.local_clouds, self.global_clouds, self.cloud_offset = local_clouds, local_clouds * self.world, 0
+            return
+        rank = dist.get_rank(self.group) if rank is None else rank
+        counts = torch.zeros(self.world, dtype=torch.int64)
+        counts[rank] = local_clouds
+        if dist.get_backend(self.group) == "nccl":
+            dev_counts = counts.cuda()
+            dist.all_reduce(dev_counts, op=dist.ReduceOp.SUM, group=self.group)
+            counts = dev_counts.cpu()
+        else:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
+        self.local_clouds, self.global_clouds = local_clouds, int(counts.sum())
+        self.cloud_offset = int(counts[:rank].sum())
+
+    def global_rows(self, rows: int) -> int:
+        """Rows of the GLOBAL batch for a tensor that has `rows` rows on this rank (every such tensor has the same number
+        of rows per cloud on every rank)."""
+        assert rows % self.local_clouds == 0, (rows, self.local_clouds)
+        return rows // self.local_clouds * self.global_clouds
 
     def allreduce(self, t: torch.Tensor) -> None:
         import torch.distributed as dist
@@ -442,7 +470,7 @@ def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, n
     if training and sync is not None:            # batch statistics of the GLOBAL batch
         stats = _stats_totals(stats, nslots, C)
         sync.allreduce(stats)
-        nslots, rows = 1, rows * sync.world
+        nslots, rows = 1, sync.global_rows(rows)
     scale = torch.empty(C, dtype=F32, device=dev)
     shift = torch.empty(C, dtype=F32, device=dev)
     mean = torch.empty(C, dtype=F32, device=dev) if training else None
@@ -474,7 +502,7 @@ def _bn_bwd_finalize(stats, slots: int, rows: int, Cc: int, dgamma, dbeta, coef,
     if sync is not None:
         tot = _stats_totals(stats, slots, Cc)
         sync.allreduce(tot)
-        H.check(H.lib().rl_bn_bwd_finalize(tot.data_ptr(), 1, rows * sync.world, Cc, None, None, coef.data_ptr(), _st()),
+        H.check(H.lib().rl_bn_bwd_finalize(tot.data_ptr(), 1, sync.global_rows(rows), Cc, None, None, coef.data_ptr(), _st()),
                 "rl_bn_bwd_finalize")
 
 
@@ -864,23 +892,24 @@ def dropout_tick(counter: torch.Tensor) -> torch.Tensor:
     return key
 
 
-def dropout_fwd(x: Lazy, key: torch.Tensor, seed: int, p: float) -> torch.Tensor:
-    """Dropout of the (activated) dense tensor x with the Philox mask of (seed, key): (rows, C) output."""
+def dropout_fwd(x: Lazy, key: torch.Tensor, seed: int, p: float, first_row: int = 0) -> torch.Tensor:
+    """Dropout of the (activated) dense tensor x with the Philox mask of (seed, key): (rows, C) output.  first_row: where
+    this tensor's row 0 sits in the whole batch's tensor (shards of one batch draw slices of one mask)."""
     _dev_check(x.raw, x.scale, x.shift, key)
     assert x.bstride == x.n and x.raw.shape == (x.rows, x.C) and x.C % 4 == 0
     out = torch.empty_like(x.raw)
     with _rec("dropout", (x.rows, x.C), 8 * x.rows * x.C, 0):
         H.check(H.lib().rl_dropout_fwd(x.raw.data_ptr(), H.ptr(x.scale), H.ptr(x.shift), x.act, x.slope, out.data_ptr(),
-                                       x.rows, x.C, key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p, _st()), "rl_dropout_fwd")
+                                       x.rows, first_row, x.C, key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p, _st()), "rl_dropout_fwd")
     return out
 
 
-def dropout_bwd(G: torch.Tensor, key: torch.Tensor, seed: int, p: float) -> None:
+def dropout_bwd(G: torch.Tensor, key: torch.Tensor, seed: int, p: float, first_row: int = 0) -> None:
     """In place: the gradient through the same mask (regenerated from (seed, key))."""
     _dev_check(G, key)
     assert G.dim() == 2 and G.shape[1] % 4 == 0
     with _rec("dropout", (G.shape[0], G.shape[1]), 8 * G.numel(), 0):
-        H.check(H.lib().rl_dropout_bwd(G.data_ptr(), G.shape[0], G.shape[1], key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p,
+        H.check(H.lib().rl_dropout_bwd(G.data_ptr(), G.shape[0], first_row, G.shape[1], key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p,
                                        _st()), "rl_dropout_bwd")
 
 
@@ -946,7 +975,7 @@ def loss_forward(logits: torch.Tensor, labels: torch.Tensor, kind: int, alpha: f
                 "rl_loss_partials")
         o = H.lib().rl_loss_totals_offset(Cc)
         sync.allreduce(work[o:o + 5 * Cc + 1])
-        H.check(H.lib().rl_loss_from_totals(B * N * sync.world, Cc, kind, alpha, gamma, int(neglect_background),
+        H.check(H.lib().rl_loss_from_totals(sync.global_rows(B * N), Cc, kind, alpha, gamma, int(neglect_background),
                                             work.data_ptr(), out.data_ptr(), _st()), "rl_loss_from_totals")
         return out, work
     with _rec("loss", (B, Cc, N), 4 * B * Cc * N + 8 * B * N, 0):
@@ -962,7 +991,7 @@ def loss_backward(logits, labels, kind: int, alpha: float, gamma: float, neglect
     dlogits = torch.empty_like(logits)
     if sync is not None:
         H.check(H.lib().rl_loss_backward_global(logits.data_ptr(), labels.data_ptr(), B, Cc, N, kind, alpha, gamma,
-                                                int(neglect_background), work.data_ptr(), grad_scale, B * N * sync.world,
+                                                int(neglect_background), work.data_ptr(), grad_scale, sync.global_rows(B * N),
                                                 dlogits.data_ptr(), _st()), "rl_loss_backward_global")
         return dlogits
     with _rec("loss", (B, Cc, N), 8 * B * Cc * N + 8 * B * N, 0):

@@ -77,6 +77,12 @@ class TrainState:
         self.flat = FlatParameters(module)
         self.engine = module.engine()
         self.world, self.pg = world_size, process_group
+        if world_size > 1:
+            # ranks train on different clouds: each draws its own Dropout masks (the equivalence mode overrides this
+            # per step: there the ranks hold slices of ONE batch and of one mask)
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.engine.drop_stream = dist.get_rank(process_group)
         self.exp_avg = torch.zeros_like(self.flat.param)
         self.exp_avg_sq = torch.zeros_like(self.flat.param)
         self.lr = torch.tensor([lr], dtype=torch.float32, device=self.dev)
@@ -113,6 +119,7 @@ class TrainStep:
         self.sync = sync
         if sync is not None:
             use_graph = False
+            sync.set_shard(B)               # shards may differ in size: global row counts / mask offsets come from here
         st = self.state
         self.module = module
         self.dev = st.dev
@@ -142,6 +149,9 @@ class TrainStep:
     # -- the schedule ------------------------------------------------------------------------
     def _fwd_bwd(self):
         self.engine.sync = self.sync
+        stream = self.engine.drop_stream
+        if self.sync is not None:
+            self.engine.drop_stream = 0     # one mask for the whole batch, sliced by sync.cloud_offset
         try:
             logits, ctx = self.engine.forward(self.inp, self.perm, True, self.p_drop)
             _, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True, out=self.out, sync=self.sync)
@@ -149,6 +159,7 @@ class TrainStep:
             self.engine.backward(ctx, dlogits, self.flat.grads)
         finally:
             self.engine.sync = None
+            self.engine.drop_stream = stream
 
     def _adam(self):
         # per-rank losses are averaged (grad / world); the equivalence mode's loss is already the global one (grad summed)
@@ -256,9 +267,11 @@ class InferStep:
         self.inp = torch.rand((B, N, 3 + s.n_features), dtype=torch.float32, device=self.dev)
         self.perm = torch.arange(N, dtype=torch.int64, device=self.dev)
         self.logits = torch.zeros((B, s.n_classes, N), dtype=torch.float32, device=self.dev)
-        self._staging = torch.empty(N, dtype=torch.int64).pin_memory()
-        self._staging_np = self._staging.numpy()
-        self._copied: Optional[torch.cuda.Event] = None
+        # pinned staging ring for the permutation (as in TrainStep): the host may run a few passes ahead of the GPU
+        self._ring = [torch.empty(N, dtype=torch.int64).pin_memory() for _ in range(4)]
+        self._ring_np = [t.numpy() for t in self._ring]
+        self._ring_events = [None] * 4
+        self._slot = 0
         self.use_graph = use_graph
         self._g: Optional[torch.cuda.CUDAGraph] = None
 
@@ -290,12 +303,15 @@ class InferStep:
             return self._step(perm)
 
     def _step(self, perm: np.ndarray) -> torch.Tensor:
-        if self._copied is not None:
-            self._copied.synchronize()         # the staging buffer is free again once its copy has executed
-        self._staging_np[:] = perm
-        self.perm.copy_(self._staging, non_blocking=True)
-        self._copied = torch.cuda.Event()
-        self._copied.record(torch.cuda.current_stream(self.dev))
+        slot = self._slot
+        self._slot = (slot + 1) % len(self._ring)
+        if self._ring_events[slot] is not None:
+            self._ring_events[slot].synchronize()    # the slot is free again once the copy that last read it has executed
+        self._ring_np[slot][:] = perm
+        self.perm.copy_(self._ring[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._ring_events[slot] = ev
         if self._g is not None:
             self._g.replay()
         else:

@@ -2,10 +2,11 @@
 
 Mirrors randlanet/utils/modules.py of matthiasverstraete/3d_recognizer: the same settings
 dataclass, class names, constructor signatures, parameter names / shapes (state_dict is
-interchangeable both ways) and forward contract - but the sub-modules are parameter containers
-only.  All arithmetic is done by the HIP kernels of librandla_hip.so, scheduled by
-`_engine.Engine`; there is no PyTorch or CPU implementation of the forward pass in this
-package, and a missing library or a non-GPU device raises instead of falling back.
+interchangeable both ways) and forward contract.  On a HIP device all arithmetic is done by the
+kernels of librandla_hip.so, scheduled by `_engine.Engine`; a missing library or a failing launch
+raises - nothing falls back.  A model PLACED on the CPU (the reference's own device choice,
+model.py:38-40: no GPU, or use_gpu=False) runs the host inference path of `_cpu.py`
+(rl_knn_f32_cpu + PyTorch-CPU rows; inference only, training needs the MI355X).
 """
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -287,6 +288,7 @@ class RandLANet(nn.Module):
         self.to(self._device)
         self._engine: Optional[Engine] = None
         self._engine_key = None
+        self._infer_steps = {}
 
     # -- reference properties (modules.py:534-540)
     @property
@@ -309,6 +311,20 @@ class RandLANet(nn.Module):
                                   {k: v.detach() for k, v in params.items()}, buffers)
             self._engine_key = key
         return self._engine
+
+    def infer_step(self, B: int, N: int):
+        """The eval forward for one batch shape as a replayable hipGraph (`_train.InferStep`), captured on first use and
+        kept while the parameters stay where they are (Trainer.evaluate's passes run through these)."""
+        from .._train import InferStep
+        eng = self.engine()
+        step = self._infer_steps.get((B, N))
+        if step is None or step.engine is not eng:
+            was_training = self.training
+            step = InferStep(self, B, N)
+            step.capture()
+            self.train(was_training)
+            self._infer_steps[(B, N)] = step
+        return step
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         """(B, N, 3+F) -> logits (B, C, N) in the original point order (modules.py:542-611).

@@ -7,6 +7,7 @@ launch schedule of RandLANet, the loss is the fused HIP loss, and accuracy + IoU
 from ONE packed device->host read instead of 2C+2 `.item()` calls (trainer.py:121-131).
 """
 import logging
+import os
 from collections import OrderedDict
 from contextlib import contextmanager
 from dataclasses import dataclass
@@ -94,7 +95,8 @@ class Trainer:
         hipGraph, a ragged last batch runs the same schedule eagerly; parameters, gradients and Adam moments
         live in flat buffers shared by both.
 
-        With torch.distributed initialised every rank trains on its shard of every batch and the gradients are
+        With torch.distributed initialised every rank trains on its shard of every batch (the ranks share one torch /
+        numpy seed per epoch, broadcast by rank 0, so they all see the same batches) and the gradients are
         all-reduced once per step.  The replicas are kept in lock-step: rank 0's parameters and BatchNorm buffers
         are broadcast before the first step; a batch with fewer clouds than ranks is skipped on ALL ranks (a rank
         without clouds would miss the gradient all-reduce the others wait in); before every validation the
@@ -123,6 +125,15 @@ class Trainer:
         warned_short = False
         for epoch in range(1, settings.epochs + 1):
             collected = MetricCollector(self._class_names)
+            if world > 1:
+                # every rank iterates the SAME loader and keeps its slice of each batch: that only partitions the data if
+                # all ranks draw the same shuffle / sampling / augmentation, i.e. share the torch and numpy streams -
+                # rank 0 draws a seed per epoch and everybody adopts it
+                seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+                seed_dev = seed.to(model.device)
+                dist.broadcast(seed_dev, 0)
+                torch.manual_seed(int(seed_dev.item()))
+                np.random.seed(int(seed_dev.item()) & 0x7FFFFFFF)
             for batch, labels, _ in tqdm(self._train_dataloader, desc="Training", leave=False, disable=rank != 0):
                 if world > 1:           # clouds are independent: each rank takes its contiguous shard
                     if batch.shape[0] < world:
@@ -177,6 +188,51 @@ class Trainer:
         best.eval()
         return best
 
+    @staticmethod
+    def _evaluate_on_device(model: RandLANet, data_loader, class_names, loss_function: str,
+                            n_evaluations: int) -> MetricCollectorBag:
+        """The seeded passes of evaluate() with the host out of the loop: every batch replays the eval forward's hipGraph
+        (`_train.InferStep`, one per batch shape, kept on the model), loss AND class counts come from ONE rl_loss_forward
+        launch into a row of a device table, and the whole table is read back ONCE after the last pass (the reference
+        does 2C+3 `.item()` round trips per batch, trainer.py:324-354).  Same numbers as the per-batch path: the same
+        kernels in the same order, the same permutation draws from the numpy stream seeded 100*i."""
+        from .. import _ops as ops
+        device = model.device
+        C = model.settings.n_classes
+        kind, alpha, gamma = ops.LOSS_KINDS[loss_function]
+        neglect = kind == 2                                    # FocalTverskyLoss(neglect_background=True), trainer.py:253-267
+        n_batches = len(data_loader)
+        table = torch.zeros((max(1, n_evaluations * n_batches), 1 + 4 * C), dtype=torch.float64, device=device)
+        rows_per_pass: List[int] = []
+        k = 0
+        with torch.cuda.device(device):
+            for i in range(n_evaluations):
+                np.random.seed(100 * i)
+                first = k
+                for batch, labels, _ in tqdm(data_loader, desc="Evaluation", leave=False):
+                    if k >= table.shape[0]:                    # a loader without a reliable len(): grow
+                        table = torch.cat([table, torch.zeros_like(table)])
+                    step = model.infer_step(batch.shape[0], batch.shape[1])
+                    step.inp.copy_(batch.to(device, torch.float32), non_blocking=True)
+                    logits = step.step(np.random.permutation(batch.shape[1]))
+                    ops.loss_forward(logits, labels.to(device, torch.int64).contiguous(), kind, alpha, gamma, neglect,
+                                     out=table[k])
+                    k += 1
+                rows_per_pass.append(k - first)
+            host = table[:k].cpu().numpy()                     # THE read-back
+        passes: List[MetricCollector] = []
+        k = 0
+        for n_rows in rows_per_pass:
+            current = MetricCollector()
+            for rec in host[k:k + n_rows]:
+                cnt = rec[1:1 + 3 * C].reshape(3, C)
+                oa, pca = accuracy_from_counts(cnt)
+                miou, pci = iou_from_counts(cnt)
+                current.push(float(np.float32(rec[0])), oa, pca, miou, pci)      # the criterion returns a float32 scalar
+            k += n_rows
+            passes.append(current)
+        return MetricCollectorBag(passes, class_names)
+
     def _log(self, epoch: int, total_epochs: int, lr: float, train_metrics: OrderedDict,
              validation_metrics: OrderedDict, writer) -> None:
         parts = [f"Epoch {epoch:3d}/{total_epochs:3d}"]
@@ -223,6 +279,11 @@ class Trainer:
         saved_rng = np.random.get_state()
         if postprocess:
             assert data_loader.batch_size == 1, "Batch size 1 required when evaluating with postprocessing!"
+        if device.type == "cuda" and not postprocess and not int(os.environ.get("RL_EVAL_EAGER", "0")):
+            with eval_mode(model), torch.no_grad():
+                bag = Trainer._evaluate_on_device(model, data_loader, class_names, loss_function, n_evaluations)
+            np.random.set_state(saved_rng)
+            return bag
         upsampler = UpSampler("nni", device)
         passes: List[MetricCollector] = []
         with eval_mode(model), torch.no_grad():

@@ -21,12 +21,17 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   strong_bs8   - (N > 1) the metric's global batch of 8 split over the N ranks
   bf16_operands- the metric's configuration with plain bf16 operands in the wide kernels (BASELINE config A says "bf16");
                  storage stays fp32 and its logits leave the 1e-3 parity bound, so it is never `value`
+  fp32_exact   - the metric's configuration with exact fp32 products everywhere (RL_WIDE_GEMM=fp32: the reference's own
+                 arithmetic)
+  config_S / config_Kt_shard - BASELINE configs[3] (65536 pts, 13 classes, 5 layers, bs=8) and the per-GPU shard of
+                 configs[4] (122880 pts, 20 classes, bs=2), each with clouds/s and its whole-step roofline fraction
+  whole_step / knn / mfma_by_level - path-level roofline figures (also kept inside `roofline`)
   roofline     - the kernel with the largest share of the step (measured with HIP events around
                  every launch of an instrumented eager pass on the launch stream): algorithmic
                  bytes per launch / mean launch duration vs the 8 TB/s HBM peak.
   cpu_baseline - the same training step on the host cores: oracle/ restatement of the
                  reference's PyTorch-CPU graph + single-threaded exact C KNN ("port"), on a
-                 bounded sample (B=2 clouds, 1 warm-up + 2 timed steps).
+                 bounded sample (B=2 clouds, 1 warm-up + 3 timed steps).
 """
 import argparse
 import json
@@ -64,11 +69,17 @@ def synthetic_batch(B, N, C, seed):
     return xyz, np.where(inside, cls, 0).astype(np.int64)
 
 
-def build_model(device, seed=0):
+# the other single-GPU BASELINE.json configurations, reported beside the metric's (never as `value`)
+CFG_S = dict(n_points=65536, n_classes=13, n_neighbors=16, layer_sizes=[16, 64, 128, 256, 512], per_gpu_batch=8)
+CFG_KT = dict(n_points=122880, n_classes=20, n_neighbors=16, layer_sizes=[16, 64, 128, 256], per_gpu_batch=2)
+
+
+def build_model(device, seed=0, cfg=None):
     from randlanet.utils.modules import RandLANet, RandLANetSettings
+    cfg = CFG if cfg is None else cfg
     torch.manual_seed(seed)
-    s = RandLANetSettings(n_classes=CFG["n_classes"], n_points=CFG["n_points"], n_neighbors=CFG["n_neighbors"],
-                          layer_sizes=list(CFG["layer_sizes"]), knn="kdtree")
+    s = RandLANetSettings(n_classes=cfg["n_classes"], n_points=cfg["n_points"], n_neighbors=cfg["n_neighbors"],
+                          layer_sizes=list(cfg["layer_sizes"]), knn="kdtree")
     return RandLANet(s, device)
 
 
@@ -82,7 +93,7 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("RL_CPU_BASELINE_CORES", "16"))))
 
 
-def cpu_baseline(steps=2, B=2):
+def cpu_baseline(steps=3, B=2):
     """The reference's training step on the host: PyTorch-CPU NCHW graph + exact C KNN (oracle/)."""
     from oracle import randlanet_oracle as O
     from oracle.loss_metrics_oracle import loss_by_name
@@ -224,12 +235,34 @@ def roofline_pass(stepper, eager_steps=3):
     return roof, breakdown
 
 
+def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs this process could use, WITHOUT any HIP call: KFD topology nodes with SIMDs (CPU nodes have simd_count 0),
+    narrowed by the *_VISIBLE_DEVICES lists when set."""
+    n = 0
+    try:
+        for node in sorted(os.listdir(sysfs)):
+            try:
+                with open(os.path.join(sysfs, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args) -> int:
-    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh children.  This parent never touches the
-    GPU (device_count() does not create a context on this image), so nothing that has initialised HIP is re-executed."""
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh children.  This parent makes no HIP call
+    at all (the device count comes from sysfs), so nothing that has initialised the GPU is ever re-executed."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = visible_gpu_count()
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible - refusing to measure fewer GPUs "
               "than asked for", file=sys.stderr)
@@ -265,16 +298,21 @@ def timed_steps(stepper, N, steps, warmup, barrier, world, dist, dev):
     return elapsed, m
 
 
+def whole_step_roofline(cfg, per_gpu_clouds_per_s, e=4):
+    """The whole step against SURVEY.md 8(d)'s fused-minimum HBM traffic (3x the forward's, e-byte activations)."""
+    min_bytes = 3 * fused_min_bytes_per_cloud(cfg["n_points"], cfg["n_neighbors"], cfg["layer_sizes"], cfg["n_classes"], e)
+    return {"bound": "hbm", "fused_min_bytes_per_cloud": min_bytes, "storage": "f32" if e == 4 else "bf16",
+            "achieved": round(per_gpu_clouds_per_s * min_bytes / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(per_gpu_clouds_per_s * min_bytes / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def step_rooflines(breakdown, B, value, world):
     """Path-level roofline figures from the instrumented pass: the whole step against the fused-minimum
     HBM traffic, the neighbour search two ways, and the matrix work per encoder level."""
-    N, K, layers, C = CFG["n_points"], CFG["n_neighbors"], CFG["layer_sizes"], CFG["n_classes"]
-    min_bytes = 3 * fused_min_bytes_per_cloud(N, K, layers, C, 4)
-    per_gpu = value / world
-    out = {"whole_step": {"bound": "hbm", "fused_min_bytes_per_cloud": min_bytes, "storage": "f32",
-                          "achieved": round(per_gpu * min_bytes / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(per_gpu * min_bytes / 1e9 / HBM_PEAK_GBS, 4),
-                          "launches_per_step": round(sum(k["launches_per_step"] for k in breakdown["kernels"].values()), 1)}}
+    layers = CFG["layer_sizes"]
+    ws = whole_step_roofline(CFG, value / world)
+    ws["launches_per_step"] = round(sum(k["launches_per_step"] for k in breakdown["kernels"].values()), 1)
+    out = {"whole_step": ws}
     rows = breakdown["all_shapes"]
     knn = [r for r in rows if r["op"].startswith("knn")]
     if knn:
@@ -311,7 +349,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary eval-forward measurement")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the config_A / strong_bs8 / bf16_operands objects")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config_A / strong_bs8 / bf16_operands / fp32_exact objects")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the config_S / config_Kt_shard objects")
     ap.add_argument("--batch", type=int, default=CFG["per_gpu_batch"], help="clouds per GPU (the metric's bs=8)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box)")
@@ -392,6 +431,40 @@ def main():
             bf16_ops["dtype"] = "f32 storage/accumulate, bf16 MFMA operands in the wide GEMMs (not the parity mode)"
         finally:
             _o.set_wide_gemm("bf16x3")
+    # ... and with the reference's own arithmetic: exact fp32 products in every kernel
+    fp32_exact = None
+    if not args.no_secondary and WIDE_GEMM == "bf16x3":
+        _o.set_wide_gemm("fp32")
+        try:
+            fp32_exact = secondary(B, "weak", "the metric's configuration with exact fp32 products in every kernel (RL_WIDE_GEMM=fp32)")
+            fp32_exact["dtype"] = "f32"
+            fp32_exact["whole_step"] = whole_step_roofline(CFG, fp32_exact["value"] / world)
+        finally:
+            _o.set_wide_gemm("bf16x3")
+
+    # the other single-GPU BASELINE.json configurations: their own model, a shorter window (they are not the metric)
+    def other_config(cfg, what):
+        m = build_model(dev, seed=0, cfg=cfg)
+        m.train()
+        Bc, Nc = cfg["per_gpu_batch"], cfg["n_points"]
+        st = TrainStep(m, Bc, Nc, loss="dice", lr=1e-2, use_graph=not args.no_graph, world_size=world)
+        xc, yc = synthetic_batch(Bc, Nc, cfg["n_classes"], 4321 + rank)
+        st.set_batch(torch.from_numpy(xc).to(dev), torch.from_numpy(yc).to(dev))
+        broadcast_flat(st.flat.param, world)
+        st.capture()
+        k = max(10, min(args.steps, 50))
+        el, mm = timed_steps(st, Nc, k, min(args.warmup, 5), barrier, world, dist, dev)
+        v = Bc * world * k / el
+        out = {"workload": what, "value": round(v, 3), "unit": "clouds/s", "per_gpu_batch": Bc, "global_batch": Bc * world,
+               "steps": k, "ms_per_step": round(1e3 * el / k, 3), "final_loss": round(mm["loss"], 5),
+               "whole_step": whole_step_roofline(cfg, v / world)}
+        del st, m
+        torch.cuda.empty_cache()
+        return out
+    config_s = config_kt = None
+    if not args.no_other_configs:
+        config_s = other_config(CFG_S, "BASELINE.json configs[3]: 65536 pts, 13 classes, 5 encoder layers [16,64,128,256,512], bs=8 per GPU")
+        config_kt = other_config(CFG_KT, "BASELINE.json configs[4] per-GPU shard: 122880 pts, 20 classes, 4 encoder layers, bs=2 per GPU")
 
     # secondary line: eval-mode forward clouds/s with the weights as trained so far, same batch shape
     infer = None
@@ -426,8 +499,10 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
+        is_metric_cfg = B == CFG["per_gpu_batch"]
         line = {
-            "metric": METRIC,
+            # BASELINE.json's metric string only for BASELINE.json's batch; any other --batch says so in the label
+            "metric": METRIC if is_metric_cfg else f"training clouds/sec, N=40960 pts, bs={B} per GPU (NOT BASELINE.json's bs=8 metric)",
             "value": round(value, 3),
             "unit": "clouds/s",
             "n_gpus": world,
@@ -440,7 +515,7 @@ def main():
             "dtype": "f32 storage/accumulate, bf16x3 MFMA in the wide GEMMs" if WIDE_GEMM == "bf16x3" else
                      ("f32" if WIDE_GEMM == "fp32" else "f32 storage/accumulate, bf16 MFMA in the wide GEMMs"),
             "data": "synthetic",
-            "config": {"workload": "RandLA-Net train step: 40960 pts/cloud, bs=8 per GPU, 2 classes, k=16, 4 encoder layers "
+            "config": {"workload": f"RandLA-Net train step: 40960 pts/cloud, bs={B} per GPU, 2 classes, k=16, 4 encoder layers "
                                    "[16,64,128,256], dice loss + Adam", "per_gpu_batch": B,
                        "global_batch": B * world, "parallelism": f"dp{world}", "graph": not args.no_graph,
                        "wide_gemm": WIDE_GEMM},
@@ -448,8 +523,15 @@ def main():
             "final_mIoU": round(metrics["mIoU"], 4),
             "roofline": roof,
             "cpu_baseline": cpu,
+            # the path-level figures once more at the top level (the driver's parser keeps flat keys only)
+            "whole_step": roof.get("whole_step") if roof else None,
+            "knn": roof.get("knn") if roof else None,
+            "mfma_by_level": roof.get("mfma_by_level") if roof else None,
             "config_A": config_a,
             "bf16_operands": bf16_ops,
+            "fp32_exact": fp32_exact,
+            "config_S": config_s,
+            "config_Kt_shard": config_kt,
             "strong_bs8": strong,
             "inference": infer,
         }

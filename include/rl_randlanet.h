@@ -560,11 +560,13 @@ int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t count, voi
  * (rows, C) tensor is kept iff philox(seed, key[0], e) >= p*2^32; kept values are scaled by 1/(1-p).  `key` is a
  * device scalar, so a captured graph draws a fresh mask per replay: rl_dropout_tick does counter[0] += 1 and copies
  * the new value to key_out[0]; forward and backward of one pass read the same key and regenerate the same mask (no
- * mask tensor).  rl_dropout_fwd also applies the producer's lazy BatchNorm + activation; dense rows (ld = C), C % 4 == 0. */
+ * mask tensor).  rl_dropout_fwd also applies the producer's lazy BatchNorm + activation; dense rows (ld = C), C % 4 == 0.
+ * `first_row`: index of row 0 in the tensor of the WHOLE batch - e = (first_row + r) * C + c - so that ranks holding
+ * shards of one batch draw the slices of ONE mask (0 for a single process). */
 int rl_dropout_tick(int64_t* counter, int64_t* key_out, void* stream);
 int rl_dropout_fwd(const float* src, const float* scale, const float* shift, int act, float slope, float* dst,
-                   int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream);
-int rl_dropout_bwd(float* G, int64_t rows, int C, const int64_t* key, uint64_t seed, float p, void* stream);
+                   int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, void* stream);
+int rl_dropout_bwd(float* G, int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, void* stream);
 
 /* UpSampler (modules.py:343-456) on channel-first features feat (B,F,N1) with neighbours
  * idx/d2 (B,N2,k) from rl_knn_i32: power 0 = nearest-neighbour interpolation (k = 1),

@@ -140,7 +140,7 @@ def attentive_pooling(P, name, x, training=False, buffers=None):
 def local_feature_aggregation(P, name, xyz, x, k, training=False, buffers=None, knn_fn=knn):
     """LocalFeatureAggregation.forward (modules.py:298-325)."""
     idx, d2 = knn_fn(xyz.contiguous(), xyz.contiguous(), k)
-    dist = torch.sqrt(d2)                                               # modules.py:149
+    dist = torch.sqrt(d2.to(xyz.dtype))                                 # modules.py:149
     kw = dict(training=training, buffers=buffers)
     f = shared_mlp(P, f"{name}.mlp1", x, act="lrelu", slope=0.2, **kw)
     r = shared_mlp(P, f"{name}.mlp_rpe1", relative_position_encoding(xyz, idx, dist), act="relu", **kw)
@@ -163,7 +163,7 @@ def upsample(features, xyz, xyz_up, approach="nni", knn_fn=knn):
         power = 2.0 if approach == "isdw" else 1.0
         k = 8
         idx, d2 = knn_fn(xyz.contiguous(), xyz_up.contiguous(), k)
-        dist = torch.sqrt(d2)
+        dist = torch.sqrt(d2.to(features.dtype))
         C = features.size(1)
         neigh = torch.gather(features.expand(-1, -1, -1, k), 2, idx.unsqueeze(1).expand(-1, C, -1, k))
         eps = 1e-7
@@ -186,7 +186,9 @@ def forward(P: Dict[str, torch.Tensor], inp: torch.Tensor, permutation: np.ndarr
     B, N, _ = inp.shape
     assert N >= min_points(layer_sizes, n_neighbors, decimation)
     kw = dict(training=training, buffers=buffers)
-    xyz = inp[..., :3].float()
+    # fp64 yardstick (tests only): float64 parameters + input run the same graph in double; the neighbour search still
+    # sees the fp32 coordinates (knn() casts), so the graph - indices and squared distances - is the fp32 one
+    xyz = inp[..., :3] if inp.dtype == torch.float64 else inp[..., :3].float()
     x = F.linear(inp, P["fc_start.weight"], P["fc_start.bias"]).transpose(-2, -1).unsqueeze(-1)
     x = F.leaky_relu(batch_norm(P, "bn_start.0", x, training, buffers), 0.2)
     perm = torch.from_numpy(np.asarray(permutation))

@@ -120,7 +120,7 @@ def _trainer_worker(rank, world, port, q):
         torch.manual_seed(7 + rank)                        # replicas start DIFFERENT: train() must broadcast
         np.random.seed(5)
         net = RandLANet(RandLANetSettings(n_classes=3, n_neighbors=8, layer_sizes=[8, 16, 32, 32]), torch.device("cpu"))
-        steps, evals = [], []
+        steps, evals, clouds_seen = [], [], []
 
         class State:
             def __init__(self, model, lr, world_):
@@ -138,6 +138,7 @@ def _trainer_worker(rank, world, port, q):
 
             def set_batch(self, inp, labels):
                 self.inp = inp
+                clouds_seen.append([int(round(float(v) * 1000.0 / (64 * 3))) for v in inp[:, 0, 0]])
 
             def step(self, perm):
                 assert self.B > 0, "a rank must never be handed an empty shard"
@@ -169,13 +170,22 @@ def _trainer_worker(rank, world, port, q):
         n = 64
         xyz = torch.arange(9 * n * 3, dtype=torch.float32).view(9, n, 3) / 1000.0
         ds = TensorDataset(xyz, torch.zeros(9, n, dtype=torch.int64), torch.arange(9))
-        loader = DataLoader(ds, batch_size=4, shuffle=False)               # batches of 4, 4 and ONE cloud (< world)
+        # batches of 4, 4 and ONE cloud (< world); SHUFFLED, and the ranks' torch streams differ (seed 7 + rank): the
+        # shards only partition a batch because train() makes the ranks share one seed per epoch
+        loader = DataLoader(ds, batch_size=4, shuffle=True)
         tr = T.Trainer(loader, loader, None, ["a", "b", "c"])
         seen = []
         out = tr.train(net, T.TrainingSettings(epochs=4, batch_size=4, early_stopping=True, early_stopping_patience=2),
                        callbacks=[lambda e, m: seen.append((e, m["val_mIoU"]))])
         assert out is net
         assert steps == [2, 2] * 4, steps                                   # 2 clouds per rank, the 1-cloud batch skipped everywhere
+        both_seen = [None] * world
+        dist.all_gather_object(both_seen, clouds_seen)
+        for step_i, (mine, theirs) in enumerate(zip(*both_seen)):           # every step: 4 DISTINCT clouds over the two ranks
+            assert len(set(mine) | set(theirs)) == 4, (step_i, mine, theirs)
+        for e in range(4):                                                  # every epoch: 8 distinct clouds trained on
+            ids = sum(both_seen[0][2 * e:2 * e + 2] + both_seen[1][2 * e:2 * e + 2], [])
+            assert len(set(ids)) == 8, (e, ids)
         # every rank followed rank 0's rising metric: 4 epochs, no early stop, same monitored values
         assert [e for e, _ in seen] == [1, 2, 3, 4] and np.allclose([v for _, v in seen], [0.1, 0.2, 0.3, 0.4])
         # replicas and their BatchNorm buffers are identical on all ranks when validation starts and at the end

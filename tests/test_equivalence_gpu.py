@@ -13,17 +13,17 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 CFG = dict(n_classes=3, n_points=1024, n_neighbors=16, layer_sizes=[8, 16, 32, 32])
-B, N = 4, 1024
+N = 1024
 
 
-def _data():
+def _data(B):
     rs = np.random.RandomState(11)
     xyz = rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
     lab = np.clip(np.floor(xyz[..., 2] * 3), 0, 2).astype(np.int64)
     return torch.from_numpy(xyz), torch.from_numpy(lab)
 
 
-def _one_step(world, rank, sync):
+def _one_step(world, rank, sync, B=4, p_drop=0.0):
     """Gradients (flat), loss and BatchNorm buffers after ONE forward + backward on this rank's shard."""
     from randlanet import _ops as ops
     from randlanet._train import TrainStep, shard_range
@@ -31,9 +31,9 @@ def _one_step(world, rank, sync):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     net = RandLANet(RandLANetSettings(**CFG), dev)
-    net.fc_end[2].p = 0.0
+    net.fc_end[2].p = p_drop
     net.train()
-    x, y = _data()
+    x, y = _data(B)
     part = shard_range(B, rank, world)
     st = TrainStep(net, len(part), N, loss="dice", use_graph=False, world_size=world,
                    sync=ops.SyncGroup(world, staged=True) if sync else None)
@@ -50,7 +50,7 @@ def _one_step(world, rank, sync):
         [(n, p.numel()) for n, p in net.named_parameters()]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, B, p_drop):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (repo, os.path.join(repo, "3d_recognizer_amd")):
@@ -59,7 +59,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        grad, loss, counts, bufs, _ = _one_step(world, rank, True)
+        grad, loss, counts, bufs, _ = _one_step(world, rank, True, B, p_drop)
         q.put((rank, "ok", grad.numpy(), loss, counts.numpy(), {k: v.numpy() for k, v in bufs.items()}))
     except Exception:  # pragma: no cover
         import traceback
@@ -69,7 +69,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step():
+@pytest.mark.parametrize("B,p_drop", [
+    (4, 0.0),
+    (5, 0.5),      # shards of 3 and 2 clouds (global row counts are exchanged, not rows * world) and Dropout(0.5) ON: the
+                   # ranks draw the slices of the whole batch's Philox mask (rl_dropout_* first_row)
+])
+def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step(B, p_drop):
     world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -77,7 +82,7 @@ def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, B, p_drop)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
@@ -85,7 +90,7 @@ def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step():
         p.join(30)
     for r in res:
         assert r[1] == "ok", f"rank {r[0]}: {r[1]}"
-    ref_grad, ref_loss, ref_counts, ref_bufs, layout = _one_step(1, 0, False)      # the whole batch, one process
+    ref_grad, ref_loss, ref_counts, ref_bufs, layout = _one_step(1, 0, False, B, p_drop)      # the whole batch, one process
     g0, g1 = torch.from_numpy(res[0][2]), torch.from_numpy(res[1][2])
     assert torch.equal(g0, g1), "ranks disagree after the gradient all-reduce"
     # the loss and the metric counts are those of the global batch, identical on both ranks
@@ -106,8 +111,8 @@ def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step():
     for k, v in ref_bufs.items():
         assert np.allclose(res[0][5][k], v.numpy(), rtol=1e-5, atol=1e-6), k
         assert np.array_equal(res[0][5][k], res[1][5][k]), k
-    print(f"equivalence mode: worst relative gradient difference {worst:.2e}, loss {res[0][3]:.7f} vs {ref_loss:.7f}")
+    print(f"equivalence mode (B={B}, Dropout {p_drop}): worst relative gradient difference {worst:.2e}, loss {res[0][3]:.7f} vs {ref_loss:.7f}")
 
     # WITHOUT the mode the sharded step is a different (standard DDP) computation: per-replica statistics and dice
-    plain = _one_step(1, 0, False)[0]
+    plain = _one_step(1, 0, False, B, p_drop)[0]
     assert torch.equal(plain, ref_grad)                  # and the single-process step is bitwise reproducible

@@ -124,32 +124,79 @@ def test_training_is_bitwise_reproducible(golden_dir):
     assert not np.array_equal(h1, h3)                 # other seeds: another run
 
 
+@pytest.mark.parametrize("tag,C,names", [("k16c3", 3, ["bg", "a", "b"]), ("k32c2", 2, ["bg", "tip"])])
+def test_same_weights_evaluation_matches_reference(golden_dir, tag, C, names):
+    """north_star: "mIoU within 0.1 pt of the reference on the held-out mock set" - stated where it is resolvable.
+
+    tests/golden/ref_trained_<tag>.zip was trained (40 epochs) and saved by the REFERENCE; eval_parity.npz holds the
+    reference's own Model.evaluate on the 4 held-out sub-samples (10 seeded passes, trainer.py:271-367; per-batch means
+    metrics.py:149-151; pass means metrics.py:239-242) for batch sizes 16 / 4 / 1 and with the full-resolution
+    post-processing.  Evaluation is deterministic on both sides, so the same weights must give the same numbers:
+    every metric - loss, OA, mAcc, mIoU, every per-class IoU, and their standard deviations over the passes - within 0.001."""
+    import json
+    from randlanet import Model
+    z = np.load(f"{golden_dir}/eval_parity.npz")
+    run = np.load(f"{golden_dir}/train_run.npz")
+    data = [(xyz, np.zeros((xyz.shape[0], 0), np.float32), np.minimum(lab.astype(np.int64), C - 1))
+            for xyz, lab in zip(run["clouds"], run["labels"])]
+    val = data[8:]
+    model = Model.load(Path(golden_dir) / f"ref_trained_{tag}.zip")
+    assert model.device.type == "cuda"
+    keys = json.loads(str(z[f"{tag}/keys"]))
+    assert keys == ["loss", "OA", "mAcc", "mIoU"] + [f"{n} IoU" for n in names]
+    worst = 0.0
+    for bs in (16, 4, 1):
+        got = model.evaluate(val, names, batch_size=bs, include_stdev=True)
+        assert list(got.keys()) == keys
+        ref = z[f"{tag}/eval_bs{bs}"]                       # (n_metrics, 2): mean, stdev over the passes
+        for k, (m_ref, s_ref) in zip(keys, ref):
+            m, s = got[k]
+            worst = max(worst, abs(m - m_ref)) if k != "loss" else worst
+            assert abs(m - m_ref) <= 1e-3, (tag, bs, k, m, m_ref)
+            assert abs(s - s_ref) <= 1e-3, (tag, bs, k, s, s_ref)
+        print(f"[mIoU parity] {tag} batch {bs}: mIoU hip {got['mIoU'][0]:.5f} vs reference {ref[3, 0]:.5f}; "
+              + ", ".join(f"{k} {got[k][0]:.5f}/{r[0]:.5f}" for k, r in zip(keys[4:], ref[4:])))
+    got = model.evaluate(val, names, batch_size=1, postprocess=True)
+    ref = z[f"{tag}/eval_post_bs1"]
+    for k, m_ref in zip(keys, ref):
+        # full-resolution nni up-sampling: a real depth cloud has exact-distance ties (SURVEY 8a-3), so a handful of the
+        # 3000 points may take their label from another equally-near sample than the reference's kd-tree order picked
+        assert abs(got[k] - m_ref) <= 1e-3, (tag, "postprocess", k, got[k], m_ref)
+    print(f"[mIoU parity] {tag} post-processed (3000-point clouds): mIoU hip {got['mIoU']:.5f} vs reference {ref[3]:.5f}; "
+          f"worst metric difference without post-processing {worst:.2e}")
+
+
 def test_miou_parity_over_seeds(golden_dir):
     """north_star: validation mIoU parity with the reference on the held-out mock set.
 
-    tests/golden/train_seeds.npz holds the REFERENCE trainer's G6 run for 64 (torch, numpy) seed pairs.  One run's
+    tests/golden/train_seeds.npz / train_seeds2.npz hold the REFERENCE trainer's G6 run for 2 x 64 (torch, numpy) seed pairs.  One run's
     final val mIoU is a noisy number in the reference itself (std over seeds ~0.1: BatchNorm momentum 0.99,
     modules.py:87, makes the running statistics those of the last batch; 6 epochs of 2 steps), so parity is a statement
     about distributions: the HIP path runs the same seeds and
         |mean_hip - mean_ref| <= max(0.001, 2 * SE_ref)
     must hold for the final val mIoU, the best val mIoU (what Trainer.train keeps, trainer.py:158) and the mean over the
     last three epochs; the paired differences and both distributions are printed."""
-    z = np.load(f"{golden_dir}/train_seeds.npz")
-    seeds, ref_h = z["seeds"], z["histories"]                 # (S,), (S, 6, 4): loss, mIoU, val_loss, val_mIoU
+    sets = [np.load(f"{golden_dir}/{f}") for f in ("train_seeds.npz", "train_seeds2.npz")]     # seeds 0..63 and 64..127
+    seeds = np.concatenate([z["seeds"] for z in sets])
+    ref_h = np.concatenate([z["histories"] for z in sets])    # (S, 6, 4): loss, mIoU, val_loss, val_mIoU
     hip_h = np.stack([_mock_training_run(golden_dir, int(s))[2] for s in seeds])
-    S = len(seeds)
 
     def stat(h):
         v = h[:, :, 3]
         return {"final": v[:, -1], "best": v.max(1), "last3": v[:, -3:].mean(1)}
-    r, g = stat(ref_h), stat(hip_h)
-    for key in ("final", "best", "last3"):
-        se = r[key].std(ddof=1) / np.sqrt(S)
-        diff = g[key] - r[key]
-        print(f"val mIoU [{key}] over {S} seeds: reference {r[key].mean():.4f} +- {r[key].std(ddof=1):.4f} (SE {se:.4f}), "
-              f"hip {g[key].mean():.4f} +- {g[key].std(ddof=1):.4f}; paired difference {diff.mean():+.4f} "
-              f"(SE {diff.std(ddof=1) / np.sqrt(S):.4f}, max |d| {np.abs(diff).max():.4f})")
-        assert abs(g[key].mean() - r[key].mean()) <= max(0.001, 2 * se), key
+    # the first set alone showed the HIP mean above the reference's on "final" and "last3" (+0.018 / +0.016, 1.5 / 1.8
+    # sigma of the paired difference): the second, independent set and the pooled 128 say whether that is a property
+    for label, sel in (("seeds 0-63", slice(0, 64)), ("seeds 64-127", slice(64, 128)), ("all 128 seeds", slice(0, 128))):
+        r, g = stat(ref_h[sel]), stat(hip_h[sel])
+        S = len(r["final"])
+        for key in ("final", "best", "last3"):
+            se = r[key].std(ddof=1) / np.sqrt(S)
+            diff = g[key] - r[key]
+            dse = diff.std(ddof=1) / np.sqrt(S)
+            print(f"val mIoU [{key}] over {label}: reference {r[key].mean():.4f} +- {r[key].std(ddof=1):.4f} (SE {se:.4f}), "
+                  f"hip {g[key].mean():.4f} +- {g[key].std(ddof=1):.4f}; paired difference {diff.mean():+.4f} "
+                  f"(SE {dse:.4f}, {diff.mean() / dse:+.2f} sigma, max |d| {np.abs(diff).max():.4f})")
+            assert abs(g[key].mean() - r[key].mean()) <= max(0.001, 2 * se), (label, key)
     # the training loss is not noisy: every seed's first epoch (two Adam steps from identical weights) within 5e-3,
     # and the seed-mean loss trajectory within 0.01 at every epoch
     np.testing.assert_allclose(hip_h[:, 0, 0], ref_h[:, 0, 0], atol=5e-3)
