@@ -63,18 +63,39 @@ def _yardstick(tag, mode, grads_hip, g32, g64):
     The fp32 oracle's own distance from fp64 measures how ill-conditioned the test point is; the exact-product mode must
     sit within a small multiple of it, the bf16x3 mode (2^-16 instead of 2^-24 per product) within the multiple its unit
     round-off buys.  Returns the worst ratio for the printed record."""
-    worst, worst_name = 0.0, ""
+    worst, worst_name, cond = 0.0, "", 0.0
     for name, g in grads_hip.items():
         r64 = g64[name]
+        scale = float(r64.abs().max())
         e_hip = float((g.double() - r64).abs().max())
         e_32 = float((g32[name].double() - r64).abs().max())
-        ratio = e_hip / max(e_32, 1e-12)
-        if e_hip > 2e-5 and ratio > worst:
+        floor = 1e-5 * scale + 1e-8            # (a bias in front of a BatchNorm: true gradient 0, see _zero_gradient)
+        if _zero_gradient(name):
+            continue
+        cond = max(cond, e_32 / max(scale, 1e-30))
+        ratio = e_hip / max(e_32, 1e-30)
+        if e_hip > floor and ratio > worst:
             worst, worst_name = ratio, name
-        assert e_hip <= YARD[mode] * e_32 + 2e-5, (tag, mode, name, e_hip, e_32)
-    print(f"[fp64 yardstick] {tag} {mode}: worst |g_hip - g64| / |g_oracle32 - g64| = {worst:.2f} ({worst_name or 'all below 2e-5'}); "
-          f"bound {YARD[mode]:g}")
+        assert e_hip <= YARD[mode] * e_32 + floor, (tag, mode, name, e_hip, e_32, scale)
+    print(f"[fp64 yardstick] {tag} {mode}: worst |g_hip - g64| / |g_oracle32 - g64| = {worst:.2f} ({worst_name or 'all at the floor'}); "
+          f"bound {YARD[mode]:g}; the fp32 oracle itself sits up to {cond:.1e} (relative) from fp64")
     return worst
+
+
+def _zero_gradient(name):
+    """A conv bias in front of a BatchNorm cancels in (y - mean): its true gradient is exactly 0 and what either side holds
+    is rounding noise of sums over up to 5 M rows."""
+    return name.endswith("conv.bias") and not name.startswith("fc_end.3")
+
+
+def _check_gradient(ctx, name, g, r, bound):
+    e, scale = float((g - r).abs().max()), float(r.abs().max())
+    if _zero_gradient(name):
+        # both are noise around 0: ours must not be noisier than a few times the oracle's
+        assert float(g.abs().max()) <= 4.0 * scale + 2e-5, ctx + (name, float(g.abs().max()), scale)
+        return 0.0
+    assert e < bound * scale + 2e-5, ctx + (name, e, scale)
+    return e / scale if scale > 1e-4 else 0.0
 
 
 @pytest.mark.parametrize("tag,C,N,K,layers,B", [
@@ -119,13 +140,7 @@ def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, laye
             worst = 0.0
             hip_grads = {name: st.flat.grads[name].cpu() for name, _ in net.named_parameters()}
             for name, g in hip_grads.items():
-                r = g32[name]
-                scale = float(r.abs().max())
-                e = float((g - r).abs().max())
-                if scale > 1e-4:
-                    worst = max(worst, e / scale)
-                # conv biases in front of a BatchNorm have a zero true gradient: rounding noise on both sides
-                assert e < GRAD_BOUND[mode] * scale + 2e-5, (tag, mode, name, e, scale)
+                worst = max(worst, _check_gradient((tag, mode), name, g, g32[name], GRAD_BOUND[mode]))
             if g64 is not None:
                 _yardstick(f"config {tag} B={B}", mode, hip_grads, g32, g64)
             # train-mode logits (batch statistics) through the module surface, same permutation
@@ -191,12 +206,7 @@ def test_train_step_k32_matches_oracle_autograd():
             worst = 0.0
             hip_grads = {name: p.grad.cpu() for name, p in net.named_parameters()}
             for name, g in hip_grads.items():
-                r = g32[name]
-                e, scale = float((g - r).abs().max()), float(r.abs().max())
-                if scale > 1e-4:
-                    worst = max(worst, e / scale)
-                # conv biases in front of a BatchNorm have a zero true gradient: rounding noise on both sides
-                assert e < GRAD_BOUND[mode] * scale + 2e-5, (mode, name, e, scale)
+                worst = max(worst, _check_gradient((mode,), name, g, g32[name], GRAD_BOUND[mode]))
             _yardstick("K=32", mode, hip_grads, g32, g64)
             print(f"[train parity] K=32 config, {mode}: worst relative gradient error {worst:.2e} (bound {GRAD_BOUND[mode]:g})")
     finally:
