@@ -63,7 +63,7 @@ def _yardstick(tag, mode, grads_hip, g32, g64):
     The fp32 oracle's own distance from fp64 measures how ill-conditioned the test point is; the exact-product mode must
     sit within a small multiple of it, the bf16x3 mode (2^-16 instead of 2^-24 per product) within the multiple its unit
     round-off buys.  Returns the worst ratio for the printed record."""
-    worst, worst_name, cond = 0.0, "", 0.0
+    worst, worst_name, cond, table = 0.0, "", 0.0, []
     for name, g in grads_hip.items():
         r64 = g64[name]
         scale = float(r64.abs().max())
@@ -72,11 +72,22 @@ def _yardstick(tag, mode, grads_hip, g32, g64):
         floor = 1e-5 * scale + 1e-8            # (a bias in front of a BatchNorm: true gradient 0, see _zero_gradient)
         if _zero_gradient(name):
             continue
-        cond = max(cond, e_32 / max(scale, 1e-30))
+        if scale > 1e-12:
+            cond = max(cond, e_32 / scale)
         ratio = e_hip / max(e_32, 1e-30)
+        table.append((ratio if e_hip > floor else 0.0, name, e_hip / max(scale, 1e-30), e_32 / max(scale, 1e-30)))
         if e_hip > floor and ratio > worst:
             worst, worst_name = ratio, name
-        assert e_hip <= YARD[mode] * e_32 + floor, (tag, mode, name, e_hip, e_32, scale)
+    for ratio, name, rh, r32 in sorted(table, reverse=True)[:6]:
+        print(f"    {name:42s} |g_hip-g64|/scale {rh:.2e}   |g_oracle32-g64|/scale {r32:.2e}   ratio {ratio:9.1f}")
+    for name, g in grads_hip.items():
+        if _zero_gradient(name):
+            continue
+        r64 = g64[name]
+        scale = float(r64.abs().max())
+        e_hip = float((g.double() - r64).abs().max())
+        e_32 = float((g32[name].double() - r64).abs().max())
+        assert e_hip <= YARD[mode] * e_32 + 1e-5 * scale + 1e-8, (tag, mode, name, e_hip, e_32, scale)
     print(f"[fp64 yardstick] {tag} {mode}: worst |g_hip - g64| / |g_oracle32 - g64| = {worst:.2f} ({worst_name or 'all at the floor'}); "
           f"bound {YARD[mode]:g}; the fp32 oracle itself sits up to {cond:.1e} (relative) from fp64")
     return worst

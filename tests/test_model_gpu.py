@@ -184,6 +184,12 @@ def test_miou_parity_over_seeds(golden_dir):
     def stat(h):
         v = h[:, :, 3]
         return {"final": v[:, -1], "best": v.max(1), "last3": v[:, -3:].mean(1)}
+    # where along the run the two part: per epoch, the paired difference of every recorded quantity over all seeds
+    for col, what in enumerate(("train loss", "train mIoU", "val loss", "val mIoU")):
+        d = hip_h[:, :, col] - ref_h[:, :, col]
+        print(f"paired difference per epoch, {what:10s}: " + "  ".join(
+            f"{d[:, e].mean():+.4f} ({d[:, e].mean() / (d[:, e].std(ddof=1) / np.sqrt(len(d))):+.1f}s, |d|max {np.abs(d[:, e]).max():.3f})"
+            for e in range(d.shape[1])))
     # the first set alone showed the HIP mean above the reference's on "final" and "last3" (+0.018 / +0.016, 1.5 / 1.8
     # sigma of the paired difference): the second, independent set and the pooled 128 say whether that is a property
     for label, sel in (("seeds 0-63", slice(0, 64)), ("seeds 64-127", slice(64, 128)), ("all 128 seeds", slice(0, 128))):
