@@ -44,25 +44,45 @@ def test_full_size_eval_logits_match_oracle(tag, C, N, K, layers):
     assert torch.equal(logits.argmax(1), ref.argmax(1)) or float((logits.argmax(1) != ref.argmax(1)).float().mean()) < 1e-4
 
 
-def _oracle_step(sd, x, y, perm, layers, K, dtype=torch.float32):
+def _oracle_step(sd, x, y, perm, layers, K, dtype=torch.float32, wide_noise=0.0, noise_seed=0):
     """The oracle's train-mode forward + dice + autograd in `dtype` (float64 = the yardstick the fp32 oracle's own rounding
-    is measured against): (logits, loss, {name: gradient})."""
+    is measured against): (logits, loss, {name: gradient}).  wide_noise > 0: every output of a layer wider than 64 channels
+    (the layers the bf16x3 kernels compute) gets independent relative noise of that size (x its rms) in the FORWARD - an
+    exact evaluation of the function at operands perturbed the way a 2^-17-per-product arithmetic perturbs them."""
     from oracle import randlanet_oracle as O
     from oracle.loss_metrics_oracle import loss_by_name
     P = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
              else (v.to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
-    ref = O.forward(P, torch.from_numpy(x).to(dtype), perm, layer_sizes=layers, n_neighbors=K, training=True, dropout_p=0.0)
-    loss = loss_by_name("dice", ref, torch.from_numpy(y))
-    loss.backward()
+    conv2d, linear, convT = O.F.conv2d, O.F.linear, O.F.conv_transpose2d
+    gen = torch.Generator().manual_seed(noise_seed)
+
+    def noisy(fn):
+        def f(inp, w, b=None, *a, **k):
+            out = fn(inp, w, b, *a, **k)
+            if max(w.shape[0], w.shape[1]) > 64:
+                out = out + wide_noise * out.detach().pow(2).mean().sqrt() * torch.randn(out.shape, generator=gen, dtype=out.dtype)
+            return out
+        return f
+    if wide_noise > 0.0:
+        O.F.conv2d, O.F.linear, O.F.conv_transpose2d = noisy(conv2d), noisy(linear), noisy(convT)
+    try:
+        ref = O.forward(P, torch.from_numpy(x).to(dtype), perm, layer_sizes=layers, n_neighbors=K, training=True, dropout_p=0.0)
+        loss = loss_by_name("dice", ref, torch.from_numpy(y))
+        loss.backward()
+    finally:
+        O.F.conv2d, O.F.linear, O.F.conv_transpose2d = conv2d, linear, convT
     return ref.detach(), float(loss.detach()), {k: v.grad for k, v in P.items() if v.requires_grad}, P
 
 
 def _yardstick(tag, mode, grads_hip, g32, g64):
     """The gradient bound stated against an fp64 evaluation of the same function: per tensor,
-        |g_hip - g_64| <= YARD[mode] * |g_oracle32 - g_64| + 2e-5     (max norms).
-    The fp32 oracle's own distance from fp64 measures how ill-conditioned the test point is; the exact-product mode must
-    sit within a small multiple of it, the bf16x3 mode (2^-16 instead of 2^-24 per product) within the multiple its unit
-    round-off buys.  Returns the worst ratio for the printed record."""
+        |g_hip - g_64| <= 4 * |g_yard - g_64| + 1e-5 * scale + 1e-8     (max norms)
+    where g_yard is, for the exact-product mode, the fp32 CPU oracle (same unit round-off: its own distance from fp64 says
+    how ill-conditioned the test point is), and for bf16x3 (2^-17 per product; the kernels measure 2-5e-5 max / ~5e-6 rms
+    of the output's rms, tools/precision_probe.py) an EXACT fp64 evaluation whose wide-layer outputs carry 5e-6 relative
+    noise in the forward (_oracle_step(wide_noise=5e-6), worst of two draws).  The response of these random-weight points
+    to such noise is far from linear (K = 32 point, fp64: noise 1e-7 -> 6e-7 of a gradient's scale, 1e-6 -> 2e-3,
+    1e-5 -> 0.5), which is why a multiple of the fp32 oracle's distance cannot serve for both modes."""
     worst, worst_name, cond, table = 0.0, "", 0.0, []
     for name, g in grads_hip.items():
         r64 = g64[name]
@@ -87,10 +107,17 @@ def _yardstick(tag, mode, grads_hip, g32, g64):
         scale = float(r64.abs().max())
         e_hip = float((g.double() - r64).abs().max())
         e_32 = float((g32[name].double() - r64).abs().max())
-        assert e_hip <= YARD[mode] * e_32 + 1e-5 * scale + 1e-8, (tag, mode, name, e_hip, e_32, scale)
+        assert e_hip <= YARD * e_32 + 1e-5 * scale + 1e-8, (tag, mode, name, e_hip, e_32, scale)
     print(f"[fp64 yardstick] {tag} {mode}: worst |g_hip - g64| / |g_oracle32 - g64| = {worst:.2f} ({worst_name or 'all at the floor'}); "
-          f"bound {YARD[mode]:g}; the fp32 oracle itself sits up to {cond:.1e} (relative) from fp64")
+          f"bound {YARD:g}; the yardstick itself sits up to {cond:.1e} (relative) from fp64")
     return worst
+
+
+def _noisy_yard(sd, x, y, perm, layers, K, g64):
+    """Per tensor, the draw (of two) of the noisy fp64 evaluation that lies further from the clean one."""
+    a = _oracle_step(sd, x, y, perm, layers, K, torch.float64, WIDE_NOISE, 1)[2]
+    b = _oracle_step(sd, x, y, perm, layers, K, torch.float64, WIDE_NOISE, 2)[2]
+    return {k: (a[k] if float((a[k] - g64[k]).abs().max()) >= float((b[k] - g64[k]).abs().max()) else b[k]) for k in g64}
 
 
 def _zero_gradient(name):
@@ -133,7 +160,10 @@ def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, laye
     y = np.where(inside, np.clip(1 + np.floor((C - 1) * x[..., 2]).astype(np.int64), 1, C - 1), 0).astype(np.int64)
     perm = np.random.RandomState(9).permutation(N)
     ref, ref_loss, g32, P = _oracle_step(sd, x, y, perm, layers, K)
-    g64 = _oracle_step(sd, x, y, perm, layers, K, torch.float64)[2] if (tag, B) == ("A", 4) else None
+    g64 = gyard = None
+    if (tag, B) == ("A", 4):
+        g64 = _oracle_step(sd, x, y, perm, layers, K, torch.float64)[2]
+        gyard = {"fp32": g32, "bf16x3": _noisy_yard(sd, x, y, perm, layers, K, g64)}
     modes = ["bf16x3", "fp32"] if tag == "A" else ["bf16x3"]
     default = ops.get_wide_gemm()
     try:
@@ -153,7 +183,7 @@ def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, laye
             for name, g in hip_grads.items():
                 worst = max(worst, _check_gradient((tag, mode), name, g, g32[name], GRAD_BOUND[mode]))
             if g64 is not None:
-                _yardstick(f"config {tag} B={B}", mode, hip_grads, g32, g64)
+                _yardstick(f"config {tag} B={B}", mode, hip_grads, gyard[mode], g64)
             # train-mode logits (batch statistics) through the module surface, same permutation
             net.load_state_dict(sd)
             np.random.seed(0)
@@ -179,9 +209,10 @@ def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, laye
 # to 3.3 % (1e-6: 4e-5 and 0.13 %; measured at the K = 32 point below).  So bf16x3 gradients are bounded by 3e-2 of each
 # tensor's largest entry - the sensitivity of the function, not an arithmetic defect - while loss and logits keep 1e-5 / 1e-3.
 GRAD_BOUND = {"fp32": 5e-3, "bf16x3": 3e-2}
-# ... and the same statement made properly, against an fp64 evaluation of the oracle (_yardstick): the multiple of the fp32
-# oracle's own distance from fp64 that a tensor's gradient may sit at.
-YARD = {"fp32": 4.0, "bf16x3": 256.0}
+# ... and the same statement made properly, against an fp64 evaluation of the oracle (_yardstick): the multiple of the
+# yardstick's own distance from fp64 that a tensor's gradient may sit at.
+YARD = 4.0
+WIDE_NOISE = 5e-6
 
 
 def test_train_step_k32_matches_oracle_autograd():
@@ -201,6 +232,7 @@ def test_train_step_k32_matches_oracle_autograd():
     perm = np.random.permutation(N)
     ref, ref_loss, g32, P = _oracle_step(sd, x, y, perm, layers, K)
     g64 = _oracle_step(sd, x, y, perm, layers, K, torch.float64)[2]
+    gyard = {"fp32": g32, "bf16x3": _noisy_yard(sd, x, y, perm, layers, K, g64)}
     default = ops.get_wide_gemm()
     try:
         for mode in ("fp32", "bf16x3"):
@@ -218,7 +250,7 @@ def test_train_step_k32_matches_oracle_autograd():
             hip_grads = {name: p.grad.cpu() for name, p in net.named_parameters()}
             for name, g in hip_grads.items():
                 worst = max(worst, _check_gradient((mode,), name, g, g32[name], GRAD_BOUND[mode]))
-            _yardstick("K=32", mode, hip_grads, g32, g64)
+            _yardstick("K=32", mode, hip_grads, gyard[mode], g64)
             print(f"[train parity] K=32 config, {mode}: worst relative gradient error {worst:.2e} (bound {GRAD_BOUND[mode]:g})")
     finally:
         ops.set_wide_gemm(default)
