@@ -59,7 +59,9 @@ def _oracle_step(sd, x, y, perm, layers, K, dtype=torch.float32, wide_noise=0.0,
     def noisy(fn):
         def f(inp, w, b=None, *a, **k):
             out = fn(inp, w, b, *a, **k)
-            if max(w.shape[0], w.shape[1]) > 64:
+            # layers the bf16x3 kernels compute: everything wider than 64 channels, and every attention score Linear
+            # (d x d, d >= 16: with 16 neighbours those run inside the fused tile kernels, bf16x3 as well)
+            if max(w.shape[0], w.shape[1]) > 64 or (fn is linear and w.shape[1] >= 16):
                 out = out + wide_noise * out.detach().pow(2).mean().sqrt() * torch.randn(out.shape, generator=gen, dtype=out.dtype)
             return out
         return f
