@@ -47,8 +47,9 @@ def test_full_size_eval_logits_match_oracle(tag, C, N, K, layers):
 def _oracle_step(sd, x, y, perm, layers, K, dtype=torch.float32, wide_noise=0.0, noise_seed=0):
     """The oracle's train-mode forward + dice + autograd in `dtype` (float64 = the yardstick the fp32 oracle's own rounding
     is measured against): (logits, loss, {name: gradient}).  wide_noise > 0: every output of a layer wider than 64 channels
-    (the layers the bf16x3 kernels compute) gets independent relative noise of that size (x its rms) in the FORWARD - an
-    exact evaluation of the function at operands perturbed the way a 2^-17-per-product arithmetic perturbs them."""
+    (the layers the bf16x3 kernels compute) gets independent relative noise of that size (x its rms), and so does the
+    gradient arriving at it in the backward - an exact evaluation of the function with the products of those layers
+    (forward, input gradient, weight gradient) perturbed the way a 2^-17-per-product arithmetic perturbs them."""
     from oracle import randlanet_oracle as O
     from oracle.loss_metrics_oracle import loss_by_name
     P = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
@@ -56,13 +57,24 @@ def _oracle_step(sd, x, y, perm, layers, K, dtype=torch.float32, wide_noise=0.0,
     conv2d, linear, convT = O.F.conv2d, O.F.linear, O.F.conv_transpose2d
     gen = torch.Generator().manual_seed(noise_seed)
 
+    class Noise(torch.autograd.Function):
+        """y = x + noise in the forward, and the same relative noise on the gradient coming back: the layer's forward
+        product, and its input / weight gradient products, all computed with a relative error of `wide_noise`."""
+        @staticmethod
+        def forward(ctx, t):
+            return t + wide_noise * t.pow(2).mean().sqrt() * torch.randn(t.shape, generator=gen, dtype=t.dtype)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g + wide_noise * g.pow(2).mean().sqrt() * torch.randn(g.shape, generator=gen, dtype=g.dtype)
+
     def noisy(fn):
         def f(inp, w, b=None, *a, **k):
             out = fn(inp, w, b, *a, **k)
             # layers the bf16x3 kernels compute: everything wider than 64 channels, and every attention score Linear
             # (d x d, d >= 16: with 16 neighbours those run inside the fused tile kernels, bf16x3 as well)
             if max(w.shape[0], w.shape[1]) > 64 or (fn is linear and w.shape[1] >= 16):
-                out = out + wide_noise * out.detach().pow(2).mean().sqrt() * torch.randn(out.shape, generator=gen, dtype=out.dtype)
+                out = Noise.apply(out)
             return out
         return f
     if wide_noise > 0.0:
@@ -82,7 +94,7 @@ def _yardstick(tag, mode, grads_hip, g32, g64):
     where g_yard is, for the exact-product mode, the fp32 CPU oracle (same unit round-off: its own distance from fp64 says
     how ill-conditioned the test point is), and for bf16x3 (2^-17 per product; the kernels measure 2-5e-5 max / ~5e-6 rms
     of the output's rms, tools/precision_probe.py) an EXACT fp64 evaluation whose wide-layer outputs carry 5e-6 relative
-    noise in the forward (_oracle_step(wide_noise=5e-6), worst of two draws).  The response of these random-weight points
+    noise, forward and backward (_oracle_step(wide_noise=5e-6), worst of two draws).  The response of these random-weight points
     to such noise is far from linear (K = 32 point, fp64: noise 1e-7 -> 6e-7 of a gradient's scale, 1e-6 -> 2e-3,
     1e-5 -> 0.5), which is why a multiple of the fp32 oracle's distance cannot serve for both modes."""
     worst, worst_name, cond, table = 0.0, "", 0.0, []
