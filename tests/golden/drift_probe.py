@@ -14,7 +14,12 @@ train_seeds.npz; paired difference against the unmodified reference runs stored 
 "de-noised" reference moves up by what separates the HIP path from the reference (+0.02 val mIoU, -0.02 val loss) and
 its training loss does not move.
 
-Usage:  python tests/golden/drift_probe.py [n_seeds]     -> prints the paired differences per epoch
+Usage:  python tests/golden/drift_probe.py [n_seeds]     -> prints the paired differences per epoch and writes
+        train_seeds_denoised.npz (the de-noised reference's histories; tests/test_model_gpu.py brackets the HIP path
+        between the reference and this)
+
+Result (64 seeds): training loss unchanged (|d| <= 3e-4 at every epoch); validation loss -0.027 ... -0.044 (2.7 - 4.8 sigma),
+validation mIoU +0.02 ... +0.04 (up to 4.2 sigma).  The HIP path sits between the two (+0.02 over 128 seeds).
 """
 import os
 import sys
@@ -62,7 +67,7 @@ def main(n_seeds=64):
         hists.append(hist)
         print(f"seed {seed}: val_mIoU {np.round(np.array(hist)[:, 3], 4).tolist()}", flush=True)
     h = np.array(hists)
-    np.save("/tmp/drift_probe_histories.npy", h)
+    np.savez_compressed(os.path.join(HERE, "train_seeds_denoised.npz"), seeds=np.arange(n_seeds), histories=h)
     for col, what in enumerate(("train loss", "train mIoU", "val loss", "val mIoU")):
         d = h[:, :, col] - ref[:, :, col]
         print(f"de-noised reference - reference, per epoch, {what:10s}: " + "  ".join(
