@@ -394,7 +394,7 @@ struct SegParams {
 };
 
 // tpr = C/4 lanes (a power of two <= 64... or 128/256 for wider rows) share one destination row, 16 bytes each
-template <int TPR>
+template <int TPR, bool SB = false>     // SB: the source rows are stored as bf16 (bf16-storage mode), sums and dst stay fp32
 __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p) {
     constexpr int RPW = 256 / TPR;      // destination rows in flight per workgroup
     const int q = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p)
         const int* off = p.offsets + (long)b * (p.n_dst + 1);
         const int s0 = off[j], s1 = off[j + 1];
         const int* ent = p.entries + (long)b * p.per;
-        const float* sb = p.src + (long)b * p.src_bstride * p.lds;
+        const long sb = (long)b * p.src_bstride * p.lds;       // element offset of the cloud's first source row
         for (int c = q * 4; c < p.C; c += TPR * 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = s0;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p)
                 for (; e + 8 <= s1; e += 8) {
                     float4 v[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) v[t] = *reinterpret_cast<const float4*>(sb + (long)r[t] * p.lds + c);
+                    for (int t = 0; t < 8; ++t) v[t] = rl_ldx4<SB>(p.src, sb + (long)r[t] * p.lds + c);
                     if (e + 16 <= s1) {
 #pragma unroll
                         for (int t = 0; t < 8; ++t) r[t] = ent[e + 8 + t];
@@ -428,17 +428,17 @@ __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p)
             }
             for (; e + 4 <= s1; e += 4) {      // four rows requested before the first is added (order of the adds is fixed)
                 const int r0 = ent[e], r1 = ent[e + 1], r2 = ent[e + 2], r3 = ent[e + 3];
-                const float4 v0 = *reinterpret_cast<const float4*>(sb + (long)r0 * p.lds + c);
-                const float4 v1 = *reinterpret_cast<const float4*>(sb + (long)r1 * p.lds + c);
-                const float4 v2 = *reinterpret_cast<const float4*>(sb + (long)r2 * p.lds + c);
-                const float4 v3 = *reinterpret_cast<const float4*>(sb + (long)r3 * p.lds + c);
+                const float4 v0 = rl_ldx4<SB>(p.src, sb + (long)r0 * p.lds + c);
+                const float4 v1 = rl_ldx4<SB>(p.src, sb + (long)r1 * p.lds + c);
+                const float4 v2 = rl_ldx4<SB>(p.src, sb + (long)r2 * p.lds + c);
+                const float4 v3 = rl_ldx4<SB>(p.src, sb + (long)r3 * p.lds + c);
                 acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
                 acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
                 acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
                 acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
             }
             for (; e < s1; ++e) {
-                const float4 v = *reinterpret_cast<const float4*>(sb + (long)ent[e] * p.lds + c);
+                const float4 v = rl_ldx4<SB>(p.src, sb + (long)ent[e] * p.lds + c);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             float4* o = reinterpret_cast<float4*>(p.dst + ((long)b * p.dst_bstride + j) * p.ldd + c);
@@ -594,7 +594,9 @@ extern "C" int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream) {
     p.dst_bstride = d->dst_bstride; p.offsets = d->offsets; p.entries = d->entries; p.n_dst = d->n_dst; p.C = d->C;
     p.per = d->entries_per_cloud; p.total = (long)d->B * d->n_dst; p.accumulate = d->accumulate;
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (d->C % 4 == 0) && (d->lds % 4 == 0) && (d->ldd % 4 == 0) && (((uintptr_t)d->src | (uintptr_t)d->dst) & 15) == 0;
+    const bool vec = (d->C % 4 == 0) && (d->lds % 4 == 0) && (d->ldd % 4 == 0) && ((uintptr_t)d->dst & 15) == 0 &&
+                     ((uintptr_t)d->src & (d->src_bf16 ? 7 : 15)) == 0;
+    RL_REQUIRE(!d->src_bf16 || vec, RL_ERR_UNSUPPORTED, "rl_segment_sum_rows: bf16 source rows need C, lds, ldd multiples of 4 and aligned tensors");
     if (vec) {
         const int c4 = d->C / 4;
         int tpr = 1;
@@ -603,17 +605,19 @@ extern "C" int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream) {
         long g = (p.total + rpw - 1) / rpw;
         if (g > 8192) g = 8192;
         if (g < 1) g = 1;
+#define SEG_CASE(T)                                                                                          \
+    case T:                                                                                                  \
+        if (d->src_bf16) hipLaunchKernelGGL((segment_sum_vec_kernel<T, true>), dim3(g), dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((segment_sum_vec_kernel<T, false>), dim3(g), dim3(256), 0, st, p);            \
+        break;
         switch (tpr) {
-            case 1:   hipLaunchKernelGGL(segment_sum_vec_kernel<1>, dim3(g), dim3(256), 0, st, p); break;
-            case 2:   hipLaunchKernelGGL(segment_sum_vec_kernel<2>, dim3(g), dim3(256), 0, st, p); break;
-            case 4:   hipLaunchKernelGGL(segment_sum_vec_kernel<4>, dim3(g), dim3(256), 0, st, p); break;
-            case 8:   hipLaunchKernelGGL(segment_sum_vec_kernel<8>, dim3(g), dim3(256), 0, st, p); break;
-            case 16:  hipLaunchKernelGGL(segment_sum_vec_kernel<16>, dim3(g), dim3(256), 0, st, p); break;
-            case 32:  hipLaunchKernelGGL(segment_sum_vec_kernel<32>, dim3(g), dim3(256), 0, st, p); break;
-            case 64:  hipLaunchKernelGGL(segment_sum_vec_kernel<64>, dim3(g), dim3(256), 0, st, p); break;
-            case 128: hipLaunchKernelGGL(segment_sum_vec_kernel<128>, dim3(g), dim3(256), 0, st, p); break;
-            default:  hipLaunchKernelGGL(segment_sum_vec_kernel<256>, dim3(g), dim3(256), 0, st, p); break;
+            SEG_CASE(1) SEG_CASE(2) SEG_CASE(4) SEG_CASE(8) SEG_CASE(16) SEG_CASE(32) SEG_CASE(64) SEG_CASE(128)
+            default:
+                if (d->src_bf16) hipLaunchKernelGGL((segment_sum_vec_kernel<256, true>), dim3(g), dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((segment_sum_vec_kernel<256, false>), dim3(g), dim3(256), 0, st, p);
+                break;
         }
+#undef SEG_CASE
         rl_note_kernel("segment_sum_vec_kernel");
     } else {
         long g = (p.total * p.C + 255) / 256;

@@ -1924,7 +1924,8 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
 // 128 x 128 tile of dW (32 accumulator registers each instead of 64), which fits 128 VGPRs: two workgroups per CU = four
 // wavefronts per SIMD, twice the loads in flight (pwgrad128_kernel<3>: 240 VGPRs, two per SIMD, 39 % of its wavefront
 // cycles parked on memory).  bf16 arithmetic modes only; same operands and MFMA sequence per accumulator -> same bits.
-template <int TERMS>   // 3: bf16x3; 1: bf16
+// RB: A and dY are stored as bf16 rows (bf16-storage mode; then TERMS = 1 is exact - the tails would be zero)
+template <int TERMS, bool RB = false>   // 3: bf16x3; 1: bf16
 __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p) {
     constexpr int BS = 40;
     constexpr int NSPL = TERMS == 3 ? 2 : 1;
@@ -1986,9 +1987,9 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
                         const int ii = (int)(R - (long)b * p.rows_per_batch);
                         off = ((long)b * p.dy_bstride + ii) * p.lddy;
                     }
-                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + ucol[i]);
+                    rd[i] = rl_ldx4<RB>(p.dY, off + n0 + ucol[i]);
                 }
-                if (ucol[i] < kvalid) ra[i] = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + ucol[i]);
+                if (ucol[i] < kvalid) ra[i] = rl_ldx4<RB>(p.a.A, a_row_offset(p.a, R) + k0 + ucol[i]);
             }
         }
     };
@@ -2248,6 +2249,7 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
     p.slab = d->slab; p.has_bias = d->dbias != nullptr;
     int nsplit; long rpb;
     const bool streaming = stream_wgrad_ok(d->N, d->K);
+    RL_REQUIRE(!(d->rows_bf16 && streaming), RL_ERR_UNSUPPORTED, "rl_wgrad: bf16 rows are supported by the wide weight-gradient kernel only");
     if (streaming) swgrad_split(p.a.M, &nsplit, &rpb);
     else wgrad_split(p.a.M, d->N, d->K, &nsplit, &rpb);
     RL_REQUIRE(d->slab_floats >= (int64_t)nsplit * ((int64_t)d->N * d->K + d->N), RL_ERR_ARGS,
@@ -2263,7 +2265,12 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         const bool pipelined = pwgrad_ok(p);
         const int T = pipelined ? wgrad_tile(d->N, d->K) : WG_T;
         dim3 grid(nsplit, rl_cdiv(d->N, T), rl_cdiv(d->K, T));
-        if (pipelined && T == 128) {
+        RL_REQUIRE(!d->rows_bf16 || (pipelined && T == 128 && wide_gemm_terms() != 0 && d->a_mode == 0), RL_ERR_UNSUPPORTED,
+                   "rl_wgrad: bf16 rows are supported by the wide (128 x 128 tile) weight-gradient kernel only");
+        if (d->rows_bf16) {
+            RL_REQUIRE(d->lda % 4 == 0 && d->lddy % 4 == 0, RL_ERR_ARGS, "rl_wgrad: bf16 rows need leading dimensions that are multiples of 4");
+            hipLaunchKernelGGL((pwgrad128w_kernel<1, true>), grid, dim3(512), 0, st, p);
+        } else if (pipelined && T == 128) {
             const int t = wide_gemm_terms();
             static const bool narrow_wg = getenv("RL_WGRAD_4WAVE") != nullptr;      // diagnostics: the 4-wavefront kernel
             if (t == 0)      hipLaunchKernelGGL(pwgrad128_kernel<0>, grid, dim3(256), 0, st, p);

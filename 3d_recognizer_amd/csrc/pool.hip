@@ -765,8 +765,11 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
     }
 }
 
-template <int DT, int TERMS, bool VIRT = false, int NW = 4>   // NW wavefronts share the staged weights
+// GB: the neighbourhood-row gradient tensors are stored as bf16 (the bf16-storage mode): DG always, GU when the rpe branch
+// is virtual (a real U tensor's gradient goes on into the fp32 GEMM chain)
+template <int DT, int TERMS, bool VIRT = false, int NW = 4, bool GB = false>   // NW wavefronts share the staged weights
 __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
+    constexpr bool GUB = GB && VIRT;
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
     __shared__ float vcl[(VIRT && VCols<DT>::INLDS) ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
             gacc[nb] = splat(0.f);
             if (p.gu_accumulate && nb * 16 + li < H) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gacc[nb][r] = p.GU[(pt * 16 + lj * 4 + r) * H + nb * 16 + li];
+                for (int r = 0; r < 4; ++r) gacc[nb][r] = rl_ldx<GUB>(p.GU, (pt * 16 + lj * 4 + r) * H + nb * 16 + li);
             }
         }
         loads_issued();
@@ -988,8 +991,8 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 if constexpr (DT <= 2) Ds[rowi * XS + col] = v;
                 else {                      // d = 64: measured better with the element stores (11 us per step)
                     const long urow = (pt * 16 + rowi) * H;
-                    if (col < H) p.GU[urow + col] = v;
-                    else p.DG[urow + (col - H)] = v;
+                    if (col < H) rl_stx<GUB>(p.GU, urow + col, v);
+                    else rl_stx<GB>(p.DG, urow + (col - H), v);
                 }
             }
         }
@@ -1000,8 +1003,8 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
             for (int c = 0; c < DT; ++c) {
                 const int k = 16 * c + 4 * lj;
                 const float4 v = *reinterpret_cast<const float4*>(Ds + li * XS + k);
-                if (k < H) *reinterpret_cast<float4*>(p.GU + orow + k) = v;
-                else *reinterpret_cast<float4*>(p.DG + orow + (k - H)) = v;
+                if (k < H) rl_stx4<GUB>(p.GU, orow + k, v);
+                else rl_stx4<GB>(p.DG, orow + (k - H), v);
             }
         }
 #pragma unroll
@@ -1082,6 +1085,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
 // weight-gradient kernel on them.  Everything else is pool_bwd_kernel: one point per wavefront, loads of the next
 // point in flight.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool GB>      // X_out, dS_out and DG stored as bf16 (GU is a real tensor's gradient: fp32)
 __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     constexpr int NW = 8;    // 70 KB of W in LDS: one workgroup per CU, so it brings eight wavefronts
     constexpr int TERMS = 3;
@@ -1139,7 +1143,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         // X leaves the kernel for the weight-gradient GEMM: row li, 16 bytes per 16-column chunk
 #pragma unroll
-        for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(p.X_out + (pt * 16 + li) * D + 16 * c + 4 * lj) = xa[c];
+        for (int c = 0; c < DT; ++c) rl_stx4<GB>(p.X_out, (pt * 16 + li) * D + 16 * c + 4 * lj, xa[c]);
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
             const float4 da = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
-            *reinterpret_cast<float4*>(p.dS_out + (pt * 16 + li) * D + 16 * c + 4 * lj) = da;
+            rl_stx4<GB>(p.dS_out, (pt * 16 + li) * D + 16 * c + 4 * lj, da);
             bf16x4 ah, al;
             split4(da, ah, al);
             // B fragment of column block nb: W[o = 16c + 4lj + j][nb*16 + li], j = 0..3 - four rows of one column.
@@ -1210,7 +1214,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                     if (p.gu_accumulate) p.GU[urow + col] += v;
                     else p.GU[urow + col] = v;
                 } else {
-                    p.DG[urow + (col - H)] = v;
+                    rl_stx<GB>(p.DG, urow + (col - H), v);
                 }
             }
         }
@@ -1222,7 +1226,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // the lane's C-layout elements of G for one point (zero in the padding columns)
-template <int DT>
+template <int DT, bool GB = false>
 __device__ __forceinline__ void load_gin(const float* __restrict__ G, long pt, int li, int lj, f32x4 (&g)[VT<DT>::DTH]) {
     constexpr int H = VT<DT>::H;
 #pragma unroll
@@ -1231,7 +1235,7 @@ __device__ __forceinline__ void load_gin(const float* __restrict__ G, long pt, i
         g[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (col < H) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[nb][r] = G[(pt * 16 + 4 * lj + r) * H + col];
+            for (int r = 0; r < 4; ++r) g[nb][r] = rl_ldx<GB>(G, (pt * 16 + 4 * lj + r) * H + col);
         }
     }
 }
@@ -1251,6 +1255,7 @@ struct RpeBwdParams {
     const float* coef;    // wgrad: 2H floats (mean g, mean g*xhat)
     float* slab;          // wgrad: [grid][H*Kin + H]
     float* GU1;           // wgrad stage 2: (P*16, H) out
+    int g_bf16;           // G and GU1 are stored as bf16
 };
 
 template <int DT>
@@ -1276,7 +1281,7 @@ struct VBwdCols {
     }
 };
 
-template <int DT, int TERMS>
+template <int DT, int TERMS, bool GB = false>
 __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q) {
     const PoolParams& p = q.pp;
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, XS = Tile<VT<DT>::DTH>::XS;
@@ -1310,7 +1315,7 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
     for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb] = splat(0.f);
     if (pt < p.P) {
         fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
-        load_gin<DT>(q.G, pt, li, lj, gin);
+        load_gin<DT, GB>(q.G, pt, li, lj, gin);
     }
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
                          // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
@@ -1320,7 +1325,7 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
         {
             const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
             fetch_rpe(p, cf, li, idx_nxt, rin_nxt);
-            load_gin<DT>(q.G, cf.pt, li, lj, gin_nxt);
+            load_gin<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
         }
         loads_issued();
         idx_nxt = idx_n2;
@@ -1359,7 +1364,7 @@ __global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q
     }
 }
 
-template <int DT, int TERMS>
+template <int DT, int TERMS, bool GB = false>
 __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     const PoolParams& p = q.pp;
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, HP = VT<DT>::HP, XS = Tile<VT<DT>::DTH>::XS, XSB = Tile<VT<DT>::DTH>::XSB;
@@ -1419,7 +1424,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb] = splat(0.f);
     if (pt < p.P) {
         fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
-        load_gin<DT>(q.G, pt, li, lj, gin);
+        load_gin<DT, GB>(q.G, pt, li, lj, gin);
     }
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
                          // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
@@ -1429,7 +1434,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
         {
             const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
             fetch_rpe(p, cf, li, idx_nxt, rin_nxt);
-            load_gin<DT>(q.G, cf.pt, li, lj, gin_nxt);
+            load_gin<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
         }
         loads_issued();
         idx_nxt = idx_n2;
@@ -1509,7 +1514,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
                 const int col = nb * 16 + li;
                 if (col < H) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) q.GU1[(pt * 16 + 4 * lj + r) * H + col] = gu[nb][r];
+                    for (int r = 0; r < 4; ++r) rl_stx<GB>(q.GU1, (pt * 16 + 4 * lj + r) * H + col, gu[nb][r]);
                 }
             }
         }
@@ -1744,12 +1749,14 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
         RL_REQUIRE((((uintptr_t)d->X_out | (uintptr_t)d->dS_out) & 15) == 0, RL_ERR_ARGS, "rl_pool_bwd: X_out / dS_out must be 16-byte aligned");
         p.X_out = d->X_out; p.dS_out = d->dS_out;
         const int g = pool_grid(p.P, p.d, true);
-        hipLaunchKernelGGL(pool128_bwd_kernel, dim3(g), dim3(512), 0, st, p);
+        if (d->rows_bf16) hipLaunchKernelGGL(pool128_bwd_kernel<true>, dim3(g), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(pool128_bwd_kernel<false>, dim3(g), dim3(512), 0, st, p);
         rl_note_kernel("pool128_bwd_kernel");
         RL_LAUNCH_CHECK("rl_pool_bwd(128)");
         return RL_OK;
     }
     RL_REQUIRE(d->dW && d->slab, RL_ERR_ARGS, "rl_pool_bwd: null gradient buffers");
+    RL_REQUIRE(!d->rows_bf16 || pool_terms(p.d) == 3, RL_ERR_UNSUPPORTED, "rl_pool_bwd: bf16 gradient rows need the bf16x3 arithmetic mode");
     const int g = pool_grid(p.P, p.d, true, p.src > 0);
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
     if (p.src > 0) {
@@ -1758,6 +1765,10 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
             if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0, true>), dim3(g), dim3(256), 0, st, p);
             else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0, true>), dim3(g), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((pool_bwd_kernel<4, 0, true, 8>), dim3(g), dim3(512), 0, st, p);
+        } else if (d->rows_bf16) {
+            if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3, true, 4, true>), dim3(g), dim3(256), 0, st, p);
+            else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3, true, 4, true>), dim3(g), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((pool_bwd_kernel<4, 3, true, 8, true>), dim3(g), dim3(512), 0, st, p);
         } else {
             if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3, true>), dim3(g), dim3(256), 0, st, p);
             else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3, true>), dim3(g), dim3(256), 0, st, p);
@@ -1773,6 +1784,10 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
         if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0>), dim3(g), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((pool_bwd_kernel<4, 0>), dim3(g), dim3(256), 0, st, p);
+    } else if (d->rows_bf16) {
+        if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3, false, 4, true>), dim3(g), dim3(256), 0, st, p);
+        else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3, false, 4, true>), dim3(g), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((pool_bwd_kernel<4, 3, false, 4, true>), dim3(g), dim3(256), 0, st, p);
     } else {
         if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3>), dim3(g), dim3(256), 0, st, p);
         else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3>), dim3(g), dim3(256), 0, st, p);
@@ -1845,12 +1860,18 @@ static int rpe_bwd_fill(RpeBwdParams* q, const rl_pool_desc* d, const float* G, 
     p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
     p.mu1 = d->mean1; p.is1 = d->invstd1; p.mu2 = d->mean2; p.is2 = d->invstd2;
     q->G = G; q->stats = nullptr; q->coef = nullptr; q->slab = nullptr; q->GU1 = nullptr;
+    q->g_bf16 = d->rows_bf16 ? 1 : 0;
+    RL_REQUIRE(!q->g_bf16 || pool_terms(d->d) == 3, RL_ERR_UNSUPPORTED, "%s: bf16 gradient rows need the bf16x3 arithmetic mode", who);
     return RL_OK;
 }
 
 #define RPE_DISPATCH(KERNEL, grid, st, q)                                                                          \
     do {                                                                                                           \
-        if (pool_terms((q).pp.d) == 0) {                                                                                \
+        if ((q).g_bf16) {                                                                                          \
+            if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 3, true>), dim3(grid), dim3(256), 0, st, q);         \
+            else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 3, true>), dim3(grid), dim3(256), 0, st, q);    \
+            else hipLaunchKernelGGL((KERNEL<4, 3, true>), dim3(grid), dim3(256), 0, st, q);                        \
+        } else if (pool_terms((q).pp.d) == 0) {                                                                         \
             if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 0>), dim3(grid), dim3(256), 0, st, q);               \
             else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 0>), dim3(grid), dim3(256), 0, st, q);          \
             else hipLaunchKernelGGL((KERNEL<4, 0>), dim3(grid), dim3(256), 0, st, q);                              \

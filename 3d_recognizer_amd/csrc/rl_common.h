@@ -71,6 +71,47 @@ __device__ __forceinline__ float rl_lazy(const RlLazy& t, float raw, int c) {
     return rl_act(raw * t.scale[c] + t.shift[c], t.act, t.slope);
 }
 
+// ---- storage type of a tensor: fp32, or bf16 in the bf16-storage throughput mode (rl_randlanet.h, "storage") ----------
+// Pointers stay typed `float*` in the parameter blocks; BF says what the bytes are.  Indices count ELEMENTS.
+typedef __bf16 rl_bf16x4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ float rl_ldx(const float* p, long i) {
+    if constexpr (BF) return (float)reinterpret_cast<const __bf16*>(p)[i];
+    else return p[i];
+}
+template <bool BF>
+__device__ __forceinline__ void rl_stx(float* p, long i, float v) {
+    if constexpr (BF) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;      // round to nearest even (v_cvt_pk_bf16_f32)
+    else p[i] = v;
+}
+// four consecutive elements, i % 4 == 0 and the row start 16-byte (fp32) / 8-byte (bf16) aligned
+template <bool BF>
+__device__ __forceinline__ float4 rl_ldx4(const float* p, long i) {
+    if constexpr (BF) {
+        const rl_bf16x4 h = *reinterpret_cast<const rl_bf16x4*>(reinterpret_cast<const __bf16*>(p) + i);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else return *reinterpret_cast<const float4*>(p + i);
+}
+template <bool BF>
+__device__ __forceinline__ void rl_stx4(float* p, long i, const float4 v) {
+    if constexpr (BF) {
+        rl_bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<rl_bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = h;
+    } else *reinterpret_cast<float4*>(p + i) = v;
+}
+// the same with the type known at run time only (a wavefront-uniform flag: one scalar branch)
+__device__ __forceinline__ float4 rl_ld4(const float* p, long i, int bf) { return bf ? rl_ldx4<true>(p, i) : rl_ldx4<false>(p, i); }
+__device__ __forceinline__ float rl_ld1(const float* p, long i, int bf) { return bf ? rl_ldx<true>(p, i) : rl_ldx<false>(p, i); }
+__device__ __forceinline__ void rl_st4(float* p, long i, const float4 v, int bf) {
+    if (bf) rl_stx4<true>(p, i, v);
+    else rl_stx4<false>(p, i, v);
+}
+__device__ __forceinline__ void rl_st1(float* p, long i, float v, int bf) {
+    if (bf) rl_stx<true>(p, i, v);
+    else rl_stx<false>(p, i, v);
+}
+
 __device__ __forceinline__ double rl_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -454,7 +454,7 @@ class Engine:
         assert init
         key = ("vgu", id(vr))
         if stage == 2:
-            GU = torch.empty((vr.rows, h), dtype=torch.float32, device=GP.device)
+            GU = torch.empty((vr.rows, h), dtype=ops.row_dtype(), device=GP.device)     # bf16 in the bf16-storage mode
             first = True
         else:
             GU, first = ctx.grads.pop(key)[0], False     # written by stage 2's Linear backward (dY2 . W2)

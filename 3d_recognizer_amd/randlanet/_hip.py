@@ -14,6 +14,8 @@ import torch
 _LIB: Optional[C.CDLL] = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc",
                          "librandla_hip.so")
+# diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
+_LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
@@ -63,7 +65,7 @@ class WgradDesc(C.Structure):
         ("dW", C.c_void_p), ("w_ks", C.c_int64), ("w_ns", C.c_int64),
         ("dbias", C.c_void_p),
         ("slab", C.c_void_p), ("slab_floats", C.c_int64),
-        ("defer_reduce", C.c_int32),
+        ("defer_reduce", C.c_int32), ("rows_bf16", C.c_int32),
     ]
 
 
@@ -121,6 +123,7 @@ class PoolDesc(C.Structure):
         ("W2", C.c_void_p), ("b2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("mean1", C.c_void_p), ("invstd1", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
         ("xyz_width", C.c_int32), ("bn_bwd_stats", C.c_void_p), ("bn_fwd_stats2", C.c_void_p),
+        ("rows_bf16", C.c_int32),
     ]
 
 
@@ -149,6 +152,7 @@ class SegsumDesc(C.Structure):
         ("dst", C.c_void_p), ("ldd", C.c_int64), ("dst_bstride", C.c_int64),
         ("offsets", C.c_void_p), ("entries", C.c_void_p), ("entries_per_cloud", C.c_int64),
         ("B", C.c_int32), ("n_dst", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32),
+        ("src_bf16", C.c_int32),
     ]
 
 

@@ -12,6 +12,31 @@ import torch
 from . import _hip as H
 
 F32 = torch.float32
+BF16 = torch.bfloat16
+
+# Storage of the neighbourhood-row tensors that only exist between two kernels of the backward pass (rl_randlanet.h
+# "bf16-storage mode"): "f32" (default, the parity mode) or "bf16" - GU / DG of the fused pooling blocks and, on the
+# 128-wide level, X / dS are then written and read as bf16 (half the bytes of the largest tensors of a step); coordinates,
+# neighbour search, BatchNorm statistics, softmax, every accumulator, parameters and Adam stay fp32.
+_STORAGE = __import__("os").environ.get("RL_STORAGE", "f32")
+
+
+def set_storage(mode: str) -> None:
+    global _STORAGE
+    if mode not in ("f32", "bf16"):
+        raise ValueError(f"storage must be 'f32' or 'bf16', got {mode!r}")
+    if mode == "bf16" and get_wide_gemm() == "fp32":
+        raise H.HipKernelError("bf16 storage needs the bf16x3 / bf16 arithmetic mode (RL_WIDE_GEMM)")
+    _STORAGE = mode
+
+
+def get_storage() -> str:
+    return _STORAGE
+
+
+def row_dtype() -> torch.dtype:
+    """dtype of the (points*K)-row gradient tensors between backward kernels."""
+    return BF16 if _STORAGE == "bf16" else F32
 
 
 @dataclass
@@ -251,7 +276,7 @@ def _fill_a(d, a):
         d.B, d.n, d.K = a.B, a.n, 10
         return a.rows, 10
     _dev_check(a.raw, a.scale, a.shift)
-    assert a.raw.dtype == F32 and a.raw.dim() == 2 and a.raw.shape[1] >= a.C
+    assert a.raw.dtype in (F32, BF16) and a.raw.dim() == 2 and a.raw.shape[1] >= a.C
     assert a.raw.shape[0] >= (a.B - 1) * a.bstride + a.n, "A operand rows out of range"
     d.a_mode = 0
     d.A, d.lda, d.a_bstride = a.raw.data_ptr(), a.raw.shape[1], a.bstride
@@ -312,6 +337,7 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     `out2_index`, atomically to the rows it names) - the two halves of a concat's gradient in one pass."""
     d = H.GemmDesc()
     M, K = _fill_a(d, a)
+    assert isinstance(a, Rpe) or a.raw.dtype == F32, "rl_gemm reads fp32 rows"
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
     _dev_check(W, bias, out, stats)
     assert W.dtype == F32 and W.numel() == K * N
@@ -375,7 +401,10 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     M, K = _fill_a(d, a)
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
     _dev_check(dY, dW, dbias)
-    assert dY.dtype == F32 and dY.dim() == 2 and dY.shape[1] >= N
+    rows_bf16 = dY.dtype == BF16
+    assert dY.dtype in (F32, BF16) and dY.dim() == 2 and dY.shape[1] >= N
+    assert isinstance(a, Rpe) or a.raw.dtype == dY.dtype, "A and dY must share their storage type"
+    d.rows_bf16 = int(rows_bf16)
     assert dY.shape[0] >= (d.B - 1) * dy_bstride + rows_per_batch
     assert dW.numel() == K * N and (dbias is None or dbias.numel() == N)
     floats = H.lib().rl_wgrad_slab_floats(M, N, K)
@@ -384,7 +413,8 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     d.dW, d.w_ks, d.w_ns, d.dbias = dW.data_ptr(), w_ks, w_ns, H.ptr(dbias)
     d.slab, d.slab_floats = slab.data_ptr(), slab.numel()
     d.defer_reduce = 0 if pending is None else 1
-    with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N + K * N), 2 * M * K * N):
+    es = 2 if rows_bf16 else 4
+    with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), es * (M * (K if not isinstance(a, Rpe) else 6) + M * N) + 4 * K * N, 2 * M * K * N):
         H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
     if pending is not None:
         it = H.WgradReduceItem()
@@ -646,17 +676,18 @@ def segment_sum_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: 
     ascending r - the gather's backward in a fixed order (no atomics, first writer needs no zero fill)."""
     _dev_check(src, dst, csr.offsets, csr.entries)
     c0, cn = src_cols
-    assert src.dtype == F32 and dst.dtype == F32 and src.dim() == 2 and dst.dim() == 2
+    assert src.dtype in (F32, BF16) and dst.dtype == F32 and src.dim() == 2 and dst.dim() == 2
     assert c0 + cn <= src.shape[1] and cn == dst.shape[1]
     assert src.shape[0] >= (csr.B - 1) * src_bstride + csr.n_src * csr.k
     assert dst.shape[0] >= (csr.B - 1) * dst_bstride + csr.n_dst
     d = H.SegsumDesc()
-    d.src, d.lds, d.src_bstride = src.data_ptr() + 4 * c0, src.shape[1], src_bstride
+    d.src, d.lds, d.src_bstride = src.data_ptr() + src.element_size() * c0, src.shape[1], src_bstride
+    d.src_bf16 = int(src.dtype == BF16)
     d.dst, d.ldd, d.dst_bstride = dst.data_ptr(), dst.shape[1], dst_bstride
     d.offsets, d.entries, d.entries_per_cloud = csr.offsets.data_ptr(), csr.entries.data_ptr(), csr.n_src * csr.k
     d.B, d.n_dst, d.C, d.accumulate = csr.B, csr.n_dst, cn, int(accumulate)
     rows = csr.B * csr.n_src * csr.k
-    with _rec("segment_sum", (rows, cn), 4 * cn * (rows + csr.B * csr.n_dst * (2 if accumulate else 1)) + 4 * rows, 0):
+    with _rec("segment_sum", (rows, cn), cn * (src.element_size() * rows + 4 * csr.B * csr.n_dst * (2 if accumulate else 1)) + 4 * rows, 0):
         H.check(H.lib().rl_segment_sum_rows(C.byref(d), _st()), "rl_segment_sum_rows")
 
 
@@ -727,7 +758,8 @@ def rpe_bn_backward(v: VirtualRpe, stage: int, G: torch.Tensor, dgamma, dbeta, s
         pd = H.PoolDesc()
         _fill_virtual(pd, v, stage)
         _dev_check(G)
-        assert G.shape == (v.rows, v.h) and G.dtype == F32
+        assert G.shape == (v.rows, v.h) and G.dtype in (F32, BF16)
+        pd.rows_bf16 = int(G.dtype == BF16)
         nslots = H.lib().rl_rpe_stats_slots(v.B * v.n)
         stats = torch.empty((nslots, 2, v.h), dtype=torch.float64, device=G.device)
         with _rec("rpe_bn_reduce", (v.rows, v.h, stage), 4 * v.rows * v.h + 8 * v.rows, 0):
@@ -746,9 +778,12 @@ def rpe_wgrad(v: VirtualRpe, stage: int, G: torch.Tensor, coef: torch.Tensor, dW
     _dev_check(G, coef, dW, dbias, GU1)
     Kin = 10 if stage == 1 else v.h
     assert dW.numel() == v.h * Kin and dbias.numel() == v.h and (stage == 1 or GU1.shape == (v.rows, v.h))
+    assert G.dtype in (F32, BF16) and (GU1 is None or GU1.dtype == G.dtype)
+    pd.rows_bf16 = int(G.dtype == BF16)
+    es = G.element_size()
     floats = H.lib().rl_rpe_wgrad_slab_floats(v.B * v.n, 2 * v.h, stage)
     slab = torch.empty(floats, dtype=F32, device=G.device)
-    with _rec("rpe_wgrad", (v.rows, Kin, v.h), 4 * v.rows * v.h * (2 if stage == 2 else 1) + 8 * v.rows, 2 * v.rows * v.h * (Kin + (v.h if stage == 2 else 0))):
+    with _rec("rpe_wgrad", (v.rows, Kin, v.h), es * v.rows * v.h * (2 if stage == 2 else 1) + 8 * v.rows, 2 * v.rows * v.h * (Kin + (v.h if stage == 2 else 0))):
         H.check(H.lib().rl_rpe_wgrad(C.byref(pd), G.data_ptr(), coef.data_ptr(), slab.data_ptr(), slab.numel(), H.ptr(GU1), _st()),
                 "rl_rpe_wgrad")
     it = H.WgradReduceItem()
@@ -815,19 +850,27 @@ def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP:
     _dev_check(dP, GU, dW)
     P = u.B * n
     assert dP.shape == (P, d) and GU.shape == (P * 16, d // 2) and dW.numel() == d * d
-    DG = torch.empty((P * 16, d // 2), dtype=F32, device=W.device)
+    rdt = row_dtype()
+    virt = isinstance(u, VirtualRpe)
+    assert GU.dtype == (rdt if virt else F32), "GU: the row storage type under a virtual rpe branch, fp32 for a real U tensor"
+    pd.rows_bf16 = int(rdt == BF16)
+    es = 2 if rdt == BF16 else 4
+    DG = torch.empty((P * 16, d // 2), dtype=rdt, device=W.device)
     if bn_bwd_stats is not None:
         _dev_check(bn_bwd_stats)
         assert stage > 0 and bn_bwd_stats.dtype == torch.float64
         assert bn_bwd_stats.numel() >= H.lib().rl_pool_bwd_slots(P, d) * d
         pd.bn_bwd_stats = bn_bwd_stats.data_ptr()
     pd.dP, pd.GU, pd.gu_accumulate, pd.DG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), DG.data_ptr(), dW.data_ptr()
-    nbytes = 4 * (3 * P * 16 * (d // 2) + P * 16 * (d // 2) * (1 + int(gu_accumulate)) + P * 16 + 2 * P * d)
+    # reads: U (a real tensor; virtual: 16 B of coordinates + 8 B of index / distance per row - counted in P*16*... below), the
+    # gathered rows, dP, idx; writes: DG and GU (read first when accumulating)
+    nbytes = (4 * (2 * P * 16 * (d // 2) + P * 16 + 2 * P * d) + es * P * 16 * (d // 2)
+              + (es if virt else 4) * P * 16 * (d // 2) * (1 + int(gu_accumulate)))
     if d == 128:
-        X = torch.empty((P * 16, d), dtype=F32, device=W.device)
-        dS = torch.empty((P * 16, d), dtype=F32, device=W.device)
+        X = torch.empty((P * 16, d), dtype=rdt, device=W.device)
+        dS = torch.empty((P * 16, d), dtype=rdt, device=W.device)
         pd.X_out, pd.dS_out = X.data_ptr(), dS.data_ptr()
-        with _rec("pool_bwd", (P, 16, d), nbytes + 8 * P * 16 * d, 4 * P * 16 * d * d):
+        with _rec("pool_bwd", (P, 16, d), nbytes + 2 * es * P * 16 * d, 4 * P * 16 * d * d):
             H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
         wgrad(plain(X, u.B, n * 16), dS, n * 16, d, dW, 1, d, None, pending=pending)
         return DG

@@ -233,6 +233,9 @@ typedef struct rl_wgrad_desc {
      * rl_wgrad_reduce_batch (one launch for all layers of a backward pass), so `slab` must be
      * private to this layer until then */
     int32_t defer_reduce;
+    /* bf16-storage mode: A and dY are bf16 rows (lda / lddy count elements).  Wide layers only (a 128 x 128 tile of dW,
+     * i.e. N or K > 64), plain A operand, outside the fp32 arithmetic mode; the products are then exact bf16 x bf16. */
+    int32_t rows_bf16;
 } rl_wgrad_desc;
 
 int64_t rl_wgrad_slab_floats(int64_t M, int N, int K);
@@ -387,6 +390,7 @@ typedef struct rl_segsum_desc {
     int64_t entries_per_cloud;
     int32_t B, n_dst, C;
     int32_t accumulate;
+    int32_t src_bf16;       /* bf16-storage mode: the source rows are bf16 (lds counts elements); sums and dst stay fp32 */
 } rl_segsum_desc;
 
 int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream);
@@ -474,6 +478,11 @@ typedef struct rl_pool_desc {
      * tile this launch has in registers) - what rl_rpe_stats with u_source 2 would compute - as partials
      * bn_fwd_stats2[slot][2][d/2], slot < rl_pool_fwd_slots(points, d).  Needs W2 / b2. */
     double* bn_fwd_stats2;
+    /* bf16-storage mode (backward entry points): the (points*16)-row gradient tensors this block WRITES are bf16 (2 bytes
+     * per element, round to nearest even) instead of fp32: DG, X_out and dS_out always; GU - and the G / GU1 arguments
+     * of rl_rpe_bn_reduce / rl_rpe_wgrad - when the rpe branch is virtual (u_source > 0).  With a real U tensor GU stays
+     * fp32 (it continues into the fp32 GEMM chain).  Needs the bf16x3 arithmetic mode.  0: everything fp32.        */
+    int32_t rows_bf16;
 } rl_pool_desc;
 
 int rl_pool_supported(int d, int nbr_k);
