@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const double* __restrict__ stats, int nslots, double count, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
-    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    const float* __restrict__ folded_bias) {
     __shared__ double red[4][2];
     const int c = blockIdx.x;          // one workgroup per channel
     double mean, var;
@@ -71,6 +72,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         mean = (double)rmean[c];
         var = (double)rvar[c];
     }
+    // folded_bias: the producer left the layer's bias OUT of the tensor (it cancels in y - mean): the statistics above are
+    // those of y - bias, and so is the tensor the (scale, shift) pair will be applied to; only the RUNNING mean is that of y
+    const float fb = folded_bias ? folded_bias[c] : 0.f;
+    if (!training) mean -= (double)fb;
     if (threadIdx.x != 0) return;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     if (save_invstd) save_invstd[c] = invstd;
     if (training && rmean && rvar) {
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * ((float)mean + fb);
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
         if (c == 0 && nbt) nbt[0] += 1;
     }
@@ -485,13 +490,13 @@ int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
 extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                               float momentum, float eps, int training, float* scale, float* shift,
-                              float* save_mean, float* save_invstd, void* stream) {
+                              float* save_mean, float* save_invstd, const float* folded_bias, void* stream) {
     RL_REQUIRE(C > 0 && scale && shift, RL_ERR_ARGS, "rl_bn_finalize: bad arguments");
     if (training) RL_REQUIRE(stats && nslots > 0 && count > 0, RL_ERR_ARGS, "rl_bn_finalize: training needs partial statistics");
     else RL_REQUIRE(running_mean && running_var, RL_ERR_ARGS, "rl_bn_finalize: eval needs running statistics");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslots,
                        (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, training,
-                       scale, shift, save_mean, save_invstd);
+                       scale, shift, save_mean, save_invstd, folded_bias);
     RL_LAUNCH_CHECK("rl_bn_finalize");
     return RL_OK;
 }

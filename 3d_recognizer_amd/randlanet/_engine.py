@@ -29,6 +29,7 @@ from ._ops import Lazy, Rpe
 
 BN_EPS = 1e-6       # modules.py:87, :497
 BN_MOMENTUM = 0.99
+FOLD_BIAS = not bool(int(__import__("os").environ.get("RL_NO_FOLD_BIAS", "0")))     # diagnostics: keep the bias in the GEMM
 
 
 class _Tape(list):
@@ -90,12 +91,12 @@ class Engine:
         w = self.P[name]
         return w.view(w.shape[0], w.shape[1])
 
-    def _bn(self, ctx: Context, out: Lazy, stats, bn_name: str, act: int, slope: float):
+    def _bn(self, ctx: Context, out: Lazy, stats, bn_name: str, act: int, slope: float, folded_bias=None):
         nbt = self.Bf.get(f"{bn_name}.num_batches_tracked")
         scale, shift, mean, invstd = ops.bn_finalize(
             stats, out.rows, 128, out.C, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
             self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
-            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync)
+            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, folded_bias=folded_bias)
         out.scale, out.shift, out.mean, out.invstd = scale, shift, mean, invstd
         out.act, out.slope, out.bn = act, slope, bn_name
 
@@ -106,11 +107,15 @@ class Engine:
         K = 10 if isinstance(a, Rpe) else a.C
         ks, ns = ops.weight_strides(W, transposed, K, n_out)
         stats = ops.new_stats(W.device, n_out) if (bn and ctx.training) else None
-        Y = ops.gemm(a, W, ks, ns, n_out, self.P[bname] if bname else None, stats=stats, wsplit=getattr(ctx, "wsplit", None))
+        # a bias in front of a BatchNorm cancels in (y - mean): the GEMM epilogue leaves it out (a bias costs a wide GEMM
+        # launch +18 %) and the BatchNorm fold accounts for it where it shows - the running mean (rl_bn_finalize)
+        fold = FOLD_BIAS and bn is not None and bname is not None
+        Y = ops.gemm(a, W, ks, ns, n_out, self.P[bname] if (bname and not fold) else None, stats=stats,
+                     wsplit=getattr(ctx, "wsplit", None))
         rpb = a.n * a.K if isinstance(a, Rpe) else a.n
         out = Lazy(Y, a.B, rpb, rpb, n_out)
         if bn:
-            self._bn(ctx, out, stats, bn, act, slope)
+            self._bn(ctx, out, stats, bn, act, slope, folded_bias=self.P[bname] if fold else None)
         else:
             assert act == H.ACT_NONE
         ctx.tape.append(("linear", a, out, wname, bname, ks, ns, a_grad))

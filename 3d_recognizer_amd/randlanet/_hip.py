@@ -190,7 +190,7 @@ _SIGNATURES = {
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "rl_wgrad_nsplit": (_i, [_l, _i, _i]),
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
-    "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_bn_reduce_slots": (_i, [_vp, _i, _i, _vp, _vp]),
     "rl_bn_bwd_slots": (_i, [_l]),
     "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),

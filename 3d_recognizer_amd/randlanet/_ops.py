@@ -494,7 +494,9 @@ def _stats_totals(stats: torch.Tensor, nslots: int, C: int) -> torch.Tensor:
 
 
 def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, nbt, momentum: float,
-                eps: float, training: bool, sync: Optional[SyncGroup] = None, nslots: Optional[int] = None):
+                eps: float, training: bool, sync: Optional[SyncGroup] = None, nslots: Optional[int] = None,
+                folded_bias: Optional[torch.Tensor] = None):
+    """folded_bias: the layer's conv bias when the producing GEMM did NOT add it (rl_bn_finalize in rl_randlanet.h)."""
     dev = gamma.device
     nslots = H.row_blocks(rows, tile) if nslots is None else nslots
     if training and sync is not None:            # batch statistics of the GLOBAL batch
@@ -505,10 +507,11 @@ def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, n
     shift = torch.empty(C, dtype=F32, device=dev)
     mean = torch.empty(C, dtype=F32, device=dev) if training else None
     invstd = torch.empty(C, dtype=F32, device=dev) if training else None
-    _dev_check(stats, gamma, beta, rmean, rvar, nbt)
+    _dev_check(stats, gamma, beta, rmean, rvar, nbt, folded_bias)
+    assert folded_bias is None or folded_bias.numel() == C
     H.check(H.lib().rl_bn_finalize(H.ptr(stats), nslots, rows, C, H.ptr(gamma), H.ptr(beta),
                                    H.ptr(rmean), H.ptr(rvar), H.ptr(nbt), momentum, eps, int(training),
-                                   scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), _st()),
+                                   scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), H.ptr(folded_bias), _st()),
             "rl_bn_finalize")
     return scale, shift, mean, invstd
 

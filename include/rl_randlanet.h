@@ -262,11 +262,15 @@ int rl_wgrad_reduce_batch(const rl_wgrad_reduce_item* items, int count, void* st
  * training != 0: mean/var from the `nslots` partial sums written by a producer over `count`
  *   rows; running stats updated as torch does (running = (1-m)*running + m*batch, unbiased
  *   variance; num_batches_tracked += 1 when nbt != NULL); saves mean and invstd for backward.
- * training == 0: scale/shift from the running statistics; stats may be NULL.               */
+ * training == 0: scale/shift from the running statistics; stats may be NULL.
+ * folded_bias (C floats or NULL): the bias of the layer in front (SharedMLP's conv bias, modules.py:93-104), when the
+ *   producer left it OUT of the tensor - it cancels in (y - mean), so the GEMM epilogue need not add it.  The statistics
+ *   and the saved mean are then those of (y - bias), (scale, shift) apply to that tensor, and the running mean is kept
+ *   as the reference keeps it: that of y (mean + bias); in eval mode the running mean is read as (running_mean - bias). */
 int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                    float momentum, float eps, int training, float* scale, float* shift,
-                   float* save_mean, float* save_invstd, void* stream);
+                   float* save_mean, float* save_invstd, const float* folded_bias, void* stream);
 
 /* BatchNorm + activation backward for a lazy tensor Y (rows x C, row (b,i) at (b*bstride+i)*ld)
  * whose activated value received gradient G (same addressing):
