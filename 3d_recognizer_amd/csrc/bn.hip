@@ -123,7 +123,6 @@ struct BwdParams {
     double* stats;
     const float* coef;
     int tile;
-    int bf16;          // G and Y are stored as bf16 (bf16-storage mode); offsets count elements either way
 };
 
 __device__ __forceinline__ long row_off(const BwdParams& p, long R) {
@@ -160,9 +159,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
                 for (int it = 0; it < 4; ++it) {
                     const int c = col + it * 256;
                     if (c < C) {
-                        const float y = rl_ld1(p.Y, off + c, p.bf16);
+                        const float y = p.Y[off + c];
                         const float sc = p.scale ? p.scale[c] : 1.f, sh = p.shift ? p.shift[c] : 0.f;
-                        const float g = rl_ld1(p.G, off + c, p.bf16) * rl_act_grad(y * sc + sh, p.act, p.slope);
+                        const float g = p.G[off + c] * rl_act_grad(y * sc + sh, p.act, p.slope);
                         const float xh = (y - p.mean[c]) * p.invstd[c];
                         sg[it] += g;
                         sx[it] += g * xh;
@@ -219,14 +218,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
         for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
             const long off = row_off(p, R);
             for (int c = col; c < C; c += 256) {
-                const float y = rl_ld1(p.Y, off + c, p.bf16);
+                const float y = p.Y[off + c];
                 const float sc = p.scale ? p.scale[c] : 1.f, sh = p.shift ? p.shift[c] : 0.f;
-                float g = rl_ld1(p.G, off + c, p.bf16) * rl_act_grad(y * sc + sh, p.act, p.slope);
+                float g = p.G[off + c] * rl_act_grad(y * sc + sh, p.act, p.slope);
                 if (p.coef) {
                     const float xh = (y - p.mean[c]) * p.invstd[c];
                     g = g - p.coef[c] - xh * p.coef[C + c];
                 }
-                rl_st1(p.G, off + c, sc * g, p.bf16);
+                p.G[off + c] = sc * g;
             }
         }
     }
@@ -235,13 +234,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
 // ---- float4 variants: C % 4 == 0, C/4 a power of two <= 256, 16-byte aligned rows ----------
 // tpr = min(C/4, 256) lanes sweep one row (16 B each), 256/tpr rows in flight per workgroup
 typedef float bnf4 __attribute__((ext_vector_type(4)));
-template <bool AB>
-__device__ __forceinline__ bnf4 ldq(const float* p, long off) {
-    const float4 v = rl_ldx4<AB>(p, off);
-    return (bnf4){v.x, v.y, v.z, v.w};
-}
-template <bool AB>
-__device__ __forceinline__ void stq(float* p, long off, const bnf4 v) { rl_stx4<AB>(p, off, make_float4(v[0], v[1], v[2], v[3])); }
 // Per-thread constants of its channel quad, loaded ONCE (the row loops used to re-load them per row - G is written through
 // a plain pointer, so the compiler could not hoist them - and to pass results through pointers to locals, which put them
 // in scratch): BatchNorm affine, saved mean / invstd, and the activation derivative as "z > 0 ? 1 : neg".
@@ -270,7 +262,6 @@ struct BnQuad {
     __device__ __forceinline__ bnf4 xhat(const bnf4 y) const { return (y - mu) * is; }
 };
 
-template <bool AB>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BwdParams p) {
     __shared__ float red[256][9];
     const int C = p.C, c4 = C >> 2;
@@ -287,15 +278,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BwdParams 
         long R = tile * p.tile + rsub;
         for (; R + rpar < rend; R += 2 * rpar) {          // two rows per trip: four loads in flight per lane
             const long o0 = row_off(p, R) + c, o1 = row_off(p, R + rpar) + c;
-            const bnf4 y0 = ldq<AB>(p.Y, o0), g0 = ldq<AB>(p.G, o0);
-            const bnf4 y1 = ldq<AB>(p.Y, o1), g1 = ldq<AB>(p.G, o1);
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
+            const bnf4 y1 = *reinterpret_cast<const bnf4*>(p.Y + o1), g1 = *reinterpret_cast<const bnf4*>(p.G + o1);
             const bnf4 d0 = k.grad(y0, g0), d1 = k.grad(y1, g1);
             a0 += d0; a1 += d0 * k.xhat(y0);
             a0 += d1; a1 += d1 * k.xhat(y1);
         }
         if (R < rend) {
             const long o0 = row_off(p, R) + c;
-            const bnf4 y0 = ldq<AB>(p.Y, o0), g0 = ldq<AB>(p.G, o0);
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
             const bnf4 d0 = k.grad(y0, g0);
             a0 += d0; a1 += d0 * k.xhat(y0);
         }
@@ -324,7 +315,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const BwdParams 
     }
 }
 
-template <bool AB>
 __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BwdParams p) {
     const int C = p.C, c4 = C >> 2;
     const int tpr = c4 < 256 ? c4 : 256;
@@ -351,15 +341,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const BwdParams p
         long R = tile * p.tile + rsub;
         for (; R + rpar < rend; R += 2 * rpar) {          // two rows per trip: four loads in flight per lane
             const long o0 = row_off(p, R) + c, o1 = row_off(p, R + rpar) + c;
-            const bnf4 y0 = ldq<AB>(p.Y, o0), g0 = ldq<AB>(p.G, o0);
-            const bnf4 y1 = ldq<AB>(p.Y, o1), g1 = ldq<AB>(p.G, o1);
-            stq<AB>(p.G, o0, row(y0, g0));
-            stq<AB>(p.G, o1, row(y1, g1));
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
+            const bnf4 y1 = *reinterpret_cast<const bnf4*>(p.Y + o1), g1 = *reinterpret_cast<const bnf4*>(p.G + o1);
+            *reinterpret_cast<bnf4*>(p.G + o0) = row(y0, g0);
+            *reinterpret_cast<bnf4*>(p.G + o1) = row(y1, g1);
         }
         if (R < rend) {
             const long o0 = row_off(p, R) + c;
-            const bnf4 y0 = ldq<AB>(p.Y, o0), g0 = ldq<AB>(p.G, o0);
-            stq<AB>(p.G, o0, row(y0, g0));
+            const bnf4 y0 = *reinterpret_cast<const bnf4*>(p.Y + o0), g0 = *reinterpret_cast<const bnf4*>(p.G + o0);
+            *reinterpret_cast<bnf4*>(p.G + o0) = row(y0, g0);
         }
     }
 }
@@ -372,9 +362,7 @@ struct ResidParams {
     double* stats1; double* stats2; const float* coef1; const float* coef2;
     int tile;
 };
-// AB: G, G2, O, Y1 and Y2 are stored as bf16
 
-template <bool AB>
 __global__ __launch_bounds__(256) void resid_bn_bwd_reduce_kernel(const ResidParams p) {
     __shared__ float red[256][13];
     const int C = p.C, c4 = C >> 2;
@@ -390,10 +378,10 @@ __global__ __launch_bounds__(256) void resid_bn_bwd_reduce_kernel(const ResidPar
         const long rend = min(p.M, (tile + 1) * p.tile);
         for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
             const long off = R * C + c;
-            const float4 gi = rl_ldx4<AB>(p.G, off);
-            const float4 o = rl_ldx4<AB>(p.O, off);
-            const float4 y1 = rl_ldx4<AB>(p.Y1, off);
-            const float4 y2 = rl_ldx4<AB>(p.Y2, off);
+            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
+            const float4 o = *reinterpret_cast<const float4*>(p.O + off);
+            const float4 y1 = *reinterpret_cast<const float4*>(p.Y1 + off);
+            const float4 y2 = *reinterpret_cast<const float4*>(p.Y2 + off);
             const float g[4] = {o.x > 0.f ? gi.x : gi.x * p.slope, o.y > 0.f ? gi.y : gi.y * p.slope,
                                 o.z > 0.f ? gi.z : gi.z * p.slope, o.w > 0.f ? gi.w : gi.w * p.slope};
             const float x1[4] = {(y1.x - mu1.x) * is1.x, (y1.y - mu1.y) * is1.y, (y1.z - mu1.z) * is1.z, (y1.w - mu1.w) * is1.w};
@@ -429,7 +417,6 @@ __global__ __launch_bounds__(256) void resid_bn_bwd_reduce_kernel(const ResidPar
     }
 }
 
-template <bool AB>
 __global__ __launch_bounds__(256) void resid_bn_bwd_apply_kernel(const ResidParams p) {
     const int C = p.C, c4 = C >> 2;
     const int tpr = c4 < 256 ? c4 : 256;
@@ -446,10 +433,10 @@ __global__ __launch_bounds__(256) void resid_bn_bwd_apply_kernel(const ResidPara
         const long rend = min(p.M, (tile + 1) * p.tile);
         for (long R = tile * p.tile + rsub; R < rend; R += rpar) {
             const long off = R * C + c;
-            const float4 gi = rl_ldx4<AB>(p.G, off);
-            const float4 o = rl_ldx4<AB>(p.O, off);
-            const float4 y1 = rl_ldx4<AB>(p.Y1, off);
-            const float4 y2 = rl_ldx4<AB>(p.Y2, off);
+            const float4 gi = *reinterpret_cast<const float4*>(p.G + off);
+            const float4 o = *reinterpret_cast<const float4*>(p.O + off);
+            const float4 y1 = *reinterpret_cast<const float4*>(p.Y1 + off);
+            const float4 y2 = *reinterpret_cast<const float4*>(p.Y2 + off);
             float4 g;
             g.x = o.x > 0.f ? gi.x : gi.x * p.slope; g.y = o.y > 0.f ? gi.y : gi.y * p.slope;
             g.z = o.z > 0.f ? gi.z : gi.z * p.slope; g.w = o.w > 0.f ? gi.w : gi.w * p.slope;
@@ -458,8 +445,8 @@ __global__ __launch_bounds__(256) void resid_bn_bwd_apply_kernel(const ResidPara
             r1.z = (g.z - a0.z - (y1.z - mu1.z) * is1.z * a1.z) * s1.z; r1.w = (g.w - a0.w - (y1.w - mu1.w) * is1.w * a1.w) * s1.w;
             r2.x = (g.x - b0.x - (y2.x - mu2.x) * is2.x * b1.x) * s2.x; r2.y = (g.y - b0.y - (y2.y - mu2.y) * is2.y * b1.y) * s2.y;
             r2.z = (g.z - b0.z - (y2.z - mu2.z) * is2.z * b1.z) * s2.z; r2.w = (g.w - b0.w - (y2.w - mu2.w) * is2.w * b1.w) * s2.w;
-            rl_stx4<AB>(p.G, off, r1);
-            rl_stx4<AB>(p.G2, off, r2);
+            *reinterpret_cast<float4*>(p.G + off) = r1;
+            *reinterpret_cast<float4*>(p.G2 + off) = r2;
         }
     }
 }
@@ -495,7 +482,6 @@ int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
     p->act = d->act; p->slope = d->slope; p->scale = d->scale; p->shift = d->shift;
     p->mean = d->mean; p->invstd = d->invstd; p->stats = d->stats; p->coef = d->coef;
     p->tile = bn_tile(p->M);
-    p->bf16 = d->act_bf16 ? 1 : 0;
     return RL_OK;
 }
 
@@ -529,11 +515,8 @@ extern "C" int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream) {
     int rc = fill(&p, d, "rl_bn_bwd_reduce");
     if (rc) return rc;
     RL_REQUIRE(p.stats && p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_reduce: needs stats/mean/invstd");
-    if (vec_ok(p) && p.bf16)
-        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<true>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
-                           (hipStream_t)stream, p);
-    else if (vec_ok(p))
-        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<false>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
+    if (vec_ok(p))
+        hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
@@ -557,11 +540,8 @@ extern "C" int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream) {
     int rc = fill(&p, d, "rl_bn_bwd_apply");
     if (rc) return rc;
     if (p.coef) RL_REQUIRE(p.mean && p.invstd, RL_ERR_ARGS, "rl_bn_bwd_apply: coef needs mean/invstd");
-    if (vec_ok(p) && p.bf16)
-        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<true>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
-                           (hipStream_t)stream, p);
-    else if (vec_ok(p))
-        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<false>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
+    if (vec_ok(p))
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
                            (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0,
@@ -581,8 +561,7 @@ extern "C" int rl_resid_bn_bwd_reduce(const rl_resid_bn_bwd_desc* d, void* strea
     int rc = resid_fill(&p, d, "rl_resid_bn_bwd_reduce");
     if (rc) return rc;
     RL_REQUIRE(p.stats1 && p.stats2, RL_ERR_ARGS, "rl_resid_bn_bwd_reduce: needs stats1 and stats2");
-    if (d->act_bf16) hipLaunchKernelGGL(resid_bn_bwd_reduce_kernel<true>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(resid_bn_bwd_reduce_kernel<false>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(resid_bn_bwd_reduce_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
     rl_note_kernel("resid_bn_bwd_reduce_kernel");
     RL_LAUNCH_CHECK("rl_resid_bn_bwd_reduce");
     return RL_OK;
@@ -593,8 +572,7 @@ extern "C" int rl_resid_bn_bwd_apply(const rl_resid_bn_bwd_desc* d, void* stream
     int rc = resid_fill(&p, d, "rl_resid_bn_bwd_apply");
     if (rc) return rc;
     RL_REQUIRE(p.G2 && p.coef1 && p.coef2, RL_ERR_ARGS, "rl_resid_bn_bwd_apply: needs G2, coef1 and coef2");
-    if (d->act_bf16) hipLaunchKernelGGL(resid_bn_bwd_apply_kernel<true>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(resid_bn_bwd_apply_kernel<false>, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(resid_bn_bwd_apply_kernel, dim3(rl_row_blocks_host(p.M, p.tile)), dim3(256), 0, (hipStream_t)stream, p);
     rl_note_kernel("resid_bn_bwd_apply_kernel");
     RL_LAUNCH_CHECK("rl_resid_bn_bwd_apply");
     return RL_OK;

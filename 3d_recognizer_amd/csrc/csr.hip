@@ -391,7 +391,6 @@ struct SegParams {
     long per;                // entries per cloud
     long total;              // B * n_dst
     int accumulate;
-    int dst_bf16;            // dst holds bf16 elements (bf16-storage mode); the sums are fp32
 };
 
 // tpr = C/4 lanes (a power of two <= 64... or 128/256 for wider rows) share one destination row, 16 bytes each
@@ -442,12 +441,12 @@ __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p)
                 const float4 v = rl_ldx4<SB>(p.src, sb + (long)ent[e] * p.lds + c);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
-            const long o = ((long)b * p.dst_bstride + j) * p.ldd + c;
+            float4* o = reinterpret_cast<float4*>(p.dst + ((long)b * p.dst_bstride + j) * p.ldd + c);
             if (p.accumulate) {
-                const float4 old = rl_ld4(p.dst, o, p.dst_bf16);
+                const float4 old = *o;
                 acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
             }
-            rl_st4(p.dst, o, acc, p.dst_bf16);
+            *o = acc;
         }
     }
 }
@@ -464,8 +463,8 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const SegParams p) {
         const float* sb = p.src + b * p.src_bstride * p.lds;
         float acc = 0.f;
         for (int e = off[j]; e < off[j + 1]; ++e) acc += sb[(long)ent[e] * p.lds + c];
-        const long o = (b * p.dst_bstride + j) * p.ldd + c;
-        rl_st1(p.dst, o, p.accumulate ? rl_ld1(p.dst, o, p.dst_bf16) + acc : acc, p.dst_bf16);
+        float* o = p.dst + (b * p.dst_bstride + j) * p.ldd + c;
+        *o = p.accumulate ? *o + acc : acc;
     }
 }
 
@@ -594,9 +593,8 @@ extern "C" int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream) {
     p.src = d->src; p.lds = d->lds; p.src_bstride = d->src_bstride; p.dst = d->dst; p.ldd = d->ldd;
     p.dst_bstride = d->dst_bstride; p.offsets = d->offsets; p.entries = d->entries; p.n_dst = d->n_dst; p.C = d->C;
     p.per = d->entries_per_cloud; p.total = (long)d->B * d->n_dst; p.accumulate = d->accumulate;
-    p.dst_bf16 = d->dst_bf16 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (d->C % 4 == 0) && (d->lds % 4 == 0) && (d->ldd % 4 == 0) && ((uintptr_t)d->dst & (d->dst_bf16 ? 7 : 15)) == 0 &&
+    const bool vec = (d->C % 4 == 0) && (d->lds % 4 == 0) && (d->ldd % 4 == 0) && ((uintptr_t)d->dst & 15) == 0 &&
                      ((uintptr_t)d->src & (d->src_bf16 ? 7 : 15)) == 0;
     RL_REQUIRE(!d->src_bf16 || vec, RL_ERR_UNSUPPORTED, "rl_segment_sum_rows: bf16 source rows need C, lds, ldd multiples of 4 and aligned tensors");
     if (vec) {

@@ -42,7 +42,6 @@ struct AOperand {
     int contig;   // mode 0: a_bstride == n
     int vec4;     // mode 0: 16-byte loads allowed (K % 4 == 0)
     int vec4p;    // mode 0: 16-byte loads allowed up to K rounded up to 4 (the row padding exists: lda >= that)
-    int bf16;     // mode 0: A holds bf16 elements (bf16-storage mode); lda and every offset count elements
 };
 
 __device__ __forceinline__ long a_row_offset(const AOperand& a, long R) {
@@ -93,7 +92,7 @@ __device__ __forceinline__ void stage_a(const AOperand& a, long row0, int nrows,
             const int kc = k0 + q * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (R < row_limit && kc < a.K) {
-                v = rl_ld4(a.A, a_row_offset(a, R) + kc, a.bf16);
+                v = *reinterpret_cast<const float4*>(a.A + a_row_offset(a, R) + kc);
                 if (a.lazy.scale) {
                     v.x = rl_lazy(a.lazy, v.x, kc + 0);
                     v.y = rl_lazy(a.lazy, v.y, kc + 1);
@@ -110,7 +109,7 @@ __device__ __forceinline__ void stage_a(const AOperand& a, long row0, int nrows,
         const long R = row0 + r;
         const int kc = k0 + c;
         float v = 0.f;
-        if (R < row_limit && kc < a.K) v = rl_lazy(a.lazy, rl_ld1(a.A, a_row_offset(a, R) + kc, a.bf16), kc);
+        if (R < row_limit && kc < a.K) v = rl_lazy(a.lazy, a.A[a_row_offset(a, R) + kc], kc);
         As[r * stride + c] = v;
     }
 }
@@ -138,7 +137,6 @@ struct GemmParams {
     long out2_bstride;
     int split_col;
     const __bf16* wsplit;      // wgemm: head plane [N][K] (k contiguous), tail plane follows at + N*K
-    int y_bf16;                // Y holds bf16 elements (bf16-storage mode; statistics come from the fp32 accumulators)
 };
 
 template <int NT>
@@ -216,8 +214,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                         if (c < N) {
                             float v = acc[rb][nb][r];
                             if (p.bias) v += p.bias[c];
-                            if (p.accumulate) v += rl_ld1(p.Y, yoff + c, p.y_bf16);
-                            rl_st1(p.Y, yoff + c, v, p.y_bf16);
+                            if (p.accumulate) v += p.Y[yoff + c];
+                            p.Y[yoff + c] = v;
                             ssum[nb] += v;
                             ssq[nb] += v * v;
                         }
@@ -262,7 +260,6 @@ struct WgradParams {
     float* slab;
     long rows_per_block;
     int has_bias;
-    int dy_bf16;     // dY holds bf16 elements (bf16-storage mode)
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
@@ -297,7 +294,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
                     const int i = (int)(R - (long)b * p.rows_per_batch);
                     off = ((long)b * p.dy_bstride + i) * p.lddy;
                 }
-                v = rl_ld1(p.dY, off + n0 + c, p.dy_bf16);
+                v = p.dY[off + n0 + c];
             }
             dYs[r * WG_S + c] = v;
         }
@@ -430,10 +427,9 @@ void wgrad_split(long M, int N, int K, int* nsplit, long* rows_per_block) {
 int fill_a(AOperand* a, const char* who, const float* A, long lda, long a_bstride, int a_mode,
            int in_act, float in_slope, const float* in_scale, const float* in_shift,
            const float* xyz, long xyz_bstride, const int32_t* nbr_idx, const float* nbr_d2, int nbr_k,
-           int B, int n, int K, int a_bf16 = 0) {
+           int B, int n, int K) {
     RL_REQUIRE(B > 0 && n > 0 && K > 0, RL_ERR_ARGS, "%s: bad sizes B=%d n=%d K=%d", who, B, n, K);
-    RL_REQUIRE(!(a_bf16 && a_mode == 1), RL_ERR_ARGS, "%s: the relative-position source is computed, not stored: a_bf16 does not apply", who);
-    a->A = A; a->lda = lda; a->a_bstride = a_bstride; a->a_mode = a_mode; a->bf16 = a_bf16 ? 1 : 0;
+    a->A = A; a->lda = lda; a->a_bstride = a_bstride; a->a_mode = a_mode;
     a->lazy.scale = in_scale; a->lazy.shift = in_shift; a->lazy.act = in_act; a->lazy.slope = in_slope;
     a->xyz = xyz; a->xyz_bstride = xyz_bstride; a->nbr_idx = nbr_idx; a->nbr_d2 = nbr_d2; a->nbr_k = nbr_k;
     a->n = n; a->K = K;
@@ -515,7 +511,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rvalid && 16 * c + 4 * lj < K) a[c] = rl_ld4(p.a.A, aoff + 16 * c + 4 * lj, p.a.bf16);
+            if (rvalid && 16 * c + 4 * lj < K) a[c] = *reinterpret_cast<const float4*>(p.a.A + aoff + 16 * c + 4 * lj);
         }
     };
     float4 a[KC], an[KC];
@@ -564,8 +560,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
                     const int n = nb * 16 + li;
                     if (n < N) {
                         float v = acc[nb][r] + bias[nb];
-                        if (p.accumulate) v += rl_ld1(p.Y, yoff + n, p.y_bf16);
-                        rl_st1(p.Y, yoff + n, v, p.y_bf16);
+                        if (p.accumulate) v += p.Y[yoff + n];
+                        p.Y[yoff + n] = v;
                         ssum[nb] += v;
                         ssq[nb] += v * v;
                     }
@@ -647,7 +643,7 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
 #pragma unroll
             for (int nb = 0; nb < NT; ++nb) {
                 const int n = nb * 16 + lc;
-                dy[u][nb] = (valid && n < N) ? rl_ld1(p.dY, doff + n, p.dy_bf16) : 0.f;
+                dy[u][nb] = (valid && n < N) ? p.dY[doff + n] : 0.f;
             }
             if (a.a_mode == 1) {
                 // relative position encoding, channel lc of row R (modules.py:173-186)
@@ -676,7 +672,7 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
 #pragma unroll
                 for (int kb = 0; kb < KT; ++kb) {
                     const int k = kb * 16 + lc;
-                    av[u][kb] = (valid && k < K) ? rl_ld1(a.A, aoff + k, a.bf16) : 0.f;
+                    av[u][kb] = (valid && k < K) ? a.A[aoff + k] : 0.f;
                 }
             }
         }
@@ -894,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (aval[i] && ka < K) ra[i] = rl_ld4(p.a.A, aoff[i] + ka, p.a.bf16);
+                if (aval[i] && ka < K) ra[i] = *reinterpret_cast<const float4*>(p.a.A + aoff[i] + ka);
             }
             if (w_ncontig) {
                 // W[k][n], n contiguous: unit u = 16 columns x 16 k; lane (q = l&3, kl = l>>2) loads 4 columns of
@@ -1136,8 +1132,8 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
                                 if (p.out2_index) atomicAdd(p.out2 + o2 + c, v);
                                 else p.out2[o2 + c] = v;
                             } else {
-                                if (p.accumulate) v += rl_ld1(p.Y, yoff + c, p.y_bf16);
-                                rl_st1(p.Y, yoff + c, v, p.y_bf16);
+                                if (p.accumulate) v += p.Y[yoff + c];
+                                p.Y[yoff + c] = v;
                                 ssum[nb] += v;
                                 ssq[nb] += v * v;
                             }
@@ -1244,7 +1240,7 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (aval[i] && ka < K) ra[i] = rl_ld4(p.a.A, aoff[i] + ka, p.a.bf16);
+                if (aval[i] && ka < K) ra[i] = *reinterpret_cast<const float4*>(p.a.A + aoff[i] + ka);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -1379,8 +1375,8 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
                             if (p.out2_index) atomicAdd(p.out2 + o2 + c, v);
                             else p.out2[o2 + c] = v;
                         } else {
-                            if (p.accumulate) v += rl_ld1(p.Y, yoff + c, p.y_bf16);
-                            rl_st1(p.Y, yoff + c, v, p.y_bf16);
+                            if (p.accumulate) v += p.Y[yoff + c];
+                            p.Y[yoff + c] = v;
                             if constexpr (STATS) {
                                 ssum[nb] += v;
                                 ssq[nb] += v * v;
@@ -1482,11 +1478,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
                     const int i = (int)(R - (long)b * p.rows_per_batch);
                     yoff = ((long)b * p.y_bstride + i) * p.ldy;
                 }
-                if (p.accumulate) {
-                    const float4 y = rl_ld4(p.Y, yoff + c, p.y_bf16);
-                    v.x += y.x; v.y += y.y; v.z += y.z; v.w += y.w;
-                }
-                rl_st4(p.Y, yoff + c, v, p.y_bf16);
+                float* y = p.Y + yoff + c;
+                if (p.accumulate) { v.x += y[0]; v.y += y[1]; v.z += y[2]; v.w += y[3]; }
+                y[0] = v.x; y[1] = v.y; y[2] = v.z; y[3] = v.w;
                 acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
                 acc[4] += v.x * v.x; acc[5] += v.y * v.y; acc[6] += v.z * v.z; acc[7] += v.w * v.w;
             }
@@ -1623,10 +1617,10 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(const WgradParams p) {
                         const int ii = (int)(R - (long)b * p.rows_per_batch);
                         off = ((long)b * p.dy_bstride + ii) * p.lddy;
                     }
-                    rd[i] = rl_ld4(p.dY, off + n0 + q4, p.dy_bf16);
+                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + q4);
                 }
                 if (q4 < kvalid) {
-                    float4 v = rl_ld4(p.a.A, a_row_offset(p.a, R) + k0 + q4, p.a.bf16);
+                    float4 v = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + q4);
                     if (lazy) {
                         v.x = rl_act(v.x * sc.x + sh.x, p.a.lazy.act, p.a.lazy.slope);
                         v.y = rl_act(v.y * sc.y + sh.y, p.a.lazy.act, p.a.lazy.slope);
@@ -1760,9 +1754,9 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
                         const int ii = (int)(R - (long)b * p.rows_per_batch);
                         off = ((long)b * p.dy_bstride + ii) * p.lddy;
                     }
-                    rd[i] = rl_ld4(p.dY, off + n0 + ucol[i], p.dy_bf16);
+                    rd[i] = *reinterpret_cast<const float4*>(p.dY + off + n0 + ucol[i]);
                 }
-                if (ucol[i] < kvalid) ra[i] = rl_ld4(p.a.A, a_row_offset(p.a, R) + k0 + ucol[i], p.a.bf16);
+                if (ucol[i] < kvalid) ra[i] = *reinterpret_cast<const float4*>(p.a.A + a_row_offset(p.a, R) + k0 + ucol[i]);
             }
         }
     };
@@ -1930,8 +1924,8 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
 // 128 x 128 tile of dW (32 accumulator registers each instead of 64), which fits 128 VGPRs: two workgroups per CU = four
 // wavefronts per SIMD, twice the loads in flight (pwgrad128_kernel<3>: 240 VGPRs, two per SIMD, 39 % of its wavefront
 // cycles parked on memory).  bf16 arithmetic modes only; same operands and MFMA sequence per accumulator -> same bits.
-// (A and dY may be stored as bf16 rows - bf16-storage mode; when both are, TERMS = 1 is exact: the tails would be zero)
-template <int TERMS>   // 3: bf16x3; 1: bf16
+// RB: A and dY are stored as bf16 rows (bf16-storage mode; then TERMS = 1 is exact - the tails would be zero)
+template <int TERMS, bool RB = false>   // 3: bf16x3; 1: bf16
 __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p) {
     constexpr int BS = 40;
     constexpr int NSPL = TERMS == 3 ? 2 : 1;
@@ -1993,9 +1987,9 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
                         const int ii = (int)(R - (long)b * p.rows_per_batch);
                         off = ((long)b * p.dy_bstride + ii) * p.lddy;
                     }
-                    rd[i] = rl_ld4(p.dY, off + n0 + ucol[i], p.dy_bf16);
+                    rd[i] = rl_ldx4<RB>(p.dY, off + n0 + ucol[i]);
                 }
-                if (ucol[i] < kvalid) ra[i] = rl_ld4(p.a.A, a_row_offset(p.a, R) + k0 + ucol[i], p.a.bf16);
+                if (ucol[i] < kvalid) ra[i] = rl_ldx4<RB>(p.a.A, a_row_offset(p.a, R) + k0 + ucol[i]);
             }
         }
     };
@@ -2116,11 +2110,11 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     GemmParams p;
     int rc = fill_a(&p.a, "rl_gemm", d->A, d->lda, d->a_bstride, d->a_mode, d->in_act, d->in_slope,
                     d->in_scale, d->in_shift, d->xyz, d->xyz_bstride, d->nbr_idx, d->nbr_d2, d->nbr_k,
-                    d->B, d->n, d->K, d->a_bf16);
+                    d->B, d->n, d->K);
     if (rc) return rc;
     RL_REQUIRE(d->N > 0 && d->W && d->Y && d->ldy > 0, RL_ERR_ARGS, "rl_gemm: bad W/Y");
     p.N = d->N; p.W = d->W; p.w_ks = d->w_ks; p.w_ns = d->w_ns; p.bias = d->bias;
-    p.Y = d->Y; p.ldy = d->ldy; p.y_bstride = d->y_bstride; p.y_bf16 = d->y_bf16 ? 1 : 0;
+    p.Y = d->Y; p.ldy = d->ldy; p.y_bstride = d->y_bstride;
     p.rows_per_batch = (d->a_mode == 1) ? d->n * d->nbr_k : d->n;
     RL_REQUIRE(d->y_bstride >= p.rows_per_batch, RL_ERR_ARGS, "rl_gemm: y_bstride smaller than rows per cloud");
     p.y_contig = (d->y_bstride == p.rows_per_batch);
@@ -2245,16 +2239,17 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
     WgradParams p;
     int rc = fill_a(&p.a, "rl_wgrad", d->A, d->lda, d->a_bstride, d->a_mode, d->in_act, d->in_slope,
                     d->in_scale, d->in_shift, d->xyz, d->xyz_bstride, d->nbr_idx, d->nbr_d2, d->nbr_k,
-                    d->B, d->n, d->K, d->a_bf16);
+                    d->B, d->n, d->K);
     if (rc) return rc;
     RL_REQUIRE(d->N > 0 && d->dY && d->dW && d->slab && d->lddy >= d->N, RL_ERR_ARGS, "rl_wgrad: bad dY/dW/slab");
-    p.N = d->N; p.dY = d->dY; p.lddy = d->lddy; p.dy_bstride = d->dy_bstride; p.dy_bf16 = d->dy_bf16 ? 1 : 0;
+    p.N = d->N; p.dY = d->dY; p.lddy = d->lddy; p.dy_bstride = d->dy_bstride;
     p.rows_per_batch = (d->a_mode == 1) ? d->n * d->nbr_k : d->n;
     RL_REQUIRE(d->dy_bstride >= p.rows_per_batch, RL_ERR_ARGS, "rl_wgrad: dy_bstride smaller than rows per cloud");
     p.dy_contig = (d->dy_bstride == p.rows_per_batch);
     p.slab = d->slab; p.has_bias = d->dbias != nullptr;
     int nsplit; long rpb;
     const bool streaming = stream_wgrad_ok(d->N, d->K);
+    RL_REQUIRE(!(d->rows_bf16 && streaming), RL_ERR_UNSUPPORTED, "rl_wgrad: bf16 rows are supported by the wide weight-gradient kernel only");
     if (streaming) swgrad_split(p.a.M, &nsplit, &rpb);
     else wgrad_split(p.a.M, d->N, d->K, &nsplit, &rpb);
     RL_REQUIRE(d->slab_floats >= (int64_t)nsplit * ((int64_t)d->N * d->K + d->N), RL_ERR_ARGS,
@@ -2270,9 +2265,11 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
         const bool pipelined = pwgrad_ok(p);
         const int T = pipelined ? wgrad_tile(d->N, d->K) : WG_T;
         dim3 grid(nsplit, rl_cdiv(d->N, T), rl_cdiv(d->K, T));
-        if (pipelined && T == 128 && d->a_bf16 && d->dy_bf16 && !p.a.lazy.scale && wide_gemm_terms() != 0) {
-            // both operands are bf16 as stored and used as they are: one bf16 product per term IS the exact product
-            hipLaunchKernelGGL(pwgrad128w_kernel<1>, grid, dim3(512), 0, st, p);
+        RL_REQUIRE(!d->rows_bf16 || (pipelined && T == 128 && wide_gemm_terms() != 0 && d->a_mode == 0), RL_ERR_UNSUPPORTED,
+                   "rl_wgrad: bf16 rows are supported by the wide (128 x 128 tile) weight-gradient kernel only");
+        if (d->rows_bf16) {
+            RL_REQUIRE(d->lda % 4 == 0 && d->lddy % 4 == 0, RL_ERR_ARGS, "rl_wgrad: bf16 rows need leading dimensions that are multiples of 4");
+            hipLaunchKernelGGL((pwgrad128w_kernel<1, true>), grid, dim3(512), 0, st, p);
         } else if (pipelined && T == 128) {
             const int t = wide_gemm_terms();
             static const bool narrow_wg = getenv("RL_WGRAD_4WAVE") != nullptr;      // diagnostics: the 4-wavefront kernel

@@ -113,7 +113,6 @@ struct PoolParams {
     const float* mu1; const float* is1; const float* mu2; const float* is2; // saved mean / invstd (backward kernels)
     double* fstats2;       // pool_fwd with virtual stage 1: [grid][2][H] partial (sum, sum of squares) of the RAW stage-2 output
     double* bstats;        // pool_bwd with a virtual stage: [grid][2][H] partial sums of g and g*xhat of that stage's BatchNorm
-    int act_bf16;          // bf16-storage mode: the activation-typed tensors - U, G, Pout, dP, and GU of a real U - hold bf16
 };
 
 template <int DT>
@@ -182,8 +181,8 @@ __device__ __forceinline__ void fetch_x(const PoolParams& p, const Cursor& cu, i
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
         if (k < H) {
-            if (p.src == 0) raw[c] = rl_ld4(p.U, row * H + k, p.act_bf16);
-        } else raw[c] = rl_ld4(p.G, (b * p.g_bstride + my_idx) * H + (k - H), p.act_bf16);
+            if (p.src == 0) raw[c] = *reinterpret_cast<const float4*>(p.U + row * H + k);
+        } else raw[c] = *reinterpret_cast<const float4*>(p.G + (b * p.g_bstride + my_idx) * H + (k - H));
     }
 }
 template <int DT>
@@ -664,7 +663,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
             float acc = sum4(s[nb] * xc);
             acc += __shfl_xor(acc, 16, 64);
             acc += __shfl_xor(acc, 32, 64);
-            if (lj == 0) rl_st1(p.Pout, pt * D + nb * 16 + li, acc, p.act_bf16);
+            if (lj == 0) p.Pout[pt * D + nb * 16 + li] = acc;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -770,10 +769,7 @@ __global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, doub
 // is virtual (a real U tensor's gradient goes on into the fp32 GEMM chain)
 template <int DT, int TERMS, bool VIRT = false, int NW = 4, bool GB = false>   // NW wavefronts share the staged weights
 __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
-    // GU: with a virtual rpe branch it is a neighbourhood-row scratch tensor (GB); with a real U it has U's type (act_bf16)
-    auto gu_ld = [&](long i) { if constexpr (VIRT) return rl_ldx<GB>(p.GU, i); else return rl_ld1(p.GU, i, p.act_bf16); };
-    auto gu_st = [&](long i, float v) { if constexpr (VIRT) rl_stx<GB>(p.GU, i, v); else rl_st1(p.GU, i, v, p.act_bf16); };
-    auto gu_st4 = [&](long i, const float4 v) { if constexpr (VIRT) rl_stx4<GB>(p.GU, i, v); else rl_st4(p.GU, i, v, p.act_bf16); };
+    constexpr bool GUB = GB && VIRT;
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
     __shared__ float vcl[(VIRT && VCols<DT>::INLDS) ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
@@ -868,7 +864,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
         if constexpr (VIRT) fetch_rpe(p, cu, li, idx_cur, rin);
 #pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp[nb] = rl_ld1(p.dP, pt * D + nb * 16 + li, p.act_bf16);
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
     }
     constexpr int NGU = DT == 1 ? 1 : DT / 2;     // column blocks that hold rpe-branch (GU) columns
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
@@ -886,14 +882,14 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
         if constexpr (VIRT) fetch_rpe(p, cf, li, pt + pstep < p.P ? idx_nxt : idx_cur, rin);
 #pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = rl_ld1(p.dP, cf.pt * D + nb * 16 + li, p.act_bf16);
+        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
         f32x4 gacc[NGU];                 // GU of this point when this launch adds to it
 #pragma unroll
         for (int nb = 0; nb < NGU; ++nb) {
             gacc[nb] = splat(0.f);
             if (p.gu_accumulate && nb * 16 + li < H) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gacc[nb][r] = gu_ld((pt * 16 + lj * 4 + r) * H + nb * 16 + li);
+                for (int r = 0; r < 4; ++r) gacc[nb][r] = rl_ldx<GUB>(p.GU, (pt * 16 + lj * 4 + r) * H + nb * 16 + li);
             }
         }
         loads_issued();
@@ -995,7 +991,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 if constexpr (DT <= 2) Ds[rowi * XS + col] = v;
                 else {                      // d = 64: measured better with the element stores (11 us per step)
                     const long urow = (pt * 16 + rowi) * H;
-                    if (col < H) gu_st(urow + col, v);
+                    if (col < H) rl_stx<GUB>(p.GU, urow + col, v);
                     else rl_stx<GB>(p.DG, urow + (col - H), v);
                 }
             }
@@ -1007,7 +1003,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
             for (int c = 0; c < DT; ++c) {
                 const int k = 16 * c + 4 * lj;
                 const float4 v = *reinterpret_cast<const float4*>(Ds + li * XS + k);
-                if (k < H) gu_st4(orow + k, v);
+                if (k < H) rl_stx4<GUB>(p.GU, orow + k, v);
                 else rl_stx4<GB>(p.DG, orow + (k - H), v);
             }
         }
@@ -1127,7 +1123,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     if (pt < p.P) {
         fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
 #pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp[nb] = rl_ld1(p.dP, pt * D + nb * 16 + li, p.act_bf16);
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
     }
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
                          // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
@@ -1141,7 +1137,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
         const Cursor cf = pt + pstep < p.P ? cn : cu;
         fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
 #pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = rl_ld1(p.dP, cf.pt * D + nb * 16 + li, p.act_bf16);
+        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
         loads_issued();
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
@@ -1215,8 +1211,8 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                 const int col = nb * 16 + li;
                 const float v = dx[nb][r];
                 if (col < H) {
-                    if (p.gu_accumulate) rl_st1(p.GU, urow + col, rl_ld1(p.GU, urow + col, p.act_bf16) + v, p.act_bf16);
-                    else rl_st1(p.GU, urow + col, v, p.act_bf16);
+                    if (p.gu_accumulate) p.GU[urow + col] += v;
+                    else p.GU[urow + col] = v;
                 } else {
                     rl_stx<GB>(p.DG, urow + (col - H), v);
                 }
@@ -1663,7 +1659,6 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->idx = d->idx; p->W = d->W; p->P = d->points; p->n = d->n; p->d = d->d;
     p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->DG = d->DG; p->slab = d->slab;
     p->X_out = nullptr; p->dS_out = nullptr;
-    p->act_bf16 = d->act_bf16 ? 1 : 0;
     p->src = d->u_source;
     RL_REQUIRE(d->u_source >= 0 && d->u_source <= 2, RL_ERR_ARGS, "%s: u_source must be 0, 1 or 2", who);
     if (d->u_source > 0) {

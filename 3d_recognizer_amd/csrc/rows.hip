@@ -25,7 +25,6 @@ struct RowsParams {
     int shared;
     int accumulate;
     RlLazy lazy;
-    int src_bf16, dst_bf16;      // bf16-storage mode: what the bytes of src / dst are (offsets count elements)
 };
 
 // I = uint32_t when the element count fits 32 bits (64-bit integer division is emulated with
@@ -70,16 +69,10 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
             }
             v4f v[4], o[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 t = rl_ld4(p.src, so[u], p.src_bf16);
-                v[u] = (v4f){t.x, t.y, t.z, t.w};
-            }
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f*>(p.src + so[u]);
             if (p.accumulate) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 t = rl_ld4(p.dst, dofs[u], p.dst_bf16);
-                    o[u] = (v4f){t.x, t.y, t.z, t.w};
-                }
+                for (int u = 0; u < 4; ++u) o[u] = *reinterpret_cast<const v4f*>(p.dst + dofs[u]);
             }
             if (lazy) {
 #pragma unroll
@@ -93,7 +86,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (p.accumulate) v[u] += o[u];
-                if (ok[u]) rl_st4(p.dst, dofs[u], make_float4(v[u][0], v[u][1], v[u][2], v[u][3]), p.dst_bf16);
+                if (ok[u]) *reinterpret_cast<v4f*>(p.dst + dofs[u]) = v[u];
             }
         }
     } else {
@@ -102,9 +95,9 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
             const int c = (int)((I)e - r * (I)cpr) * VEC;
             const long so = src_row<I>(p, r) * p.lds + c;
             const long dofs = (long)r * p.ldd + c;
-            float v = rl_lazy(p.lazy, rl_ld1(p.src, so, p.src_bf16), c);
-            if (p.accumulate) v += rl_ld1(p.dst, dofs, p.dst_bf16);
-            rl_st1(p.dst, dofs, v, p.dst_bf16);
+            float v = rl_lazy(p.lazy, p.src[so], c);
+            if (p.accumulate) v += p.dst[dofs];
+            p.dst[dofs] = v;
         }
     }
 }
@@ -129,7 +122,6 @@ int fill(RowsParams* p, const rl_rows_desc* d, const char* who) {
     p->rows = d->rows; p->rows_per_batch = d->rows_per_batch; p->C = d->C; p->i32 = d->index32;
     p->i64 = d->index64; p->shared = d->index_shared; p->accumulate = d->accumulate;
     p->lazy.scale = d->scale; p->lazy.shift = d->shift; p->lazy.act = d->act; p->lazy.slope = d->slope;
-    p->src_bf16 = d->src_bf16 ? 1 : 0; p->dst_bf16 = d->dst_bf16 ? 1 : 0;
     return RL_OK;
 }
 
@@ -258,21 +250,20 @@ __global__ __launch_bounds__(256) void attpool_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void add_act_fwd_vec_kernel(const float* __restrict__ Y1, const float* __restrict__ s1,
                                                               const float* __restrict__ b1, const float* __restrict__ Y2,
                                                               const float* __restrict__ s2, const float* __restrict__ b2,
-                                                              long quads, int C, float slope, float* __restrict__ O, int bf16) {
+                                                              long quads, int C, float slope, float* __restrict__ O) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const unsigned cq = (unsigned)C >> 2;
     const long stride = (long)gridDim.x * 256;
     auto one = [&](long q) {
         const int c = (int)((unsigned long)q % cq) * 4;
-        const float4 t1 = rl_ld4(Y1, q * 4, bf16), t2 = rl_ld4(Y2, q * 4, bf16);
-        const v4f y1 = {t1.x, t1.y, t1.z, t1.w}, y2 = {t2.x, t2.y, t2.z, t2.w};
+        const v4f y1 = *reinterpret_cast<const v4f*>(Y1 + q * 4), y2 = *reinterpret_cast<const v4f*>(Y2 + q * 4);
         const v4f a1 = *reinterpret_cast<const v4f*>(s1 + c), c1 = *reinterpret_cast<const v4f*>(b1 + c);
         const v4f a2 = *reinterpret_cast<const v4f*>(s2 + c), c2 = *reinterpret_cast<const v4f*>(b2 + c);
         const v4f z = (y1 * a1 + c1) + (y2 * a2 + c2);
         v4f o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = z[j] > 0.f ? z[j] : z[j] * slope;
-        rl_st4(O, q * 4, make_float4(o[0], o[1], o[2], o[3]), bf16);
+        *reinterpret_cast<v4f*>(O + q * 4) = o;
     };
     long q = (long)blockIdx.x * 256 + threadIdx.x;
     for (; q + stride < quads; q += 2 * stride) { one(q); one(q + stride); }
@@ -283,20 +274,18 @@ template <typename I>
 __global__ __launch_bounds__(256) void add_act_fwd_kernel(const float* __restrict__ Y1, const float* __restrict__ s1,
                                                           const float* __restrict__ b1, const float* __restrict__ Y2,
                                                           const float* __restrict__ s2, const float* __restrict__ b2,
-                                                          long total, int C, float slope, float* __restrict__ O, int bf16) {
+                                                          long total, int C, float slope, float* __restrict__ O) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int c = (int)((I)e % (I)C);
-        const float z = (rl_ld1(Y1, e, bf16) * s1[c] + b1[c]) + (rl_ld1(Y2, e, bf16) * s2[c] + b2[c]);
-        rl_st1(O, e, z > 0.f ? z : z * slope, bf16);
+        const float z = (Y1[e] * s1[c] + b1[c]) + (Y2[e] * s2[c] + b2[c]);
+        O[e] = z > 0.f ? z : z * slope;
     }
 }
 
 __global__ __launch_bounds__(256) void add_act_bwd_kernel(float* __restrict__ G, const float* __restrict__ O, long total,
-                                                          float slope, int bf16) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const float g = rl_ld1(G, e, bf16);
-        rl_st1(G, e, rl_ld1(O, e, bf16) > 0.f ? g : g * slope, bf16);
-    }
+                                                          float slope) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256)
+        G[e] = O[e] > 0.f ? G[e] : G[e] * slope;
 }
 
 // one lane per neighbourhood row: 2 gathers of 12 B from the (L2-resident) coordinates, 48 B written
@@ -350,13 +339,13 @@ __global__ void dropout_tick_kernel(int64_t* counter, int64_t* key_out) {
 template <bool FWD>
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ src, RlLazy lazy, int C, float* __restrict__ dst,
                                                       long quads, const int64_t* __restrict__ key, unsigned long long seed,
-                                                      unsigned threshold, float scale, unsigned long long first_quad, int bf16) {
+                                                      unsigned threshold, float scale, unsigned long long first_quad) {
     const unsigned long long k = (unsigned long long)key[0];
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
         const unsigned long long gq = first_quad + (unsigned long long)q;     // index in the WHOLE batch's tensor (shards of one batch)
         const uint4 r = philox4x32_10(make_uint4((unsigned)gq, (unsigned)(gq >> 32), (unsigned)k, (unsigned)(k >> 32)),
                                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
-        float4 v = rl_ld4(src, q * 4, bf16);
+        float4 v = *reinterpret_cast<const float4*>(src + q * 4);
         if (FWD && lazy.scale) {
             const int c = (int)(((unsigned)q * 4u) % (unsigned)C);      // elements < 2^32 (host check); C % 4 == 0: a quad stays inside one row
             v.x = rl_lazy(lazy, v.x, c + 0); v.y = rl_lazy(lazy, v.y, c + 1);
@@ -366,7 +355,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
         v.y = r.y >= threshold ? v.y * scale : 0.f;
         v.z = r.z >= threshold ? v.z * scale : 0.f;
         v.w = r.w >= threshold ? v.w * scale : 0.f;
-        rl_st4(dst, q * 4, v, bf16);
+        *reinterpret_cast<float4*>(dst + q * 4) = v;
     }
 }
 
@@ -499,7 +488,7 @@ extern "C" int rl_attpool_bwd(const float* X, const float* S, const float* Pout,
 }
 
 extern "C" int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1, const float* Y2, const float* s2,
-                              const float* b2, int64_t rows, int C, float slope, float* O, int act_bf16, void* stream) {
+                              const float* b2, int64_t rows, int C, float slope, float* O, void* stream) {
     RL_REQUIRE(Y1 && s1 && b1 && Y2 && s2 && b2 && O && rows >= 0 && C > 0, RL_ERR_ARGS, "rl_add_act_fwd: bad arguments");
     if (rows == 0) return RL_OK;
     const bool vec = C % 4 == 0 && ((((uintptr_t)Y1) | ((uintptr_t)Y2) | ((uintptr_t)O) | ((uintptr_t)s1) | ((uintptr_t)b1) |
@@ -507,23 +496,23 @@ extern "C" int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1,
     if (vec) {
         const long quads = (long)rows * (C / 4);
         hipLaunchKernelGGL(add_act_fwd_vec_kernel, dim3(grid_for((quads + 1) / 2)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
-                           s2, b2, quads, C, slope, O, act_bf16);
+                           s2, b2, quads, C, slope, O);
     } else if (fits32(rows * C))
         hipLaunchKernelGGL(add_act_fwd_kernel<uint32_t>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
-                           s2, b2, (long)rows * C, C, slope, O, act_bf16);
+                           s2, b2, (long)rows * C, C, slope, O);
     else
         hipLaunchKernelGGL(add_act_fwd_kernel<int64_t>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, Y1, s1, b1, Y2,
-                           s2, b2, (long)rows * C, C, slope, O, act_bf16);
+                           s2, b2, (long)rows * C, C, slope, O);
     rl_note_kernel("add_act_fwd_kernel");
     RL_LAUNCH_CHECK("rl_add_act_fwd");
     return RL_OK;
 }
 
-extern "C" int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, int act_bf16, void* stream) {
+extern "C" int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, void* stream) {
     RL_REQUIRE(G && O && rows >= 0 && C > 0, RL_ERR_ARGS, "rl_add_act_bwd: bad arguments");
     if (rows == 0) return RL_OK;
     hipLaunchKernelGGL(add_act_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, G, O,
-                       (long)rows * C, slope, act_bf16);
+                       (long)rows * C, slope);
     rl_note_kernel("add_act_bwd_kernel");
     RL_LAUNCH_CHECK("rl_add_act_bwd");
     return RL_OK;
@@ -581,8 +570,7 @@ static int dropout_args(const float* src, float* dst, int64_t rows, int64_t firs
 }
 
 extern "C" int rl_dropout_fwd(const float* src, const float* scale, const float* shift, int act, float slope, float* dst,
-                              int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, int act_bf16,
-                              void* stream) {
+                              int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, void* stream) {
     unsigned thr;
     int rc = dropout_args(src, dst, rows, first_row, C, key, p, "rl_dropout_fwd", &thr);
     if (rc) return rc;
@@ -591,14 +579,14 @@ extern "C" int rl_dropout_fwd(const float* src, const float* scale, const float*
     RlLazy lz; lz.scale = scale; lz.shift = shift; lz.act = act; lz.slope = slope;
     const long quads = (long)rows * C / 4;
     hipLaunchKernelGGL(dropout_kernel<true>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, src, lz, C, dst, quads, key,
-                       (unsigned long long)seed, thr, 1.0f / (1.0f - p), (unsigned long long)first_row * (unsigned)C / 4u, act_bf16);
+                       (unsigned long long)seed, thr, 1.0f / (1.0f - p), (unsigned long long)first_row * (unsigned)C / 4u);
     rl_note_kernel("dropout_kernel");
     RL_LAUNCH_CHECK("rl_dropout_fwd");
     return RL_OK;
 }
 
 extern "C" int rl_dropout_bwd(float* G, int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p,
-                              int act_bf16, void* stream) {
+                              void* stream) {
     unsigned thr;
     int rc = dropout_args(G, G, rows, first_row, C, key, p, "rl_dropout_bwd", &thr);
     if (rc) return rc;
@@ -606,7 +594,7 @@ extern "C" int rl_dropout_bwd(float* G, int64_t rows, int64_t first_row, int C, 
     RlLazy lz; lz.scale = nullptr; lz.shift = nullptr; lz.act = 0; lz.slope = 0.f;
     const long quads = (long)rows * C / 4;
     hipLaunchKernelGGL(dropout_kernel<false>, dim3(grid_for(quads)), dim3(256), 0, (hipStream_t)stream, G, lz, C, G, quads, key,
-                       (unsigned long long)seed, thr, 1.0f / (1.0f - p), (unsigned long long)first_row * (unsigned)C / 4u, act_bf16);
+                       (unsigned long long)seed, thr, 1.0f / (1.0f - p), (unsigned long long)first_row * (unsigned)C / 4u);
     rl_note_kernel("dropout_kernel");
     RL_LAUNCH_CHECK("rl_dropout_bwd");
     return RL_OK;

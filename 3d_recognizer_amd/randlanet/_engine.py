@@ -110,9 +110,8 @@ class Engine:
         # a bias in front of a BatchNorm cancels in (y - mean): the GEMM epilogue leaves it out (a bias costs a wide GEMM
         # launch +18 %) and the BatchNorm fold accounts for it where it shows - the running mean (rl_bn_finalize)
         fold = FOLD_BIAS and bn is not None and bname is not None
-        # (a layer without BatchNorm is fc_end.3: the logits stay fp32 in every storage mode)
         Y = ops.gemm(a, W, ks, ns, n_out, self.P[bname] if (bname and not fold) else None, stats=stats,
-                     wsplit=getattr(ctx, "wsplit", None), out_dtype=None if bn else torch.float32)
+                     wsplit=getattr(ctx, "wsplit", None))
         rpb = a.n * a.K if isinstance(a, Rpe) else a.n
         out = Lazy(Y, a.B, rpb, rpb, n_out)
         if bn:
@@ -147,7 +146,7 @@ class Engine:
         X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
         ops.copy_rows(u.raw, (0, h), n * K, X, (0, h), rows, n * K, lazy=u)
         ops.copy_rows(g.raw, (0, h), g.bstride, X, (h, h), rows, n * K, index=idx, lazy=g)
-        S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None, wsplit=getattr(ctx, "wsplit", None), out_dtype=torch.float32)
+        S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None, wsplit=getattr(ctx, "wsplit", None))
         Pt = ops.attpool_fwd(X, S, B * n, K)
         pooled = ops.plain(Pt, B, n)
         ctx.tape.append(("pool", name, u, g, csr, X, S, pooled, n, d))
@@ -291,7 +290,7 @@ class Engine:
             assert nn.shape == (B, n_f, 1)
             skip = skips.pop()
             assert skip.n == n_f and x.n == n_c
-            cat = torch.empty((B * n_f, x.C + skip.C), dtype=x.raw.dtype, device=dev)
+            cat = torch.empty((B * n_f, x.C + skip.C), dtype=torch.float32, device=dev)
             ops.copy_rows(x.raw, (0, x.C), x.bstride, cat, (0, x.C), B * n_f, n_f, index=nn, lazy=x)
             ops.copy_rows(skip.raw, (0, skip.C), skip.bstride, cat, (x.C, skip.C), B * n_f, n_f)
             catl = ops.plain(cat, B, n_f)
@@ -314,8 +313,6 @@ class Engine:
                 dropped = ops.plain(ops.dropout_fwd(x, key, seed, dropout_p, first_row), B, N)
                 ctx.tape.append(("dropout_philox", x, dropped, key, dropout_p, seed, first_row))
             else:
-                if x.raw.dtype != torch.float32:
-                    raise H.HipKernelError("an explicit Dropout mask (parity tests) needs the fp32 storage mode")
                 t = torch.empty((B * N, 32), dtype=torch.float32, device=dev)
                 ops.copy_rows(x.raw, (0, 32), N, t, (0, 32), B * N, N, lazy=x)
                 ops.scale_mask(t, keep_mask, 1.0 / (1.0 - dropout_p))

@@ -45,7 +45,6 @@ class GemmDesc(C.Structure):
         ("addend", C.c_void_p), ("out2", C.c_void_p), ("out2_index", C.c_void_p), ("out2_bstride", C.c_int64),
         ("split_col", C.c_int32),
         ("W_split", C.c_void_p),
-        ("a_bf16", C.c_int32), ("y_bf16", C.c_int32),
     ]
 
 
@@ -66,7 +65,7 @@ class WgradDesc(C.Structure):
         ("dW", C.c_void_p), ("w_ks", C.c_int64), ("w_ns", C.c_int64),
         ("dbias", C.c_void_p),
         ("slab", C.c_void_p), ("slab_floats", C.c_int64),
-        ("defer_reduce", C.c_int32), ("a_bf16", C.c_int32), ("dy_bf16", C.c_int32),
+        ("defer_reduce", C.c_int32), ("rows_bf16", C.c_int32),
     ]
 
 
@@ -93,7 +92,7 @@ class BnBwdDesc(C.Structure):
         ("B", C.c_int32), ("n", C.c_int32), ("C", C.c_int32), ("act", C.c_int32),
         ("slope", C.c_float),
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-        ("stats", C.c_void_p), ("coef", C.c_void_p), ("act_bf16", C.c_int32),
+        ("stats", C.c_void_p), ("coef", C.c_void_p),
     ]
 
 
@@ -124,7 +123,7 @@ class PoolDesc(C.Structure):
         ("W2", C.c_void_p), ("b2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
         ("mean1", C.c_void_p), ("invstd1", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
         ("xyz_width", C.c_int32), ("bn_bwd_stats", C.c_void_p), ("bn_fwd_stats2", C.c_void_p),
-        ("rows_bf16", C.c_int32), ("act_bf16", C.c_int32),
+        ("rows_bf16", C.c_int32),
     ]
 
 
@@ -134,7 +133,6 @@ class ResidBnBwdDesc(C.Structure):
         ("Y1", C.c_void_p), ("scale1", C.c_void_p), ("mean1", C.c_void_p), ("invstd1", C.c_void_p),
         ("Y2", C.c_void_p), ("scale2", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
         ("stats1", C.c_void_p), ("stats2", C.c_void_p), ("coef1", C.c_void_p), ("coef2", C.c_void_p),
-        ("act_bf16", C.c_int32),
     ]
 
 
@@ -154,7 +152,7 @@ class SegsumDesc(C.Structure):
         ("dst", C.c_void_p), ("ldd", C.c_int64), ("dst_bstride", C.c_int64),
         ("offsets", C.c_void_p), ("entries", C.c_void_p), ("entries_per_cloud", C.c_int64),
         ("B", C.c_int32), ("n_dst", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32),
-        ("src_bf16", C.c_int32), ("dst_bf16", C.c_int32),
+        ("src_bf16", C.c_int32),
     ]
 
 
@@ -168,7 +166,6 @@ class RowsDesc(C.Structure):
         ("index_shared", C.c_int32), ("accumulate", C.c_int32), ("act", C.c_int32),
         ("slope", C.c_float),
         ("scale", C.c_void_p), ("shift", C.c_void_p),
-        ("src_bf16", C.c_int32), ("dst_bf16", C.c_int32),
     ]
 
 
@@ -220,15 +217,15 @@ _SIGNATURES = {
     "rl_pool_bwd": (_i, [C.POINTER(PoolDesc), _vp]),
     "rl_attpool_fwd": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp]),
     "rl_attpool_bwd": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp]),
-    "rl_add_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp, _i, _vp]),
-    "rl_add_act_bwd": (_i, [_vp, _vp, _l, _i, _f, _i, _vp]),
+    "rl_add_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp, _vp]),
+    "rl_add_act_bwd": (_i, [_vp, _vp, _l, _i, _f, _vp]),
     "rl_rpe_build": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_rpe_build_dist": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_batch_assemble": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
     "rl_dropout_tick": (_i, [_vp, _vp, _vp]),
-    "rl_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _l, _l, _i, _vp, C.c_uint64, _f, _i, _vp]),
-    "rl_dropout_bwd": (_i, [_vp, _l, _l, _i, _vp, C.c_uint64, _f, _i, _vp]),
+    "rl_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _l, _l, _i, _vp, C.c_uint64, _f, _vp]),
+    "rl_dropout_bwd": (_i, [_vp, _l, _l, _i, _vp, C.c_uint64, _f, _vp]),
     "rl_upsample_cf": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rl_logits_unpermute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_logits_permute_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -14,12 +14,10 @@ from . import _hip as H
 F32 = torch.float32
 BF16 = torch.bfloat16
 
-# Storage mode (rl_randlanet.h "bf16-storage mode"): "f32" (default, the parity mode) or "bf16" - the throughput mode
-# BASELINE.json's config A names.  In "bf16" every activation the network keeps in HBM (raw SharedMLP outputs, pooled
-# features, residual outputs, decoder concatenations) and every gradient of such a tensor is stored as bf16, and so are the
-# neighbourhood-row gradient tensors between backward kernels (GU / DG, level-2 X / dS).  fp32 stay: coordinates and the
-# neighbour search, BatchNorm statistics (doubles), softmax, every accumulator, the logits, parameters, Adam, and the
-# un-fused 256-wide pooling tensors.  A kernel learns a tensor's type from flags derived from the tensor's dtype HERE.
+# Storage of the neighbourhood-row tensors that only exist between two kernels of the backward pass (rl_randlanet.h
+# "bf16-storage mode"): "f32" (default, the parity mode) or "bf16" - GU / DG of the fused pooling blocks and, on the
+# 128-wide level, X / dS are then written and read as bf16 (half the bytes of the largest tensors of a step); coordinates,
+# neighbour search, BatchNorm statistics, softmax, every accumulator, parameters and Adam stay fp32.
 _STORAGE = __import__("os").environ.get("RL_STORAGE", "f32")
 
 
@@ -39,15 +37,6 @@ def get_storage() -> str:
 def row_dtype() -> torch.dtype:
     """dtype of the (points*K)-row gradient tensors between backward kernels."""
     return BF16 if _STORAGE == "bf16" else F32
-
-
-def act_dtype() -> torch.dtype:
-    """dtype of the activations (and their gradients) the network keeps in HBM."""
-    return BF16 if _STORAGE == "bf16" else F32
-
-
-def _bf(t) -> int:
-    return int(t is not None and t.dtype == BF16)
 
 
 @dataclass
@@ -290,7 +279,6 @@ def _fill_a(d, a):
     assert a.raw.dtype in (F32, BF16) and a.raw.dim() == 2 and a.raw.shape[1] >= a.C
     assert a.raw.shape[0] >= (a.B - 1) * a.bstride + a.n, "A operand rows out of range"
     d.a_mode = 0
-    d.a_bf16 = _bf(a.raw)
     d.A, d.lda, d.a_bstride = a.raw.data_ptr(), a.raw.shape[1], a.bstride
     if a.scale is not None:
         assert a.scale.numel() == a.C and a.shift.numel() == a.C
@@ -343,20 +331,21 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
          accumulate: bool = False, stats: Optional[torch.Tensor] = None,
          addend: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
          out2_index: Optional[torch.Tensor] = None, out2_bstride: int = 0, split_col: int = 0,
-         wsplit: Optional[dict] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+         wsplit: Optional[dict] = None) -> torch.Tensor:
     """Y = A'.W (+ bias).  With `out2` (split epilogue, wide layers only): v = A'.W + addend; columns < split_col go to
     `out` (which then has split_col columns), the others to the dense (M, N - split_col) tensor `out2` (or, with
     `out2_index`, atomically to the rows it names) - the two halves of a concat's gradient in one pass."""
     d = H.GemmDesc()
     M, K = _fill_a(d, a)
+    assert isinstance(a, Rpe) or a.raw.dtype == F32, "rl_gemm reads fp32 rows"
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
     _dev_check(W, bias, out, stats)
     assert W.dtype == F32 and W.numel() == K * N
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype or act_dtype(), device=W.device)
+        out = torch.empty((M, N), dtype=F32, device=W.device)
         out_bstride = rows_per_batch
     else:
-        assert out.dtype in (F32, BF16) and out.dim() == 2 and out.shape[1] >= (split_col if out2 is not None else N)
+        assert out.dtype == F32 and out.dim() == 2 and out.shape[1] >= (split_col if out2 is not None else N)
         out_bstride = rows_per_batch if out_bstride is None else out_bstride
         assert out.shape[0] >= (d.B - 1) * out_bstride + rows_per_batch, "Y rows out of range"
     if bias is not None:
@@ -368,7 +357,6 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     if planes is not None:
         d.W_split = planes.data_ptr()
     d.Y, d.ldy, d.y_bstride, d.accumulate = out.data_ptr(), out.shape[1], out_bstride, int(accumulate)
-    d.y_bf16 = _bf(out)
     d.stats = H.ptr(stats)
     if addend is not None or out2 is not None:
         _dev_check(addend, out2, out2_index)
@@ -386,8 +374,7 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     if kfloats > 0:
         kslab = _slab(W.device, kfloats)
         d.kslab, d.kslab_floats = kslab.data_ptr(), kslab.numel()
-    ea = 4 if isinstance(a, Rpe) else a.raw.element_size()
-    with _rec("gemm_rpe" if isinstance(a, Rpe) else "gemm", (M, K, N), ea * M * (K if not isinstance(a, Rpe) else 6) + out.element_size() * M * N * (2 if accumulate else 1) + 4 * K * N, 2 * M * K * N):
+    with _rec("gemm_rpe" if isinstance(a, Rpe) else "gemm", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N * (2 if accumulate else 1) + K * N), 2 * M * K * N):
         H.check(H.lib().rl_gemm(C.byref(d), _st()), "rl_gemm")
     return out
 
@@ -414,8 +401,10 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     M, K = _fill_a(d, a)
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
     _dev_check(dY, dW, dbias)
+    rows_bf16 = dY.dtype == BF16
     assert dY.dtype in (F32, BF16) and dY.dim() == 2 and dY.shape[1] >= N
-    d.dy_bf16 = _bf(dY)
+    assert isinstance(a, Rpe) or a.raw.dtype == dY.dtype, "A and dY must share their storage type"
+    d.rows_bf16 = int(rows_bf16)
     assert dY.shape[0] >= (d.B - 1) * dy_bstride + rows_per_batch
     assert dW.numel() == K * N and (dbias is None or dbias.numel() == N)
     floats = H.lib().rl_wgrad_slab_floats(M, N, K)
@@ -424,8 +413,8 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     d.dW, d.w_ks, d.w_ns, d.dbias = dW.data_ptr(), w_ks, w_ns, H.ptr(dbias)
     d.slab, d.slab_floats = slab.data_ptr(), slab.numel()
     d.defer_reduce = 0 if pending is None else 1
-    ea = 4 if isinstance(a, Rpe) else a.raw.element_size()
-    with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), ea * M * (K if not isinstance(a, Rpe) else 6) + dY.element_size() * M * N + 4 * K * N, 2 * M * K * N):
+    es = 2 if rows_bf16 else 4
+    with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), es * (M * (K if not isinstance(a, Rpe) else 6) + M * N) + 4 * K * N, 2 * M * K * N):
         H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
     if pending is not None:
         it = H.WgradReduceItem()
@@ -536,8 +525,6 @@ def _bn_bwd_desc(G: torch.Tensor, g_bstride: int, y: Lazy) -> H.BnBwdDesc:
     d.G, d.Y, d.ld, d.bstride = G.data_ptr(), y.raw.data_ptr(), y.raw.shape[1], y.bstride
     d.B, d.n, d.C, d.act, d.slope = y.B, y.n, y.C, y.act, y.slope
     d.scale, d.shift, d.mean, d.invstd = H.ptr(y.scale), H.ptr(y.shift), H.ptr(y.mean), H.ptr(y.invstd)
-    assert G.dtype == y.raw.dtype and G.dtype in (F32, BF16)
-    d.act_bf16 = _bf(G)
     return d
 
 
@@ -560,18 +547,17 @@ def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta:
         stats = new_stats(G.device, y.C)
         coef = torch.empty(2 * y.C, dtype=F32, device=G.device)
         d.stats = stats.data_ptr()
-        with _rec("bn_bwd_reduce", (y.rows, y.C), 2 * G.element_size() * y.rows * y.C, 0):
+        with _rec("bn_bwd_reduce", (y.rows, y.C), 8 * y.rows * y.C, 0):
             H.check(H.lib().rl_bn_bwd_reduce(C.byref(d), _st()), "rl_bn_bwd_reduce")
         _bn_bwd_finalize(stats, H.lib().rl_bn_bwd_slots(y.rows), y.rows, y.C, dgamma, dbeta, coef, sync)
         d.coef = coef.data_ptr()
-    with _rec("bn_bwd_apply", (y.rows, y.C), 3 * G.element_size() * y.rows * y.C, 0):
+    with _rec("bn_bwd_apply", (y.rows, y.C), 12 * y.rows * y.C, 0):
         H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
 
 
 def resid_bn_supported(y1: Lazy, y2: Lazy) -> bool:
     dense = all(y.bstride == y.n and y.raw.shape == (y.B * y.n, y.C) and y.mean is not None and y.act == H.ACT_NONE for y in (y1, y2))
-    return (dense and y1.C == y2.C and y1.rows == y2.rows and y1.raw.dtype == y2.raw.dtype
-            and bool(H.lib().rl_resid_bn_bwd_supported(y1.rows, y1.C)))
+    return dense and y1.C == y2.C and y1.rows == y2.rows and bool(H.lib().rl_resid_bn_bwd_supported(y1.rows, y1.C))
 
 
 def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, y2: Lazy, dgamma1, dbeta1, dgamma2, dbeta2,
@@ -581,10 +567,7 @@ def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, 
     _dev_check(G, O, y1.raw, y2.raw)
     rows, Cc = y1.rows, y1.C
     assert G.shape == O.shape == (rows, Cc)
-    assert G.dtype == O.dtype == y1.raw.dtype == y2.raw.dtype
     d = H.ResidBnBwdDesc()
-    d.act_bf16 = _bf(G)
-    es = G.element_size()
     G2 = torch.empty_like(G)
     st1, st2 = new_stats(G.device, Cc), new_stats(G.device, Cc)
     c1 = torch.empty(2 * Cc, dtype=F32, device=G.device)
@@ -593,12 +576,12 @@ def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, 
     d.Y1, d.scale1, d.mean1, d.invstd1 = y1.raw.data_ptr(), y1.scale.data_ptr(), y1.mean.data_ptr(), y1.invstd.data_ptr()
     d.Y2, d.scale2, d.mean2, d.invstd2 = y2.raw.data_ptr(), y2.scale.data_ptr(), y2.mean.data_ptr(), y2.invstd.data_ptr()
     d.stats1, d.stats2, d.coef1, d.coef2 = st1.data_ptr(), st2.data_ptr(), c1.data_ptr(), c2.data_ptr()
-    with _rec("resid_bn_bwd_reduce", (rows, Cc), 4 * es * rows * Cc, 0):
+    with _rec("resid_bn_bwd_reduce", (rows, Cc), 16 * rows * Cc, 0):
         H.check(H.lib().rl_resid_bn_bwd_reduce(C.byref(d), _st()), "rl_resid_bn_bwd_reduce")
     slots = H.lib().rl_bn_bwd_slots(rows)
     _bn_bwd_finalize(st1, slots, rows, Cc, dgamma1, dbeta1, c1, sync)
     _bn_bwd_finalize(st2, slots, rows, Cc, dgamma2, dbeta2, c2, sync)
-    with _rec("resid_bn_bwd_apply", (rows, Cc), 6 * es * rows * Cc, 0):
+    with _rec("resid_bn_bwd_apply", (rows, Cc), 24 * rows * Cc, 0):
         H.check(H.lib().rl_resid_bn_bwd_apply(C.byref(d), _st()), "rl_resid_bn_bwd_apply")
     return G2
 
@@ -611,13 +594,12 @@ def copy_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, ds
     _dev_check(src, dst, index)
     d = H.RowsDesc()
     es = src.element_size()
-    assert src.dtype in (F32, BF16) and dst.dtype in (F32, BF16) and src.dim() == 2 and dst.dim() == 2
-    d.src_bf16, d.dst_bf16 = _bf(src), _bf(dst)
+    assert src.dtype == F32 and dst.dtype == F32 and src.dim() == 2 and dst.dim() == 2
     c0s, cn = src_cols
     c0d, cn2 = dst_cols
     assert cn == cn2 and c0s + cn <= src.shape[1] and c0d + cn <= dst.shape[1] and dst.shape[0] >= rows
     d.src, d.lds, d.src_bstride = src.data_ptr() + c0s * es, src.shape[1], src_bstride
-    d.dst, d.ldd = dst.data_ptr() + c0d * dst.element_size(), dst.shape[1]
+    d.dst, d.ldd = dst.data_ptr() + c0d * es, dst.shape[1]
     d.rows, d.rows_per_batch, d.C = rows, rows_per_batch, cn
     if index is not None:
         if index.dtype == torch.int32:
@@ -630,7 +612,7 @@ def copy_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, ds
     if lazy is not None and lazy.scale is not None:
         assert c0s == 0 and cn == lazy.C
         d.scale, d.shift, d.act, d.slope = lazy.scale.data_ptr(), lazy.shift.data_ptr(), lazy.act, lazy.slope
-    with _rec("copy_rows", (rows, cn, index is not None), (es + dst.element_size() * (1 + int(accumulate))) * rows * cn, 0):
+    with _rec("copy_rows", (rows, cn, index is not None), (8 + 4 * int(accumulate)) * rows * cn, 0):
         H.check(H.lib().rl_copy_rows(C.byref(d), _st()), "rl_copy_rows")
 
 
@@ -697,18 +679,18 @@ def segment_sum_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: 
     ascending r - the gather's backward in a fixed order (no atomics, first writer needs no zero fill)."""
     _dev_check(src, dst, csr.offsets, csr.entries)
     c0, cn = src_cols
-    assert src.dtype in (F32, BF16) and dst.dtype in (F32, BF16) and src.dim() == 2 and dst.dim() == 2
+    assert src.dtype in (F32, BF16) and dst.dtype == F32 and src.dim() == 2 and dst.dim() == 2
     assert c0 + cn <= src.shape[1] and cn == dst.shape[1]
     assert src.shape[0] >= (csr.B - 1) * src_bstride + csr.n_src * csr.k
     assert dst.shape[0] >= (csr.B - 1) * dst_bstride + csr.n_dst
     d = H.SegsumDesc()
     d.src, d.lds, d.src_bstride = src.data_ptr() + src.element_size() * c0, src.shape[1], src_bstride
-    d.src_bf16, d.dst_bf16 = _bf(src), _bf(dst)
+    d.src_bf16 = int(src.dtype == BF16)
     d.dst, d.ldd, d.dst_bstride = dst.data_ptr(), dst.shape[1], dst_bstride
     d.offsets, d.entries, d.entries_per_cloud = csr.offsets.data_ptr(), csr.entries.data_ptr(), csr.n_src * csr.k
     d.B, d.n_dst, d.C, d.accumulate = csr.B, csr.n_dst, cn, int(accumulate)
     rows = csr.B * csr.n_src * csr.k
-    with _rec("segment_sum", (rows, cn), cn * (src.element_size() * rows + dst.element_size() * csr.B * csr.n_dst * (2 if accumulate else 1)) + 4 * rows, 0):
+    with _rec("segment_sum", (rows, cn), cn * (src.element_size() * rows + 4 * csr.B * csr.n_dst * (2 if accumulate else 1)) + 4 * rows, 0):
         H.check(H.lib().rl_segment_sum_rows(C.byref(d), _st()), "rl_segment_sum_rows")
 
 
@@ -826,13 +808,11 @@ def _pool_desc(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, s
     assert g.raw.shape[1] == h and g.C == h and g.n == n and g.raw.shape[0] >= (B - 1) * g.bstride + n
     assert W.numel() == d * d
     pd = H.PoolDesc()
-    pd.act_bf16 = _bf(g.raw)
     if isinstance(u, VirtualRpe):
         assert stage in (1, 2) and u.h == h and u.n == n and u.bn1 is not None and (stage == 1 or u.bn2 is not None)
         _fill_virtual(pd, u, stage)
     else:
         _dev_check(u.raw, u.scale, u.shift)
-        assert u.raw.dtype == g.raw.dtype, "U and G must share their storage type"
         assert u.raw.shape == (B * n * 16, h) and u.bstride == u.n == n * 16 and u.C == h
         pd.U, pd.u_scale, pd.u_shift, pd.u_act, pd.u_slope = u.raw.data_ptr(), H.ptr(u.scale), H.ptr(u.shift), u.act, u.slope
     pd.G, pd.g_bstride = g.raw.data_ptr(), g.bstride
@@ -851,7 +831,7 @@ def pool_fwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, sta
         ns = H.lib().rl_pool_fwd_slots(u.B * n, d)
         stats2 = torch.empty((ns, 2, d // 2), dtype=torch.float64, device=W.device)
         pd.bn_fwd_stats2 = stats2.data_ptr()
-    out = torch.empty((u.B * n, d), dtype=g.raw.dtype, device=W.device)
+    out = torch.empty((u.B * n, d), dtype=F32, device=W.device)
     pd.Pout = out.data_ptr()
     P = u.B * n
     virt = isinstance(u, VirtualRpe)
@@ -875,8 +855,7 @@ def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP:
     assert dP.shape == (P, d) and GU.shape == (P * 16, d // 2) and dW.numel() == d * d
     rdt = row_dtype()
     virt = isinstance(u, VirtualRpe)
-    assert GU.dtype == (rdt if virt else g.raw.dtype), "GU: the row storage type under a virtual rpe branch, U's type for a real U tensor"
-    assert dP.dtype == g.raw.dtype, "dP must have the activations' storage type"
+    assert GU.dtype == (rdt if virt else F32), "GU: the row storage type under a virtual rpe branch, fp32 for a real U tensor"
     pd.rows_bf16 = int(rdt == BF16)
     es = 2 if rdt == BF16 else 4
     DG = torch.empty((P * 16, d // 2), dtype=rdt, device=W.device)
@@ -930,19 +909,18 @@ def attpool_bwd(X, S, Pout, dP, P: int, K: int):
 
 def add_act_fwd(y1: Lazy, y2: Lazy, slope: float) -> torch.Tensor:
     assert y1.rows == y2.rows and y1.C == y2.C and y1.bstride == y1.n and y2.bstride == y2.n
-    assert y1.raw.dtype == y2.raw.dtype
-    out = torch.empty((y1.rows, y1.C), dtype=y1.raw.dtype, device=y1.raw.device)
-    with _rec("add_act", (y1.rows, y1.C), 3 * out.element_size() * y1.rows * y1.C, 0):
+    out = torch.empty((y1.rows, y1.C), dtype=F32, device=y1.raw.device)
+    with _rec("add_act", (y1.rows, y1.C), 12 * y1.rows * y1.C, 0):
         H.check(H.lib().rl_add_act_fwd(y1.raw.data_ptr(), y1.scale.data_ptr(), y1.shift.data_ptr(), y2.raw.data_ptr(),
                                        y2.scale.data_ptr(), y2.shift.data_ptr(), y1.rows, y1.C, slope, out.data_ptr(),
-                                       _bf(out), _st()), "rl_add_act_fwd")
+                                       _st()), "rl_add_act_fwd")
     return out
 
 
 def add_act_bwd(G: torch.Tensor, O: torch.Tensor, slope: float) -> None:
-    assert G.shape == O.shape and G.is_contiguous() and O.is_contiguous() and G.dtype == O.dtype
-    with _rec("add_act", (G.shape[0], G.shape[1]), 3 * G.element_size() * G.numel(), 0):
-        H.check(H.lib().rl_add_act_bwd(G.data_ptr(), O.data_ptr(), G.shape[0], G.shape[1], slope, _bf(G), _st()), "rl_add_act_bwd")
+    assert G.shape == O.shape and G.is_contiguous() and O.is_contiguous()
+    with _rec("add_act", (G.shape[0], G.shape[1]), 12 * G.numel(), 0):
+        H.check(H.lib().rl_add_act_bwd(G.data_ptr(), O.data_ptr(), G.shape[0], G.shape[1], slope, _st()), "rl_add_act_bwd")
 
 
 def scale_mask(x: torch.Tensor, mask: torch.Tensor, scale: float) -> None:
@@ -966,10 +944,9 @@ def dropout_fwd(x: Lazy, key: torch.Tensor, seed: int, p: float, first_row: int 
     _dev_check(x.raw, x.scale, x.shift, key)
     assert x.bstride == x.n and x.raw.shape == (x.rows, x.C) and x.C % 4 == 0
     out = torch.empty_like(x.raw)
-    with _rec("dropout", (x.rows, x.C), 2 * out.element_size() * x.rows * x.C, 0):
+    with _rec("dropout", (x.rows, x.C), 8 * x.rows * x.C, 0):
         H.check(H.lib().rl_dropout_fwd(x.raw.data_ptr(), H.ptr(x.scale), H.ptr(x.shift), x.act, x.slope, out.data_ptr(),
-                                       x.rows, first_row, x.C, key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p, _bf(out), _st()),
-                "rl_dropout_fwd")
+                                       x.rows, first_row, x.C, key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p, _st()), "rl_dropout_fwd")
     return out
 
 
@@ -977,9 +954,9 @@ def dropout_bwd(G: torch.Tensor, key: torch.Tensor, seed: int, p: float, first_r
     """In place: the gradient through the same mask (regenerated from (seed, key))."""
     _dev_check(G, key)
     assert G.dim() == 2 and G.shape[1] % 4 == 0
-    with _rec("dropout", (G.shape[0], G.shape[1]), 2 * G.element_size() * G.numel(), 0):
+    with _rec("dropout", (G.shape[0], G.shape[1]), 8 * G.numel(), 0):
         H.check(H.lib().rl_dropout_bwd(G.data_ptr(), G.shape[0], first_row, G.shape[1], key.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, p,
-                                       _bf(G), _st()), "rl_dropout_bwd")
+                                       _st()), "rl_dropout_bwd")
 
 
 def upsample_cf(feat: torch.Tensor, idx: torch.Tensor, d2: Optional[torch.Tensor], power: int) -> torch.Tensor:

@@ -107,7 +107,7 @@ class SharedMLP(nn.Module):
         bn = self.batch_norm
         train_stats = bn is not None and self.training
         stats = ops.new_stats(rows.device, n_out) if train_stats else None
-        Y = ops.gemm(ops.plain(rows, 1, M), W2, ks, ns, n_out, self.conv.bias.detach(), stats=stats, out_dtype=torch.float32)
+        Y = ops.gemm(ops.plain(rows, 1, M), W2, ks, ns, n_out, self.conv.bias.detach(), stats=stats)
         act, slope = _act_code(self.activation)
         if bn is not None:
             scale, shift, _, _ = ops.bn_finalize(stats, M, 128, n_out, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
@@ -169,7 +169,7 @@ class AttentivePooling(nn.Module):
         B, d, N, K = input.shape
         with torch.cuda.device(input.device), torch.no_grad():
             X = _to_rows(input)
-            S = ops.gemm(ops.plain(X, B, N * K), self.score_fn[0].weight.detach(), 1, d, d, None, out_dtype=torch.float32)
+            S = ops.gemm(ops.plain(X, B, N * K), self.score_fn[0].weight.detach(), 1, d, d, None)
             pooled = ops.attpool_fwd(X, S, B * N, K)
             return _from_rows(self.mlp._rows_forward(pooled), B, N, 1)
 

@@ -176,10 +176,6 @@ typedef struct rl_gemm_desc {
      * 16-byte aligned, K % 8 == 0).  Selects the 8-wavefront kernel: no conversion of the weight per tile, four
      * wavefronts per SIMD instead of two.  Same arithmetic, same results as without it. */
     const void* W_split;
-    /* bf16-storage mode: A (a_mode 0) / Y hold bf16 elements instead of fp32 (lda / ldy and the batch strides count
-     * elements either way; 8-byte aligned rows).  Accumulators, bias, statistics (taken from the fp32 accumulators before
-     * the rounding store) stay fp32; addend / out2 of the split epilogue are always fp32.                      */
-    int32_t a_bf16, y_bf16;
 } rl_gemm_desc;
 
 /* Splits weights for rl_gemm_desc.W_split: out (2*N*K bf16) <- heads, then tails, of W(k, n) = W[k*w_ks + n*w_ns].
@@ -237,9 +233,9 @@ typedef struct rl_wgrad_desc {
      * rl_wgrad_reduce_batch (one launch for all layers of a backward pass), so `slab` must be
      * private to this layer until then */
     int32_t defer_reduce;
-    /* bf16-storage mode: A / dY hold bf16 elements (lda / lddy count elements); any combination, every kernel.  When both
-     * are bf16 and A carries no lazy BatchNorm, the wide kernel uses one bf16 product per term - exact for such operands. */
-    int32_t a_bf16, dy_bf16;
+    /* bf16-storage mode: A and dY are bf16 rows (lda / lddy count elements).  Wide layers only (a 128 x 128 tile of dW,
+     * i.e. N or K > 64), plain A operand, outside the fp32 arithmetic mode; the products are then exact bf16 x bf16. */
+    int32_t rows_bf16;
 } rl_wgrad_desc;
 
 int64_t rl_wgrad_slab_floats(int64_t M, int N, int K);
@@ -296,7 +292,6 @@ typedef struct rl_bn_bwd_desc {
     const float* invstd;
     double* stats;      /* reduce: out */
     const float* coef;  /* apply: in, 2*C floats, or NULL */
-    int32_t act_bf16;   /* bf16-storage mode: G and Y are bf16 (ld counts elements) */
 } rl_bn_bwd_desc;
 
 /* (nslots, 2, C) per-workgroup partials -> (2, C) totals in slot order.  SyncBN / equivalence mode: the caller
@@ -328,7 +323,6 @@ typedef struct rl_resid_bn_bwd_desc {
     const float* Y2; const float* scale2; const float* mean2; const float* invstd2;
     double* stats1; double* stats2;          /* reduce: out */
     const float* coef1; const float* coef2;  /* apply: in (2*C floats each) */
-    int32_t act_bf16;                        /* bf16-storage mode: G, G2, O, Y1 and Y2 are bf16 */
 } rl_resid_bn_bwd_desc;
 
 int rl_resid_bn_bwd_supported(int64_t rows, int C);
@@ -357,7 +351,6 @@ typedef struct rl_rows_desc {
     float slope;
     const float* scale;
     const float* shift;
-    int32_t src_bf16, dst_bf16;   /* bf16-storage mode: src / dst hold bf16 elements (lds / ldd count elements) */
 } rl_rows_desc;
 
 int rl_copy_rows(const rl_rows_desc* d, void* stream);
@@ -401,8 +394,7 @@ typedef struct rl_segsum_desc {
     int64_t entries_per_cloud;
     int32_t B, n_dst, C;
     int32_t accumulate;
-    int32_t src_bf16;       /* bf16-storage mode: the source rows are bf16 (lds counts elements); the sums are fp32 */
-    int32_t dst_bf16;       /* ... and so are the destination rows */
+    int32_t src_bf16;       /* bf16-storage mode: the source rows are bf16 (lds counts elements); sums and dst stay fp32 */
 } rl_segsum_desc;
 
 int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream);
@@ -495,9 +487,6 @@ typedef struct rl_pool_desc {
      * of rl_rpe_bn_reduce / rl_rpe_wgrad - when the rpe branch is virtual (u_source > 0).  With a real U tensor GU stays
      * fp32 (it continues into the fp32 GEMM chain).  Needs the bf16x3 arithmetic mode.  0: everything fp32.        */
     int32_t rows_bf16;
-    /* bf16-storage mode: the activation-typed tensors of the block hold bf16: U (a real one), G (the gathered rows),
-     * Pout, dP, and GU when U is a real tensor (its gradient continues into the GEMM chain with U's type).          */
-    int32_t act_bf16;
 } rl_pool_desc;
 
 int rl_pool_supported(int d, int nbr_k);
@@ -532,8 +521,8 @@ int rl_rpe_wgrad(const rl_pool_desc* d, const float* G, const float* coef, float
  *   O = lrelu(Y1*s1+b1 + Y2*s2+b2);  backward (in place): G <- G * (O > 0 ? 1 : slope)       */
 int rl_add_act_fwd(const float* Y1, const float* s1, const float* b1, const float* Y2,
                    const float* s2, const float* b2, int64_t rows, int C, float slope, float* O,
-                   int act_bf16, void* stream);     /* act_bf16: Y1, Y2 and O are bf16 (bf16-storage mode) */
-int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, int act_bf16, void* stream);
+                   void* stream);
+int rl_add_act_bwd(float* G, const float* O, int64_t rows, int C, float slope, void* stream);
 
 /* RelativePositionEncoding (modules.py:173-186) written out once per level: row (b, i, j) of out, 12 floats
  * apart, holds [x_i, x_nbr, x_i - x_nbr, sqrt(d2)] (10 channels) and two zeros of padding, so that the row
@@ -589,9 +578,8 @@ int rl_scale_mask(float* x, const uint8_t* mask, float scale, int64_t count, voi
  * shards of one batch draw the slices of ONE mask (0 for a single process). */
 int rl_dropout_tick(int64_t* counter, int64_t* key_out, void* stream);
 int rl_dropout_fwd(const float* src, const float* scale, const float* shift, int act, float slope, float* dst,
-                   int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, int act_bf16, void* stream);
-int rl_dropout_bwd(float* G, int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, int act_bf16,
-                   void* stream);
+                   int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, void* stream);
+int rl_dropout_bwd(float* G, int64_t rows, int64_t first_row, int C, const int64_t* key, uint64_t seed, float p, void* stream);
 
 /* UpSampler (modules.py:343-456) on channel-first features feat (B,F,N1) with neighbours
  * idx/d2 (B,N2,k) from rl_knn_i32: power 0 = nearest-neighbour interpolation (k = 1),

@@ -1,8 +1,7 @@
-"""The bf16-storage throughput mode (BASELINE.json configs[1] "bf16"; rl_randlanet.h "bf16-storage mode"): every activation
-the network keeps in HBM, every gradient of one, and the neighbourhood-row gradient tensors between backward kernels are
-bf16; coordinates, neighbour search, statistics, softmax, accumulators, logits, parameters and Adam stay fp32.  Stored values
-carry 2^-9 relative rounding, so this mode is NOT the parity mode: it is held against the parity mode's step here and
-against the reference's evaluation in test_model_gpu.py."""
+"""The bf16-storage throughput mode (BASELINE.json configs[1] "bf16"; rl_randlanet.h `rows_bf16`): the neighbourhood-row
+tensors that live between two backward kernels are bf16 in HBM, everything that accumulates stays fp32.  The forward is
+untouched by it, so loss and logits are those of the parity mode bit for bit; gradients carry bf16 rounding (2^-9 relative
+per stored element) and are held against the parity mode's."""
 import numpy as np
 import pytest
 import torch
@@ -38,13 +37,7 @@ def _step(ops, mode, C, N, K, layers, B, seed=5):
     st.perm.copy_(torch.from_numpy(np.random.RandomState(4).permutation(N)).to(DEV))
     st._fwd_bwd()
     torch.cuda.synchronize()
-    grads = {n: g.detach().cpu().clone() for n, g in st.flat.grads.items()}
-    net.load_state_dict(sd)
-    net.eval()
-    np.random.seed(1)
-    with torch.no_grad():
-        logits = net(torch.from_numpy(x).to(DEV)).cpu()
-    return float(st.out[0]), grads, logits
+    return float(st.out[0]), {n: g.detach().cpu().clone() for n, g in st.flat.grads.items()}
 
 
 @pytest.mark.parametrize("C,N,K,layers,B", [
@@ -53,14 +46,10 @@ def _step(ops, mode, C, N, K, layers, B, seed=5):
 ])
 def test_bf16_row_storage_against_the_parity_mode(storage, C, N, K, layers, B):
     ops = storage
-    loss32, g32, lg32 = _step(ops, "f32", C, N, K, layers, B)
-    loss16, g16, lg16 = _step(ops, "bf16", C, N, K, layers, B)
+    loss32, g32 = _step(ops, "f32", C, N, K, layers, B)
+    loss16, g16 = _step(ops, "bf16", C, N, K, layers, B)
     assert ops.get_storage() == "bf16"
-    assert lg16.dtype == torch.float32           # the logits stay fp32
-    dl = float((lg16 - lg32).abs().max())
-    print(f"[bf16 storage] layers {layers}: loss {loss16:.6f} vs {loss32:.6f}; eval logits max |diff| {dl:.2e} "
-          f"(range {float(lg32.abs().max()):.2f})")
-    assert abs(loss16 - loss32) < 5e-3 and dl < 2e-2 * max(1.0, float(lg32.abs().max()))
+    assert loss16 == loss32                      # the forward does not depend on the mode
     worst, worst_name = 0.0, ""
     for name, a in g32.items():
         if name.endswith("conv.bias") and not name.startswith("fc_end.3"):
@@ -69,8 +58,8 @@ def test_bf16_row_storage_against_the_parity_mode(storage, C, N, K, layers, B):
         err = float((g16[name] - a).abs().max())
         if scale > 1e-6 and err / scale > worst:
             worst, worst_name = err / scale, name
-        # every stored activation / gradient is off by <= 2^-9 of its value; these random-weight points amplify that
-        assert err <= 0.25 * scale + 2e-6, (name, err, scale)
+        # a bf16-stored gradient row is off by <= 2^-9 of its value; sums over thousands of rows average that down
+        assert err <= 2e-2 * scale + 2e-6, (name, err, scale)
     print(f"[bf16 storage] layers {layers}: worst gradient difference to the fp32-storage step {worst:.2e} of its scale ({worst_name})")
     assert worst > 0.0                           # the mode really took another path
 
