@@ -52,7 +52,7 @@ def test_bf16_row_storage_against_the_parity_mode(storage, C, N, K, layers, B):
     assert loss16 == loss32                      # the forward does not depend on the mode
     worst, worst_name = 0.0, ""
     for name, a in g32.items():
-        if name.endswith("conv.bias") and not name.startswith("fc_end.3"):
+        if (name.endswith("conv.bias") and not name.startswith("fc_end.3")) or name == "fc_start.bias":
             continue                             # in front of a BatchNorm: true gradient 0, rounding noise in both modes
         scale = float(a.abs().max())
         err = float((g16[name] - a).abs().max())
