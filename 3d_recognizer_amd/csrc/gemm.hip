@@ -2120,6 +2120,9 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     p.y_contig = (d->y_bstride == p.rows_per_batch);
     p.accumulate = d->accumulate; p.stats = d->stats;
     p.addend = d->addend; p.out2 = d->out2; p.out2_index = d->out2_index; p.out2_bstride = d->out2_bstride;
+    RL_REQUIRE(!d->out2_index || rl_float_atomics_allowed(), RL_ERR_UNSUPPORTED,
+               "rl_gemm: out2_index scatters with fp32 atomics (order-dependent); the deterministic path is a dense out2 + "
+               "rl_segment_sum_rows (set RL_ALLOW_FLOAT_ATOMICS=1 to use it anyway)");
     p.split_col = d->out2 ? d->split_col : d->N;
     p.wsplit = reinterpret_cast<const __bf16*>(d->W_split);
     const bool split = d->addend != nullptr || d->out2 != nullptr;

@@ -34,6 +34,14 @@ int rl_wide_terms();
 
 static inline int rl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// The two entry points that add with fp32 atomics (rl_scatter_add_rows, rl_gemm's out2_index) are NOT part of the network's
+// schedule - nothing on the path is order-dependent - and refuse to run unless the caller opts in.
+#include <stdlib.h>
+static inline bool rl_float_atomics_allowed() {
+    const char* e = getenv("RL_ALLOW_FLOAT_ATOMICS");
+    return e && e[0] == '1';
+}
+
 // Number of row blocks a row-streaming kernel uses for M rows (one partial-statistics slot per
 // block); shared by the producers (gemm / reduce kernels) and the finalize kernels.
 static inline int rl_row_blocks_host(long rows, int rows_per_tile) {

@@ -444,6 +444,9 @@ extern "C" int rl_scatter_add_rows(const rl_rows_desc* d, void* stream) {
     int rc = fill(&p, d, "rl_scatter_add_rows");
     if (rc) return rc;
     RL_REQUIRE(p.i32 || p.i64, RL_ERR_ARGS, "rl_scatter_add_rows: needs an index");
+    RL_REQUIRE(rl_float_atomics_allowed(), RL_ERR_UNSUPPORTED,
+               "rl_scatter_add_rows: fp32 atomics are order-dependent; the deterministic path is rl_csr_build + rl_segment_sum_rows "
+               "(set RL_ALLOW_FLOAT_ATOMICS=1 to use this entry point anyway)");
     RL_REQUIRE(p.lazy.scale == nullptr, RL_ERR_ARGS, "rl_scatter_add_rows: no lazy transform here");
     if (p.rows == 0) return RL_OK;
     if (fits32(p.rows * p.C) && fits32(p.rows_per_batch))

@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  storage stays fp32 and its logits leave the 1e-3 parity bound, so it is never `value`
   fp32_exact   - the metric's configuration with exact fp32 products everywhere (RL_WIDE_GEMM=fp32: the reference's own
                  arithmetic)
+  bf16_storage - the metric's configuration with the neighbourhood-row gradient tensors stored as bf16 (rl_set_storage)
   config_S / config_Kt_shard - BASELINE configs[3] (65536 pts, 13 classes, 5 layers, bs=8) and the per-GPU shard of
                  configs[4] (122880 pts, 20 classes, bs=2), each with clouds/s and its whole-step roofline fraction
   whole_step / knn / mfma_by_level - path-level roofline figures (also kept inside `roofline`)
@@ -442,6 +443,19 @@ def main():
         finally:
             _o.set_wide_gemm("bf16x3")
 
+    # BASELINE config A's "bf16" as far as it pays here: bf16 STORAGE of the neighbourhood-row gradient tensors (GU / DG of
+    # the fused pooling blocks, level-2 X / dS); arithmetic as in the parity mode.  profiles/r03_bf16_storage_experiment.md
+    # holds what storing every activation as bf16 measured (no net gain with these kernels) and why.
+    bf16_storage = None
+    if not args.no_secondary and WIDE_GEMM == "bf16x3" and _o.get_storage() == "f32":
+        _o.set_storage("bf16")
+        try:
+            bf16_storage = secondary(B, "weak", "the metric's configuration with bf16 storage of the neighbourhood-row gradient tensors")
+            bf16_storage["dtype"] = "bf16 storage of GU / DG / level-2 X, dS; f32 activations and accumulators, bf16x3 MFMA"
+            bf16_storage["whole_step"] = whole_step_roofline(CFG, bf16_storage["value"] / world)
+        finally:
+            _o.set_storage("f32")
+
     # the other single-GPU BASELINE.json configurations: their own model, a shorter window (they are not the metric)
     def other_config(cfg, what):
         m = build_model(dev, seed=0, cfg=cfg)
@@ -515,6 +529,7 @@ def main():
             "dtype": "f32 storage/accumulate, bf16x3 MFMA in the wide GEMMs" if WIDE_GEMM == "bf16x3" else
                      ("f32" if WIDE_GEMM == "fp32" else "f32 storage/accumulate, bf16 MFMA in the wide GEMMs"),
             "data": "synthetic",
+            "storage": _o.get_storage(),
             "config": {"workload": f"RandLA-Net train step: 40960 pts/cloud, bs={B} per GPU, 2 classes, k=16, 4 encoder layers "
                                    "[16,64,128,256], dice loss + Adam", "per_gpu_batch": B,
                        "global_batch": B * world, "parallelism": f"dp{world}", "graph": not args.no_graph,
@@ -530,6 +545,7 @@ def main():
             "config_A": config_a,
             "bf16_operands": bf16_ops,
             "fp32_exact": fp32_exact,
+            "bf16_storage": bf16_storage,
             "config_S": config_s,
             "config_Kt_shard": config_kt,
             "strong_bs8": strong,

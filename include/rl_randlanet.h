@@ -356,7 +356,10 @@ typedef struct rl_rows_desc {
 int rl_copy_rows(const rl_rows_desc* d, void* stream);
 
 /* Transposed movement (gather backward): dst[(b*src_bstride + index[r])*ldd + c] += src[r*lds + c]
- * (src_bstride names the batch stride of the INDEXED tensor, here dst) with fp32 atomics (order-dependent in the last bits; dst must be zeroed by the caller).    */
+ * (src_bstride names the batch stride of the INDEXED tensor, here dst) with fp32 atomics.  NON-DETERMINISTIC (the order of
+ * the adds is not fixed; dst must be zeroed by the caller) and NOT used by the network's schedule, whose gather backward is
+ * rl_csr_build + rl_segment_sum_rows: refused with RL_ERR_UNSUPPORTED unless RL_ALLOW_FLOAT_ATOMICS=1 is in the environment
+ * (the same holds for rl_gemm's out2_index).                                                                          */
 int rl_scatter_add_rows(const rl_rows_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------

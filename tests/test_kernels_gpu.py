@@ -7,6 +7,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+os.environ.setdefault("RL_ALLOW_FLOAT_ATOMICS", "1")     # the two non-deterministic (fp32-atomic) entry points are tested too
 
 from knn_parity import check_knn  # noqa: E402
 
@@ -824,3 +825,14 @@ def test_wide_gemm_with_presplit_weights(ops, M, K, N, orient):
     ops.gemm(a, W, ks, ns, N, None, out=o0, out_bstride=M, addend=addend, out2=d0, split_col=h)
     ops.gemm(a, W, ks, ns, N, None, out=o1, out_bstride=M, addend=addend, out2=d1, split_col=h, wsplit=ws)
     assert torch.equal(o0, o1) and torch.equal(d0, d1)
+
+
+def test_float_atomic_entry_points_need_an_opt_in(ops, monkeypatch):
+    """rl_scatter_add_rows / rl_gemm(out2_index) add with fp32 atomics: not part of the schedule, refused by default."""
+    monkeypatch.delenv("RL_ALLOW_FLOAT_ATOMICS", raising=False)
+    src = torch.ones(8, 4, device=DEV)
+    dst = torch.zeros(4, 4, device=DEV)
+    idx = torch.zeros(8, dtype=torch.int32, device=DEV)
+    with pytest.raises(Exception, match="RL_ALLOW_FLOAT_ATOMICS"):
+        ops.scatter_add_rows(src, (0, 4), dst, 4, 8, 8, idx)
+    assert float(dst.abs().sum()) == 0.0
