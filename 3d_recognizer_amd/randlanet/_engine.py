@@ -29,6 +29,9 @@ from ._ops import Lazy, Rpe
 
 BN_EPS = 1e-6       # modules.py:87, :497
 BN_MOMENTUM = 0.99
+# the CSR transposes of the neighbour graphs (backward only) on a second stream beside the forward: ONE fork and ONE join
+# in the replayed graph - measured 7.96 -> 8.12 ms per step (a cross-stream edge costs more than the 0.3 ms it could hide), so OFF
+CSR_SIDE_STREAM = bool(int(__import__("os").environ.get("RL_CSR_SIDE_STREAM", "0")))
 FOLD_BIAS = not bool(int(__import__("os").environ.get("RL_NO_FOLD_BIAS", "0")))     # diagnostics: keep the bias in the GEMM
 
 
@@ -266,7 +269,21 @@ class Engine:
         # training: the transpose of every neighbour graph ("who gathered from me"), so that the gathers' backward sums
         # each destination row in a fixed order (bitwise reproducible steps; torch's scatter_add_ has no defined order)
         csrs = [None] * (2 * L)
-        if training:
+        ctx.csr_ready = None
+        if training and CSR_SIDE_STREAM:
+            # only the backward needs the transposes, and they depend on the neighbour indices alone: built on a second
+            # stream beside the forward (ONE fork here, ONE join at the top of backward - two graph edges, not two per layer)
+            main = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self._side.wait_event(fork)
+            with torch.cuda.stream(self._side):
+                csrs = ops.csr_build([(searches[i][0], tasks[i][0]) for i in range(2 * L)])
+                ctx.csr_ready = torch.cuda.Event()
+                ctx.csr_ready.record(self._side)
+        elif training:
             csrs = ops.csr_build([(searches[i][0], tasks[i][0]) for i in range(2 * L)])
 
         # fc_start + bn_start (modules.py:565-566)
@@ -347,6 +364,9 @@ class Engine:
         self._main = torch.cuda.current_stream(dlogits.device)
         if self._side is None:
             self._side = torch.cuda.Stream(dlogits.device)
+        if getattr(ctx, "csr_ready", None) is not None:
+            self._main.wait_event(ctx.csr_ready)       # the graph transposes built beside the forward
+            ctx.csr_ready = None
         ctx.hold = []
         ctx.bn_done = set()       # raw tensors whose BatchNorm backward already happened (fused at the residual junction)
         # weight-gradient slabs are summed by ONE launch after the last layer (they are only needed by the optimiser)
