@@ -1926,7 +1926,7 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
 // cycles parked on memory).  bf16 arithmetic modes only; same operands and MFMA sequence per accumulator -> same bits.
 // RB: A and dY are stored as bf16 rows (bf16-storage mode; then TERMS = 1 is exact - the tails would be zero)
 template <int TERMS, bool RB = false>   // 3: bf16x3; 1: bf16
-__global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p) {
+__device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int bx, const int by, const int bz) {
     constexpr int BS = 40;
     constexpr int NSPL = TERMS == 3 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) __bf16 lds_d[PW2_T * BS * NSPL];
@@ -1941,9 +1941,9 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int N = p.N, K = p.a.K;
-    const int n0 = blockIdx.y * PW2_T, k0 = blockIdx.z * PW2_T;
+    const int n0 = by * PW2_T, k0 = bz * PW2_T;
     const int nvalid = min(PW2_T, N - n0), kvalid = min(PW2_T, K - k0);
-    const long r_begin = (long)blockIdx.x * p.rows_per_block;
+    const long r_begin = (long)bx * p.rows_per_block;
     const long r_end = min(p.a.M, r_begin + p.rows_per_block);
     const bool lazy = p.a.lazy.scale != nullptr;
     const bool relu = p.a.lazy.act == RL_ACT_RELU;
@@ -2030,7 +2030,7 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
         commit(r0);
         __syncthreads();
         if (r0 + PW2_RB < r_end) fetch(r0 + PW2_RB);
-        if (p.has_bias && blockIdx.z == 0 && tid < PW2_T) {
+        if (p.has_bias && bz == 0 && tid < PW2_T) {
 #pragma unroll
             for (int j = 0; j < PW2_RB / 8; ++j) {
                 const bf16x8 h = *reinterpret_cast<const bf16x8*>(Dh + tid * BS + j * 8);
@@ -2070,7 +2070,7 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
             }
         }
     }
-    float* out = p.slab + (long)blockIdx.x * ((long)N * K + N);
+    float* out = p.slab + (long)bx * ((long)N * K + N);
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
         const int k = k0 + kb * 16 + lr;
@@ -2080,7 +2080,50 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p)
             if (n < N && k < K) out[(long)n * K + k] = acc[kb][r];
         }
     }
-    if (p.has_bias && blockIdx.z == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
+    if (p.has_bias && bz == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
+}
+
+template <int TERMS, bool RB = false>
+__global__ __launch_bounds__(512, 4) void pwgrad128w_kernel(const WgradParams p) {
+    pwgrad128w_body<TERMS, RB>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- the same kernel for SEVERAL layers in one launch (rl_wgrad_batch) -----------------------------------------------
+// The wide weight gradients of a backward pass are independent of each other and of the dY -> dX chain (only the optimiser
+// needs them), and most of them are small: 80 - 216 workgroups on a chip that holds 512 of these.  Launched one by one each
+// leaves most CUs idle for 10 - 30 us; launched together (workgroup -> (layer, tile) through the prefix table in the
+// kernel arguments) they fill the chip.  Same per-workgroup arithmetic, same slabs: bitwise the results of rl_wgrad.
+struct WBItem {
+    const float* A; const float* dY; const float* sc; const float* sh; float* slab;
+    long lda, a_bstride, lddy, dy_bstride, rows_per_block, M;
+    int N, K, n, rows_per_batch, act;
+    float slope;
+    int first_block;           // of this layer in the launch
+    unsigned short gy, gz;     // its column-tile / k-tile counts
+    unsigned char a_contig, dy_contig, has_bias, pad;
+};
+constexpr int WB_MAX = 24;     // 24 x 136 B + 8 B of header: well inside the 4 KB of kernel arguments
+struct WgradBatch {
+    WBItem item[WB_MAX];
+    int count, pad;
+};
+template <int TERMS>
+__global__ __launch_bounds__(512, 4) void pwgrad128w_batch_kernel(const WgradBatch b) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.item[i + 1].first_block) ++i;
+    const WBItem& it = b.item[i];
+    const int local = (int)blockIdx.x - it.first_block;
+    const int per = (int)it.gy * (int)it.gz;
+    const int bx = local / per, rem = local - bx * per;
+    const int by = rem / (int)it.gz, bz = rem - by * (int)it.gz;
+    WgradParams p;
+    p.a.A = it.A; p.a.lda = it.lda; p.a.a_bstride = it.a_bstride; p.a.a_mode = 0;
+    p.a.lazy.scale = it.sc; p.a.lazy.shift = it.sh; p.a.lazy.act = it.act; p.a.lazy.slope = it.slope;
+    p.a.xyz = nullptr; p.a.xyz_bstride = 0; p.a.nbr_idx = nullptr; p.a.nbr_d2 = nullptr; p.a.nbr_k = 0;
+    p.a.n = it.n; p.a.K = it.K; p.a.M = it.M; p.a.contig = it.a_contig; p.a.vec4 = 1; p.a.vec4p = 1;
+    p.N = it.N; p.dY = it.dY; p.lddy = it.lddy; p.dy_bstride = it.dy_bstride; p.rows_per_batch = it.rows_per_batch;
+    p.dy_contig = it.dy_contig; p.slab = it.slab; p.rows_per_block = it.rows_per_block; p.has_bias = it.has_bias;
+    pwgrad128w_body<TERMS, false>(p, bx, by, bz);
 }
 
 inline bool pwgrad_ok(const WgradParams& p) {
@@ -2237,9 +2280,10 @@ extern "C" int64_t rl_wgrad_slab_floats(int64_t M, int N, int K) {
     return (int64_t)nsplit * ((int64_t)N * K + N);
 }
 
-extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
+// descriptor -> kernel parameters + slab split (shared by rl_wgrad and rl_wgrad_batch)
+static int wgrad_fill(const rl_wgrad_desc* d, WgradParams* pp, int* nsplit_out, bool* streaming_out) {
     RL_REQUIRE(d != nullptr, RL_ERR_ARGS, "rl_wgrad: null descriptor");
-    WgradParams p;
+    WgradParams& p = *pp;
     int rc = fill_a(&p.a, "rl_wgrad", d->A, d->lda, d->a_bstride, d->a_mode, d->in_act, d->in_slope,
                     d->in_scale, d->in_shift, d->xyz, d->xyz_bstride, d->nbr_idx, d->nbr_d2, d->nbr_k,
                     d->B, d->n, d->K);
@@ -2258,6 +2302,66 @@ extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
     RL_REQUIRE(d->slab_floats >= (int64_t)nsplit * ((int64_t)d->N * d->K + d->N), RL_ERR_ARGS,
                "rl_wgrad: slab too small (%ld floats)", (long)d->slab_floats);
     p.rows_per_block = rpb;
+    *nsplit_out = nsplit; *streaming_out = streaming;
+    return RL_OK;
+}
+
+// can this layer join a grouped launch (rl_wgrad_batch)?  The wide 128 x 128-tile kernel in a bf16 arithmetic mode, fp32 rows
+static bool wgrad_batchable(const rl_wgrad_desc* d, const WgradParams& p, bool streaming) {
+    return !streaming && !d->rows_bf16 && pwgrad_ok(p) && wgrad_tile(d->N, d->K) == 128 && wide_gemm_terms() != 0 &&
+           getenv("RL_WGRAD_4WAVE") == nullptr && rl_cdiv(d->N, 128) < 65536 && rl_cdiv(d->K, 128) < 65536;
+}
+
+extern "C" int rl_wgrad_batchable(const rl_wgrad_desc* d) {
+    WgradParams p;
+    int nsplit; bool streaming;
+    if (wgrad_fill(d, &p, &nsplit, &streaming) != RL_OK) return 0;
+    return wgrad_batchable(d, p, streaming) ? 1 : 0;
+}
+
+extern "C" int rl_wgrad_batch(const rl_wgrad_desc* descs, int count, void* stream) {
+    RL_REQUIRE(descs != nullptr && count >= 0, RL_ERR_ARGS, "rl_wgrad_batch: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int terms = wide_gemm_terms();
+    for (int base = 0; base < count; base += WB_MAX) {
+        WgradBatch b;
+        b.count = count - base < WB_MAX ? count - base : WB_MAX;
+        b.pad = 0;
+        long blocks = 0;
+        for (int i = 0; i < b.count; ++i) {
+            const rl_wgrad_desc* d = descs + base + i;
+            WgradParams p;
+            int nsplit; bool streaming;
+            int rc = wgrad_fill(d, &p, &nsplit, &streaming);
+            if (rc) return rc;
+            RL_REQUIRE(wgrad_batchable(d, p, streaming), RL_ERR_UNSUPPORTED,
+                       "rl_wgrad_batch: layer %d (N = %d, K = %d) does not run on the wide kernel - check rl_wgrad_batchable first", base + i, d->N, d->K);
+            RL_REQUIRE(d->defer_reduce, RL_ERR_ARGS, "rl_wgrad_batch: the layers' slabs are summed by rl_wgrad_reduce_batch (defer_reduce must be set)");
+            WBItem& it = b.item[i];
+            it.A = p.a.A; it.dY = p.dY; it.sc = p.a.lazy.scale; it.sh = p.a.lazy.shift; it.slab = p.slab;
+            it.lda = p.a.lda; it.a_bstride = p.a.a_bstride; it.lddy = p.lddy; it.dy_bstride = p.dy_bstride;
+            it.rows_per_block = p.rows_per_block; it.M = p.a.M;
+            it.N = p.N; it.K = p.a.K; it.n = p.a.n; it.rows_per_batch = p.rows_per_batch; it.act = p.a.lazy.act; it.slope = p.a.lazy.slope;
+            it.first_block = (int)blocks;
+            it.gy = (unsigned short)rl_cdiv(d->N, 128); it.gz = (unsigned short)rl_cdiv(d->K, 128);
+            it.a_contig = (unsigned char)p.a.contig; it.dy_contig = (unsigned char)p.dy_contig; it.has_bias = (unsigned char)p.has_bias; it.pad = 0;
+            blocks += (long)nsplit * it.gy * it.gz;
+            RL_REQUIRE(blocks < (1l << 30), RL_ERR_ARGS, "rl_wgrad_batch: too many workgroups");
+        }
+        if (blocks == 0) continue;
+        if (terms == 1) hipLaunchKernelGGL(pwgrad128w_batch_kernel<1>, dim3((unsigned)blocks), dim3(512), 0, st, b);
+        else            hipLaunchKernelGGL(pwgrad128w_batch_kernel<3>, dim3((unsigned)blocks), dim3(512), 0, st, b);
+        RL_LAUNCH_CHECK("rl_wgrad_batch");
+    }
+    rl_note_kernel("pwgrad128w_batch_kernel");
+    return RL_OK;
+}
+
+extern "C" int rl_wgrad(const rl_wgrad_desc* d, void* stream) {
+    WgradParams p;
+    int nsplit; bool streaming;
+    int rc = wgrad_fill(d, &p, &nsplit, &streaming);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (streaming) {
         if (d->K <= 16)      launch_swgrad<1>(d->N, dim3(nsplit), st, p);

@@ -371,6 +371,8 @@ class Engine:
         ctx.bn_done = set()       # raw tensors whose BatchNorm backward already happened (fused at the residual junction)
         # weight-gradient slabs are summed by ONE launch after the last layer (they are only needed by the optimiser)
         ctx.pending = None if (ops.SIDE_STREAM_WGRAD or ops.NO_DEFERRED_WGRAD) else []
+        # ... and the wide layers' weight-gradient KERNELS wait as well: one grouped launch for all of them at the end
+        ctx.wbatch = [] if ctx.pending is not None else None
         for rec, lvl in zip(reversed(ctx.tape), reversed(ctx.tape.levels)):
             ops.LEVEL = lvl
             kind = rec[0]
@@ -387,7 +389,7 @@ class Engine:
                 assert init
                 gu, gg = self._gbuf(ctx, u), self._gbuf(ctx, g)
                 DG = ops.pool_bwd(u, g, idx, self.P[f"{name}.score_fn.0.weight"], n, d, GP, gu[0], gu[1],
-                                  grads[f"{name}.score_fn.0.weight"], pending=ctx.pending)
+                                  grads[f"{name}.score_fn.0.weight"], pending=ctx.pending, batch=ctx.wbatch)
                 gu[1] = True
                 # gradient of the gather: every gathered point sums its slots in a fixed order
                 ops.segment_sum_rows(DG, (0, d // 2), n * self.K, csr, gg[0], g.bstride, accumulate=gg[1])
@@ -434,6 +436,7 @@ class Engine:
         ops.LEVEL = -1
         self._main.wait_stream(self._side)
         if ctx.pending is not None:
+            ops.wgrad_batch_flush(ctx.wbatch)
             ops.wgrad_flush(ctx.pending)
         ctx.tape.clear()
         ctx.grads.clear()
@@ -459,7 +462,7 @@ class Engine:
             ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True, sync=self.sync)
         n_out = out.C
         self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,
-                                            grads[bname] if bname else None, pending=ctx.pending), G)
+                                            grads[bname] if bname else None, pending=ctx.pending, batch=ctx.wbatch), G)
         if a_grad and isinstance(a, Lazy):
             ga = self._gbuf(ctx, a)
             if not ga[1]:
@@ -512,7 +515,7 @@ class Engine:
         dS, dX = ops.attpool_bwd(X, S, pooled.raw, GP, B * n, K)
         Ws = self.P[f"{name}.score_fn.0.weight"]
         self._beside(ctx, lambda: ops.wgrad(ops.plain(X, B, n * K), dS, n * K, d,
-                                            grads[f"{name}.score_fn.0.weight"], 1, d, None, pending=ctx.pending), X, dS)
+                                            grads[f"{name}.score_fn.0.weight"], 1, d, None, pending=ctx.pending, batch=ctx.wbatch), X, dS)
         gu = self._gbuf(ctx, u)
         gg = self._gbuf(ctx, g)
         if ops.NO_SPLIT_SCATTER or d <= 64:      # the epilogue lives in the wide (LDS-tiled) kernel only

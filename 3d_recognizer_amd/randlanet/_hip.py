@@ -189,6 +189,8 @@ _SIGNATURES = {
     "rl_get_wide_gemm": (C.c_char_p, []),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "rl_wgrad_nsplit": (_i, [_l, _i, _i]),
+    "rl_wgrad_batchable": (_i, [C.POINTER(WgradDesc)]),
+    "rl_wgrad_batch": (_i, [C.POINTER(WgradDesc), _i, _vp]),
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
     "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_bn_reduce_slots": (_i, [_vp, _i, _i, _vp, _vp]),

@@ -393,10 +393,15 @@ def _slab(device, floats: int) -> torch.Tensor:
     return buf
 
 
+NO_WGRAD_BATCH = bool(int(__import__("os").environ.get("RL_NO_WGRAD_BATCH", "0")))      # diagnostics: one launch per layer
+
+
 def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: int, w_ns: int,
-          dbias: Optional[torch.Tensor] = None, pending: Optional[list] = None) -> None:
+          dbias: Optional[torch.Tensor] = None, pending: Optional[list] = None, batch: Optional[list] = None) -> None:
     """dW / dbias of a layer.  With `pending` (a list) only the per-workgroup partial slabs are produced, in a
-    slab of their own, and the layer is queued for `wgrad_flush` - one reduction launch for a whole backward."""
+    slab of their own, and the layer is queued for `wgrad_flush` - one reduction launch for a whole backward.
+    With `batch` (a list, needs `pending`) a wide layer is not even launched here: its descriptor is queued for
+    `wgrad_batch_flush`, which runs all of them as ONE grouped launch (they are independent of each other and small)."""
     d = H.WgradDesc()
     M, K = _fill_a(d, a)
     rows_per_batch = a.n * a.K if isinstance(a, Rpe) else a.n
@@ -414,13 +419,28 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     d.slab, d.slab_floats = slab.data_ptr(), slab.numel()
     d.defer_reduce = 0 if pending is None else 1
     es = 2 if rows_bf16 else 4
-    with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), es * (M * (K if not isinstance(a, Rpe) else 6) + M * N) + 4 * K * N, 2 * M * K * N):
-        H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
+    nbytes, flops = es * (M * (K if not isinstance(a, Rpe) else 6) + M * N) + 4 * K * N, 2 * M * K * N
+    if batch is not None and pending is not None and not NO_WGRAD_BATCH and H.lib().rl_wgrad_batchable(C.byref(d)):
+        # (the operands stay referenced by the queue entry until the grouped launch has been issued)
+        batch.append((d, nbytes, flops, a, dY, slab))
+    else:
+        with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), nbytes, flops):
+            H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
     if pending is not None:
         it = H.WgradReduceItem()
         it.slab, it.dW, it.dbias, it.w_ks, it.w_ns = slab.data_ptr(), dW.data_ptr(), H.ptr(dbias), w_ks, w_ns
         it.nsplit, it.N, it.K = H.lib().rl_wgrad_nsplit(M, N, K), N, K
         pending.append((it, slab, dW, dbias))
+
+
+def wgrad_batch_flush(batch: list) -> None:
+    """The queued wide weight gradients as one grouped launch (rl_wgrad_batch); before `wgrad_flush`."""
+    if not batch:
+        return
+    arr = (H.WgradDesc * len(batch))(*[b[0] for b in batch])
+    with _rec("wgrad_batch", (len(batch),), sum(b[1] for b in batch), sum(b[2] for b in batch)):
+        H.check(H.lib().rl_wgrad_batch(arr, len(batch), _st()), "rl_wgrad_batch")
+    batch.clear()
 
 
 def wgrad_flush(pending: list) -> None:
@@ -844,7 +864,7 @@ def pool_fwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, sta
 
 def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP: torch.Tensor,
              GU: torch.Tensor, gu_accumulate: bool, dW: torch.Tensor, pending: Optional[list] = None,
-             stage: int = 0, bn_bwd_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+             stage: int = 0, bn_bwd_stats: Optional[torch.Tensor] = None, batch: Optional[list] = None) -> torch.Tensor:
     """Backward of the fused pooling block.  Returns DG ((points*16) x d/2): the gradient of the gathered row of every
     neighbourhood slot, to be summed per gathered point with segment_sum_rows.  d <= 64: dW comes out of the kernel.
     d = 128: the kernel writes X and dS and the weight gradient is the ordinary wide kernel on them (queued on `pending`
@@ -875,7 +895,7 @@ def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP:
         pd.X_out, pd.dS_out = X.data_ptr(), dS.data_ptr()
         with _rec("pool_bwd", (P, 16, d), nbytes + 2 * es * P * 16 * d, 4 * P * 16 * d * d):
             H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
-        wgrad(plain(X, u.B, n * 16), dS, n * 16, d, dW, 1, d, None, pending=pending)
+        wgrad(plain(X, u.B, n * 16), dS, n * 16, d, dW, 1, d, None, pending=pending, batch=batch)
         return DG
     floats = H.lib().rl_pool_slab_floats(P, d)
     slab = _slab(W.device, floats)

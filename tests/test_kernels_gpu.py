@@ -836,3 +836,37 @@ def test_float_atomic_entry_points_need_an_opt_in(ops, monkeypatch):
     with pytest.raises(Exception, match="RL_ALLOW_FLOAT_ATOMICS"):
         ops.scatter_add_rows(src, (0, 4), dst, 4, 8, 8, idx)
     assert float(dst.abs().sum()) == 0.0
+
+
+def test_grouped_wide_weight_gradients_equal_the_single_launches_bitwise(ops):
+    """rl_wgrad_batch: several wide layers' weight gradients as ONE launch - same split, same per-workgroup arithmetic, so
+    the same bits as one rl_wgrad launch per layer; narrow layers are not batchable and run on the spot."""
+    torch.manual_seed(5)
+    shapes = [(5000, 128, 256, False), (2000, 256, 128, True), (700, 512, 256, False), (9000, 96, 160, False), (3000, 32, 32, False)]
+    layers = []
+    for M, K, N, lazy in shapes:
+        A = torch.randn(M, K, device=DEV)
+        dY = torch.randn(M, N, device=DEV)
+        a = ops.Lazy(A, 1, M, M, K, torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1, 2, 0.2) if lazy else ops.plain(A, 1, M)
+        layers.append((a, dY, M, K, N))
+
+    def run(batched):
+        outs, pending, batch = [], [], ([] if batched else None)
+        for a, dY, M, K, N in layers:
+            dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+            ops.wgrad(a, dY, M, N, dW, 1, K, db, pending=pending, batch=batch)
+            outs.append((dW, db))
+        queued = len(batch) if batched else 0
+        if batched:
+            ops.wgrad_batch_flush(batch)
+        ops.wgrad_flush(pending)
+        torch.cuda.synchronize()
+        return outs, queued
+    single, _ = run(False)
+    grouped, queued = run(True)
+    assert queued == 4                                   # the 32 x 32 layer runs on the streaming kernel, on the spot
+    for (w0, b0), (w1, b1), (a, dY, M, K, N) in zip(single, grouped, layers):
+        assert torch.equal(w0, w1) and torch.equal(b0, b1), (M, K, N)
+    a, dY, M, K, N = layers[0]
+    ref = dY.double().t() @ a.raw.double()
+    assert float((grouped[0][0].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
