@@ -417,6 +417,11 @@ void wgrad_split(long M, int N, int K, int* nsplit, long* rows_per_block) {
         const long round = 512 / ((long)ny * nz);
         if (round >= 1 && want > round) want = round;
     }
+    // the wide layers of a backward pass run as ONE grouped launch (rl_wgrad_batch), so a layer need not fill the chip alone:
+    // half the row splits = half the partial-slab traffic (measured: wgrad_reduce_batch 0.102 -> 0.080 ms, step 7.83 -> 7.78 ms;
+    // a quarter: no further gain, an eighth: the grouped launch itself slows down).  RL_WGRAD_SHARE overrides (diagnostics).
+    static const long share = getenv("RL_WGRAD_SHARE") ? atol(getenv("RL_WGRAD_SHARE")) : 2;
+    if (share > 1 && T == 128) { want /= share; if (want < 1) want = 1; }
     long rpb = (M + want - 1) / want;
     rpb = ((rpb + 63) / 64) * 64;   // multiple of both kernels' row chunks (32 / 64)
     *rows_per_block = rpb;
