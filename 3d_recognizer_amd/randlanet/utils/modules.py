@@ -8,6 +8,7 @@ raises - nothing falls back.  A model PLACED on the CPU (the reference's own dev
 model.py:38-40: no GPU, or use_gpu=False) runs the host inference path of `_cpu.py`
 (rl_knn_f32_cpu + PyTorch-CPU rows; inference only, training needs the MI355X).
 """
+import ctypes
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -56,9 +57,10 @@ class RandLANetSettings:
 # ---------------------------------------------------------------------------------------------------------------
 # Stand-alone forwards of the sub-modules (reference modules.py:93-104, 159-186, 199-221, 246-253, 298-325).  Inside
 # RandLANet.forward the blocks run as one fused launch schedule (_engine.py); called on their own they take and return the
-# reference's (B, C, N, K) tensors and run the same HIP kernels one block at a time.  Forward only: the result carries no
-# autograd graph (training goes through RandLANet / TrainStep).  Layout changes are views / copies; all arithmetic is in
-# librandla_hip.so.
+# reference's (B, C, N, K) tensors and run the same HIP kernels one block at a time.  SharedMLP is differentiable on its own
+# (input, conv weight / bias, BatchNorm weight / bias: `_SharedMLPRows`, the kernels of the network's backward); the other
+# blocks are forward only when called alone - training goes through RandLANet / TrainStep.  Layout changes are views / copies;
+# all arithmetic is in librandla_hip.so.
 def _act_code(activation) -> tuple:
     if activation is None:
         return H.ACT_NONE, 0.0
@@ -82,6 +84,63 @@ def _from_rows(rows: torch.Tensor, B: int, N: int, K: int) -> torch.Tensor:
 def _require_device(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise H.HipKernelError(f"{what} runs on an MI355X (HIP) device: move the module and its input there")
+
+
+class _SharedMLPRows(torch.autograd.Function):
+    """rows (M, n_in) -> act(BN(rows . W + b)) as an autograd node over the HIP kernels: forward = rl_gemm (+ batch
+    statistics) + rl_bn_finalize + the lazy application; backward = rl_bn_bwd_* + rl_wgrad + rl_gemm with swapped strides."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias, gamma, beta, mod):
+        M = rows.shape[0]
+        transposed = isinstance(mod.conv, nn.ConvTranspose2d)
+        n_in, n_out = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
+        W2 = weight.detach().view(weight.shape[0], weight.shape[1])
+        ks, ns = ops.weight_strides(W2, transposed, n_in, n_out)
+        bn = mod.batch_norm
+        train_stats = bn is not None and mod.training
+        stats = ops.new_stats(rows.device, n_out) if train_stats else None
+        a = ops.plain(rows.detach(), 1, M)
+        Y = ops.gemm(a, W2, ks, ns, n_out, bias.detach(), stats=stats)
+        act, slope = _act_code(mod.activation)
+        y = ops.Lazy(Y, 1, M, M, n_out, None, None, act, slope)
+        if bn is not None:
+            y.scale, y.shift, y.mean, y.invstd = ops.bn_finalize(
+                stats, M, 128, n_out, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
+                bn.num_batches_tracked if train_stats else None, 0.99, 1e-6, train_stats)
+            if not train_stats:      # eval mode: the "batch" statistics of the backward formulas are the running ones
+                y.mean, y.invstd = bn.running_mean.clone(), torch.rsqrt(bn.running_var + 1e-6)
+        elif act != H.ACT_NONE:
+            y.scale, y.shift = torch.ones(n_out, device=rows.device), torch.zeros(n_out, device=rows.device)
+        ctx.saved = (a, W2, ks, ns, y, bn is not None, train_stats)
+        if y.scale is None:
+            return Y
+        out = torch.empty_like(Y)
+        ops.copy_rows(Y, (0, n_out), M, out, (0, n_out), M, M, lazy=y)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a, W2, ks, ns, y, has_bn, train_stats = ctx.saved
+        M, n_out, dev = y.rows, y.C, grad_out.device
+        with torch.cuda.device(dev):
+            G = grad_out.to(torch.float32).contiguous().clone()
+            dgamma = torch.zeros(n_out, device=dev) if has_bn else None
+            dbeta = torch.zeros(n_out, device=dev) if has_bn else None
+            if has_bn and not train_stats:
+                # eval mode: dgamma / dbeta are plain sums (no batch-statistics terms in the input gradient)
+                st = ops.new_stats(dev, n_out)
+                d = ops._bn_bwd_desc(G, y.bstride, y)
+                d.stats = st.data_ptr()
+                H.check(H.lib().rl_bn_bwd_reduce(ctypes.byref(d), ops._st()), "rl_bn_bwd_reduce")
+                ops._bn_bwd_finalize(st, H.lib().rl_bn_bwd_slots(M), M, n_out, dgamma, dbeta, torch.empty(2 * n_out, device=dev), None)
+                y.mean = None                               # -> bn_backward applies the activation derivative and the scale only
+            if y.scale is not None:
+                ops.bn_backward(G, y, dgamma, dbeta, train_stats)
+            dW, db = torch.empty_like(W2), torch.empty(n_out, device=dev)
+            ops.wgrad(a, G, M, n_out, dW, ks, ns, db)
+            d_rows = ops.gemm(ops.plain(G, 1, M), W2, ns, ks, a.C, None)
+        return d_rows, dW.view(W2.shape[0], W2.shape[1], 1, 1), db, dgamma, dbeta, None
 
 
 class SharedMLP(nn.Module):
@@ -124,8 +183,14 @@ class SharedMLP(nn.Module):
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         _require_device(input, "SharedMLP")
         B, _, N, K = input.shape
-        with torch.cuda.device(input.device), torch.no_grad():
-            return _from_rows(self._rows_forward(_to_rows(input)), B, N, K)
+        with torch.cuda.device(input.device):
+            if torch.is_grad_enabled() and (input.requires_grad or self.conv.weight.requires_grad):
+                bn = self.batch_norm
+                rows = _SharedMLPRows.apply(_to_rows(input), self.conv.weight, self.conv.bias,
+                                            bn.weight if bn is not None else None, bn.bias if bn is not None else None, self)
+                return _from_rows(rows, B, N, K)
+            with torch.no_grad():
+                return _from_rows(self._rows_forward(_to_rows(input)), B, N, K)
 
 
 class RelativePositionEncoding(nn.Module):
