@@ -310,9 +310,21 @@ struct VWeights {
     // all threads of the workgroup; a barrier must follow
     __device__ __forceinline__ void stage(const PoolParams& p, int nthreads) {
         constexpr int H = VT<DT>::H;
-        for (int e = threadIdx.x; e < HP * 16; e += nthreads) {
-            const int n = e >> 4, k = e & 15;
-            w1f[n * VT<DT>::S1 + k] = (n < H && k < 10) ? p.W1[n * 10 + k] : 0.f;
+        // The first stage in the form rpe_gemm uses it.  With the channels [x_i, x_j, x_i - x_j, dist] and x_j = x_i - (x_i - x_j):
+        //   W1 . rpe = (Wa + Wb) . x_i  +  (Wc - Wb) . (x_i - x_j)  +  wd * dist
+        // - the first term is the same for the 16 neighbours of a point, the rest has FOUR inputs: one exact fp32 MFMA
+        // (16 x 16 x 4) per column block instead of four dependent ones.  Row n: [V0 V1 V2 wd | U0 U1 U2 0], V = Wc - Wb,
+        // U = Wa + Wb (the weights are combined in fp32: one rounding each, like any other fp32 evaluation order).
+        for (int e = threadIdx.x; e < HP * 8; e += nthreads) {
+            const int n = e >> 3, k = e & 7;
+            float v = 0.f;
+            if (n < H) {
+                const float* w = p.W1 + n * 10;
+                if (k < 3) v = w[6 + k] - w[3 + k];
+                else if (k == 3) v = w[9];
+                else if (k < 7) v = w[k - 4] + w[3 + k - 4];
+            }
+            w1f[n * VT<DT>::S1 + k] = v;
         }
         if (p.src >= 2 || p.fstats2) {
             for (int e = threadIdx.x; e < HP * HP; e += nthreads) {
@@ -419,17 +431,19 @@ __device__ __forceinline__ float4 rpe_frag(const RpeIn& r, int lj) {
     return o;
 }
 
-// acc[nb] (C layout) = rpe tile (16 x 16, A layout) . W1^T, exact fp32 products in every arithmetic mode
+// acc[nb] (C layout) = rpe rows (10 channels) . W1^T for the 16 neighbours of one point, exact fp32 products in every
+// arithmetic mode, in the reduced form staged by VWeights::stage: U . x_i + [V | wd] . [x_i - x_j, dist] - two 16 x 16 x 4
+// MFMAs (lane (li, lj) supplies input lj of neighbour li and weight lj of column li) instead of four over the ten channels
 template <int DT, int TERMS>
-__device__ __forceinline__ void rpe_gemm(const float4 a, const VWeights<DT, TERMS>& w, int li, int lj, f32x4 (&acc)[VT<DT>::DTH]) {
+__device__ __forceinline__ void rpe_gemm(const RpeIn& r, const VWeights<DT, TERMS>& w, int li, int lj, f32x4 (&acc)[VT<DT>::DTH]) {
+    const float dx = r.a.x - r.c.x, dy = r.a.y - r.c.y, dz = r.a.z - r.c.z, dist = __fsqrt_rn(r.dd);
+    const float a1 = lj == 0 ? dx : lj == 1 ? dy : lj == 2 ? dz : dist;        // [x_i - x_j, dist] of neighbour li, input lj
+    const float a2 = lj == 0 ? r.a.x : lj == 1 ? r.a.y : lj == 2 ? r.a.z : 0.f;  // x_i (the same for every neighbour)
 #pragma unroll
     for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
-        acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float4 b = *reinterpret_cast<const float4*>(w.w1f + (nb * 16 + li) * VT<DT>::S1 + 4 * lj);
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nb], 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nb], 0, 0, 0);
+        const float* wr = w.w1f + (nb * 16 + li) * VT<DT>::S1;
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, wr[4 + lj], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wr[lj], acc[nb], 0, 0, 0);
     }
 }
 
@@ -441,7 +455,7 @@ __device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in,
                                            const VCols<DT>& vc, int li, int lj, float* scratch, int XS,
                                            f32x4 (&raw)[VT<DT>::DTH], float* Xs) {
     constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH;
-    rpe_gemm<DT, TERMS>(rpe_frag(in, lj), w, li, lj, raw);
+    rpe_gemm<DT, TERMS>(in, w, li, lj, raw);
 #pragma unroll
     for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b1(nb));
     if (stage == 1) {
