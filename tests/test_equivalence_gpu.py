@@ -12,8 +12,12 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-CFG = dict(n_classes=3, n_points=1024, n_neighbors=16, layer_sizes=[8, 16, 32, 32])
-N = 1024
+# 2048 points: the deepest level keeps 32 points per cloud.  With 1024 it keeps 16 = K: every neighbourhood is then the whole
+# cloud, the pooled rows of a cloud are nearly identical, their BatchNorm divides by sqrt(var + 1e-6) with var ~ 0 and a
+# last-bit difference in the statistics (all this mode changes) comes out 1e3 ... 1e4 times larger in the gradients - a
+# property of that degenerate configuration (two evaluation orders of the SAME single-process step differ by 3e-3 there).
+CFG = dict(n_classes=3, n_points=2048, n_neighbors=16, layer_sizes=[8, 16, 32, 32])
+N = 2048
 
 
 def _data(B):
