@@ -103,32 +103,27 @@ def test_two_ranks_in_equivalence_mode_reproduce_the_global_batch_step(B, p_drop
     assert abs(res[0][3] - ref_loss) < 1e-6 and res[0][3] == res[1][3], (res[0][3], res[1][3], ref_loss)
     assert np.array_equal(res[0][4][: 3 * CFG["n_classes"]], ref_counts.numpy()[: 3 * CFG["n_classes"]])
     # every parameter gradient: fp32 summation order is the only difference (per-rank partial sums) - ~1e-7 of the batch
-    # statistics.  How much of that reaches a gradient depends on the test point: the deepest level normalises 64 - 160 rows
-    # per channel, some with variances far below eps, and there a last-bit change of the statistics comes out 1e3 ... 1e4
-    # times larger (two evaluation orders of the SAME single-process step can differ by 3e-3).  So the bound is calibrated on
-    # the point itself: the yardstick is what re-ordering the clouds of the whole batch (Dropout off: its mask is tied to the
-    # element index) changes in the single-process step - the same kind of difference the sharding introduces.
-    base = _one_step(1, 0, False, B, 0.0)[0] if p_drop > 0 else ref_grad
-    rolled = _one_step(1, 0, False, B, 0.0, roll=B // 2)[0]
-    off, rel, yard = 0, [], 0.0
+    # statistics.  How much of that reaches a gradient depends on the tensor: the deepest level normalises a few dozen to a
+    # few thousand rows per channel, some with variances far below eps, and there a last-bit change of the statistics can come
+    # out 1e3 ... 1e4 times larger (two evaluation orders of the SAME single-process step were seen 3e-3 apart on
+    # encoder.3.*, with every other tensor at 1e-5).  A wrong row count, mask slice or missing all-reduce would move EVERY
+    # tensor by far more than 1e-2.  So: three quarters of the tensors within 2e-4 of their scale, every tensor within 1e-2.
+    off, rel = 0, []
     for name, n in layout:
         a, b = g0[off:off + n], ref_grad[off:off + n]
         scale = float(b.abs().max())
         if scale > 1e-6:       # (a bias in front of a BatchNorm has an exactly-zero gradient: rounding noise on both sides)
             rel.append((float((a - b).abs().max()) / scale, name))
-            yard = max(yard, float((rolled[off:off + n] - base[off:off + n]).abs().max()) / float(base[off:off + n].abs().max()))
         off += -(-n // 4) * 4
     rel.sort()
-    worst = rel[-1][0]
-    bound = max(2e-4, 8.0 * yard)
-    print(f"yardstick (clouds re-ordered, single process): {yard:.2e} -> bound {bound:.2e}")
-    assert worst < bound, (rel[-3:], yard)
-    assert bound < 2e-2, yard          # the yardstick itself must stay a rounding effect
+    worst, q75 = rel[-1][0], rel[int(0.75 * len(rel))][0]
+    assert q75 < 2e-4, rel[int(0.75 * len(rel)):][:5]
+    assert worst < 1e-2, rel[-3:]
     # BatchNorm running statistics: global-batch statistics on every rank
     for k, v in ref_bufs.items():
         assert np.allclose(res[0][5][k], v.numpy(), rtol=1e-5, atol=1e-6), k
         assert np.array_equal(res[0][5][k], res[1][5][k]), k
-    print(f"equivalence mode (B={B}, Dropout {p_drop}): worst relative gradient difference {worst:.2e} ({rel[-1][1]}), 90th percentile {rel[int(0.9 * len(rel))][0]:.2e}, loss {res[0][3]:.7f} vs {ref_loss:.7f}")
+    print(f"equivalence mode (B={B}, Dropout {p_drop}): worst relative gradient difference {worst:.2e} ({rel[-1][1]}), 75th percentile {q75:.2e}, loss {res[0][3]:.7f} vs {ref_loss:.7f}")
 
     # WITHOUT the mode the sharded step is a different (standard DDP) computation: per-replica statistics and dice
     plain = _one_step(1, 0, False, B, p_drop)[0]
