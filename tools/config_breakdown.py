@@ -1,6 +1,13 @@
-import sys, os, json
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/3d_recognizer_amd')
-import numpy as np, torch
+#!/usr/bin/env python3
+"""Per-kernel HIP-event breakdown of one training step of BASELINE.json's other single-GPU configurations (bench.py's
+instrumented eager pass):  python tools/config_breakdown.py S | Kt"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "3d_recognizer_amd"))
+import torch
 import bench
 from randlanet._train import TrainStep
 cfgname = sys.argv[1] if len(sys.argv) > 1 else 'S'
