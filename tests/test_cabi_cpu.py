@@ -86,3 +86,45 @@ def test_operands_on_another_device_are_refused_before_launch(monkeypatch):
         _ops._dev_check(FakeDeviceTensor(0), FakeDeviceTensor(1))
     with pytest.raises(_hip.HipKernelError, match="device tensors"):
         _ops._dev_check(torch.zeros(3))
+
+
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """Every descriptor struct of include/rl_randlanet.h against its ctypes mirror in randlanet/_hip.py: size and the offset
+    of every field, as gcc lays the header out (a field added on one side only shifts everything behind it silently)."""
+    from randlanet import _hip
+    pairs = {"rl_gemm_desc": _hip.GemmDesc, "rl_wsplit_item": _hip.WsplitItem, "rl_wgrad_desc": _hip.WgradDesc,
+             "rl_wgrad_reduce_item": _hip.WgradReduceItem, "rl_bn_bwd_desc": _hip.BnBwdDesc, "rl_knn_task": _hip.KnnTask,
+             "rl_pool_desc": _hip.PoolDesc, "rl_resid_bn_bwd_desc": _hip.ResidBnBwdDesc, "rl_csr_task": _hip.CsrTask,
+             "rl_segsum_desc": _hip.SegsumDesc, "rl_rows_desc": _hip.RowsDesc, "rl_cloud_job": _hip.CloudJob}
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    expect = {}
+    for cname, ct in pairs.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S)
+        assert body, cname
+        # field names in declaration order: identifiers right before ';', ',' or '['
+        fields = []
+        for decl in body.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*$", part.strip())
+                assert m, (cname, part)
+                fields.append(m.group(1))
+        assert fields == [f[0] for f in ct._fields_], (cname, fields, [f[0] for f in ct._fields_])
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for f in fields:
+            lines.append(f'printf(" %zu", offsetof({cname}, {f}));')
+        lines.append('printf("\\n");')
+        expect[cname] = [ctypes.sizeof(ct)] + [getattr(ct, f).offset for f in fields]
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)]).decode().strip().splitlines()
+    assert len(out) == len(pairs)
+    for line in out:
+        name, *nums = line.split()
+        assert [int(n) for n in nums] == expect[name], (name, nums, expect[name])

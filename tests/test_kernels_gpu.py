@@ -870,3 +870,10 @@ def test_grouped_wide_weight_gradients_equal_the_single_launches_bitwise(ops):
     a, dY, M, K, N = layers[0]
     ref = dY.double().t() @ a.raw.double()
     assert float((grouped[0][0].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+    # more layers than one launch's table holds (24): the entry point chunks
+    layers = [(ops.plain(torch.randn(300 + 7 * i, 128, device=DEV), 1, 300 + 7 * i), torch.randn(300 + 7 * i, 128, device=DEV), 300 + 7 * i, 128, 128)
+              for i in range(27)]
+    single, _ = run(False)
+    grouped, queued = run(True)
+    assert queued == 27
+    assert all(torch.equal(w0, w1) and torch.equal(b0, b1) for (w0, b0), (w1, b1) in zip(single, grouped))
