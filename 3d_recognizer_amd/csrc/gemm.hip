@@ -817,6 +817,122 @@ constexpr int PG_AS = 36;   // LDS row stride (floats): 16-byte aligned rows, 16
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
+// Epilogue of the LDS-tiled GEMMs (pgemm_kernel / wgemm_kernel / wgemm2_kernel) for one 16-row block of a wavefront: rows
+// Rb .. Rb + 15, acc[nb][r] = element (row lq * 4 + r, column col0 + nb * 16 + lr).  The run-time options (bias, accumulate,
+// addend, split store) are uniform per launch: the common case - everything goes to Y - is a straight-line path of its own
+// (the options tested once per row, all loads of a row issued together); written as one loop with the tests inside, the
+// unrolled epilogue was ~200 scalar branches per tile and cost as much as the tile's K loop (tools/wgemm_ab.py).
+template <int NT, bool STATS>
+__device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f32x4 (&acc)[NT], long Rb, int col0, int lr, int lq,
+                                                   float (&ssum)[NT], float (&ssq)[NT]) {
+    constexpr int BN = 16 * NT;
+    const int N = p.N;
+    const long M = p.a.M;
+    if (!p.addend && !p.out2) {
+        const bool full = col0 + BN <= N;
+        const bool has_bias = p.bias != nullptr;
+        float bv[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int c = col0 + nb * 16 + lr;
+            bv[nb] = (has_bias && c < N) ? p.bias[c] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long R = Rb + lq * 4 + r;
+            if (R < M) {
+                long yoff;
+                if (p.y_contig) yoff = R * p.ldy;
+                else {
+                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                    const int i = (int)(R - (long)b * p.rows_per_batch);
+                    yoff = ((long)b * p.y_bstride + i) * p.ldy;
+                }
+                float* y = p.Y + yoff + col0 + lr;
+                float v[NT];
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) v[nb] = acc[nb][r];
+                if (has_bias) {
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) v[nb] += bv[nb];
+                }
+                if (p.accumulate) {
+                    float o[NT];
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) o[nb] = (full || col0 + nb * 16 + lr < N) ? y[nb * 16] : 0.f;
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) v[nb] += o[nb];
+                }
+                if (full) {
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        y[nb * 16] = v[nb];
+                        if constexpr (STATS) {
+                            ssum[nb] += v[nb];
+                            ssq[nb] += v[nb] * v[nb];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        if (col0 + nb * 16 + lr < N) {
+                            y[nb * 16] = v[nb];
+                            if constexpr (STATS) {
+                                ssum[nb] += v[nb];
+                                ssq[nb] += v[nb] * v[nb];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // split store (the two halves of a concat's gradient) and / or an addend: no statistics on this path (rl_gemm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long R = Rb + lq * 4 + r;
+        if (R < M) {
+            long yoff;
+            if (p.y_contig) yoff = R * p.ldy;
+            else {
+                const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                const int i = (int)(R - (long)b * p.rows_per_batch);
+                yoff = ((long)b * p.y_bstride + i) * p.ldy;
+            }
+            long o2 = 0;
+            if (p.out2) {
+                if (p.out2_index) {
+                    const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                    o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
+                } else {
+                    o2 = R * (N - p.split_col) - p.split_col;      // dense: one row per source row
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                const int c = col0 + nb * 16 + lr;
+                if (c < N) {
+                    float v = acc[nb][r];
+                    if (p.bias) v += p.bias[c];
+                    if (p.addend) v += p.addend[R * N + c];
+                    if (p.out2 && c >= p.split_col) {
+                        if (p.out2_index) atomicAdd(p.out2 + o2 + c, v);
+                        else p.out2[o2 + c] = v;
+                    } else {
+                        if (p.accumulate) v += p.Y[yoff + c];
+                        p.Y[yoff + c] = v;
+                        if constexpr (STATS) {
+                            ssum[nb] += v;
+                            ssq[nb] += v * v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // fp32 value -> bf16 head + bf16 tail (v = hi + lo up to 2^-17 relative)
 __device__ __forceinline__ void split_bf16(const float4 v, bf16x4& hi, bf16x4& lo) {
     hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
@@ -1105,48 +1221,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const GemmParams p) {
             continue;
         }
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long R = row0 + wave * 32 + rb * 16 + lq * 4 + r;
-                if (R < M) {
-                    long yoff;
-                    if (p.y_contig) yoff = R * p.ldy;
-                    else {
-                        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
-                        const int i = (int)(R - (long)b * p.rows_per_batch);
-                        yoff = ((long)b * p.y_bstride + i) * p.ldy;
-                    }
-                    long o2 = 0;
-                    if (p.out2) {
-                        if (p.out2_index) {
-                            const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
-                            o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
-                        } else {
-                            o2 = R * (N - p.split_col) - p.split_col;      // dense: one row per source row
-                        }
-                    }
-#pragma unroll
-                    for (int nb = 0; nb < NT; ++nb) {
-                        const int c = col0 + nb * 16 + lr;
-                        if (c < N) {
-                            float v = acc[rb][nb][r];
-                            if (p.bias) v += p.bias[c];
-                            if (p.addend) v += p.addend[R * N + c];
-                            if (p.out2 && c >= p.split_col) {
-                                if (p.out2_index) atomicAdd(p.out2 + o2 + c, v);
-                                else p.out2[o2 + c] = v;
-                            } else {
-                                if (p.accumulate) v += p.Y[yoff + c];
-                                p.Y[yoff + c] = v;
-                                ssum[nb] += v;
-                                ssq[nb] += v * v;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        for (int rb = 0; rb < 2; ++rb) tile_rows_epilogue<NT, true>(p, acc[rb], row0 + wave * 32 + rb * 16, col0, lr, lq, ssum, ssq);
     }
     if (p.stats && p.ksplit <= 1) {
 #pragma unroll
@@ -1344,53 +1419,10 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
             }
             continue;
         }
-        float ssum[STATS ? NT : 1], ssq[STATS ? NT : 1];
-        if constexpr (STATS) {
+        float ssum[NT], ssq[NT];
 #pragma unroll
-            for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long R = row0 + wave * 16 + lq * 4 + r;
-            if (R < M) {
-                long yoff;
-                if (p.y_contig) yoff = R * p.ldy;
-                else {
-                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
-                    const int i = (int)(R - (long)b * p.rows_per_batch);
-                    yoff = ((long)b * p.y_bstride + i) * p.ldy;
-                }
-                long o2 = 0;
-                if (p.out2) {
-                    if (p.out2_index) {
-                        const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
-                        o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
-                    } else {
-                        o2 = R * (N - p.split_col) - p.split_col;
-                    }
-                }
-#pragma unroll
-                for (int nb = 0; nb < NT; ++nb) {
-                    const int c = col0 + nb * 16 + lr;
-                    if (c < N) {
-                        float v = acc[nb][r];
-                        if (p.bias) v += p.bias[c];
-                        if (p.addend) v += p.addend[R * N + c];
-                        if (p.out2 && c >= p.split_col) {
-                            if (p.out2_index) atomicAdd(p.out2 + o2 + c, v);
-                            else p.out2[o2 + c] = v;
-                        } else {
-                            if (p.accumulate) v += p.Y[yoff + c];
-                            p.Y[yoff + c] = v;
-                            if constexpr (STATS) {
-                                ssum[nb] += v;
-                                ssq[nb] += v * v;
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+        tile_rows_epilogue<NT, STATS>(p, acc, row0 + wave * 16, col0, lr, lq, ssum, ssq);
         if constexpr (STATS) if (p.stats && p.ksplit <= 1) {
             __syncthreads();                                        // the operand tiles are free: reuse them for the reduction
             double* red = reinterpret_cast<double*>(lds_a);         // [8][2][128] doubles = 16 KB <= 20 KB (10 KB in bf16 mode: use both)
@@ -1417,6 +1449,301 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
     }
     if constexpr (STATS) if (p.stats && p.ksplit <= 1) {
         if (tid < BN && col0 + tid < N) {
+            p.stats[((long)bx * 2 + 0) * N + col0 + tid] = tot_s;
+            p.stats[((long)bx * 2 + 1) * N + col0 + tid] = tot_q;
+            for (long slot = bx + p.gx; slot < p.stat_slots; slot += p.gx) {
+                p.stats[(slot * 2 + 0) * N + col0 + tid] = 0.0;
+                p.stats[(slot * 2 + 1) * N + col0 + tid] = 0.0;
+            }
+        }
+    }
+}
+
+// ===========================================================================================
+// wgemm2_kernel: wgemm_kernel's tile and arithmetic as a PERSISTENT workgroup per CU whose operands arrive by LDS-DMA
+// (global_load_lds_dwordx4) from dedicated loader wavefronts.
+// wgemm_kernel keeps one 32-deep chunk of loads in flight per workgroup, in registers, behind two barriers per chunk; its
+// wavefronts wait 63 % of their life (profiles/r03_pmc_sq_step.md), the under-filled launches of the deep levels pay one
+// full memory latency per chunk and every tile starts with an empty pipeline.  Here
+//   * twelve wavefronts: 0-7 compute (16 rows x 128 columns each, as before), 8-9 issue the A pieces, 10-11 the W pieces.
+//     vmcnt retires in order PER WAVEFRONT: the loaders' queues hold nothing but their own DMA (no epilogue stores, and
+//     the deep A queue does not drain for the shallow W queue), so a counted s_waitcnt says exactly which chunk landed;
+//   * the fp32 A tile goes to LDS RAW, AS chunks deep (no staging registers: the depth is an LDS budget); the lazy
+//     BatchNorm + activation and the bf16 head / tail split happen on the fragment, after the ds_read - every element is
+//     still converted exactly once, by the wavefront that owns its 16 rows; the pre-split weight planes follow 2 deep;
+//   * the chunk stream runs ACROSS the workgroup's tiles: while the compute wavefronts store tile t, the first chunks of
+//     tile t+1 are already in flight;
+//   * one raw s_barrier per chunk.  Loaders: wait (counted vmcnt) -> barrier -> refill the stage chunk q-1 freed.
+//     Compute: barrier -> fragments -> 24 MFMAs (type-major: dependent MFMAs eight apart);
+//   * LDS image of an A chunk: [128 rows][8 pieces of 16 B], piece p of row r stored at p ^ ((r >> 1) & 7) - the DMA writes
+//     lane-linear (1 KB per wavefront instruction = 8 rows), so the swizzle is applied to the SOURCE address and again
+//     on the fragment read: the 64 lanes of a ds_read_b128 fall on 16 distinct 16-byte slots, 4 lanes each.
+// LDS: AS * 16 (A) + 32 (W) + 8 (scale / shift) + 16 (statistics) KB = 136 KB at AS = 5; 3 wavefronts per SIMD (168 VGPRs).
+// Same products in the same order per accumulator as wgemm_kernel: Y is bitwise the same; the BatchNorm partial sums are
+// grouped per wavefront over the workgroup's tiles (another, equally fixed, order of the same doubles).
+// Needs K % 32 == 0 and K <= 1024.
+// ===========================================================================================
+// The DMA is issued from inline asm ON PURPOSE: hipcc (ROCm 7.2) follows a __builtin_amdgcn_global_load_lds with
+// s_waitcnt vmcnt(0) in front of the next ds_read of the same __shared__ object - every chunk would wait for the loads it
+// has just issued.  Hidden in asm, the only waits are the counted ones below.  l: LDS byte address (wavefront-uniform),
+// the wavefront's 64 lanes land at l + 16 * lane.
+typedef __attribute__((address_space(3))) unsigned char rl_lds_byte;
+__device__ __forceinline__ unsigned lds_address(const void* q) {
+    return (unsigned)(uintptr_t)(const rl_lds_byte*)q;
+}
+__device__ __forceinline__ void glds16x4(const void* g0, const void* g1, const void* g2, const void* g3, unsigned l0, unsigned l1,
+                                         unsigned l2, unsigned l3) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(l0), "s"(l1), "s"(l2), "s"(l3) : "memory");
+}
+template <int PER>       // s_waitcnt vmcnt(PER * n): PER instructions per chunk, n = 0 .. 4 chunks may stay in flight (wavefront-uniform)
+__device__ __forceinline__ void wait_vm_chunks(int n) {
+    static_assert(PER == 4 || PER == 8, "pieces per loader wavefront and chunk");
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) { if (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else if (n == 2) { if (PER == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (n == 3) { if (PER == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+    else { if (PER == 8) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+}
+__device__ __forceinline__ void raw_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");          // (compiler-only: no LDS access may move over the barrier)
+}
+
+#ifndef W2_ABLATE
+#define W2_ABLATE 0      // diagnostics builds only: 1 = a quarter of the B fragment reads, 2 = no Y stores, 3 = no MFMAs
+#endif
+constexpr int W2_KMAX = 1024;
+constexpr int W2_THREADS = 768;
+template <int TERMS, bool STATS, int AS, int WS>
+__global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) {
+    static_assert(AS >= 3 && AS <= 6 && WS >= 2 && WS <= 6, "ring depths vs the wait table");
+    constexpr int BN = 128, NT = 8;
+    constexpr int A_STAGE = 128 * 128;          // bytes: 128 rows x 32 fp32
+    constexpr int W_PLANE = 128 * 64;           // bytes: 128 columns x 32 bf16
+    constexpr int W_STAGE = 2 * W_PLANE;
+    constexpr int OFF_W = AS * A_STAGE, OFF_SC = OFF_W + WS * W_STAGE, OFF_RED = OFF_SC + 2 * W2_KMAX * 4;
+    constexpr int TOTAL = OFF_RED + (STATS ? 8 * 2 * BN * 8 : 0);
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[TOTAL];       // ONE object
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx = blockIdx.x, by = 0;
+    if (p.ny > 1) {
+        const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+        by = s % p.ny;
+        bx = (s / p.ny) * 8 + xcd;
+        if (bx >= p.gx) return;
+    }
+    const int col0 = by * BN;
+    const int K = p.a.K, N = p.N;
+    const long M = p.a.M;
+    const long ntiles = (M + GM_BM - 1) / GM_BM;
+    const bool lazy = p.a.lazy.scale != nullptr;
+    float* lsc = reinterpret_cast<float*>(lds + OFF_SC);
+    float* lsh = lsc + W2_KMAX;
+    double* red = reinterpret_cast<double*>(lds + OFF_RED);        // [8 wavefronts][2][128]
+    const unsigned lds0 = lds_address(lds);
+    if (lazy) {
+        for (int k = tid; k < K; k += W2_THREADS) {
+            lsc[k] = p.a.lazy.scale[k];
+            lsh[k] = p.a.lazy.shift[k];
+        }
+    }
+    if constexpr (STATS) {
+        for (int i = tid; i < 8 * 2 * BN; i += W2_THREADS) red[i] = 0.0;
+    }
+    __syncthreads();
+
+    const int k_begin = (p.ksplit > 1) ? blockIdx.z * p.kchunk : 0;
+    const int k_end = (p.ksplit > 1) ? min(K, k_begin + p.kchunk) : K;
+    const int nch = (k_end - k_begin) / PG_BK;
+    const int my_tiles = bx < ntiles ? (int)((ntiles - 1 - bx) / p.gx) + 1 : 0;
+    const int T = my_tiles * nch;                                  // chunk steps of this workgroup = barriers every wavefront passes
+
+    if (wave >= 10) {
+        // ---- W loaders: 16 (8 in the bf16 mode) pieces of 1 KB per chunk, two chunks deep ---------------------------------
+        constexpr int WI = TERMS == 3 ? 8 : 4;
+        const int lw = wave - 10;
+        const __bf16* wsrc[WI];
+        unsigned wdst[WI];
+#pragma unroll
+        for (int j = 0; j < WI; ++j) {
+            const int idx = lw * WI + j, plane = idx >> 3, rg = idx & 7;
+            int col = col0 + rg * 16 + (lane >> 2);
+            col = col < N ? col : N - 1;        // columns past N are never stored
+            wsrc[j] = p.wsplit + (long)plane * N * K + (long)col * K + (lane & 3) * 8 + k_begin;
+            wdst[j] = lds0 + OFF_W + plane * W_PLANE + rg * 1024;
+        }
+        auto issue_w = [&](int q) {
+            const int k = (q % nch) * PG_BK;
+            const unsigned o = __builtin_amdgcn_readfirstlane((q % WS) * W_STAGE);
+#pragma unroll
+            for (int j = 0; j < WI; j += 4)
+                glds16x4(wsrc[j] + k, wsrc[j + 1] + k, wsrc[j + 2] + k, wsrc[j + 3] + k, wdst[j] + o, wdst[j + 1] + o, wdst[j + 2] + o,
+                         wdst[j + 3] + o);
+        };
+        for (int q = 0; q < WS - 1 && q < T; ++q) issue_w(q);
+        for (int q = 0; q < T; ++q) {
+            wait_vm_chunks<WI>(min(WS - 2, T - 1 - q));
+            raw_barrier();
+            if (q + WS - 1 < T) issue_w(q + WS - 1);
+        }
+    } else if (wave >= 8) {
+        // ---- A loaders: 16 pieces of 1 KB (8 rows x 128 B) per chunk, AS - 1 chunks ahead, across the tiles -----------------
+        const int lw = wave - 8;
+        const float* asrc[8];
+        auto tile_sources = [&](int j) {        // j-th tile of this workgroup
+            const long row0 = ((long)bx + (long)j * p.gx) * GM_BM;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (lw * 8 + i) * 8 + (lane >> 3);
+                long R = row0 + r;
+                R = R < M ? R : M - 1;          // rows past M are never stored
+                asrc[i] = p.a.A + a_row_offset(p.a, R) + (((lane & 7) ^ ((r >> 1) & 7)) << 2) + k_begin;
+            }
+        };
+        int iq = 0, ic = 0;                     // next chunk step to issue, its chunk inside its tile
+        auto issue_a = [&]() {
+            if (ic == 0) tile_sources(iq / nch);
+            const int k = ic * PG_BK;
+            const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (iq % AS) * A_STAGE + lw * 8192);
+            glds16x4(asrc[0] + k, asrc[1] + k, asrc[2] + k, asrc[3] + k, l, l + 1024, l + 2048, l + 3072);
+            glds16x4(asrc[4] + k, asrc[5] + k, asrc[6] + k, asrc[7] + k, l + 4096, l + 5120, l + 6144, l + 7168);
+            ++iq;
+            ic = ic + 1 == nch ? 0 : ic + 1;
+        };
+        while (iq < AS - 1 && iq < T) issue_a();
+        for (int q = 0; q < T; ++q) {
+            wait_vm_chunks<8>(min(AS - 2, T - 1 - q));
+            raw_barrier();
+            if (iq < T) issue_a();
+        }
+    } else {
+        // ---- compute ---------------------------------------------------------------------------------------------------------
+        const int lr = lane & 15, lq = lane >> 4;
+        const bool relu = p.a.lazy.act == RL_ACT_RELU;
+        const float nslope = p.a.lazy.act == RL_ACT_NONE ? 1.f : p.a.lazy.slope;
+        const int frow = wave * 16 + lr;                             // this lane's fragment row in the tile
+        const int fsw = (frow >> 1) & 7;
+        const int a_frag0 = frow * 128 + (((2 * lq) ^ fsw) << 4), a_frag1 = frow * 128 + (((2 * lq + 1) ^ fsw) << 4);
+        const int w_frag = lr * 64 + lq * 16;
+        auto actf = [&](float z) {
+            const float neg = relu ? 0.f : z * nslope;
+            return z > 0.f ? z : neg;
+        };
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+        long tile = bx;
+        for (int q = 0; q < T; ++q) {
+            raw_barrier();
+            const unsigned char* Ab = lds + (q % AS) * A_STAGE;
+            const unsigned char* Wb = lds + OFF_W + (q % WS) * W_STAGE;
+            float4 v0 = *reinterpret_cast<const float4*>(Ab + a_frag0);
+            float4 v1 = *reinterpret_cast<const float4*>(Ab + a_frag1);
+            if (lazy) {
+                const int kk = k_begin + c * PG_BK + lq * 8;
+                const float4 sc0 = *reinterpret_cast<const float4*>(lsc + kk), sc1 = *reinterpret_cast<const float4*>(lsc + kk + 4);
+                const float4 sh0 = *reinterpret_cast<const float4*>(lsh + kk), sh1 = *reinterpret_cast<const float4*>(lsh + kk + 4);
+                v0.x = actf(v0.x * sc0.x + sh0.x); v0.y = actf(v0.y * sc0.y + sh0.y);
+                v0.z = actf(v0.z * sc0.z + sh0.z); v0.w = actf(v0.w * sc0.w + sh0.w);
+                v1.x = actf(v1.x * sc1.x + sh1.x); v1.y = actf(v1.y * sc1.y + sh1.y);
+                v1.z = actf(v1.z * sc1.z + sh1.z); v1.w = actf(v1.w * sc1.w + sh1.w);
+            }
+            bf16x4 h0, l0, h1, l1;
+            split_bf16(v0, h0, l0);
+            split_bf16(v1, h1, l1);
+            const bf16x8 a_h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 a_l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            bf16x8 b_h[NT], b_l[NT];
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+#if W2_ABLATE == 1
+                const int nbs = nb & 1;
+#else
+                const int nbs = nb;
+#endif
+                b_h[nb] = *reinterpret_cast<const bf16x8*>(Wb + w_frag + nbs * 1024);
+                if constexpr (TERMS == 3) b_l[nb] = *reinterpret_cast<const bf16x8*>(Wb + W_PLANE + w_frag + nbs * 1024);
+            }
+#if W2_ABLATE == 3
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) { acc[nb][0] += (float)b_h[nb][0] * (float)a_h[0]; acc[nb][1] += (float)b_l[nb][1] * (float)a_l[1]; }
+#else
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[nb], acc[nb], 0, 0, 0);
+            if constexpr (TERMS == 3) {
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h[nb], acc[nb], 0, 0, 0);
+            }
+#endif
+            if (++c < nch) continue;
+            // ---- the tile is complete: epilogue (the loaders are already AS - 1 chunks into the next tile) -------------------
+            c = 0;
+            const long row0 = tile * GM_BM;
+            tile += p.gx;
+#if W2_ABLATE == 4
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) asm volatile("" :: "v"(acc[nb]));
+            if (p.ksplit > 1000) {
+#else
+            if (p.ksplit > 1) {
+#endif
+                float* slab = p.kslab + (long)blockIdx.z * M * N;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long R = row0 + wave * 16 + lq * 4 + r;
+                    if (R < M) {
+#pragma unroll
+                        for (int nb = 0; nb < NT; ++nb) {
+                            const int cc = col0 + nb * 16 + lr;
+                            if (cc < N) slab[R * N + cc] = acc[nb][r];
+                        }
+                    }
+                }
+#if W2_ABLATE == 4
+            } else if (p.ksplit > 1000) {
+#else
+            } else {
+#endif
+                float ssum[NT], ssq[NT];
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+                tile_rows_epilogue<NT, STATS>(p, acc, row0 + wave * 16, col0, lr, lq, ssum, ssq);
+                if constexpr (STATS) if (p.stats) {
+                    // this wavefront's own slice of the scratch: no other wavefront touches it before the final barrier
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        float sv = ssum[nb], qv = ssq[nb];
+                        sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+                        qv += __shfl_xor(qv, 16, 64); qv += __shfl_xor(qv, 32, 64);
+                        if (lane < 16) {
+                            red[(wave * 2 + 0) * BN + nb * 16 + lane] += (double)sv;
+                            red[(wave * 2 + 1) * BN + nb * 16 + lane] += (double)qv;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if constexpr (STATS) if (p.stats && p.ksplit <= 1) {
+        __syncthreads();
+        if (tid < BN && col0 + tid < N) {
+            double tot_s = 0.0, tot_q = 0.0;
+            for (int w = 0; w < 8; ++w) {
+                tot_s += red[(w * 2 + 0) * BN + tid];
+                tot_q += red[(w * 2 + 1) * BN + tid];
+            }
             p.stats[((long)bx * 2 + 0) * N + col0 + tid] = tot_s;
             p.stats[((long)bx * 2 + 1) * N + col0 + tid] = tot_q;
             for (long slot = bx + p.gx; slot < p.stat_slots; slot += p.gx) {
@@ -1554,10 +1881,35 @@ void launch_pgemm(dim3 logical, hipStream_t st, GemmParams p) {
 inline bool wgemm_ok(const GemmParams& p) {
     return p.wsplit != nullptr && wide_gemm_terms() != 0 && (p.a.K % 8 == 0) && (((uintptr_t)p.wsplit & 15) == 0);
 }
+constexpr int W2_AS = 4, W2_WS = 4;
+// 0: register-staged wgemm_kernel, 1: LDS-DMA wgemm2_kernel (same results bitwise).  RL_WGEMM_STAGING / rl_set_wgemm_staging.
+int g_wgemm_staging = -1;
+inline int wgemm_staging() {
+    if (g_wgemm_staging < 0) {
+        const char* e = getenv("RL_WGEMM_STAGING");
+        g_wgemm_staging = (e && !strcmp(e, "dma")) ? 1 : 0;
+    }
+    return g_wgemm_staging;
+}
 void launch_wgemm(dim3 logical, hipStream_t st, GemmParams p) {
     p.gx = (int)logical.x; p.ny = (int)logical.y;
     const dim3 grid(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : logical.x, 1, logical.z);
     const bool stats = p.stats != nullptr && p.ksplit <= 1;
+    if (wgemm_staging() == 1 && p.a.K % PG_BK == 0 && p.a.K <= W2_KMAX && (((uintptr_t)p.a.A | (uintptr_t)(p.a.lda * 4)) & 15) == 0) {
+        // one persistent workgroup per CU: the row tiles are dealt round-robin to gx = 256 / ny workgroup rows
+        int cap = 256 / (p.ny > 0 ? p.ny : 1) / 8 * 8;
+        if (cap < 8) cap = 8;
+        if (p.gx > cap) p.gx = cap;
+        const dim3 g2(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : (unsigned)p.gx, 1, logical.z);
+        if (wide_gemm_terms() == 1) {
+            if (stats) hipLaunchKernelGGL((wgemm2_kernel<1, true, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
+            else       hipLaunchKernelGGL((wgemm2_kernel<1, false, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
+        } else {
+            if (stats) hipLaunchKernelGGL((wgemm2_kernel<3, true, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
+            else       hipLaunchKernelGGL((wgemm2_kernel<3, false, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
+        }
+        return;
+    }
     if (wide_gemm_terms() == 1) {
         if (stats) hipLaunchKernelGGL((wgemm_kernel<1, true>), grid, dim3(512), 0, st, p);
         else       hipLaunchKernelGGL((wgemm_kernel<1, false>), grid, dim3(512), 0, st, p);
@@ -2146,6 +2498,12 @@ extern "C" int rl_set_wide_gemm(const char* mode) {
     const int t = parse_wide(mode);
     RL_REQUIRE(mode != nullptr && t >= 0, RL_ERR_ARGS, "rl_set_wide_gemm: mode must be \"fp32\", \"bf16x3\" or \"bf16\"");
     g_wide_terms = t;
+    return RL_OK;
+}
+extern "C" int rl_set_wgemm_staging(const char* how) {
+    RL_REQUIRE(how != nullptr && (!strcmp(how, "registers") || !strcmp(how, "dma")), RL_ERR_ARGS,
+               "rl_set_wgemm_staging: \"registers\" or \"dma\"");
+    g_wgemm_staging = !strcmp(how, "dma");
     return RL_OK;
 }
 extern "C" const char* rl_get_wide_gemm(void) {

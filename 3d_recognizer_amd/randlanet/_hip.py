@@ -187,6 +187,7 @@ _SIGNATURES = {
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_set_wide_gemm": (_i, [C.c_char_p]),
     "rl_get_wide_gemm": (C.c_char_p, []),
+    "rl_set_wgemm_staging": (_i, [C.c_char_p]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "rl_wgrad_nsplit": (_i, [_l, _i, _i]),
     "rl_wgrad_batchable": (_i, [C.POINTER(WgradDesc)]),

@@ -251,6 +251,11 @@ def get_wide_gemm() -> str:
     return H.lib().rl_get_wide_gemm().decode()
 
 
+def set_wgemm_staging(how: str) -> None:
+    """Operand staging of the wide GEMM in the bf16 modes: "registers" or "dma" (rl_set_wgemm_staging); same results."""
+    H.check(H.lib().rl_set_wgemm_staging(how.encode()), "rl_set_wgemm_staging")
+
+
 def rpe_build(a: "Rpe", distances: bool = False) -> Lazy:
     """The relative position encoding of every neighbourhood row, written out once (rows x 12 floats: 10 channels +
     2 of padding) so that mlp_rpe1's forward and weight gradient read a plain tensor (modules.py:173-186)."""

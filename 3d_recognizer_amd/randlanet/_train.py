@@ -55,11 +55,11 @@ def broadcast_flat(buf: torch.Tensor, world: int, group=None, src: int = 0) -> N
         dist.broadcast(buf, src, group=group)
 
 
-def sync_gradients(flat_grad: torch.Tensor, world: int, group=None) -> None:
+def sync_gradients(flat_grad: torch.Tensor, world: int, group=None, always: bool = False) -> None:
     """THE collective of the path: one all-reduce(SUM) over the flat gradient buffer (5.29 MB for
     config A) - RCCL over xGMI on the GPUs, gloo in the CPU tests.  The division by `world`
-    is folded into the Adam kernel (grad_scale)."""
-    if world > 1:
+    is folded into the Adam kernel (grad_scale).  always: issue it for a one-rank group too."""
+    if world > 1 or always:
         import torch.distributed as dist
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
 
@@ -111,8 +111,10 @@ class TrainStep:
 
     def __init__(self, module, B: int, N: int, loss: str = "dice", lr: float = 1e-2, use_graph: bool = True,
                  process_group=None, world_size: int = 1, state: Optional[TrainState] = None,
-                 sync: Optional[ops.SyncGroup] = None):
-        """sync: the data-parallel EQUIVALENCE mode - BatchNorm batch statistics and the loss' class
+                 sync: Optional[ops.SyncGroup] = None, split_schedule: bool = False):
+        """split_schedule: run the multi-rank schedule (forward + backward graph, gradient all-reduce, Adam graph) with ONE
+        rank too - a one-rank RCCL group then exercises the collective path on a single GPU (tests/test_rccl_gpu.py).
+        sync: the data-parallel EQUIVALENCE mode - BatchNorm batch statistics and the loss' class
         sums of the GLOBAL batch (all-reduced), gradients summed instead of averaged: N ranks on shards reproduce the
         single-process step on the whole batch.  Eager launches only (collectives between kernels)."""
         self.state = state if state is not None else TrainState(module, lr, process_group, world_size)
@@ -129,6 +131,7 @@ class TrainStep:
         self.flat, self.engine = st.flat, st.engine
         self.p_drop = float(module.fc_end[2].p)
         self.world, self.pg = st.world, st.pg
+        self.split = bool(split_schedule) or self.world > 1
         self.exp_avg, self.exp_avg_sq, self.lr, self.step_count = st.exp_avg, st.exp_avg_sq, st.lr, st.step_count
         # static buffers; all start VALID (the capture pass launches kernels that index with them)
         self.inp = torch.rand((B, N, 3 + s.n_features), dtype=torch.float32, device=self.dev)
@@ -171,7 +174,7 @@ class TrainStep:
             if self.sync.world > 1:
                 self.sync.allreduce(self.flat.grad)
             return
-        sync_gradients(self.flat.grad, self.world, self.pg)
+        sync_gradients(self.flat.grad, self.world, self.pg, always=self.split)
 
     def capture(self, warmup: int = 2) -> None:
         """Run a few eager steps on a side stream (allocator warm-up), then capture."""
@@ -195,9 +198,9 @@ class TrainStep:
         self._g_main = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_main, capture_error_mode="thread_local"):
             self._fwd_bwd()
-            if self.world == 1:
+            if not self.split:
                 self._adam()
-        if self.world > 1:
+        if self.split:
             self._g_adam = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_adam, capture_error_mode="thread_local"):
                 self._adam()
@@ -226,7 +229,7 @@ class TrainStep:
         self._perm_events[slot] = ev
         if self._g_main is not None:
             self._g_main.replay()
-            if self.world > 1:
+            if self.split:
                 self._allreduce()
                 self._g_adam.replay()
         else:

@@ -201,6 +201,10 @@ int64_t rl_gemm_kslab_floats(int64_t M, int N, int K);
  * narrow (streaming) kernels are fp32 in every mode.  Not thread-safe against concurrent launches.           */
 int rl_set_wide_gemm(const char* mode);
 const char* rl_get_wide_gemm(void);
+/* How the wide forward / input-gradient GEMM of the bf16 modes stages its operands: "registers" (global loads, converted
+ * on their way into LDS, one chunk ahead) or "dma" (LDS-DMA, the fp32 tile five chunks deep, converted on the fragment).
+ * Same products in the same order: bitwise the same results.  RL_WGEMM_STAGING sets the initial choice.        */
+int rl_set_wgemm_staging(const char* how);
 int rl_gemm(const rl_gemm_desc* d, void* stream);
 
 /* Weight / bias gradient of the same layer:  dW(k,c) = sum_r A'[r][k] * dY[r][c],
