@@ -505,6 +505,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
     }
     const bool lazy = p.a.lazy.scale != nullptr;
     const float es = (!lazy || p.a.lazy.act == RL_ACT_NONE) ? 1.f : (p.a.lazy.act == RL_ACT_RELU ? 0.f : p.a.lazy.slope);
+    const bool full = N == 16 * NT;
 
     const long nblk = (M + 15) >> 4;
     const long bstep = (long)gridDim.x * 4;
@@ -560,15 +561,24 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
                     const int i = (int)(R - (long)b * p.rows_per_batch);
                     yoff = ((long)b * p.y_bstride + i) * p.ldy;
                 }
+                // (the options are tested once per row and a row's loads are issued together: see tile_rows_epilogue)
+                float* y = p.Y + yoff + li;
+                float v[NT];
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) v[nb] = acc[nb][r] + bias[nb];
+                if (p.accumulate) {
+                    float o[NT];
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) o[nb] = (full || nb * 16 + li < N) ? y[nb * 16] : 0.f;
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) v[nb] += o[nb];
+                }
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb) {
-                    const int n = nb * 16 + li;
-                    if (n < N) {
-                        float v = acc[nb][r] + bias[nb];
-                        if (p.accumulate) v += p.Y[yoff + n];
-                        p.Y[yoff + n] = v;
-                        ssum[nb] += v;
-                        ssq[nb] += v * v;
+                    if (full || nb * 16 + li < N) {
+                        y[nb * 16] = v[nb];
+                        ssum[nb] += v[nb];
+                        ssq[nb] += v[nb] * v[nb];
                     }
                 }
             }
@@ -819,18 +829,23 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 // Epilogue of the LDS-tiled GEMMs (pgemm_kernel / wgemm_kernel / wgemm2_kernel) for one 16-row block of a wavefront: rows
 // Rb .. Rb + 15, acc[nb][r] = element (row lq * 4 + r, column col0 + nb * 16 + lr).  The run-time options (bias, accumulate,
-// addend, split store) are uniform per launch: the common case - everything goes to Y - is a straight-line path of its own
-// (the options tested once per row, all loads of a row issued together); written as one loop with the tests inside, the
-// unrolled epilogue was ~200 scalar branches per tile and cost as much as the tile's K loop (tools/wgemm_ab.py).
+// addend, split store) are uniform per launch and a block lies on one side of split_col unless a tile straddles it: the
+// common cases are a straight-line path (the options tested once per row, all loads of a row issued together); written
+// as one loop with the tests inside, the unrolled epilogue was ~200 scalar branches per tile and cost as much as the
+// tile's K loop (tools/wgemm_ab.py).
 template <int NT, bool STATS>
 __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f32x4 (&acc)[NT], long Rb, int col0, int lr, int lq,
                                                    float (&ssum)[NT], float (&ssq)[NT]) {
     constexpr int BN = 16 * NT;
     const int N = p.N;
     const long M = p.a.M;
-    if (!p.addend && !p.out2) {
+    // where this block's columns go: all to Y, all to the dense out2, or (a tile that straddles split_col, indexed out2) mixed
+    const bool to_y = !p.out2 || col0 + BN <= p.split_col;
+    const bool to_out2 = p.out2 && !p.out2_index && col0 >= p.split_col;
+    if (to_y || to_out2) {
         const bool full = col0 + BN <= N;
         const bool has_bias = p.bias != nullptr;
+        const bool accumulate = to_y && p.accumulate;
         float bv[NT];
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) {
@@ -841,14 +856,19 @@ __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f3
         for (int r = 0; r < 4; ++r) {
             const long R = Rb + lq * 4 + r;
             if (R < M) {
-                long yoff;
-                if (p.y_contig) yoff = R * p.ldy;
-                else {
-                    const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
-                    const int i = (int)(R - (long)b * p.rows_per_batch);
-                    yoff = ((long)b * p.y_bstride + i) * p.ldy;
+                float* y;
+                if (to_y) {
+                    long yoff;
+                    if (p.y_contig) yoff = R * p.ldy;
+                    else {
+                        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+                        const int i = (int)(R - (long)b * p.rows_per_batch);
+                        yoff = ((long)b * p.y_bstride + i) * p.ldy;
+                    }
+                    y = p.Y + yoff + col0 + lr;
+                } else {
+                    y = p.out2 + R * (N - p.split_col) - p.split_col + col0 + lr;
                 }
-                float* y = p.Y + yoff + col0 + lr;
                 float v[NT];
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb) v[nb] = acc[nb][r];
@@ -856,7 +876,15 @@ __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f3
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) v[nb] += bv[nb];
                 }
-                if (p.accumulate) {
+                if (p.addend) {
+                    const float* ad = p.addend + R * N + col0 + lr;
+                    float o[NT];
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) o[nb] = (full || col0 + nb * 16 + lr < N) ? ad[nb * 16] : 0.f;
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) v[nb] += o[nb];
+                }
+                if (accumulate) {
                     float o[NT];
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) o[nb] = (full || col0 + nb * 16 + lr < N) ? y[nb * 16] : 0.f;
@@ -888,7 +916,7 @@ __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f3
         }
         return;
     }
-    // split store (the two halves of a concat's gradient) and / or an addend: no statistics on this path (rl_gemm)
+    // a tile that straddles split_col, or the indexed (atomic) out2: element by element
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const long R = Rb + lq * 4 + r;

@@ -112,7 +112,10 @@ def bench():
             ops.set_wgemm_staging(how)
             def fn(i):
                 a, Y = sets[i % nset]
-                ops.gemm(a, W, 1, K, N, None, out=Y, out_bstride=M, stats=stats, wsplit=ws)
+                if split:       # the input-gradient GEMM of a concat: addend + the two halves to two tensors
+                    ops.gemm(a, W, 1, K, N, None, out=Y[:, :N // 2], out_bstride=M, wsplit=ws, addend=addend, out2=out2, split_col=N // 2)
+                else:
+                    ops.gemm(a, W, 1, K, N, None, out=Y, out_bstride=M, stats=stats, wsplit=ws)
             for i in range(3):
                 fn(i)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
