@@ -1910,16 +1910,17 @@ inline bool wgemm_ok(const GemmParams& p) {
     return p.wsplit != nullptr && wide_gemm_terms() != 0 && (p.a.K % 8 == 0) && (((uintptr_t)p.wsplit & 15) == 0);
 }
 constexpr int W2_AS = 4, W2_WS = 4;
-// 0: register-staged wgemm_kernel, 1: LDS-DMA wgemm2_kernel (same results bitwise).  RL_WGEMM_STAGING / rl_set_wgemm_staging.
+// 0: register-staged wgemm_kernel, 1 (default): LDS-DMA wgemm2_kernel - the same Y bitwise.  RL_WGEMM_STAGING / rl_set_wgemm_staging.
 int g_wgemm_staging = -1;
 inline int wgemm_staging() {
     if (g_wgemm_staging < 0) {
         const char* e = getenv("RL_WGEMM_STAGING");
-        g_wgemm_staging = (e && !strcmp(e, "dma")) ? 1 : 0;
+        g_wgemm_staging = (e && !strcmp(e, "registers")) ? 0 : 1;
     }
     return g_wgemm_staging;
 }
-void launch_wgemm(dim3 logical, hipStream_t st, GemmParams p) {
+// returns the kernel function it dispatched to
+const char* launch_wgemm(dim3 logical, hipStream_t st, GemmParams p, bool splitk = false) {
     p.gx = (int)logical.x; p.ny = (int)logical.y;
     const dim3 grid(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : logical.x, 1, logical.z);
     const bool stats = p.stats != nullptr && p.ksplit <= 1;
@@ -1936,7 +1937,7 @@ void launch_wgemm(dim3 logical, hipStream_t st, GemmParams p) {
             if (stats) hipLaunchKernelGGL((wgemm2_kernel<3, true, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
             else       hipLaunchKernelGGL((wgemm2_kernel<3, false, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
         }
-        return;
+        return splitk ? "wgemm2_kernel+splitk" : "wgemm2_kernel";
     }
     if (wide_gemm_terms() == 1) {
         if (stats) hipLaunchKernelGGL((wgemm_kernel<1, true>), grid, dim3(512), 0, st, p);
@@ -1945,6 +1946,7 @@ void launch_wgemm(dim3 logical, hipStream_t st, GemmParams p) {
         if (stats) hipLaunchKernelGGL((wgemm_kernel<3, true>), grid, dim3(512), 0, st, p);
         else       hipLaunchKernelGGL((wgemm_kernel<3, false>), grid, dim3(512), 0, st, p);
     }
+    return splitk ? "wgemm_kernel+splitk" : "wgemm_kernel";
 }
 
 inline bool pgemm_ok(const GemmParams& p) {
@@ -2579,9 +2581,11 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         if (d->N <= 16)      launch_pgemm<1>(dim3(gx, 1), st, p);
         else if (d->N <= 32) launch_pgemm<2>(dim3(gx, 1), st, p);
         else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
-        else if (wgemm_ok(p)) launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
+        const char* wide = nullptr;
+        if (d->N <= 64) {}
+        else if (wgemm_ok(p)) wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
         else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
-        rl_note_kernel(d->N > 64 && wgemm_ok(p) ? "wgemm_kernel" : "pgemm_kernel<8>");
+        rl_note_kernel(wide ? wide : d->N <= 64 ? "pgemm_kernel" : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(split-scatter)");
         return RL_OK;
     }
@@ -2605,9 +2609,10 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
             p.kchunk = ((d->K + ks - 1) / ks + 31) / 32 * 32;
             p.ksplit = (d->K + p.kchunk - 1) / p.kchunk;
             p.kslab = d->kslab;
-            if (wgemm_ok(p)) launch_wgemm(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p);
+            const char* wide = nullptr;
+            if (wgemm_ok(p)) wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p, true);
             else launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p);
-            rl_note_kernel(wgemm_ok(p) ? "wgemm_kernel+splitk" : "pgemm_kernel<8>+splitk");
+            rl_note_kernel(wide ? wide : "pgemm_kernel<8>+splitk");
             RL_LAUNCH_CHECK("rl_gemm(split-K)");
             if ((long)gx * rl_cdiv(d->N, 64) >= 256)
                 hipLaunchKernelGGL(gemm_splitk_reduce_kernel<64>, dim3(gx, rl_cdiv(d->N, 64)), dim3(256), 0, st, p);
@@ -2621,9 +2626,11 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         if (d->N <= 16)      launch_pgemm<1>(dim3(gx, 1), st, p);
         else if (d->N <= 32) launch_pgemm<2>(dim3(gx, 1), st, p);
         else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
-        else if (wgemm_ok(p)) launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
+        const char* wide = nullptr;
+        if (d->N <= 64) {}
+        else if (wgemm_ok(p)) wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
         else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
-        rl_note_kernel(d->N <= 16 ? "pgemm_kernel<1>" : d->N <= 32 ? "pgemm_kernel<2>" : d->N <= 64 ? "pgemm_kernel<4>" : wgemm_ok(p) ? "wgemm_kernel" : "pgemm_kernel<8>");
+        rl_note_kernel(d->N <= 16 ? "pgemm_kernel<1>" : d->N <= 32 ? "pgemm_kernel<2>" : d->N <= 64 ? "pgemm_kernel<4>" : wide ? wide : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(pipelined)");
         return RL_OK;
     }

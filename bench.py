@@ -57,7 +57,7 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6  # same guide: ~2.5 PF dense = 16x the fp32 matri
 # (logits within 2.5e-6 of the oracle on configs A/S/Kt, tests/test_configs_gpu.py); "fp32": v_mfma_f32_16x16x4_f32;
 # "bf16": heads only (throughput mode, 1e-3 logits parity NOT met)
 WIDE_GEMM = os.environ.get("RL_WIDE_GEMM", "bf16x3")   # main() checks it against what the library reports
-WIDE_KERNELS = ("wgemm_kernel", "pgemm_kernel", "pwgrad128")
+WIDE_KERNELS = ("wgemm_kernel", "wgemm2_kernel", "pgemm_kernel", "pwgrad128")
 
 
 def synthetic_batch(B, N, C, seed):
@@ -147,7 +147,7 @@ def fused_min_bytes_per_cloud(N, K, layers, C, e, dec=4):
     return tot + 4 * C * N
 
 
-MFMA_KERNELS = ("wgemm_kernel", "pgemm_kernel", "pwgrad", "wgrad_kernel", "sgemm_kernel", "swgrad_kernel", "gemm_kernel",
+MFMA_KERNELS = ("wgemm_kernel", "wgemm2_kernel", "pgemm_kernel", "pwgrad", "wgrad_kernel", "sgemm_kernel", "swgrad_kernel", "gemm_kernel",
                 "pool_fwd_kernel", "pool_bwd_kernel", "pool128_bwd_kernel", "rpe_wgrad_kernel", "rpe_stats_kernel")
 
 

@@ -201,9 +201,13 @@ int64_t rl_gemm_kslab_floats(int64_t M, int N, int K);
  * narrow (streaming) kernels are fp32 in every mode.  Not thread-safe against concurrent launches.           */
 int rl_set_wide_gemm(const char* mode);
 const char* rl_get_wide_gemm(void);
-/* How the wide forward / input-gradient GEMM of the bf16 modes stages its operands: "registers" (global loads, converted
- * on their way into LDS, one chunk ahead) or "dma" (LDS-DMA, the fp32 tile five chunks deep, converted on the fragment).
- * Same products in the same order: bitwise the same results.  RL_WGEMM_STAGING sets the initial choice.        */
+/* How the wide forward / input-gradient GEMM of the bf16 modes stages its operands:
+ *   "dma" (default)  wgemm2_kernel: one persistent 12-wavefront workgroup per CU; four loader wavefronts bring the raw fp32
+ *                    rows and the pre-split weight planes into LDS rings by LDS-DMA (global_load_lds_dwordx4), four chunks
+ *                    deep and across the workgroup's tiles; eight compute wavefronts convert on the fragment
+ *   "registers"      wgemm_kernel: global loads converted on their way into LDS, one chunk ahead, two workgroups per CU
+ * Same products in the same order: Y is bitwise the same (the BatchNorm partial sums are grouped differently).
+ * K % 32 != 0 or K > 1024 always takes "registers".  RL_WGEMM_STAGING sets the initial choice.                        */
 int rl_set_wgemm_staging(const char* how);
 int rl_gemm(const rl_gemm_desc* d, void* stream);
 
