@@ -436,9 +436,13 @@ __device__ __forceinline__ float4 rpe_frag(const RpeIn& r, int lj) {
 // MFMAs (lane (li, lj) supplies input lj of neighbour li and weight lj of column li) instead of four over the ten channels
 template <int DT, int TERMS>
 __device__ __forceinline__ void rpe_gemm(const RpeIn& r, const VWeights<DT, TERMS>& w, int li, int lj, f32x4 (&acc)[VT<DT>::DTH]) {
-    const float dx = r.a.x - r.c.x, dy = r.a.y - r.c.y, dz = r.a.z - r.c.z, dist = __fsqrt_rn(r.dd);
+    float dx = r.a.x - r.c.x, dy = r.a.y - r.c.y, dz = r.a.z - r.c.z, dist = __fsqrt_rn(r.dd);
+    float px = r.a.x, py = r.a.y, pz = r.a.z;
+    // every lane computes all candidates and SELECTS (v_cndmask on lane-constant masks).  Without the pin hipcc sinks the
+    // square root and the differences into exec-masked branches per lj - ~35 instructions and 8 branches for two selects.
+    asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz), "+v"(dist), "+v"(px), "+v"(py), "+v"(pz));
     const float a1 = lj == 0 ? dx : lj == 1 ? dy : lj == 2 ? dz : dist;        // [x_i - x_j, dist] of neighbour li, input lj
-    const float a2 = lj == 0 ? r.a.x : lj == 1 ? r.a.y : lj == 2 ? r.a.z : 0.f;  // x_i (the same for every neighbour)
+    const float a2 = lj == 0 ? px : lj == 1 ? py : lj == 2 ? pz : 0.f;         // x_i (the same for every neighbour)
 #pragma unroll
     for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
         const float* wr = w.w1f + (nb * 16 + li) * VT<DT>::S1;

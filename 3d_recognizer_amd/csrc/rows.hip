@@ -44,11 +44,11 @@ __device__ __forceinline__ long src_row(const RowsParams& p, I r) {
 // accumulating) the old destinations - four independent chains in flight per lane instead of one index -> row -> store
 // chain at a time; the lazy scale / shift come as two 16-byte loads (they were eight scalar ones) and the activation is
 // max(z, z*e) (e = 1 none, 0 ReLU, slope LeakyReLU) instead of a switch per element.
-template <int VEC, typename I>
-__global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
-    const int cpr = p.C / VEC;  // chunks per row
+template <typename I>
+__device__ __forceinline__ void copy_rows_quads(const RowsParams& p) {
+    const int cpr = p.C / 4;    // chunks per row
     const long total = p.rows * cpr;
-    if constexpr (VEC == 4) {
+    {
         typedef float v4f __attribute__((ext_vector_type(4)));
         const bool lazy = p.lazy.scale != nullptr;
         const float es = (!lazy || p.lazy.act == RL_ACT_NONE) ? 1.f : (p.lazy.act == RL_ACT_RELU ? 0.f : p.lazy.slope);
@@ -89,6 +89,15 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
                 if (ok[u]) *reinterpret_cast<v4f*>(p.dst + dofs[u]) = v[u];
             }
         }
+    }
+}
+
+template <int VEC, typename I>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
+    const int cpr = p.C / VEC;  // chunks per row
+    const long total = p.rows * cpr;
+    if constexpr (VEC == 4) {
+        copy_rows_quads<I>(p);
     } else {
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
             const I r = (I)e / (I)cpr;
@@ -100,6 +109,16 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const RowsParams p) {
             p.dst[dofs] = v;
         }
     }
+}
+
+// Two independent row copies in ONE launch (the two halves of a concat: blockIdx.y picks the copy) - a dependent launch
+// costs ~4.6 us in a replayed graph whatever it does, and neither half fills the chip for long.
+struct RowsPair {
+    RowsParams p[2];
+};
+__global__ __launch_bounds__(256) void copy_rows_pair_kernel(const RowsPair q) {
+    const RowsParams& p = q.p[blockIdx.y];
+    copy_rows_quads<uint32_t>(p);
 }
 
 // dst[(b*dst_bstride + index[r])*ldd + c] += src[r*lds + c]
@@ -436,6 +455,31 @@ extern "C" int rl_copy_rows(const rl_rows_desc* d, void* stream) {
     else              hipLaunchKernelGGL((copy_rows_kernel<1, int64_t>), dim3(grid_for(p.rows * p.C)), dim3(256), 0, st, p);
     rl_note_kernel("copy_rows_kernel");
     RL_LAUNCH_CHECK("rl_copy_rows");
+    return RL_OK;
+}
+
+extern "C" int rl_copy_rows_pair(const rl_rows_desc* d0, const rl_rows_desc* d1, void* stream) {
+    RowsPair q;
+    int rc = fill(&q.p[0], d0, "rl_copy_rows_pair");
+    if (rc) return rc;
+    rc = fill(&q.p[1], d1, "rl_copy_rows_pair");
+    if (rc) return rc;
+    bool ok = true;
+    long quads = 0;
+    for (const RowsParams& p : q.p) {
+        ok = ok && p.rows > 0 && (p.C % 4 == 0) && (p.lds % 4 == 0) && (p.ldd % 4 == 0) && (((uintptr_t)p.src & 15) == 0) &&
+             (((uintptr_t)p.dst & 15) == 0) && (!p.lazy.scale || ((((uintptr_t)p.lazy.scale) | ((uintptr_t)p.lazy.shift)) & 15) == 0) &&
+             fits32(p.rows * p.C) && fits32(p.rows_per_batch);
+        const long q4 = (p.rows * (p.C / 4) + 3) / 4;
+        quads = q4 > quads ? q4 : quads;
+    }
+    if (!ok) {      // shapes the 16-byte path does not take: two ordinary launches
+        rc = rl_copy_rows(d0, stream);
+        return rc ? rc : rl_copy_rows(d1, stream);
+    }
+    hipLaunchKernelGGL(copy_rows_pair_kernel, dim3(grid_for(quads), 2), dim3(256), 0, (hipStream_t)stream, q);
+    rl_note_kernel("copy_rows_pair_kernel");
+    RL_LAUNCH_CHECK("rl_copy_rows_pair");
     return RL_OK;
 }
 

@@ -147,8 +147,8 @@ class Engine:
             ctx.tape.append(("pool_fused", name, u, g, csr, idx, pooled, n, d, stage))
             return self._mlp(ctx, pooled, f"{name}.mlp", n_out, H.ACT_RELU)
         X = torch.empty((rows, d), dtype=torch.float32, device=u.raw.device)
-        ops.copy_rows(u.raw, (0, h), n * K, X, (0, h), rows, n * K, lazy=u)
-        ops.copy_rows(g.raw, (0, h), g.bstride, X, (h, h), rows, n * K, index=idx, lazy=g)
+        ops.copy_rows_pair(((u.raw, (0, h), n * K, X, (0, h), rows, n * K), dict(lazy=u)),
+                           ((g.raw, (0, h), g.bstride, X, (h, h), rows, n * K), dict(index=idx, lazy=g)))
         S = ops.gemm(ops.plain(X, B, n * K), Ws, 1, d, d, None, wsplit=getattr(ctx, "wsplit", None))
         Pt = ops.attpool_fwd(X, S, B * n, K)
         pooled = ops.plain(Pt, B, n)
@@ -308,8 +308,8 @@ class Engine:
             skip = skips.pop()
             assert skip.n == n_f and x.n == n_c
             cat = torch.empty((B * n_f, x.C + skip.C), dtype=torch.float32, device=dev)
-            ops.copy_rows(x.raw, (0, x.C), x.bstride, cat, (0, x.C), B * n_f, n_f, index=nn, lazy=x)
-            ops.copy_rows(skip.raw, (0, skip.C), skip.bstride, cat, (x.C, skip.C), B * n_f, n_f)
+            ops.copy_rows_pair(((x.raw, (0, x.C), x.bstride, cat, (0, x.C), B * n_f, n_f), dict(index=nn, lazy=x)),
+                               ((skip.raw, (0, skip.C), skip.bstride, cat, (x.C, skip.C), B * n_f, n_f), {}))
             catl = ops.plain(cat, B, n_f)
             ctx.tape.append(("interp_concat", x, skip, csrs[L + j], catl))
             n_out = 8 if j == L - 1 else 2 * self.layers[L - 2 - j]

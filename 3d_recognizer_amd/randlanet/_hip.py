@@ -203,6 +203,7 @@ _SIGNATURES = {
     "rl_resid_bn_bwd_reduce": (_i, [C.POINTER(ResidBnBwdDesc), _vp]),
     "rl_resid_bn_bwd_apply": (_i, [C.POINTER(ResidBnBwdDesc), _vp]),
     "rl_copy_rows": (_i, [C.POINTER(RowsDesc), _vp]),
+    "rl_copy_rows_pair": (_i, [C.POINTER(RowsDesc), C.POINTER(RowsDesc), _vp]),
     "rl_scatter_add_rows": (_i, [C.POINTER(RowsDesc), _vp]),
     "rl_csr_workspace_bytes": (_l, [C.POINTER(CsrTask), _i, _i]),
     "rl_csr_build": (_i, [C.POINTER(CsrTask), _i, _i, _vp, _l, _vp]),

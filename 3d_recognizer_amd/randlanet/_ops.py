@@ -612,10 +612,9 @@ def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, 
 
 
 # ------------------------------------------------------------------------------------ rows
-def copy_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, dst: torch.Tensor,
-              dst_cols: Tuple[int, int], rows: int, rows_per_batch: int, *, index=None,
-              index_shared: bool = False, accumulate: bool = False, lazy: Optional[Lazy] = None) -> None:
-    """dst[r, dst_cols] (=|+=) f(src[b*src_bstride + idx, src_cols]); column ranges are (start, count)."""
+def _rows_desc(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, dst: torch.Tensor,
+               dst_cols: Tuple[int, int], rows: int, rows_per_batch: int, *, index=None,
+               index_shared: bool = False, accumulate: bool = False, lazy: Optional[Lazy] = None):
     _dev_check(src, dst, index)
     d = H.RowsDesc()
     es = src.element_size()
@@ -637,8 +636,32 @@ def copy_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, ds
     if lazy is not None and lazy.scale is not None:
         assert c0s == 0 and cn == lazy.C
         d.scale, d.shift, d.act, d.slope = lazy.scale.data_ptr(), lazy.shift.data_ptr(), lazy.act, lazy.slope
-    with _rec("copy_rows", (rows, cn, index is not None), (8 + 4 * int(accumulate)) * rows * cn, 0):
+    return d, (8 + 4 * int(accumulate)) * rows * cn
+
+
+def copy_rows(src: torch.Tensor, src_cols: Tuple[int, int], src_bstride: int, dst: torch.Tensor,
+              dst_cols: Tuple[int, int], rows: int, rows_per_batch: int, *, index=None,
+              index_shared: bool = False, accumulate: bool = False, lazy: Optional[Lazy] = None) -> None:
+    """dst[r, dst_cols] (=|+=) f(src[b*src_bstride + idx, src_cols]); column ranges are (start, count)."""
+    d, nbytes = _rows_desc(src, src_cols, src_bstride, dst, dst_cols, rows, rows_per_batch, index=index,
+                           index_shared=index_shared, accumulate=accumulate, lazy=lazy)
+    with _rec("copy_rows", (rows, src_cols[1], index is not None), nbytes, 0):
         H.check(H.lib().rl_copy_rows(C.byref(d), _st()), "rl_copy_rows")
+
+
+NO_COPY_PAIR = bool(int(__import__("os").environ.get("RL_NO_COPY_PAIR", "0")))      # diagnostics: one launch per copy
+
+
+def copy_rows_pair(a: tuple, b: tuple) -> None:
+    """Two independent copy_rows in one launch: a, b = (args, kwargs) of copy_rows (the two halves of a concat)."""
+    if NO_COPY_PAIR:
+        copy_rows(*a[0], **a[1])
+        copy_rows(*b[0], **b[1])
+        return
+    d0, n0 = _rows_desc(*a[0], **a[1])
+    d1, n1 = _rows_desc(*b[0], **b[1])
+    with _rec("copy_rows_pair", (a[0][5], a[0][1][1], b[0][1][1]), n0 + n1, 0):
+        H.check(H.lib().rl_copy_rows_pair(C.byref(d0), C.byref(d1), _st()), "rl_copy_rows_pair")
 
 
 def scatter_add_rows(src: torch.Tensor, src_cols: Tuple[int, int], dst: torch.Tensor, dst_bstride: int,

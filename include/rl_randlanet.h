@@ -369,6 +369,8 @@ typedef struct rl_rows_desc {
 } rl_rows_desc;
 
 int rl_copy_rows(const rl_rows_desc* d, void* stream);
+/* Two independent copies (e.g. the two halves of a concat, modules.py:183 / 362) in one launch; same results as two calls. */
+int rl_copy_rows_pair(const rl_rows_desc* d0, const rl_rows_desc* d1, void* stream);
 
 /* Transposed movement (gather backward): dst[(b*src_bstride + index[r])*ldd + c] += src[r*lds + c]
  * (src_bstride names the batch stride of the INDEXED tensor, here dst) with fp32 atomics.  NON-DETERMINISTIC (the order of

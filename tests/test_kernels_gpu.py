@@ -457,6 +457,26 @@ def test_residual_junction_bn_backward(ops, C, rows):
                                       ops.Lazy(Y[1].detach()[:, :6].contiguous(), 1, rows, rows, 6, scale[:6], scale[:6], 0, 0.0, mean[:6], invstd[:6]))
 
 
+def test_copy_rows_pair_equals_two_copies(ops):
+    """rl_copy_rows_pair: the two halves of a concat in one launch (decoder concat modules.py:362, level-3 X = [rpe | gathered]
+    modules.py:183) - bitwise what two rl_copy_rows calls leave, also on a shape the 16-byte path does not take."""
+    torch.manual_seed(6)
+    B, n_src, n, K = 2, 300, 170, 16
+    for Ca, Cb in ((8, 24), (128, 128), (6, 8)):          # (6, 8): 6 % 4 != 0 -> the entry falls back to two launches
+        U = torch.randn(B * n * K, Ca, device=DEV)
+        src = torch.randn(B * n_src, Cb, device=DEV)
+        idx = torch.randint(0, n_src, (B, n, K), device=DEV, dtype=torch.int32)
+        lz = ops.Lazy(src, B, n, n_src, Cb, torch.rand(Cb, device=DEV) + 0.5, torch.randn(Cb, device=DEV), 1, 0.0)
+        rows = B * n * K
+        X1 = torch.zeros(rows, Ca + Cb, device=DEV)
+        X2 = torch.zeros(rows, Ca + Cb, device=DEV)
+        ops.copy_rows(U, (0, Ca), n * K, X1, (0, Ca), rows, n * K)
+        ops.copy_rows(src, (0, Cb), n_src, X1, (Ca, Cb), rows, n * K, index=idx, lazy=lz)
+        ops.copy_rows_pair(((U, (0, Ca), n * K, X2, (0, Ca), rows, n * K), {}),
+                           ((src, (0, Cb), n_src, X2, (Ca, Cb), rows, n * K), dict(index=idx, lazy=lz)))
+        assert torch.equal(X1, X2), (Ca, Cb)
+
+
 def test_copy_rows_gather_concat_scatter(ops):
     torch.manual_seed(5)
     B, n_src, n, K, Cc = 2, 500, 200, 16, 8
