@@ -847,6 +847,60 @@ def test_wide_gemm_with_presplit_weights(ops, M, K, N, orient):
     assert torch.equal(o0, o1) and torch.equal(d0, d1)
 
 
+@pytest.mark.parametrize("M,K,N", [(4099, 128, 192), (2560, 1024, 256), (130, 32, 128), (20480, 256, 256)])
+def test_wide_gemm_stagings_agree_bitwise(ops, M, K, N):
+    """The two operand stagings of the wide GEMM (rl_set_wgemm_staging: "dma" = wgemm2_kernel, persistent workgroups fed by
+    LDS-DMA loader wavefronts, the default; "registers" = wgemm_kernel) run the same products in the same order per
+    accumulator: Y is bitwise the same with every epilogue option, rows / columns that do not fill a tile, split-K, a tile
+    that straddles split_col; the partial statistics agree after summation (other tiles per slot)."""
+    if ops.get_wide_gemm() == "fp32":
+        pytest.skip("the pre-split path exists in the bf16 arithmetic modes")
+    from randlanet import _hip as H
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K, device=DEV)
+    a = ops.plain(A, 1, M)
+    a.scale, a.shift, a.act, a.slope = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.3, 1, 0.0
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    ws = ops.split_weights([(W, 1, K, K, N)])
+    bias, addend, old = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV), torch.randn(M, N, device=DEV)
+    nsl = H.row_blocks(M, 128)
+    h = N // 2 if N % 256 == 0 else 96              # 96: the first 128-column tile straddles the split
+
+    def run():
+        res = []
+        st = ops.new_stats(DEV, N)
+        res.append(ops.gemm(a, W, 1, K, N, bias, stats=st, wsplit=ws))
+        res.append(st[:nsl].sum(0))
+        acc = old.clone()
+        ops.gemm(a, W, 1, K, N, None, out=acc, out_bstride=M, accumulate=True, wsplit=ws)
+        res.append(acc)
+        o, d = torch.zeros(M, h, device=DEV), torch.zeros(M, N - h, device=DEV)
+        ops.gemm(a, W, 1, K, N, None, out=o, out_bstride=M, addend=addend, out2=d, split_col=h, wsplit=ws)
+        res += [o, d]
+        if M % 4 == 0:                               # Y with a batch stride
+            ab = ops.plain(A, 4, M // 4)
+            ab.scale, ab.shift, ab.act, ab.slope = a.scale, a.shift, a.act, a.slope
+            Yb = torch.zeros(4 * (M // 4 + 5), N, device=DEV)
+            ops.gemm(ab, W, 1, K, N, bias, out=Yb, out_bstride=M // 4 + 5, wsplit=ws)
+            res.append(Yb)
+        torch.cuda.synchronize()
+        return res
+    try:
+        ops.set_wgemm_staging("registers")
+        r0 = run()
+        ops.set_wgemm_staging("dma")
+        r1 = run()
+    finally:
+        ops.set_wgemm_staging("dma")
+    ref = torch.relu(A * a.scale + a.shift).double() @ W.double().t() + bias.double()
+    assert float((r1[0].double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    for i, (x, y) in enumerate(zip(r0, r1)):
+        if x.dtype == torch.float64:
+            assert torch.allclose(x, y, rtol=1e-12, atol=0.0), i
+        else:
+            assert torch.equal(x, y), i
+
+
 def test_float_atomic_entry_points_need_an_opt_in(ops, monkeypatch):
     """rl_scatter_add_rows / rl_gemm(out2_index) add with fp32 atomics: not part of the schedule, refused by default."""
     monkeypatch.delenv("RL_ALLOW_FLOAT_ATOMICS", raising=False)
