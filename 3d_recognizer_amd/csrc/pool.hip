@@ -23,6 +23,16 @@
 
 namespace {
 
+// The (points * 16)-row tensors the pooling backward writes (GU, DG, X_out, dS_out) are read once, by a later kernel:
+// non-temporal stores (pool_bwd<1> accumulate 248 -> 225 us, pool_bwd<4> 228 -> 220; -DRL_POOL_PLAIN_STORES for the A/B).
+#ifdef RL_POOL_PLAIN_STORES
+#define RL_ST1 rl_stx
+#define RL_ST4 rl_stx4
+#else
+#define RL_ST1 rl_stx_nt
+#define RL_ST4 rl_stx4_nt
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -1009,8 +1019,8 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 if constexpr (DT <= 2) Ds[rowi * XS + col] = v;
                 else {                      // d = 64: measured better with the element stores (11 us per step)
                     const long urow = (pt * 16 + rowi) * H;
-                    if (col < H) rl_stx<GUB>(p.GU, urow + col, v);
-                    else rl_stx<GB>(p.DG, urow + (col - H), v);
+                    if (col < H) RL_ST1<GUB>(p.GU, urow + col, v);
+                    else RL_ST1<GB>(p.DG, urow + (col - H), v);
                 }
             }
         }
@@ -1021,8 +1031,8 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
             for (int c = 0; c < DT; ++c) {
                 const int k = 16 * c + 4 * lj;
                 const float4 v = *reinterpret_cast<const float4*>(Ds + li * XS + k);
-                if (k < H) rl_stx4<GUB>(p.GU, orow + k, v);
-                else rl_stx4<GB>(p.DG, orow + (k - H), v);
+                if (k < H) RL_ST4<GUB>(p.GU, orow + k, v);
+                else RL_ST4<GB>(p.DG, orow + (k - H), v);
             }
         }
 #pragma unroll
@@ -1161,7 +1171,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         // X leaves the kernel for the weight-gradient GEMM: row li, 16 bytes per 16-column chunk
 #pragma unroll
-        for (int c = 0; c < DT; ++c) rl_stx4<GB>(p.X_out, (pt * 16 + li) * D + 16 * c + 4 * lj, xa[c]);
+        for (int c = 0; c < DT; ++c) RL_ST4<GB>(p.X_out, (pt * 16 + li) * D + 16 * c + 4 * lj, xa[c]);
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1188,7 +1198,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
             const float4 da = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
-            rl_stx4<GB>(p.dS_out, (pt * 16 + li) * D + 16 * c + 4 * lj, da);
+            RL_ST4<GB>(p.dS_out, (pt * 16 + li) * D + 16 * c + 4 * lj, da);
             bf16x4 ah, al;
             split4(da, ah, al);
             // B fragment of column block nb: W[o = 16c + 4lj + j][nb*16 + li], j = 0..3 - four rows of one column.
@@ -1232,7 +1242,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                     if (p.gu_accumulate) p.GU[urow + col] += v;
                     else p.GU[urow + col] = v;
                 } else {
-                    rl_stx<GB>(p.DG, urow + (col - H), v);
+                    RL_ST1<GB>(p.DG, urow + (col - H), v);
                 }
             }
         }

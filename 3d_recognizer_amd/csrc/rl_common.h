@@ -108,6 +108,25 @@ __device__ __forceinline__ void rl_stx4(float* p, long i, const float4 v) {
         *reinterpret_cast<rl_bf16x4*>(reinterpret_cast<__bf16*>(p) + i) = h;
     } else *reinterpret_cast<float4*>(p + i) = v;
 }
+// streaming stores: rows written once and read once by a LATER kernel (GU / DG / X_out / dS_out of the pooling backward) bypass
+// the L2 allocation, which the same kernel needs for the rows it gathers 16 times over
+template <bool BF>
+__device__ __forceinline__ void rl_stx_nt(float* p, long i, float v) {
+    if constexpr (BF) __builtin_nontemporal_store((__bf16)v, reinterpret_cast<__bf16*>(p) + i);
+    else __builtin_nontemporal_store(v, p + i);
+}
+template <bool BF>
+__device__ __forceinline__ void rl_stx4_nt(float* p, long i, const float4 v) {
+    typedef float rl_f32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (BF) {
+        rl_bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        __builtin_nontemporal_store(h, reinterpret_cast<rl_bf16x4*>(reinterpret_cast<__bf16*>(p) + i));
+    } else {
+        const rl_f32x4 w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<rl_f32x4*>(p + i));
+    }
+}
 // the same with the type known at run time only (a wavefront-uniform flag: one scalar branch)
 __device__ __forceinline__ float4 rl_ld4(const float* p, long i, int bf) { return bf ? rl_ldx4<true>(p, i) : rl_ldx4<false>(p, i); }
 __device__ __forceinline__ float rl_ld1(const float* p, long i, int bf) { return bf ? rl_ldx<true>(p, i) : rl_ldx<false>(p, i); }
