@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
                 const int col = nb * 16 + li;
                 if (col < H) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) rl_stx<GB>(q.GU1, (pt * 16 + 4 * lj + r) * H + col, gu[nb][r]);
+                    for (int r = 0; r < 4; ++r) RL_ST1<GB>(q.GU1, (pt * 16 + 4 * lj + r) * H + col, gu[nb][r]);
                 }
             }
         }
