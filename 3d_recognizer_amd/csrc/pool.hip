@@ -24,7 +24,9 @@
 namespace {
 
 // The (points * 16)-row tensors the pooling backward writes (GU, DG, X_out, dS_out) are read once, by a later kernel:
-// non-temporal stores (pool_bwd<1> accumulate 248 -> 225 us, pool_bwd<4> 228 -> 220; -DRL_POOL_PLAIN_STORES for the A/B).
+// non-temporal stores in the d <= 64 kernels (pool_bwd<1> accumulate 248 -> 225 us, pool_bwd<4> 228 -> 220, rpe_wgrad 162 ->
+// 150; -DRL_POOL_PLAIN_STORES for the A/B).  Not in pool128_bwd: 182 -> 195 us inside a step (its X / dS go straight into the
+// grouped weight-gradient launch).
 #ifdef RL_POOL_PLAIN_STORES
 #define RL_ST1 rl_stx
 #define RL_ST4 rl_stx4
@@ -1171,7 +1173,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         // X leaves the kernel for the weight-gradient GEMM: row li, 16 bytes per 16-column chunk
 #pragma unroll
-        for (int c = 0; c < DT; ++c) RL_ST4<GB>(p.X_out, (pt * 16 + li) * D + 16 * c + 4 * lj, xa[c]);
+        for (int c = 0; c < DT; ++c) rl_stx4<GB>(p.X_out, (pt * 16 + li) * D + 16 * c + 4 * lj, xa[c]);
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1198,7 +1200,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
             const float4 da = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
-            RL_ST4<GB>(p.dS_out, (pt * 16 + li) * D + 16 * c + 4 * lj, da);
+            rl_stx4<GB>(p.dS_out, (pt * 16 + li) * D + 16 * c + 4 * lj, da);
             bf16x4 ah, al;
             split4(da, ah, al);
             // B fragment of column block nb: W[o = 16c + 4lj + j][nb*16 + li], j = 0..3 - four rows of one column.
@@ -1242,7 +1244,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                     if (p.gu_accumulate) p.GU[urow + col] += v;
                     else p.GU[urow + col] = v;
                 } else {
-                    RL_ST1<GB>(p.DG, urow + (col - H), v);
+                    rl_stx<GB>(p.DG, urow + (col - H), v);
                 }
             }
         }
