@@ -1919,14 +1919,26 @@ inline int wgemm_staging() {
     }
     return g_wgemm_staging;
 }
+// compute units of the current device (256 on an MI355X; fewer in a partitioned mode), asked once per device
+inline int cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n : 256;
+    }
+    return cached[dev];
+}
+
 // returns the kernel function it dispatched to
 const char* launch_wgemm(dim3 logical, hipStream_t st, GemmParams p, bool splitk = false) {
     p.gx = (int)logical.x; p.ny = (int)logical.y;
     const dim3 grid(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : logical.x, 1, logical.z);
     const bool stats = p.stats != nullptr && p.ksplit <= 1;
     if (wgemm_staging() == 1 && p.a.K % PG_BK == 0 && p.a.K <= W2_KMAX && (((uintptr_t)p.a.A | (uintptr_t)(p.a.lda * 4)) & 15) == 0) {
-        // one persistent workgroup per CU: the row tiles are dealt round-robin to gx = 256 / ny workgroup rows
-        int cap = 256 / (p.ny > 0 ? p.ny : 1) / 8 * 8;
+        // one persistent workgroup per CU: the row tiles are dealt round-robin to gx = CUs / ny workgroup rows
+        int cap = cu_count() / (p.ny > 0 ? p.ny : 1) / 8 * 8;
         if (cap < 8) cap = 8;
         if (p.gx > cap) p.gx = cap;
         const dim3 g2(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : (unsigned)p.gx, 1, logical.z);
