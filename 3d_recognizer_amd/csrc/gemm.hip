@@ -1593,6 +1593,7 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
     const int my_tiles = bx < ntiles ? (int)((ntiles - 1 - bx) / p.gx) + 1 : 0;
     const int T = my_tiles * nch;                                  // chunk steps of this workgroup = barriers every wavefront passes
 
+    if (wave >= 8) __builtin_amdgcn_s_setprio(3);      // the loaders' few instructions go first: 1 - 2 % on the mid-size shapes
     if (wave >= 10) {
         // ---- W loaders: 16 (8 in the bf16 mode) pieces of 1 KB per chunk, two chunks deep ---------------------------------
         constexpr int WI = TERMS == 3 ? 8 : 4;

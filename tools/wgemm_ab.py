@@ -106,7 +106,11 @@ def bench():
             sets.append((a, torch.empty(M, N, device=dev)))
         W = torch.randn(N, K, device=dev) / K ** 0.5
         ws = ops.split_weights([(W, 1, K, K, N)])
-        stats = ops.new_stats(dev, N)
+        stats = None if os.environ.get("WAB_NOSTATS") else ops.new_stats(dev, N)
+        split = bool(os.environ.get("WAB_SPLIT"))
+        if split:
+            addend, out2 = torch.randn(M, N, device=dev), torch.empty(M, N - N // 2, device=dev)
+            sets = [(a, torch.empty(M, N // 2, device=dev)) for a, _ in sets]
         line = []
         for how in ("registers", "dma", "registers", "dma"):
             ops.set_wgemm_staging(how)
