@@ -1498,7 +1498,8 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
 //     the deep A queue does not drain for the shallow W queue), so a counted s_waitcnt says exactly which chunk landed;
 //   * the fp32 A tile goes to LDS RAW, AS chunks deep (no staging registers: the depth is an LDS budget); the lazy
 //     BatchNorm + activation and the bf16 head / tail split happen on the fragment, after the ds_read - every element is
-//     still converted exactly once, by the wavefront that owns its 16 rows; the pre-split weight planes follow 2 deep;
+//     still converted exactly once, by the wavefront that owns its 16 rows; the pre-split weight planes follow in a ring of their own, WS chunks deep
+//     (two put the weight's L2 latency on every step's critical path);
 //   * the chunk stream runs ACROSS the workgroup's tiles: while the compute wavefronts store tile t, the first chunks of
 //     tile t+1 are already in flight;
 //   * one raw s_barrier per chunk.  Loaders: wait (counted vmcnt) -> barrier -> refill the stage chunk q-1 freed.
@@ -1506,7 +1507,8 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
 //   * LDS image of an A chunk: [128 rows][8 pieces of 16 B], piece p of row r stored at p ^ ((r >> 1) & 7) - the DMA writes
 //     lane-linear (1 KB per wavefront instruction = 8 rows), so the swizzle is applied to the SOURCE address and again
 //     on the fragment read: the 64 lanes of a ds_read_b128 fall on 16 distinct 16-byte slots, 4 lanes each.
-// LDS: AS * 16 (A) + 32 (W) + 8 (scale / shift) + 16 (statistics) KB = 136 KB at AS = 5; 3 wavefronts per SIMD (168 VGPRs).
+// LDS: AS * 16 (A) + WS * 16 (W) + 8 (scale / shift) + 16 (statistics) KB = 152 KB at AS = WS = 4; 3 wavefronts per SIMD (124 of
+// 168 VGPRs).
 // Same products in the same order per accumulator as wgemm_kernel: Y is bitwise the same; the BatchNorm partial sums are
 // grouped per wavefront over the workgroup's tiles (another, equally fixed, order of the same doubles).
 // Needs K % 32 == 0 and K <= 1024.
@@ -1595,7 +1597,7 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
 
     if (wave >= 8) __builtin_amdgcn_s_setprio(3);      // the loaders' few instructions go first: 1 - 2 % on the mid-size shapes
     if (wave >= 10) {
-        // ---- W loaders: 16 (8 in the bf16 mode) pieces of 1 KB per chunk, two chunks deep ---------------------------------
+        // ---- W loaders: 16 (8 in the bf16 mode) pieces of 1 KB per chunk, WS - 1 chunks ahead -------------------------------
         constexpr int WI = TERMS == 3 ? 8 : 4;
         const int lw = wave - 10;
         const __bf16* wsrc[WI];
