@@ -89,7 +89,8 @@ def check():
         err = float((outs[1][0][:, :8].double() - ref[:, :8]).abs().max()) if variant in ("plain", "lazy_relu", "dgrad") else 0.0
         if not same or err > 1e-3:
             bad += 1
-        print(f"M={M:6d} K={K:4d} N={N:4d} {variant:11s} {'bitwise equal' if same else 'DIFFERENT'}" + (f"  |err vs fp64| {err:.1e}" if err else ""), flush=True)
+        if not same or err > 1e-3 or not os.environ.get("WAB_REPEAT"):
+            print(f"M={M:6d} K={K:4d} N={N:4d} {variant:11s} {'bitwise equal' if same else 'DIFFERENT'}" + (f"  |err vs fp64| {err:.1e}" if err else ""), flush=True)
     return bad
 
 
@@ -139,9 +140,12 @@ def bench():
 if os.environ.get("WAB_SHAPES"):
     STEP = [tuple(int(v) for v in t.split("x")) + (1,) for t in os.environ["WAB_SHAPES"].split(",")]
 if not os.environ.get("WAB_BENCH_ONLY"):
-    bad = check()
-    print("check:", "ok" if not bad else f"{bad} FAILED")
-    if bad:
-        sys.exit(1)
+    # WAB_REPEAT=n: the race screen - the same 70 cases n times over with fresh random operands (a misplaced wait shows as a
+    # rare wrong tile, not as a steady failure)
+    for rep in range(int(os.environ.get("WAB_REPEAT", "1"))):
+        bad = check()
+        print(f"check (pass {rep}):", "ok" if not bad else f"{bad} FAILED", flush=True)
+        if bad:
+            sys.exit(1)
 if not os.environ.get("WAB_CHECK_ONLY"):
     bench()
