@@ -1871,13 +1871,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
     }
 }
 
-// how many K splits a wide GEMM with few output tiles should use (1 = none).  deep: the LDS-DMA kernel will run it - its
-// rings keep a workgroup fed through a long K loop, so a split (more, smaller workgroups + a reduce launch) pays only from
-// K = 1024 on (tools/wgemm_ab.py, HBM-cold, split vs none: 1280 x 512 x 512 28 -> 20 us, 5120 x 256 x 256 16.4 -> 14.4,
-// 5120 x 1024 x 256 24 -> 34)
-inline int gemm_ksplit(long M, int N, int K, bool deep = false) {
+// how many K splits a wide GEMM with few output tiles should use (1 = none)
+inline int gemm_ksplit(long M, int N, int K) {
     if (N % 4) return 1;
-    if (deep && K < 1024) return 1;
     const long tiles = ((M + GM_BM - 1) / GM_BM) * ((N + 127) / 128);
     if (tiles >= 128 || K < 256) return 1;
     long s = 256 / tiles;
@@ -1938,17 +1934,12 @@ inline int cu_count() {
     return cached[dev];
 }
 
-// the LDS-DMA kernel takes it (else the register-staged one)
-inline bool wgemm2_ok(const GemmParams& p) {
-    return wgemm_staging() == 1 && p.a.K % PG_BK == 0 && p.a.K <= W2_KMAX && (((uintptr_t)p.a.A | (uintptr_t)(p.a.lda * 4)) & 15) == 0;
-}
-
 // returns the kernel function it dispatched to
 const char* launch_wgemm(dim3 logical, hipStream_t st, GemmParams p, bool splitk = false) {
     p.gx = (int)logical.x; p.ny = (int)logical.y;
     const dim3 grid(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : logical.x, 1, logical.z);
     const bool stats = p.stats != nullptr && p.ksplit <= 1;
-    if (wgemm2_ok(p)) {
+    if (wgemm_staging() == 1 && p.a.K % PG_BK == 0 && p.a.K <= W2_KMAX && (((uintptr_t)p.a.A | (uintptr_t)(p.a.lda * 4)) & 15) == 0) {
         // one persistent workgroup per CU: the row tiles are dealt round-robin to gx = CUs / ny workgroup rows
         int cap = cu_count() / (p.ny > 0 ? p.ny : 1) / 8 * 8;
         if (cap < 8) cap = 8;
@@ -2627,7 +2618,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     }
     p.ksplit = 1; p.kchunk = 0; p.kslab = nullptr;
     if (pgemm_ok(p) && d->N > 64 && d->kslab != nullptr) {
-        const int ks = gemm_ksplit(p.a.M, d->N, d->K, wgemm_ok(p) && wgemm2_ok(p));
+        const int ks = gemm_ksplit(p.a.M, d->N, d->K);
         if (ks > 1 && d->kslab_floats >= (int64_t)ks * p.a.M * d->N) {
             p.ksplit = ks;
             p.kchunk = ((d->K + ks - 1) / ks + 31) / 32 * 32;
