@@ -611,14 +611,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
 
 constexpr int SW_U = 4;  // row groups (of 4 rows) in flight per wavefront
 
+// (bx: the workgroup's slab / row block; red: KT * NT * 4 * 64 + NT * 64 floats of LDS)
 template <int KT, int NT>
-__global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
-    __shared__ float red[KT * NT * 4 * 64 + NT * 64];
+__device__ __forceinline__ void swgrad_body(const WgradParams& p, const int bx, float* red) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int lc = lane & 15, lr = lane >> 4;
     const int N = p.N, K = p.a.K;
     const AOperand& a = p.a;
-    const long r_begin = (long)blockIdx.x * p.rows_per_block;
+    const long r_begin = (long)bx * p.rows_per_block;
     const long r_end = min(a.M, r_begin + p.rows_per_block);
 
     float sc[KT], sh[KT];
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
         }
     }
     if (wave == 0) {
-        float* out = p.slab + (long)blockIdx.x * ((long)N * K + N);
+        float* out = p.slab + (long)bx * ((long)N * K + N);
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) {
 #pragma unroll
@@ -779,6 +779,12 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
             if (p.has_bias && lr == 0 && n < N) out[(long)N * K + n] = bsum[nb];
         }
     }
+}
+
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
+    __shared__ float red[KT * NT * 4 * 64 + NT * 64];
+    swgrad_body<KT, NT>(p, (int)blockIdx.x, red);
 }
 
 // slab split for the streaming wgrad: one slab per workgroup
@@ -2528,6 +2534,36 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_batch_kernel(const WgradBat
     pwgrad128w_body<TERMS, false>(p, bx, by, bz);
 }
 
+// The narrow (streaming) weight gradients of a backward pass in one launch as well: sixteen launches of 5 - 46 us, most
+// of them one or two workgroups per CU, become one.  gy = 4 * log2(KT) + log2(NT) names the layer's (KT, NT) body; a
+// workgroup runs exactly the arithmetic of its swgrad_kernel<KT, NT> launch: bitwise the same slabs.
+__global__ __launch_bounds__(256) void swgrad_batch_kernel(const WgradBatch b) {
+    __shared__ float red[4 * 4 * 4 * 64 + 8 * 64];      // the largest body's (KT * NT <= 16, NT <= 8)
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.item[i + 1].first_block) ++i;
+    const WBItem& it = b.item[i];
+    WgradParams p;
+    p.a.A = it.A; p.a.lda = it.lda; p.a.a_bstride = it.a_bstride; p.a.a_mode = 0;
+    p.a.lazy.scale = it.sc; p.a.lazy.shift = it.sh; p.a.lazy.act = it.act; p.a.lazy.slope = it.slope;
+    p.a.xyz = nullptr; p.a.xyz_bstride = 0; p.a.nbr_idx = nullptr; p.a.nbr_d2 = nullptr; p.a.nbr_k = 0;
+    p.a.n = it.n; p.a.K = it.K; p.a.M = it.M; p.a.contig = it.a_contig; p.a.vec4 = 0; p.a.vec4p = 0;
+    p.N = it.N; p.dY = it.dY; p.lddy = it.lddy; p.dy_bstride = it.dy_bstride; p.rows_per_batch = it.rows_per_batch;
+    p.dy_contig = it.dy_contig; p.slab = it.slab; p.rows_per_block = it.rows_per_block; p.has_bias = it.has_bias;
+    const int bx = (int)blockIdx.x - it.first_block;
+    switch (it.gy) {
+        case 0: swgrad_body<1, 1>(p, bx, red); break;
+        case 1: swgrad_body<1, 2>(p, bx, red); break;
+        case 2: swgrad_body<1, 4>(p, bx, red); break;
+        case 3: swgrad_body<1, 8>(p, bx, red); break;
+        case 4: swgrad_body<2, 1>(p, bx, red); break;
+        case 5: swgrad_body<2, 2>(p, bx, red); break;
+        case 6: swgrad_body<2, 4>(p, bx, red); break;
+        case 8: swgrad_body<4, 1>(p, bx, red); break;
+        case 9: swgrad_body<4, 2>(p, bx, red); break;
+        default: swgrad_body<4, 4>(p, bx, red); break;
+    }
+}
+
 inline bool pwgrad_ok(const WgradParams& p) {
     if (p.a.a_mode != 0 || !p.a.vec4) return false;
     if ((p.N % 4) || (p.lddy % 4) || (((uintptr_t)p.dY) & 15)) return false;
@@ -2720,7 +2756,12 @@ static int wgrad_fill(const rl_wgrad_desc* d, WgradParams* pp, int* nsplit_out, 
 }
 
 // can this layer join a grouped launch (rl_wgrad_batch)?  The wide 128 x 128-tile kernel in a bf16 arithmetic mode, fp32 rows
+static bool swgrad_batchable(const rl_wgrad_desc* d, bool streaming) {
+    static const bool off = getenv("RL_NO_SWGRAD_BATCH") != nullptr;       // diagnostics: one launch per narrow layer
+    return streaming && !off && d->a_mode == 0 && !d->rows_bf16;
+}
 static bool wgrad_batchable(const rl_wgrad_desc* d, const WgradParams& p, bool streaming) {
+    if (swgrad_batchable(d, streaming)) return true;
     return !streaming && !d->rows_bf16 && pwgrad_ok(p) && wgrad_tile(d->N, d->K) == 128 && wide_gemm_terms() != 0 &&
            getenv("RL_WGRAD_4WAVE") == nullptr && rl_cdiv(d->N, 128) < 65536 && rl_cdiv(d->K, 128) < 65536;
 }
@@ -2729,44 +2770,65 @@ extern "C" int rl_wgrad_batchable(const rl_wgrad_desc* d) {
     WgradParams p;
     int nsplit; bool streaming;
     if (wgrad_fill(d, &p, &nsplit, &streaming) != RL_OK) return 0;
-    return wgrad_batchable(d, p, streaming) ? 1 : 0;
+    return wgrad_batchable(d, p, streaming) ? (streaming ? 2 : 1) : 0;      // 1: the wide tile kernel, 2: the streaming kernel
 }
 
 extern "C" int rl_wgrad_batch(const rl_wgrad_desc* descs, int count, void* stream) {
     RL_REQUIRE(descs != nullptr && count >= 0, RL_ERR_ARGS, "rl_wgrad_batch: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int terms = wide_gemm_terms();
-    for (int base = 0; base < count; base += WB_MAX) {
+    // the queue holds wide layers (128 x 128-tile kernel) and narrow ones (streaming kernel): one grouped launch per kind
+    // and per WB_MAX layers
+    bool any[2] = {false, false};
+    for (int kind = 0; kind < 2; ++kind) {
         WgradBatch b;
-        b.count = count - base < WB_MAX ? count - base : WB_MAX;
-        b.pad = 0;
+        b.count = 0; b.pad = 0;
         long blocks = 0;
-        for (int i = 0; i < b.count; ++i) {
-            const rl_wgrad_desc* d = descs + base + i;
+        auto flush = [&]() -> int {
+            if (b.count == 0 || blocks == 0) { b.count = 0; blocks = 0; return RL_OK; }
+            if (kind == 1)       hipLaunchKernelGGL(swgrad_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+            else if (terms == 1) hipLaunchKernelGGL(pwgrad128w_batch_kernel<1>, dim3((unsigned)blocks), dim3(512), 0, st, b);
+            else                 hipLaunchKernelGGL(pwgrad128w_batch_kernel<3>, dim3((unsigned)blocks), dim3(512), 0, st, b);
+            RL_LAUNCH_CHECK("rl_wgrad_batch");
+            b.count = 0; blocks = 0;
+            return RL_OK;
+        };
+        for (int i = 0; i < count; ++i) {
+            const rl_wgrad_desc* d = descs + i;
             WgradParams p;
             int nsplit; bool streaming;
             int rc = wgrad_fill(d, &p, &nsplit, &streaming);
             if (rc) return rc;
             RL_REQUIRE(wgrad_batchable(d, p, streaming), RL_ERR_UNSUPPORTED,
-                       "rl_wgrad_batch: layer %d (N = %d, K = %d) does not run on the wide kernel - check rl_wgrad_batchable first", base + i, d->N, d->K);
+                       "rl_wgrad_batch: layer %d (N = %d, K = %d) cannot join a grouped launch - check rl_wgrad_batchable first", i, d->N, d->K);
             RL_REQUIRE(d->defer_reduce, RL_ERR_ARGS, "rl_wgrad_batch: the layers' slabs are summed by rl_wgrad_reduce_batch (defer_reduce must be set)");
-            WBItem& it = b.item[i];
+            if ((streaming ? 1 : 0) != kind) continue;
+            any[kind] = true;
+            WBItem& it = b.item[b.count];
             it.A = p.a.A; it.dY = p.dY; it.sc = p.a.lazy.scale; it.sh = p.a.lazy.shift; it.slab = p.slab;
             it.lda = p.a.lda; it.a_bstride = p.a.a_bstride; it.lddy = p.lddy; it.dy_bstride = p.dy_bstride;
             it.rows_per_block = p.rows_per_block; it.M = p.a.M;
             it.N = p.N; it.K = p.a.K; it.n = p.a.n; it.rows_per_batch = p.rows_per_batch; it.act = p.a.lazy.act; it.slope = p.a.lazy.slope;
             it.first_block = (int)blocks;
-            it.gy = (unsigned short)rl_cdiv(d->N, 128); it.gz = (unsigned short)rl_cdiv(d->K, 128);
+            if (streaming) {
+                const int kt = d->K <= 16 ? 0 : d->K <= 32 ? 1 : 2, nt = d->N <= 16 ? 0 : d->N <= 32 ? 1 : d->N <= 64 ? 2 : 3;
+                it.gy = (unsigned short)(4 * kt + nt); it.gz = 1;
+                blocks += nsplit;
+            } else {
+                it.gy = (unsigned short)rl_cdiv(d->N, 128); it.gz = (unsigned short)rl_cdiv(d->K, 128);
+                blocks += (long)nsplit * it.gy * it.gz;
+            }
             it.a_contig = (unsigned char)p.a.contig; it.dy_contig = (unsigned char)p.dy_contig; it.has_bias = (unsigned char)p.has_bias; it.pad = 0;
-            blocks += (long)nsplit * it.gy * it.gz;
             RL_REQUIRE(blocks < (1l << 30), RL_ERR_ARGS, "rl_wgrad_batch: too many workgroups");
+            if (++b.count == WB_MAX) {
+                rc = flush();
+                if (rc) return rc;
+            }
         }
-        if (blocks == 0) continue;
-        if (terms == 1) hipLaunchKernelGGL(pwgrad128w_batch_kernel<1>, dim3((unsigned)blocks), dim3(512), 0, st, b);
-        else            hipLaunchKernelGGL(pwgrad128w_batch_kernel<3>, dim3((unsigned)blocks), dim3(512), 0, st, b);
-        RL_LAUNCH_CHECK("rl_wgrad_batch");
+        const int rc = flush();
+        if (rc) return rc;
     }
-    rl_note_kernel("pwgrad128w_batch_kernel");
+    rl_note_kernel(any[1] && !any[0] ? "swgrad_batch_kernel" : "pwgrad128w_batch_kernel");
     return RL_OK;
 }
 

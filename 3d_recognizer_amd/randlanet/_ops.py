@@ -425,9 +425,10 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     d.defer_reduce = 0 if pending is None else 1
     es = 2 if rows_bf16 else 4
     nbytes, flops = es * (M * (K if not isinstance(a, Rpe) else 6) + M * N) + 4 * K * N, 2 * M * K * N
-    if batch is not None and pending is not None and not NO_WGRAD_BATCH and H.lib().rl_wgrad_batchable(C.byref(d)):
+    kind = H.lib().rl_wgrad_batchable(C.byref(d)) if (batch is not None and pending is not None and not NO_WGRAD_BATCH) else 0
+    if kind:
         # (the operands stay referenced by the queue entry until the grouped launch has been issued)
-        batch.append((d, nbytes, flops, a, dY, slab))
+        batch.append((d, nbytes, flops, a, dY, slab, kind))
     else:
         with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), nbytes, flops):
             H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
@@ -439,12 +440,15 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
 
 
 def wgrad_batch_flush(batch: list) -> None:
-    """The queued wide weight gradients as one grouped launch (rl_wgrad_batch); before `wgrad_flush`."""
-    if not batch:
-        return
-    arr = (H.WgradDesc * len(batch))(*[b[0] for b in batch])
-    with _rec("wgrad_batch", (len(batch),), sum(b[1] for b in batch), sum(b[2] for b in batch)):
-        H.check(H.lib().rl_wgrad_batch(arr, len(batch), _st()), "rl_wgrad_batch")
+    """The queued weight gradients as grouped launches (rl_wgrad_batch): one for the wide layers, one for the narrow
+    (streaming) ones; before `wgrad_flush`."""
+    for kind, name in ((1, "wgrad_batch"), (2, "swgrad_batch")):
+        part = [b for b in batch if b[6] == kind]
+        if not part:
+            continue
+        arr = (H.WgradDesc * len(part))(*[b[0] for b in part])
+        with _rec(name, (len(part),), sum(b[1] for b in part), sum(b[2] for b in part)):
+            H.check(H.lib().rl_wgrad_batch(arr, len(part), _st()), "rl_wgrad_batch")
     batch.clear()
 
 

@@ -263,11 +263,14 @@ typedef struct rl_wgrad_reduce_item {
 } rl_wgrad_reduce_item;
 
 int rl_wgrad_nsplit(int64_t M, int N, int K);
-/* Several layers' weight gradients in ONE launch: the wide (128 x 128-tile) layers of a backward pass are independent of
- * each other and mostly small (80 - 216 workgroups each on a chip that holds 512), so one by one they leave most CUs idle.
- * Every descriptor must satisfy rl_wgrad_batchable (wide kernel, fp32 rows, bf16x3 / bf16 arithmetic) and have defer_reduce
- * set; the partial slabs are exactly those of rl_wgrad (same split, same per-workgroup arithmetic: bitwise equal results)
- * and are summed by rl_wgrad_reduce_batch as before.                                                                  */
+/* Several layers' weight gradients in ONE launch: the layers of a backward pass are independent of each other and mostly
+ * small (the wide ones 80 - 216 workgroups each on a chip that holds 512, the narrow ones 5 - 46 us each), so one by one
+ * they leave most CUs idle and pay a launch each.  rl_wgrad_batchable: 0 = must go through rl_wgrad, 1 = joins the grouped
+ * launch of the wide (128 x 128-tile) kernel (fp32 rows, bf16x3 / bf16 arithmetic), 2 = joins the grouped launch of the
+ * narrow (streaming) kernel (K, N <= 64, fp32 rows, tensor operand).  rl_wgrad_batch takes a queue of either or both kinds
+ * (one launch per kind and per 24 layers); every descriptor must have defer_reduce set; the partial slabs are exactly
+ * those of rl_wgrad (same split, same per-workgroup arithmetic: bitwise equal results) and are summed by
+ * rl_wgrad_reduce_batch as before.                                                                                    */
 int rl_wgrad_batchable(const rl_wgrad_desc* d);
 int rl_wgrad_batch(const rl_wgrad_desc* descs, int count, void* stream);
 int rl_wgrad_reduce_batch(const rl_wgrad_reduce_item* items, int count, void* stream);

@@ -913,10 +913,13 @@ def test_float_atomic_entry_points_need_an_opt_in(ops, monkeypatch):
 
 
 def test_grouped_wide_weight_gradients_equal_the_single_launches_bitwise(ops):
-    """rl_wgrad_batch: several wide layers' weight gradients as ONE launch - same split, same per-workgroup arithmetic, so
-    the same bits as one rl_wgrad launch per layer; narrow layers are not batchable and run on the spot."""
+    """rl_wgrad_batch: several layers' weight gradients as ONE launch per kind (wide 128 x 128-tile kernel / narrow streaming
+    kernel, every (KT, NT) body of it) - same split, same per-workgroup arithmetic, so the same bits as one rl_wgrad launch
+    per layer."""
     torch.manual_seed(5)
-    shapes = [(5000, 128, 256, False), (2000, 256, 128, True), (700, 512, 256, False), (9000, 96, 160, False), (3000, 32, 32, False)]
+    shapes = [(5000, 128, 256, False), (2000, 256, 128, True), (700, 512, 256, False), (9000, 96, 160, False), (3000, 32, 32, False),
+              (7001, 8, 8, True), (4000, 16, 32, False), (3333, 8, 64, True), (2500, 10, 128, False), (6000, 32, 16, True),
+              (5000, 24, 64, False), (4100, 64, 8, True), (3900, 64, 32, False), (8000, 64, 64, True), (100, 48, 40, False)]
     layers = []
     for M, K, N, lazy in shapes:
         A = torch.randn(M, K, device=DEV)
@@ -938,7 +941,7 @@ def test_grouped_wide_weight_gradients_equal_the_single_launches_bitwise(ops):
         return outs, queued
     single, _ = run(False)
     grouped, queued = run(True)
-    assert queued == 4                                   # the 32 x 32 layer runs on the streaming kernel, on the spot
+    assert queued == len(layers)                         # four wide layers, eleven narrow ones: two grouped launches
     for (w0, b0), (w1, b1), (a, dY, M, K, N) in zip(single, grouped, layers):
         assert torch.equal(w0, w1) and torch.equal(b0, b1), (M, K, N)
     a, dY, M, K, N = layers[0]
