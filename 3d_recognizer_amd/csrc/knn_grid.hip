@@ -622,7 +622,9 @@ __device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned lo
 
 // one launch serves every task of a k bucket, whatever its lane count: the tasks run side by side
 template <int KMAX>
-__global__ __launch_bounds__(256) void grid_query_kernel(const KMulti m) {
+// (KMAX <= 16: 170 VGPRs would round to 176 = two wavefronts per SIMD; capped at 168 the kernel keeps three - it waits on
+// chains of dependent loads, occupancy is what hides them; the K = 32 / 64 bodies would spill at that cap)
+__global__ __launch_bounds__(256, KMAX <= 16 ? 3 : 1) void grid_query_kernel(const KMulti m) {
     __shared__ unsigned long long lds[KMAX <= 16 ? 256 * KMAX : 1];
     const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
     const KTask& T = m.t[task];
