@@ -18,6 +18,10 @@
 
 namespace {
 
+// candidates per round trip of a lane (8: 170 VGPRs, 6: spills at the four-wavefront cap, 4: 16 B of scratch, 3: none; 2 is slower)
+constexpr int KNN_SB = 3;
+
+
 struct GridGeom {
     float lo[3];
     float inv[3];
@@ -291,7 +295,7 @@ __device__ __forceinline__ void take_batch(const float4 (&cand)[SB], unsigned va
 template <int KMAX>
 __device__ __forceinline__ void scan_range(const float4* __restrict__ pts, int begin, int end, float qx, float qy,
                                            float qz, unsigned long long (&best)[KMAX]) {
-    constexpr int SB = 8;      // candidates per round trip (16 measured no better)
+    constexpr int SB = KNN_SB;
     for (int t = begin; t < end; t += SB) {
         float4 cand[SB];
         unsigned valid = 0;
@@ -487,7 +491,7 @@ __device__ __forceinline__ unsigned long long group_bound(const unsigned long lo
 template <int KMAX, int LANES>
 __device__ __forceinline__ void scan_range_n(const float4* __restrict__ pts, int begin, int end, int sub, float qx, float qy,
                                             float qz, unsigned long long (&best)[KMAX]) {
-    constexpr int SB = 8;
+    constexpr int SB = KNN_SB;
     for (int t = begin + sub; t < end; t += LANES * SB) {
         float4 cand[SB];
         unsigned valid = 0;
@@ -622,9 +626,11 @@ __device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned lo
 
 // one launch serves every task of a k bucket, whatever its lane count: the tasks run side by side
 template <int KMAX>
-// (KMAX <= 16: 170 VGPRs would round to 176 = two wavefronts per SIMD; capped at 168 the kernel keeps three - it waits on
-// chains of dependent loads, occupancy is what hides them; the K = 32 / 64 bodies would spill at that cap)
-__global__ __launch_bounds__(256, KMAX <= 16 ? 3 : 1) void grid_query_kernel(const KMulti m) {
+// Occupancy is what this kernel runs on (it waits on chains of dependent loads: cell start -> points -> next cell): with
+// 8 candidates per round trip it needed 170 VGPRs = TWO wavefronts per SIMD; three candidates per trip fit 126 = FOUR
+// (all searches of a bs = 8 step: 535 us -> 476 at 168 VGPRs / three wavefronts -> 418).  The K = 32 / 64 bodies would
+// spill under the cap and keep their registers.
+__global__ __launch_bounds__(256, KMAX <= 16 ? 4 : 1) void grid_query_kernel(const KMulti m) {
     __shared__ unsigned long long lds[KMAX <= 16 ? 256 * KMAX : 1];
     const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
     const KTask& T = m.t[task];
