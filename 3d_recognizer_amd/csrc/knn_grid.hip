@@ -680,12 +680,15 @@ void bind(KTask* t, const Plan& p, char* w) {
 }
 
 // lanes per query: the more queries a search has, the less it gains from splitting one (the split costs a weaker
-// pruning bound and a merge); RL_KNN_LANES = 1 | 2 | 4 forces one choice
+// pruning bound and a merge).  At four wavefronts per SIMD one lane per query wins from 16384 queries on (bs = 8 step, all
+// searches: threshold 131072 418 us, 65536 379, 16384 376, 4096 390); RL_KNN_LANES = 1 | 2 | 4 forces one choice,
+// RL_KNN_LANE_THR moves the threshold
 inline int lanes_for(long queries, int k) {
     static const int force = getenv("RL_KNN_LANES") ? atoi(getenv("RL_KNN_LANES")) : 0;
     if (k > 16) return 1;
     if (force == 1 || force == 2 || force == 4) return force;
-    return queries >= 131072 ? 1 : 4;
+    static const long thr = getenv("RL_KNN_LANE_THR") ? atol(getenv("RL_KNN_LANE_THR")) : 16384;
+    return queries >= thr ? 1 : 4;
 }
 
 int run_multi(const KMulti& m_in, hipStream_t st) {
