@@ -901,6 +901,28 @@ def test_wide_gemm_stagings_agree_bitwise(ops, M, K, N):
             assert torch.equal(x, y), i
 
 
+def test_wide_gemm_dispatch_names_the_kernel_it_ran(ops):
+    """rl_last_kernel after rl_gemm: the LDS-DMA kernel by default where it applies (K % 32 == 0, K <= 1024, pre-split weights),
+    the register-staged one on request and for K % 32 != 0, the 4-wavefront kernel without planes, the streaming kernel for
+    narrow layers - so a silent fallback to a slower path shows up in a test, not in a profile."""
+    if ops.get_wide_gemm() == "fp32":
+        pytest.skip("the pre-split path exists in the bf16 arithmetic modes")
+    from randlanet import _hip as H
+    last = lambda: H.lib().rl_last_kernel().decode()
+    for M, K, N, planes, staging, want in [(20000, 256, 128, True, "dma", "wgemm2_kernel"), (20000, 256, 128, True, "registers", "wgemm_kernel"),
+                                           (20000, 40, 128, True, "dma", "wgemm_kernel"), (20000, 256, 128, False, "dma", "pgemm_kernel<8>"),
+                                           (3000, 512, 256, True, "dma", "wgemm2_kernel+splitk"), (3000, 64, 64, False, "dma", "sgemm_kernel")]:
+        A = torch.randn(M, K, device=DEV)
+        W = torch.randn(N, K, device=DEV)
+        ws = ops.split_weights([(W, 1, K, K, N)]) if planes else None
+        try:
+            ops.set_wgemm_staging(staging)
+            ops.gemm(ops.plain(A, 1, M), W, 1, K, N, wsplit=ws)
+            assert last() == want, (M, K, N, planes, staging, last())
+        finally:
+            ops.set_wgemm_staging("dma")
+
+
 def test_float_atomic_entry_points_need_an_opt_in(ops, monkeypatch):
     """rl_scatter_add_rows / rl_gemm(out2_index) add with fp32 atomics: not part of the schedule, refused by default."""
     monkeypatch.delenv("RL_ALLOW_FLOAT_ATOMICS", raising=False)
