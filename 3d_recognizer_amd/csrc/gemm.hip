@@ -789,7 +789,8 @@ __global__ __launch_bounds__(256) void swgrad_kernel(const WgradParams p) {
 
 // slab split for the streaming wgrad: one slab per workgroup
 void swgrad_split(long M, int* nsplit, long* rows_per_block) {
-    long want = (M + 255) / 256;        // 256 rows per workgroup (512: 387 -> 367 us per step over all launches; 1024+: 480)
+    static const long rows_wg = getenv("RL_SWGRAD_ROWS") ? atol(getenv("RL_SWGRAD_ROWS")) : 256;
+    long want = (M + rows_wg - 1) / rows_wg;        // 256 rows per workgroup (512: 387 -> 367 us per step over all launches; 1024+: 480)
     const long fill = (M + 127) / 128 < 256 ? (M + 127) / 128 : 256;   // one workgroup per CU where the rows allow
     if (want < fill) want = fill;
     if (want < 1) want = 1;
