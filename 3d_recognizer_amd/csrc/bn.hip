@@ -53,14 +53,12 @@ __device__ __forceinline__ void slot_sums(const double* __restrict__ stats, int 
 }
 
 // one workgroup per channel
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+__device__ __forceinline__ void bn_finalize_body(
     const double* __restrict__ stats, int nslots, double count, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-    const float* __restrict__ folded_bias) {
-    __shared__ double red[4][2];
-    const int c = blockIdx.x;          // one workgroup per channel
+    const float* __restrict__ folded_bias, const int c, double (*red)[2]) {
     double mean, var;
     if (training) {
         double s, q;
@@ -90,6 +88,30 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
         if (c == 0 && nbt) nbt[0] += 1;
     }
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const double* __restrict__ stats, int nslots, double count, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+    int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    const float* __restrict__ folded_bias) {
+    __shared__ double red[4][2];
+    bn_finalize_body(stats, nslots, count, C, gamma, beta, rmean, rvar, nbt, momentum, eps, training, scale, shift, save_mean,
+                     save_invstd, folded_bias, (int)blockIdx.x, red);
+}
+// Several independent layers' folds in ONE launch (blockIdx.y = layer, blockIdx.x = channel): a fold is a 5 us launch that
+// does 0.5 us of work, and the folds of layers at one dependency depth (mlp1 / shortcut / mlp_rpe1 of an encoder level,
+// pool1.mlp / mlp_rpe2) are all wanted at the same moment.
+constexpr int BNF_MAX = 8;
+struct BnFoldBatch {
+    rl_bn_finalize_item it[BNF_MAX];
+};
+__global__ __launch_bounds__(256) void bn_finalize_batch_kernel(const BnFoldBatch b) {
+    __shared__ double red[4][2];
+    const rl_bn_finalize_item& t = b.it[blockIdx.y];
+    if ((int)blockIdx.x >= t.C) return;
+    bn_finalize_body(t.stats, t.nslots, (double)t.count, t.C, t.gamma, t.beta, t.running_mean, t.running_var, t.num_batches_tracked,
+                     t.momentum, t.eps, t.training, t.scale, t.shift, t.save_mean, t.save_invstd, t.folded_bias, (int)blockIdx.x, red);
 }
 
 // (nslots, 2, C) partials -> (2, C) totals, one wavefront per channel, fixed order: the piece a data-parallel caller
@@ -192,11 +214,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BwdParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nslots,
-                                                              double count, int C, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
-    __shared__ double red[4][2];
-    const int c = blockIdx.x;          // one workgroup per channel
+__device__ __forceinline__ void bn_bwd_finalize_body(const double* __restrict__ stats, int nslots, double count, int C,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ coef, const int c, double (*red)[2]) {
     double s, q;
     slot_sums_wg(stats, nslots, C, c, red, s, q);
     if (threadIdx.x != 0) return;
@@ -204,6 +224,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
     if (dgamma) dgamma[c] = (float)q;
     coef[c] = (float)(s / count);
     coef[C + c] = (float)(q / count);
+}
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nslots,
+                                                              double count, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double red[4][2];
+    bn_bwd_finalize_body(stats, nslots, count, C, dgamma, dbeta, coef, (int)blockIdx.x, red);     // one workgroup per channel
+}
+// the two BatchNorms behind a residual junction (mlp2 and shortcut) in one launch: blockIdx.y = layer
+__global__ __launch_bounds__(256) void bn_bwd_finalize_pair_kernel(const double* __restrict__ stats0, const double* __restrict__ stats1,
+                                                                   int nslots, double count, int C, float* dgamma0, float* dbeta0,
+                                                                   float* coef0, float* dgamma1, float* dbeta1, float* coef1) {
+    __shared__ double red[4][2];
+    if (blockIdx.y == 0) bn_bwd_finalize_body(stats0, nslots, count, C, dgamma0, dbeta0, coef0, (int)blockIdx.x, red);
+    else bn_bwd_finalize_body(stats1, nslots, count, C, dgamma1, dbeta1, coef1, (int)blockIdx.x, red);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
@@ -498,6 +532,35 @@ extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, in
                        (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, training,
                        scale, shift, save_mean, save_invstd, folded_bias);
     RL_LAUNCH_CHECK("rl_bn_finalize");
+    return RL_OK;
+}
+
+extern "C" int rl_bn_finalize_batch(const rl_bn_finalize_item* items, int count, void* stream) {
+    RL_REQUIRE(items != nullptr && count >= 0, RL_ERR_ARGS, "rl_bn_finalize_batch: bad arguments");
+    for (int base = 0; base < count; base += BNF_MAX) {
+        BnFoldBatch b;
+        const int n = count - base < BNF_MAX ? count - base : BNF_MAX;
+        int maxc = 1;
+        for (int i = 0; i < n; ++i) {
+            const rl_bn_finalize_item& t = items[base + i];
+            RL_REQUIRE(t.C > 0 && t.scale && t.shift, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: bad arguments", base + i);
+            if (t.training) RL_REQUIRE(t.stats && t.nslots > 0 && t.count > 0, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: training needs partial statistics", base + i);
+            else RL_REQUIRE(t.running_mean && t.running_var, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: eval needs running statistics", base + i);
+            b.it[i] = t;
+            maxc = t.C > maxc ? t.C : maxc;
+        }
+        hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(maxc, n), dim3(256), 0, (hipStream_t)stream, b);
+        RL_LAUNCH_CHECK("rl_bn_finalize_batch");
+    }
+    return RL_OK;
+}
+
+extern "C" int rl_bn_bwd_finalize_pair(const double* stats0, const double* stats1, int nslots, int64_t count, int C, float* dgamma0,
+                                       float* dbeta0, float* coef0, float* dgamma1, float* dbeta1, float* coef1, void* stream) {
+    RL_REQUIRE(stats0 && stats1 && nslots > 0 && count > 0 && C > 0 && coef0 && coef1, RL_ERR_ARGS, "rl_bn_bwd_finalize_pair: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_pair_kernel, dim3(C, 2), dim3(256), 0, (hipStream_t)stream, stats0, stats1, nslots, (double)count,
+                       C, dgamma0, dbeta0, coef0, dgamma1, dbeta1, coef1);
+    RL_LAUNCH_CHECK("rl_bn_bwd_finalize_pair");
     return RL_OK;
 }
 

@@ -99,7 +99,8 @@ class Engine:
         scale, shift, mean, invstd = ops.bn_finalize(
             stats, out.rows, 128, out.C, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
             self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
-            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, folded_bias=folded_bias)
+            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, folded_bias=folded_bias,
+            defer=getattr(ctx, "bn_defer", None))
         out.scale, out.shift, out.mean, out.invstd = scale, shift, mean, invstd
         out.act, out.slope, out.bn = act, slope, bn_name
 
@@ -164,7 +165,8 @@ class Engine:
         scale, shift, mean, invstd = ops.bn_finalize(
             stats, vr.rows, 128, vr.h, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
             self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
-            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, nslots=nslots)
+            nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, nslots=nslots,
+            defer=getattr(ctx, "bn_defer", None))
         rec = Lazy(vr.d2, vr.B, vr.n * 16, vr.n * 16, vr.h, scale, shift, H.ACT_RELU, 0.0, mean, invstd, bn_name)
         return rec
 
@@ -173,6 +175,9 @@ class Engine:
         e = f"encoder.{l}"
         B, K, h = xin.B, self.K, d // 2
         ctx.keep += [idx, d2]
+        # BatchNorm folds wanted at the same moment go out as ONE launch: (mlp1, shortcut, mlp_rpe1), then (pool1.mlp, mlp_rpe2).
+        # ctx.bn_defer collects them; every flush sits in front of the first kernel that reads one of the (scale, shift) pairs
+        ctx.bn_defer = [] if self.sync is None else None
         f0 = self._mlp(ctx, xin, f"{e}.mlp1", h, H.ACT_LRELU, 0.2)
         sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
         if ops.virtual_rpe_supported(d, K):
@@ -180,10 +185,13 @@ class Engine:
             vr = ops.VirtualRpe(ctx.xyz4 if getattr(ctx, "xyz4", None) is not None else xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
                                 self.P[f"{e}.mlp_rpe2.conv.weight"], self.P[f"{e}.mlp_rpe2.conv.bias"])
             vr.bn1 = self._virtual_bn(ctx, vr, 1, f"{e}.mlp_rpe1.batch_norm")
+            ops.bn_finalize_flush(ctx.bn_defer)
             # in training pool1's kernel also leaves the batch statistics of mlp_rpe2's raw output (it has the tile)
             q1 = self._pool(ctx, f"{e}.pool1", vr, f0, idx, csr, n, d, h, stage=1, next_stats=ctx.training)
             vr.bn2 = self._virtual_bn(ctx, vr, 2, f"{e}.mlp_rpe2.batch_norm", *getattr(ctx, "next_stats", (None, 1)))
             ctx.next_stats = (None, 1)
+            ops.bn_finalize_flush(ctx.bn_defer)
+            ctx.bn_defer = None
             q2 = self._pool(ctx, f"{e}.pool2", vr, q1, idx, csr, n, d, d, stage=2)
         else:
             rpe = Rpe(xyz, idx, d2, B, n, K)
@@ -192,8 +200,11 @@ class Engine:
                 # a plain 12-float row lets mlp_rpe1 run on the streaming GEMM / weight-gradient kernels (up to 128 columns)
                 rpe = ops.rpe_build(rpe)
             u1 = self._mlp(ctx, rpe, f"{e}.mlp_rpe1", h, H.ACT_RELU, a_grad=False)
+            ops.bn_finalize_flush(ctx.bn_defer)
             q1 = self._pool(ctx, f"{e}.pool1", u1, f0, idx, csr, n, d, h)
             u2 = self._mlp(ctx, u1, f"{e}.mlp_rpe2", h, H.ACT_RELU)
+            ops.bn_finalize_flush(ctx.bn_defer)
+            ctx.bn_defer = None
             q2 = self._pool(ctx, f"{e}.pool2", u2, q1, idx, csr, n, d, d)
         m2 = self._mlp(ctx, q2, f"{e}.mlp2", 2 * d)
         O = ops.plain(ops.add_act_fwd(m2, sc, 0.01), B, n)

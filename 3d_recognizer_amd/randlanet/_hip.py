@@ -146,6 +146,16 @@ class CsrTask(C.Structure):
 CSR_MAX_TASKS = 8
 
 
+class BnFinalizeItem(C.Structure):
+    _fields_ = [
+        ("stats", C.c_void_p), ("count", C.c_int64), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+        ("folded_bias", C.c_void_p), ("nslots", C.c_int32), ("C", C.c_int32), ("training", C.c_int32),
+        ("momentum", C.c_float), ("eps", C.c_float), ("reserved", C.c_int32),
+    ]
+
+
 class SegsumDesc(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("lds", C.c_int64), ("src_bstride", C.c_int64),
@@ -194,6 +204,8 @@ _SIGNATURES = {
     "rl_wgrad_batch": (_i, [C.POINTER(WgradDesc), _i, _vp]),
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
     "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rl_bn_finalize_batch": (_i, [C.POINTER(BnFinalizeItem), _i, _vp]),
+    "rl_bn_bwd_finalize_pair": (_i, [_vp, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_bn_reduce_slots": (_i, [_vp, _i, _i, _vp, _vp]),
     "rl_bn_bwd_slots": (_i, [_l]),
     "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),

@@ -522,10 +522,15 @@ def _stats_totals(stats: torch.Tensor, nslots: int, C: int) -> torch.Tensor:
     return out
 
 
+NO_BN_BATCH = bool(int(__import__("os").environ.get("RL_NO_BN_BATCH", "0")))      # diagnostics: one launch per BatchNorm fold
+
+
 def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, nbt, momentum: float,
                 eps: float, training: bool, sync: Optional[SyncGroup] = None, nslots: Optional[int] = None,
-                folded_bias: Optional[torch.Tensor] = None):
-    """folded_bias: the layer's conv bias when the producing GEMM did NOT add it (rl_bn_finalize in rl_randlanet.h)."""
+                folded_bias: Optional[torch.Tensor] = None, defer: Optional[list] = None):
+    """folded_bias: the layer's conv bias when the producing GEMM did NOT add it (rl_bn_finalize in rl_randlanet.h).
+    defer (a list): the fold is only queued - the returned tensors are filled by `bn_finalize_flush(defer)`, which runs all
+    queued folds as ONE launch; the caller flushes before anything reads them."""
     dev = gamma.device
     nslots = H.row_blocks(rows, tile) if nslots is None else nslots
     if training and sync is not None:            # batch statistics of the GLOBAL batch
@@ -538,11 +543,28 @@ def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, n
     invstd = torch.empty(C, dtype=F32, device=dev) if training else None
     _dev_check(stats, gamma, beta, rmean, rvar, nbt, folded_bias)
     assert folded_bias is None or folded_bias.numel() == C
+    if defer is not None and not NO_BN_BATCH:
+        it = H.BnFinalizeItem()
+        it.stats, it.count, it.gamma, it.beta = H.ptr(stats), rows, H.ptr(gamma), H.ptr(beta)
+        it.running_mean, it.running_var, it.num_batches_tracked = H.ptr(rmean), H.ptr(rvar), H.ptr(nbt)
+        it.scale, it.shift, it.save_mean, it.save_invstd = scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd)
+        it.folded_bias, it.nslots, it.C, it.training, it.momentum, it.eps = H.ptr(folded_bias), nslots, C, int(training), momentum, eps
+        defer.append((it, stats, scale, shift, mean, invstd))       # (the tensors stay referenced until the launch is issued)
+        return scale, shift, mean, invstd
     H.check(H.lib().rl_bn_finalize(H.ptr(stats), nslots, rows, C, H.ptr(gamma), H.ptr(beta),
                                    H.ptr(rmean), H.ptr(rvar), H.ptr(nbt), momentum, eps, int(training),
                                    scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), H.ptr(folded_bias), _st()),
             "rl_bn_finalize")
     return scale, shift, mean, invstd
+
+
+def bn_finalize_flush(defer: Optional[list]) -> None:
+    """The queued BatchNorm folds as one launch (rl_bn_finalize_batch)."""
+    if not defer:
+        return
+    arr = (H.BnFinalizeItem * len(defer))(*[d[0] for d in defer])
+    H.check(H.lib().rl_bn_finalize_batch(arr, len(defer), _st()), "rl_bn_finalize_batch")
+    defer.clear()
 
 
 def _bn_bwd_desc(G: torch.Tensor, g_bstride: int, y: Lazy) -> H.BnBwdDesc:
@@ -608,8 +630,12 @@ def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, 
     with _rec("resid_bn_bwd_reduce", (rows, Cc), 16 * rows * Cc, 0):
         H.check(H.lib().rl_resid_bn_bwd_reduce(C.byref(d), _st()), "rl_resid_bn_bwd_reduce")
     slots = H.lib().rl_bn_bwd_slots(rows)
-    _bn_bwd_finalize(st1, slots, rows, Cc, dgamma1, dbeta1, c1, sync)
-    _bn_bwd_finalize(st2, slots, rows, Cc, dgamma2, dbeta2, c2, sync)
+    if sync is None and not NO_BN_BATCH:
+        H.check(H.lib().rl_bn_bwd_finalize_pair(st1.data_ptr(), st2.data_ptr(), slots, rows, Cc, H.ptr(dgamma1), H.ptr(dbeta1), c1.data_ptr(),
+                                                H.ptr(dgamma2), H.ptr(dbeta2), c2.data_ptr(), _st()), "rl_bn_bwd_finalize_pair")
+    else:
+        _bn_bwd_finalize(st1, slots, rows, Cc, dgamma1, dbeta1, c1, sync)
+        _bn_bwd_finalize(st2, slots, rows, Cc, dgamma2, dbeta2, c2, sync)
     with _rec("resid_bn_bwd_apply", (rows, Cc), 24 * rows * Cc, 0):
         H.check(H.lib().rl_resid_bn_bwd_apply(C.byref(d), _st()), "rl_resid_bn_bwd_apply")
     return G2

@@ -290,6 +290,28 @@ int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const 
                    float momentum, float eps, int training, float* scale, float* shift,
                    float* save_mean, float* save_invstd, const float* folded_bias, void* stream);
 
+/* Several independent layers' folds in one launch (same arithmetic per layer as rl_bn_finalize: same results).  The folds of
+ * the layers at one dependency depth of an encoder level - mlp1 / shortcut / mlp_rpe1, then pool1.mlp / mlp_rpe2 - are wanted
+ * at the same moment, and a fold is a launch that costs ten times its work.                                              */
+typedef struct rl_bn_finalize_item {
+    const double* stats;
+    int64_t count;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float* scale;
+    float* shift;
+    float* save_mean;
+    float* save_invstd;
+    const float* folded_bias;
+    int32_t nslots, C, training;
+    float momentum, eps;
+    int32_t reserved;
+} rl_bn_finalize_item;
+int rl_bn_finalize_batch(const rl_bn_finalize_item* items, int count, void* stream);
+
 /* BatchNorm + activation backward for a lazy tensor Y (rows x C, row (b,i) at (b*bstride+i)*ld)
  * whose activated value received gradient G (same addressing):
  *   g = G * act'(Y*scale+shift);  xhat = (Y-mean)*invstd
@@ -320,6 +342,9 @@ int rl_bn_bwd_slots(int64_t rows);
 int rl_bn_bwd_reduce(const rl_bn_bwd_desc* d, void* stream);
 int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, float* dgamma,
                        float* dbeta, float* coef, void* stream);
+/* rl_bn_bwd_finalize for the two BatchNorms behind a residual junction (same row and channel counts) in one launch. */
+int rl_bn_bwd_finalize_pair(const double* stats0, const double* stats1, int nslots, int64_t count, int C, float* dgamma0,
+                            float* dbeta0, float* coef0, float* dgamma1, float* dbeta1, float* coef1, void* stream);
 int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream);
 
 /* Backward of the residual junction of LocalFeatureAggregation (modules.py:325):

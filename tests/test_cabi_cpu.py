@@ -95,6 +95,7 @@ def test_ctypes_structures_have_the_headers_layout(tmp_path):
     pairs = {"rl_gemm_desc": _hip.GemmDesc, "rl_wsplit_item": _hip.WsplitItem, "rl_wgrad_desc": _hip.WgradDesc,
              "rl_wgrad_reduce_item": _hip.WgradReduceItem, "rl_bn_bwd_desc": _hip.BnBwdDesc, "rl_knn_task": _hip.KnnTask,
              "rl_pool_desc": _hip.PoolDesc, "rl_resid_bn_bwd_desc": _hip.ResidBnBwdDesc, "rl_csr_task": _hip.CsrTask,
+             "rl_bn_finalize_item": _hip.BnFinalizeItem,
              "rl_segsum_desc": _hip.SegsumDesc, "rl_rows_desc": _hip.RowsDesc, "rl_cloud_job": _hip.CloudJob}
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
