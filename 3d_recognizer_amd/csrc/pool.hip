@@ -1609,6 +1609,1337 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
     }
 }
 
+
+// ===============================================================================================================
+// The virtual rpe branch in the TRANSPOSED orientation (round 4).  The kernels above build a point's rpe tile in C layout
+// (the MFMA output of rows = slots, columns = channels) and carry it through LDS into the A layout the score GEMM wants -
+// per stage four masked ds_write_b32, a wave barrier, a masked ds_read_b128, a lane-divergent region each.  With the MFMA
+// operands EXCHANGED - weights as the A operand, the point's inputs as the B operand - the product comes out transposed:
+//     lane (slot = l & 15, q = l >> 4), register r  ->  channel 16*nb + 4*q + r of that slot
+// which IS the A layout (lane (slot, lj) holds channels 16c + 4lj .. +3): the rpe half of X is born where the score GEMM
+// reads it, stage 2 consumes stage 1 straight from registers, and the BatchNorm sums / statistics of the branch accumulate
+// as float4s per lane.  Nothing of the branch goes through LDS, and nothing is lane-divergent:
+//   * a lane loads ONE coordinate component of its point and of its neighbour (input lj of slot li), not two float4s;
+//   * conv biases are folded into lane constants (shift' = b*scale + shift, mean' = mean - b; the statistics kernels add
+//     the bias to their sums at the very end) - the raw tile is W.x without the bias everywhere, the same expression in
+//     every kernel, so that forward and backward agree on every activation's sign;
+//   * d = 16 (the tile's ONE 16-column chunk is half rpe, half gathered): lanes lj < 2 "gather" 16 bytes of zeros through a
+//     per-lane base pointer / stride, and the gathered rows arrive as the C operand of the rpe MFMA - one mixed raw tile.
+// The softmax / pooling reductions over the four lane groups use v_permlane16_swap / v_permlane32_swap (gfx950) instead of
+// ds_bpermute round trips.
+// ===============================================================================================================
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// all-reduce over the four lane groups (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float lg_sum(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// max(a, b) of finite values as med3(a, b, FLT_MAX): fmaxf (and med3 against +inf, which the compiler folds back into it)
+// canonicalises every operand first (a v_max_f32 v, v, v each - MFMA results could be signalling NaNs for all it knows), and
+// an inline-asm v_max hides the MFMA -> VALU read hazard from the hazard recogniser (no s_nop: it read accumulators before
+// they were written)
+__device__ __forceinline__ float vmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 0x1.fffffep127f); }
+__device__ __forceinline__ float lg_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// sum over the 16 lanes of a lane group (end-of-kernel reductions of the A-layout accumulators)
+__device__ __forceinline__ float li_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// bf16 head / tail of an A-layout tile as MFMA fragments: split ONCE, used by every product the tile enters
+template <int DT> struct Frag { bf16x8 h[DT / 2], l[DT / 2]; };
+template <> struct Frag<1> { bf16x4 h[1], l[1]; };
+template <int DT>
+__device__ __forceinline__ void split_tile(const float4 (&a)[DT], Frag<DT>& f) {
+    if constexpr (DT == 1) split4(a[0], f.h[0], f.l[0]);
+    else {
+#pragma unroll
+        for (int b = 0; b < DT / 2; ++b) {
+            bf16x4 h0, l0, h1, l1;
+            split4(a[2 * b], h0, l0);
+            split4(a[2 * b + 1], h1, l1);
+            f.h[b] = cat8(h0, h1);
+            f.l[b] = cat8(l0, l1);
+        }
+    }
+}
+// acc[nb] += tile . B with B given transposed in LDS as bf16 head / tail planes ([n][k], row stride STR); NPU of the tile's
+// k pairs (32 k each; DT == 1: its one 16-k block) enter.  SWAP exchanges the MFMA operands: acc then holds the TRANSPOSED
+// product - lane (row, q) gets columns 16nb + 4q .. +3 of its row, i.e. the A layout.
+template <int DT, int NB, int NPU, bool SWAP>
+__device__ __forceinline__ void gemm_frag(const Frag<DT>& f, const __bf16* Bh, const __bf16* Bl, int STR, int li, int lj,
+                                          f32x4 (&acc)[NB]) {
+    if constexpr (DT == 1) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int o = (nb * 16 + li) * STR + 4 * lj;
+            const bf16x4 bh = *reinterpret_cast<const bf16x4*>(Bh + o);
+            const bf16x4 bl = *reinterpret_cast<const bf16x4*>(Bl + o);
+            if constexpr (SWAP) {
+                acc[nb] = mfma16(bh, f.h[0], acc[nb]);
+                acc[nb] = mfma16(bl, f.h[0], acc[nb]);
+                acc[nb] = mfma16(bh, f.l[0], acc[nb]);
+            } else {
+                acc[nb] = mfma16(f.h[0], bh, acc[nb]);
+                acc[nb] = mfma16(f.h[0], bl, acc[nb]);
+                acc[nb] = mfma16(f.l[0], bh, acc[nb]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NPU; ++b) {
+            constexpr int NG = NB < 4 ? NB : 4;      // column blocks per round: bounds the fragment registers
+#pragma unroll
+            for (int n0 = 0; n0 < NB; n0 += NG) {
+                bf16x8 bh[NG], bl[NG];
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const int o = ((n0 + j) * 16 + li) * STR + 32 * b + 4 * lj;
+                    bh[j] = cat8(*reinterpret_cast<const bf16x4*>(Bh + o), *reinterpret_cast<const bf16x4*>(Bh + o + 16));
+                    bl[j] = cat8(*reinterpret_cast<const bf16x4*>(Bl + o), *reinterpret_cast<const bf16x4*>(Bl + o + 16));
+                }
+                if constexpr (SWAP) {
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], f.h[b], acc[n0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], f.h[b], acc[n0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], f.l[b], acc[n0 + j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.h[b], bh[j], acc[n0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.h[b], bl[j], acc[n0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NG; ++j) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.l[b], bh[j], acc[n0 + j], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+// the same in exact fp32 (v_mfma_f32_16x16x4_f32): NC of the tile's 16-k chunks against a float image ([n][k], stride STR)
+template <int DT, int NC, int NB, bool SWAP>
+__device__ __forceinline__ void gemm_f32(const float4 (&a)[DT], const float* Bt, int STR, int li, int lj, f32x4 (&acc)[NB]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float av[4] = {a[c].x, a[c].y, a[c].z, a[c].w};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float4 b = *reinterpret_cast<const float4*>(Bt + (nb * 16 + li) * STR + 16 * c + 4 * lj);
+            const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[nb] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], av[s], acc[nb], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[nb], 0, 0, 0);
+        }
+    }
+}
+
+// geometry of the branch for a level of width d = 16*DT
+template <int DT>
+struct VX {
+    static constexpr int H = 8 * DT;                  // channels of the rpe branch
+    static constexpr int NCH = DT == 1 ? 1 : DT / 2;  // A-layout chunks (= 16-row blocks of the transposed products) that hold them
+    static constexpr int HP = 16 * NCH;
+    static constexpr int KP2 = DT == 1 ? 16 : 32;     // k extent of the stage-2 product as the MFMA sees it (zero-padded W2)
+    static constexpr int S2B = KP2 + 8;               // row strides of the W2 image: bf16 planes / floats
+    static constexpr int S2F = KP2 + 4;
+    static constexpr int NC2 = DT == 4 ? 2 : 1;       // A-layout chunks of the stage-1 tile that enter the stage-2 product
+    static constexpr bool INLDS = DT >= 4;            // per-channel constants: LDS float4s instead of registers
+    enum { S1 = 0, H1, S2, H2, MU, IS, NCONST };      // folded BatchNorm of stage 1 / 2 (shift' carries the conv bias), mean' / invstd of the stage being differentiated
+};
+
+// what a lane needs of one point: input lj of slot li for the first stage - ONE component of the point and of its neighbour
+struct RpeIn2 {
+    float pc, nc, dd;
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(pc), "+v"(nc), "+v"(dd)); }
+};
+// comp = lj < 3 ? lj : 0 (lane constant; lane group 3 supplies the distance, its coordinate loads are dummies)
+__device__ __forceinline__ void fetch_rpe2(const PoolParams& p, const Cursor& cu, int li, int comp, int nbr, RpeIn2& r) {
+    const float* xb = p.xyz + (long)cu.b * p.xyz_bstride * p.xyz_w + comp;
+    r.pc = xb[(long)cu.i * p.xyz_w];
+    r.nc = xb[(long)nbr * p.xyz_w];
+    r.dd = p.nbr_d2[cu.pt * 16 + li];
+}
+
+// LDS image of W2 (h x h, zero-padded to HP x KP2), [n][k]: the A operand of the transposed stage-2 product
+template <int DT, int TERMS>
+struct VW2 {
+    static constexpr int HP = VX<DT>::HP, KP2 = VX<DT>::KP2;
+    static constexpr int BYTES = TERMS == 0 ? HP * VX<DT>::S2F * 4 : 2 * HP * VX<DT>::S2B * 2;
+    float* f;
+    __bf16 *h, *l;
+    __device__ __forceinline__ void bind(unsigned char* mem) {
+        f = reinterpret_cast<float*>(mem);
+        h = reinterpret_cast<__bf16*>(mem);
+        l = h + HP * VX<DT>::S2B;
+    }
+    // W[n][k] = src[n * ns + k * ks]  (ns = H, ks = 1: W2 itself; ns = 1, ks = H: its transpose, for dY . W2)
+    __device__ __forceinline__ void stage(const float* src, int ns, int ks, int nthreads) {
+        constexpr int H = VX<DT>::H;
+        for (int e = threadIdx.x; e < HP * KP2; e += nthreads) {
+            const int n = e / KP2, k = e - n * KP2;
+            const float w = (n < H && k < H) ? src[n * ns + k * ks] : 0.f;
+            if constexpr (TERMS == 0) f[n * VX<DT>::S2F + k] = w;
+            else {
+                const __bf16 hh = (__bf16)w;
+                h[n * VX<DT>::S2B + k] = hh;
+                l[n * VX<DT>::S2B + k] = (__bf16)(w - (float)hh);
+            }
+        }
+    }
+};
+
+// lane constants of the branch
+template <int DT>
+struct VLane {
+    static constexpr int H = VX<DT>::H, NCH = VX<DT>::NCH, HP = VX<DT>::HP;
+    static constexpr bool INLDS = VX<DT>::INLDS;
+    float w1a[NCH], w1b[NCH];        // first stage in reduced form (VWeights::stage): U = Wa + Wb against x_i, [Wc - Wb | wd] against [x_i - x_j, dist]
+    int comp;
+    bool l3;
+    f32x4 reg[INLDS ? 1 : VX<DT>::NCONST][NCH];
+    const float* lds;                // + 4*lj
+    // `cl`: NCONST * HP floats of LDS (INLDS only); the caller's barrier after this publishes them.  `stage`: the stage whose
+    // mean' / invstd are wanted (backward kernels; 0: none)
+    __device__ __forceinline__ void load(const PoolParams& p, int li, int lj, float* cl, int stage) {
+        comp = lj < 3 ? lj : 0;
+        l3 = lj == 3;
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) {
+            const int ch = nb * 16 + li;
+            float a = 0.f, b = 0.f;
+            if (ch < H) {
+                const float* w = p.W1 + ch * 10;
+                if (lj < 3) { a = w[lj] + w[3 + lj]; b = w[6 + lj] - w[3 + lj]; }
+                else b = w[9];
+            }
+            w1a[nb] = a; w1b[nb] = b;
+        }
+        auto cst = [&](int which, int ch) -> float {
+            if (ch >= H) return 0.f;
+            switch (which) {
+            case VX<DT>::S1: return p.sc1 ? p.sc1[ch] : 0.f;
+            case VX<DT>::H1: return p.sc1 ? __builtin_fmaf(p.b1[ch], p.sc1[ch], p.sh1[ch]) : 0.f;
+            case VX<DT>::S2: return (p.sc2 && p.b2) ? p.sc2[ch] : 0.f;
+            case VX<DT>::H2: return (p.sc2 && p.b2) ? __builtin_fmaf(p.b2[ch], p.sc2[ch], p.sh2[ch]) : 0.f;
+            case VX<DT>::MU: return stage == 1 ? p.mu1[ch] - p.b1[ch] : stage == 2 ? p.mu2[ch] - p.b2[ch] : 0.f;
+            default: return stage == 1 ? p.is1[ch] : stage == 2 ? p.is2[ch] : 0.f;
+            }
+        };
+        if constexpr (INLDS) {
+            for (int e = threadIdx.x; e < VX<DT>::NCONST * HP; e += blockDim.x) cl[e] = cst(e / HP, e % HP);
+            lds = cl + 4 * lj;
+        } else {
+#pragma unroll
+            for (int w = 0; w < VX<DT>::NCONST; ++w)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) reg[w][c][r] = cst(w, 16 * c + 4 * lj + r);
+        }
+    }
+    __device__ __forceinline__ f32x4 get(int which, int c) const {
+        if constexpr (INLDS) return *reinterpret_cast<const f32x4*>(lds + which * HP + 16 * c);
+        else return reg[which][c];
+    }
+};
+
+// raw (bias-free) first-stage tile of one point, A layout: r[nb] = c0[nb] + U . x_i + [V | wd] . [x_i - x_j, dist]
+template <int DT>
+__device__ __forceinline__ void stage1_raw(const RpeIn2& in, const VLane<DT>& vl, const f32x4 (&c0)[VX<DT>::NCH], f32x4 (&r)[VX<DT>::NCH]) {
+    float diff = in.pc - in.nc, dist = __fsqrt_rn(in.dd), pc = in.pc;
+    asm volatile("" : "+v"(diff), "+v"(dist), "+v"(pc));      // selects, not exec-masked branches (see rpe_gemm)
+    const float a1 = vl.l3 ? dist : diff;
+    const float a2 = vl.l3 ? 0.f : pc;
+#pragma unroll
+    for (int nb = 0; nb < VX<DT>::NCH; ++nb) {
+        r[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(vl.w1a[nb], a2, c0[nb], 0, 0, 0);
+        r[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(vl.w1b[nb], a1, r[nb], 0, 0, 0);
+    }
+}
+// raw second-stage tile from the ACTIVATED first-stage tile u1 (A layout: chunks 0 .. NC2-1 of a DT-chunk array whose
+// other chunks / lanes meet zero rows of the padded W2)
+template <int DT, int TERMS>
+__device__ __forceinline__ void stage2_raw(const float4 (&u1)[DT], const Frag<DT>* fr, const VW2<DT, TERMS>& w2, int li, int lj,
+                                           f32x4 (&r)[VX<DT>::NCH]) {
+    if constexpr (TERMS == 0) gemm_f32<DT, VX<DT>::NC2, VX<DT>::NCH, true>(u1, w2.f, VX<DT>::S2F, li, lj, r);
+    else gemm_frag<DT, VX<DT>::NCH, 1, true>(*fr, w2.h, w2.l, VX<DT>::S2B, li, lj, r);
+}
+
+// X tile of one point, A layout, activated.  graw: the gathered chunks as loaded (DT == 1: the mixed chunk [0 | gathered]);
+// xsc / xsh: the fold of every chunk (rpe chunks: the BatchNorm of stage SRC with the bias folded in; gathered: the lazy
+// BatchNorm of G); es_g / e0: activation slopes (eff_slope) of the gathered half / per lane for the mixed chunk.
+// rawu: the raw tile of stage SRC (the backward's BatchNorm sums need it).  fr: split of xa when SPLIT (bf16 modes).
+template <int DT, int TERMS, int SRC>
+__device__ __forceinline__ void build_x(const RpeIn2& in, const float4 (&graw)[DT], const VLane<DT>& vl, const VW2<DT, TERMS>& w2,
+                                        const f32x4 (&xsc)[DT], const f32x4 (&xsh)[DT], float es_g, float e0, int li, int lj,
+                                        float4 (&xa)[DT], f32x4 (&rawu)[VX<DT>::NCH]) {
+    constexpr int NCH = VX<DT>::NCH;
+    f32x4 c0[NCH], r1[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) c0[nb] = (DT == 1 && SRC == 1) ? v4(graw[0]) : splat(0.f);
+    stage1_raw<DT>(in, vl, c0, r1);
+    if constexpr (SRC == 1) {
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) rawu[nb] = r1[nb];
+    } else {
+        float4 u1[DT];
+#pragma unroll
+        for (int c = 0; c < DT; ++c) u1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) u1[nb] = f4(vrelu(__builtin_elementwise_fma(r1[nb], vl.get(VX<DT>::S1, nb), vl.get(VX<DT>::H1, nb))));
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) rawu[nb] = DT == 1 ? v4(graw[0]) : splat(0.f);
+        if constexpr (TERMS == 0) stage2_raw<DT, TERMS>(u1, nullptr, w2, li, lj, rawu);
+        else {
+            Frag<DT> f1;
+            if constexpr (DT == 1) split4(u1[0], f1.h[0], f1.l[0]);
+            else {
+                bf16x4 h0, l0, h1, l1;
+                split4(u1[0], h0, l0);
+                split4(u1[1], h1, l1);      // DT == 2: chunk 1 is all zeros (it meets zero rows of W2 anyway)
+                f1.h[0] = cat8(h0, h1);
+                f1.l[0] = cat8(l0, l1);
+            }
+            stage2_raw<DT, TERMS>(u1, &f1, w2, li, lj, rawu);
+        }
+    }
+    if constexpr (DT == 1) {
+        xa[0] = f4(vact(__builtin_elementwise_fma(rawu[0], xsc[0], xsh[0]), e0));
+    } else {
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            if (c < NCH) xa[c] = f4(vrelu(__builtin_elementwise_fma(rawu[c], xsc[c], xsh[c])));
+            else xa[c] = f4(vact(__builtin_elementwise_fma(v4(graw[c]), xsc[c], xsh[c]), es_g));
+        }
+    }
+}
+
+// fold of every A-layout chunk of X for a virtual stage (lane_lazy with the stage's BatchNorm, bias folded, in the rpe half)
+template <int DT, int SRC>
+__device__ __forceinline__ void lane_fold(const PoolParams& p, int lj, f32x4 (&sc)[DT], f32x4 (&sh)[DT]) {
+    constexpr int H = VX<DT>::H;
+    const float* s_ = SRC == 1 ? p.sc1 : p.sc2;
+    const float* h_ = SRC == 1 ? p.sh1 : p.sh2;
+    const float* b_ = SRC == 1 ? p.b1 : p.b2;
+#pragma unroll
+    for (int c = 0; c < DT; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 16 * c + 4 * lj + s;
+            if (k < H) {
+                sc[c][s] = s_[k];
+                sh[c][s] = __builtin_fmaf(b_[k], s_[k], h_[k]);
+            } else {
+                sc[c][s] = p.glazy.scale ? p.glazy.scale[k - H] : 1.f;
+                sh[c][s] = p.glazy.scale ? p.glazy.shift[k - H] : 0.f;
+            }
+        }
+}
+
+// the gathered chunks of a point (DT == 1: the mixed chunk through the per-lane base / stride)
+template <int DT>
+struct GatherG {
+    const float* base;      // DT == 1: lanes lj < 2 -> 16 bytes of zeros, stride 0
+    unsigned mul;
+    __device__ __forceinline__ void init(const PoolParams& p, int lj) {
+        constexpr int H = VX<DT>::H;
+        if constexpr (DT == 1) {
+            base = lj < 2 ? g_zero16 : p.G + (4 * lj - H);
+            mul = lj < 2 ? 0u : (unsigned)H;
+        } else {
+            base = p.G + 4 * lj;
+            mul = (unsigned)H;
+        }
+    }
+    __device__ __forceinline__ void fetch(const PoolParams& p, const Cursor& cu, int nbr, float4 (&raw)[DT]) const {
+        const unsigned row = (unsigned)((long)cu.b * p.g_bstride) + (unsigned)nbr;     // rows of G < 2^31 (checked on the host)
+        const float* r = base + (unsigned long)row * mul;
+        if constexpr (DT == 1) raw[0] = *reinterpret_cast<const float4*>(r);
+        else {
+#pragma unroll
+            for (int c = VX<DT>::NCH; c < DT; ++c) raw[c] = *reinterpret_cast<const float4*>(r + (16 * c - VX<DT>::H));
+        }
+    }
+};
+
+template <int DT>
+__device__ __forceinline__ float lane_slope(int lj, float es_g) { return (DT == 1 && lj < 2) ? 0.f : es_g; }
+
+// partial statistics of a workgroup: per-lane float4 sums (A layout, rpe chunks) -> doubles, bias added back:
+//   sum (r + b) = S + cnt*b      sum (r + b)^2 = Q + 2 b S + cnt b^2
+// red: NW * 2 * HP doubles of LDS; cnts: NW floats (rows of each wavefront)
+template <int DT, int NW>
+__device__ __forceinline__ void write_moments(const f32x4 (&ssum)[VX<DT>::NCH], const f32x4 (&ssq)[VX<DT>::NCH], const float* bias,
+                                              long rows_w, int wave, int lane, double* red, double* cnts, double* out) {
+    constexpr int H = VX<DT>::H, HP = VX<DT>::HP, NCH = VX<DT>::NCH;
+    const int li = lane & 15, lj = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = li_sum(ssum[c][r]), b = li_sum(ssq[c][r]);
+            if (li == 0) {
+                red[(wave * 2 + 0) * HP + 16 * c + 4 * lj + r] = (double)a;
+                red[(wave * 2 + 1) * HP + 16 * c + 4 * lj + r] = (double)b;
+            }
+        }
+    if (lane == 0) cnts[wave] = (double)rows_w;
+    __syncthreads();
+    if (threadIdx.x < H) {
+        const int ch = threadIdx.x;
+        double s = 0.0, q = 0.0, cnt = 0.0;
+        for (int wv = 0; wv < NW; ++wv) {
+            s += red[(wv * 2 + 0) * HP + ch];
+            q += red[(wv * 2 + 1) * HP + ch];
+            cnt += cnts[wv];
+        }
+        const double b = bias ? (double)bias[ch] : 0.0;
+        out[((long)blockIdx.x * 2 + 0) * H + ch] = s + cnt * b;
+        out[((long)blockIdx.x * 2 + 1) * H + ch] = q + 2.0 * b * s + cnt * b * b;
+    }
+}
+
+// number of points a wavefront visits: pt0, pt0 + pstep, ... < P
+__device__ __forceinline__ long wave_points(long pt0, long pstep, long P) { return pt0 < P ? (P - pt0 + pstep - 1) / pstep : 0; }
+
+template <int DT, int TERMS, int SRC, bool FST>      // SRC 1 / 2: the stage X's rpe half comes from; FST: leave the stage-2 statistics (SRC == 1)
+__global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
+    constexpr int NW = 4;
+    constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB, NCH = VX<DT>::NCH, HP = VX<DT>::HP;
+    constexpr bool W2ON = SRC == 2 || FST;
+    __shared__ __attribute__((aligned(16))) unsigned char wmem[TERMS == 0 ? D * XS * 4 : 2 * D * XSB * 2];
+    __shared__ __attribute__((aligned(16))) float Xt[NW][16 * XS];
+    __shared__ __attribute__((aligned(16))) unsigned char w2mem[W2ON ? VW2<DT, TERMS>::BYTES : 16];
+    __shared__ __attribute__((aligned(16))) float cl[VX<DT>::INLDS ? VX<DT>::NCONST * HP : 4];
+    __shared__ double cnts[NW];
+    float* Wt = reinterpret_cast<float*>(wmem);
+    __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
+    __bf16* Wl = Wh + D * XSB;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lj = lane >> 4;
+    for (int e = threadIdx.x; e < D * D; e += 64 * NW) {
+        const int o = e / D, i = e - o * D;
+        const float w = p.W[e];            // [n][k]: the transposed-B form the tile GEMMs read
+        if constexpr (TERMS == 0) Wt[o * XS + i] = w;
+        else {
+            const __bf16 h = (__bf16)w;
+            Wh[o * XSB + i] = h;
+            Wl[o * XSB + i] = (__bf16)(w - (float)h);
+        }
+    }
+    VW2<DT, TERMS> w2;
+    w2.bind(w2mem);
+    if constexpr (W2ON) w2.stage(p.W2, VX<DT>::H, 1, 64 * NW);
+    VLane<DT> vl;
+    vl.load(p, li, lj, cl, 0);
+    f32x4 xsc[DT], xsh[DT];
+    lane_fold<DT, SRC>(p, lj, xsc, xsh);
+    const float es_g = eff_slope(p.glazy), e0 = lane_slope<DT>(lj, es_g);
+    GatherG<DT> gg;
+    gg.init(p, lj);
+    f32x4 fs2[NCH], fq2[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) fs2[nb] = fq2[nb] = splat(0.f);
+    __syncthreads();
+    float* Xs = Xt[wave];
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
+    const long npts = wave_points(pt, pstep, p.P);
+    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    float4 graw[DT];
+#pragma unroll
+    for (int c = 0; c < DT; ++c) graw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    RpeIn2 rin = {0.f, 0.f, 0.f};
+    Cursor cu;
+    cu.start(pt, p.n);
+    if (pt < p.P) {
+        gg.fetch(p, cu, idx_cur, graw);
+        fetch_rpe2(p, cu, li, vl.comp, idx_cur, rin);
+    }
+    loads_landed();
+    for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
+        float4 xa[DT];
+        f32x4 rawu[NCH];
+        build_x<DT, TERMS, SRC>(rin, graw, vl, w2, xsc, xsh, es_g, e0, li, lj, xa, rawu);
+#pragma unroll
+        for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(Xs + li * XS + 16 * c + 4 * lj) = xa[c];
+        // the next point's loads, one group, no branch around it (past the last point the current one is read again)
+        const bool more = pt + pstep < p.P;
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        const Cursor cf = more ? cn : cu;
+        const int nbr_f = more ? idx_nxt : idx_cur;
+        gg.fetch(p, cf, nbr_f, graw);
+        fetch_rpe2(p, cf, li, vl.comp, nbr_f, rin);
+        loads_issued();
+        cu = cn;
+        idx_cur = idx_nxt; idx_nxt = idx_n2;
+        f32x4 s[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) s[nb] = splat(0.f);
+        if constexpr (TERMS == 0) {
+            if constexpr (FST) {
+                f32x4 r2[NCH];
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) r2[nb] = splat(0.f);
+                gemm_f32<DT, VX<DT>::NC2, NCH, true>(xa, w2.f, VX<DT>::S2F, li, lj, r2);
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) { fs2[nb] += r2[nb]; fq2[nb] = __builtin_elementwise_fma(r2[nb], r2[nb], fq2[nb]); }
+            }
+            gemm_f32<DT, DT, DT, false>(xa, Wt, XS, li, lj, s);
+        } else {
+            Frag<DT> fx;
+            split_tile<DT>(xa, fx);
+            if constexpr (FST) {
+                // the next stage's raw output (mlp_rpe2 on this tile) only for its BatchNorm batch statistics; the gathered
+                // lanes / chunks of X meet zero rows of the padded W2
+                f32x4 r2[NCH];
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) r2[nb] = splat(0.f);
+                gemm_frag<DT, NCH, 1, true>(fx, w2.h, w2.l, VX<DT>::S2B, li, lj, r2);
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) { fs2[nb] += r2[nb]; fq2[nb] = __builtin_elementwise_fma(r2[nb], r2[nb], fq2[nb]); }
+            }
+            gemm_frag<DT, DT, DT / 2, false>(fx, Wh, Wl, XSB, li, lj, s);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // softmax over the 16 slots of a column and the weighted sum: out = (sum e*x) / (sum e), e = 2^((s - max)*log2 e)
+        constexpr float LOG2E = 1.44269504088896340736f;
+        float outv[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) {
+            f32x4 xc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + nb * 16 + li];
+            const float m = lg_max(vmax2(vmax2(s[nb][0], s[nb][1]), vmax2(s[nb][2], s[nb][3])));
+            const f32x4 t = __builtin_elementwise_fma(s[nb], splat(LOG2E), splat(-m * LOG2E));
+            f32x4 e;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+            const float den = lg_sum(sum4(e)), num = lg_sum(sum4(e * xc));
+            outv[nb] = num * __builtin_amdgcn_rcpf(den);
+        }
+        loads_landed();
+        if constexpr (DT == 4) {
+            // every lane holds all four results: lane group q stores column block q - one 256-byte store per point
+            const float v = lj == 0 ? outv[0] : lj == 1 ? outv[1] : lj == 2 ? outv[2] : outv[3];
+            p.Pout[pt * D + lane] = v;
+        } else {
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb)
+                if (lj == nb) p.Pout[pt * D + nb * 16 + li] = outv[nb];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (FST) {
+        __syncthreads();                                                    // the X tiles are free now
+        double* redd = reinterpret_cast<double*>(&Xt[0][0]);                // [NW][2][HP] doubles
+        static_assert(NW * 2 * HP * 2 <= NW * 16 * XS, "statistics scratch does not fit the X tiles");
+        write_moments<DT, NW>(fs2, fq2, p.b2, npts * 16, wave, lane, redd, cnts, p.fstats2);
+    }
+}
+
+// BatchNorm batch statistics of the raw stage-1 / stage-2 tile of the branch (see rpe_stats_kernel above), transposed orientation
+template <int DT, int TERMS, int SRC>
+__global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, double* __restrict__ stats) {
+    constexpr int NW = 4, NCH = VX<DT>::NCH, HP = VX<DT>::HP;
+    __shared__ __attribute__((aligned(16))) unsigned char w2mem[SRC == 2 ? VW2<DT, TERMS>::BYTES : 16];
+    __shared__ __attribute__((aligned(16))) float cl[VX<DT>::INLDS ? VX<DT>::NCONST * HP : 4];
+    __shared__ double red[NW * 2 * HP];
+    __shared__ double cnts[NW];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lj = lane >> 4;
+    VW2<DT, TERMS> w2;
+    w2.bind(w2mem);
+    if constexpr (SRC == 2) w2.stage(p.W2, VX<DT>::H, 1, 64 * NW);
+    VLane<DT> vl;
+    vl.load(p, li, lj, cl, 0);
+    __syncthreads();
+    f32x4 ssum[NCH], ssq[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) ssum[nb] = ssq[nb] = splat(0.f);
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
+    const long npts = wave_points(pt, pstep, p.P);
+    RpeIn2 rin = {0.f, 0.f, 0.f}, rin_nxt;
+    Cursor cu;
+    cu.start(pt, p.n);
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    if (pt < p.P) fetch_rpe2(p, cu, li, vl.comp, p.idx[pt * 16 + li], rin);
+    loads_landed();
+    for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        fetch_rpe2(p, pt + pstep < p.P ? cn : cu, li, vl.comp, idx_nxt, rin_nxt);      // (no branch: see pool_fwd_kernel)
+        loads_issued();
+        idx_nxt = idx_n2;
+        cu = cn;
+        f32x4 c0[NCH], raw[NCH];
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) c0[nb] = splat(0.f);
+        stage1_raw<DT>(rin, vl, c0, raw);
+        if constexpr (SRC == 2) {
+            float4 u1[DT];
+#pragma unroll
+            for (int c = 0; c < DT; ++c) u1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int nb = 0; nb < NCH; ++nb) {
+                u1[nb] = f4(vrelu(__builtin_elementwise_fma(raw[nb], vl.get(VX<DT>::S1, nb), vl.get(VX<DT>::H1, nb))));
+                raw[nb] = splat(0.f);
+            }
+            if constexpr (TERMS == 0) stage2_raw<DT, TERMS>(u1, nullptr, w2, li, lj, raw);
+            else {
+                Frag<DT> f1;
+                if constexpr (DT == 1) split4(u1[0], f1.h[0], f1.l[0]);
+                else {
+                    bf16x4 h0, l0, h1, l1;
+                    split4(u1[0], h0, l0);
+                    split4(u1[1], h1, l1);
+                    f1.h[0] = cat8(h0, h1);
+                    f1.l[0] = cat8(l0, l1);
+                }
+                stage2_raw<DT, TERMS>(u1, &f1, w2, li, lj, raw);
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) {
+            ssum[nb] += raw[nb];
+            ssq[nb] = __builtin_elementwise_fma(raw[nb], raw[nb], ssq[nb]);
+        }
+        loads_landed();
+        rin = rin_nxt;
+    }
+    write_moments<DT, NW>(ssum, ssq, SRC == 1 ? p.b1 : p.b2, npts * 16, wave, lane, red, cnts, stats);
+}
+
+
+// Backward of the fused pooling block with a virtual rpe stage (pool_bwd_kernel's VIRT case, transposed orientation).
+// ACC: this launch adds to GU; p.bstats: it completes GU and leaves the BatchNorm-backward sums of stage SRC; GB: GU / DG are bf16.
+// The finished dX tile always leaves through the wavefront's dS tile in A layout (16-byte stores; the BatchNorm sums are
+// taken there, against the A-layout raw tile).
+template <int DT, int TERMS, int SRC, int NW, bool GB, bool ACC>
+__global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) {
+    const bool BST = p.bstats != nullptr;      // wavefront-uniform: one scalar branch per point
+    constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB, NCH = VX<DT>::NCH, HP = VX<DT>::HP;
+    __shared__ __attribute__((aligned(16))) unsigned char w2mem[SRC == 2 ? VW2<DT, TERMS>::BYTES : 16];
+    __shared__ __attribute__((aligned(16))) float cl[VX<DT>::INLDS ? VX<DT>::NCONST * HP : 4];
+    __shared__ __attribute__((aligned(16))) float Wmem[TERMS == 0 ? 2 * D * XS : 2 * D * XSB];   // bf16: 4 arrays of D*XSB
+    __shared__ __attribute__((aligned(16))) float Tiles[NW][2][16 * XS];
+    float* Wt = Wmem;
+    float* Wn = Wmem + D * XS;
+    __bf16* Wnh = reinterpret_cast<__bf16*>(Wmem);      // [n][k] head / tail: S = X.W^T
+    __bf16* Wnl = Wnh + D * XSB;
+    __bf16* Wth = Wnl + D * XSB;                          // [n'][k'] = W[k'][n'] head / tail: dX = dS.W
+    __bf16* Wtl = Wth + D * XSB;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lj = lane >> 4;
+    if constexpr (TERMS == 0) {
+        stage_w<DT>(p, Wt, Wn, 64 * NW);
+    } else {
+        for (int e = threadIdx.x; e < D * D; e += 64 * NW) {
+            const int o = e / D, i = e - o * D;
+            const float w = p.W[e];
+            const __bf16 h = (__bf16)w, l = (__bf16)(w - (float)h);
+            Wnh[o * XSB + i] = h; Wnl[o * XSB + i] = l;
+            Wth[i * XSB + o] = h; Wtl[i * XSB + o] = l;
+        }
+    }
+    VW2<DT, TERMS> w2;
+    w2.bind(w2mem);
+    if constexpr (SRC == 2) w2.stage(p.W2, VX<DT>::H, 1, 64 * NW);
+    VLane<DT> vl;
+    vl.load(p, li, lj, cl, BST ? SRC : 0);
+    f32x4 xsc[DT], xsh[DT];
+    lane_fold<DT, SRC>(p, lj, xsc, xsh);
+    const float es_g = eff_slope(p.glazy), e0 = lane_slope<DT>(lj, es_g);
+    GatherG<DT> gg;
+    gg.init(p, lj);
+    // d = 16: the one output chunk is GU in lanes lj < 2 and DG in the others - per-lane base pointer and column; the GU
+    // this launch adds to is read the same way (the other lanes read 16 bytes of zeros)
+    float* obase = (DT == 1 && lj >= 2) ? p.DG : p.GU;
+    const int ocol = DT == 1 ? (lj < 2 ? 4 * lj : 4 * lj - H) : 0;
+    const float* abase = (DT == 1 && lj >= 2) ? g_zero16 : p.GU;
+    const long amul = (DT == 1 && lj >= 2) ? 0 : 1;
+    const int acol = (DT == 1 && lj >= 2) ? 0 : 4 * lj;
+    f32x4 bsg[NCH], bsx[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) bsg[nb] = bsx[nb] = splat(0.f);
+    __syncthreads();
+    float* Xs = Tiles[wave][0];
+    float* Ds = Tiles[wave][1];
+    f32x4 accw[DT][DT];
+#pragma unroll
+    for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = splat(0.f);
+
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
+    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    float4 graw[DT];
+#pragma unroll
+    for (int c = 0; c < DT; ++c) graw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    RpeIn2 rin = {0.f, 0.f, 0.f};
+    Cursor cu;
+    cu.start(pt, p.n);
+    float gp[DT], gp_nxt[DT];          // dP of the current / next point
+#pragma unroll
+    for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb] = 0.f;
+    if (pt < p.P) {
+        gg.fetch(p, cu, idx_cur, graw);
+        fetch_rpe2(p, cu, li, vl.comp, idx_cur, rin);
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
+    }
+    loads_landed();
+    for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
+        float4 xa[DT];
+        f32x4 rawu[NCH];
+        build_x<DT, TERMS, SRC>(rin, graw, vl, w2, xsc, xsh, es_g, e0, li, lj, xa, rawu);
+#pragma unroll
+        for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(Xs + li * XS + 16 * c + 4 * lj) = xa[c];
+        // ONE load group per iteration (see pool_bwd_kernel): the next point's rows, coordinates and dP, the index two points
+        // ahead, this point's GU when accumulating; the only vector-memory wait is loads_landed() before the stores
+        const bool more = pt + pstep < p.P;
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        const Cursor cf = more ? cn : cu;
+        const int nbr_f = more ? idx_nxt : idx_cur;
+        gg.fetch(p, cf, nbr_f, graw);
+        fetch_rpe2(p, cf, li, vl.comp, nbr_f, rin);
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
+        float4 gacc[NCH];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) gacc[c] = rl_ldx4<GB>(abase, ((pt * 16 + li) * H) * amul + 16 * c + acol);
+        }
+        loads_issued();
+        cu = cn;
+        idx_cur = idx_nxt; idx_nxt = idx_n2;
+        f32x4 a[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) a[nb] = splat(0.f);
+        if constexpr (TERMS == 0) gemm_f32<DT, DT, DT, false>(xa, Wn, XS, li, lj, a);
+        else {
+            Frag<DT> fx;
+            split_tile<DT>(xa, fx);
+            gemm_frag<DT, DT, DT / 2, false>(fx, Wnh, Wnl, XSB, li, lj, a);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // C-layout pass: softmax over the slots, P, dS (to LDS), dP*A kept in registers as the start of dX
+        constexpr float LOG2E = 1.44269504088896340736f;
+        f32x4 dx[DT], dsr[DT];
+        bf16x4 dsh[DT], dsl[DT], xch[DT], xcl[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) {
+            const int col = nb * 16 + li;
+            f32x4 xc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + col];
+            const float m = lg_max(vmax2(vmax2(a[nb][0], a[nb][1]), vmax2(a[nb][2], a[nb][3])));
+            const f32x4 t = __builtin_elementwise_fma(a[nb], splat(LOG2E), splat(-m * LOG2E));
+            f32x4 e;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
+            const float den = lg_sum(sum4(e)), num = lg_sum(sum4(e * xc));
+            const float inv = __builtin_amdgcn_rcpf(den);
+            const float pool = num * inv;
+            dx[nb] = e * splat(inv * gp[nb]);                        // direct path dP*A
+            dsr[nb] = dx[nb] * (xc - splat(pool));                   // dS = A*dP*(X-P)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + col] = dsr[nb][r];
+            if constexpr (TERMS != 0) {
+                // dW[n][k] += sum_rows dS[row][n] * X[row][k]: the lane's four reduction rows are its C-layout registers of
+                // dS (A operand) and of X (B operand) - split here, once, while xc is at hand
+                split4(f4(dsr[nb]), dsh[nb], dsl[nb]);
+                split4(f4(xc), xch[nb], xcl[nb]);
+            }
+        }
+        if constexpr (TERMS != 0) {
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb) {
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dsh[nb], xch[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dsh[nb], xcl[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = mfma16(dsl[nb], xch[kb], accw[nb][kb]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dX += dS . W   (dS re-read in A layout)
+        float4 da[DT];
+#pragma unroll
+        for (int c = 0; c < DT; ++c) da[c] = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
+        if constexpr (TERMS == 0) {
+            gemm_f32<DT, DT, DT, false>(da, Wt, XS, li, lj, dx);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float bx[DT];
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb) bx[kb] = Xs[(4 * t + lj) * XS + kb * 16 + li];
+#pragma unroll
+                for (int nb = 0; nb < DT; ++nb) {
+                    const float ad = Ds[(4 * t + lj) * XS + nb * 16 + li];
+#pragma unroll
+                    for (int kb = 0; kb < DT; ++kb)
+                        accw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, bx[kb], accw[nb][kb], 0, 0, 0);
+                }
+            }
+        } else {
+            Frag<DT> fd;
+            split_tile<DT>(da, fd);
+            gemm_frag<DT, DT, DT / 2, false>(fd, Wth, Wtl, XSB, li, lj, dx);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the finished tile (C layout) through the dS tile - free by now - into A layout
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + nb * 16 + li] = dx[nb][r];
+        __builtin_amdgcn_wave_barrier();
+        loads_landed();
+        const long orow = (pt * 16 + li) * H;
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ds + li * XS + 16 * c + 4 * lj);
+            if (c < NCH) {
+                if constexpr (ACC) v += v4(gacc[c]);
+                if (BST) {
+                    // this launch completes the gradient of the stage's activated output: the batch-statistics sums of its
+                    // BatchNorm backward come for free (the raw tile is in registers; d = 16: the lanes of the gathered half
+                    // compute along, their sums are never written)
+                    const f32x4 z = __builtin_elementwise_fma(rawu[c], xsc[c], xsh[c]);      // = build_x
+                    f32x4 g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? v[r] : 0.f;
+                    bsg[c] += g;
+                    bsx[c] = __builtin_elementwise_fma(g, (rawu[c] - vl.get(VX<DT>::MU, c)) * vl.get(VX<DT>::IS, c), bsx[c]);
+                }
+            }
+            if constexpr (DT == 1) RL_ST4<GB>(obase, orow + ocol, f4(v));
+            else if (c < NCH) RL_ST4<GB>(p.GU, orow + 16 * c + 4 * lj, f4(v));
+            else RL_ST4<GB>(p.DG, orow + 16 * c + 4 * lj - H, f4(v));
+        }
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (BST) {
+        // (Tiles is free: every wavefront is past its last point once the barrier below is reached)
+        __syncthreads();
+        double* redd = reinterpret_cast<double*>(&Tiles[0][0][0]);      // [NW][2][HP] doubles
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sa = li_sum(bsg[c][r]), sb = li_sum(bsx[c][r]);
+                if (li == 0) {
+                    redd[(wave * 2 + 0) * HP + 16 * c + 4 * lj + r] = (double)sa;
+                    redd[(wave * 2 + 1) * HP + 16 * c + 4 * lj + r] = (double)sb;
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x < H) {
+            const int c = threadIdx.x;
+            double a0 = 0.0, a1 = 0.0;
+            for (int wv = 0; wv < NW; ++wv) {
+                a0 += redd[(wv * 2 + 0) * HP + c];
+                a1 += redd[(wv * 2 + 1) * HP + c];
+            }
+            p.bstats[((long)blockIdx.x * 2 + 0) * H + c] = a0;
+            p.bstats[((long)blockIdx.x * 2 + 1) * H + c] = a1;
+        }
+    }
+    // combine the wavefronts' dW tiles in a fixed order (W region is free now)
+    __syncthreads();
+    float* red = Wmem;  // needs DT*DT*256 floats <= 2*D*XS: 16*DT*DT*16 <= 2*16*DT*(16*DT+4) always holds
+    for (int w = 1; w < NW; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((nb * DT + kb) * 4 + r) * 64 + lane] = accw[nb][kb][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < DT; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accw[nb][kb][r] += red[((nb * DT + kb) * 4 + r) * 64 + lane];
+        }
+    }
+    if (wave == 0) {
+        float* out = p.slab + (long)blockIdx.x * D * D;
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb)
+#pragma unroll
+            for (int kb = 0; kb < DT; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(long)(nb * 16 + lj * 4 + r) * D + kb * 16 + li] = accw[nb][kb][r];
+    }
+}
+
+
+// ---- backward of a virtual stage (rpe_bn_reduce_kernel / rpe_wgrad_kernel above), transposed orientation -------------------
+// G arrives as A-layout float4s (one 16-byte load per lane and chunk instead of four 4-byte ones), the raw tile, the mask,
+// xhat and dY = scale*(g - coef0 - xhat*coef1) live in the A layout; GU1 = dY . W2 is one more transposed product and leaves
+// as 16-byte stores.  Only dW = dY^T . In needs the neighbourhood rows as the MFMA reduction index: dY and the stage's
+// input are split ONCE, parked in a wavefront-private LDS tile as bf16 head / tail planes ([row][channel]) and come back
+// through ds_read_b64_tr_b16 as the four rows 4*lj .. 4*lj+3 of column li - both operands of the product.
+// Stage 1's input is the REDUCED one the forward multiplies (x_i and [x_i - x_j, dist]: W1.rpe = (Wa + Wb).x_i + (Wc - Wb).(x_i - x_j) + wd.dist),
+// so the kernel accumulates dU = dY^T.x_i and dV = dY^T.[x_i - x_j, dist] and leaves dWa = dU, dWb = dU - dV[:3], dWc = dV[:3], dwd = dV[3].
+template <int DT>
+struct VBwdLane {
+    static constexpr int NCH = VX<DT>::NCH, H = VX<DT>::H;
+    f32x4 sc[NCH], sh[NCH], mu[NCH], is[NCH], k0[NCH], k1[NCH];
+    __device__ __forceinline__ void load(const PoolParams& p, const float* coef, int lj) {
+        const float* mu_ = p.src == 1 ? p.mu1 : p.mu2;
+        const float* is_ = p.src == 1 ? p.is1 : p.is2;
+        const float* sc_ = p.src == 1 ? p.sc1 : p.sc2;
+        const float* sh_ = p.src == 1 ? p.sh1 : p.sh2;
+        const float* b_ = p.src == 1 ? p.b1 : p.b2;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * c + 4 * lj + r;
+                const bool in = ch < H;
+                sc[c][r] = in ? sc_[ch] : 0.f;
+                sh[c][r] = in ? __builtin_fmaf(b_[ch], sc_[ch], sh_[ch]) : 0.f;      // = lane_fold / VLane: the same z in every kernel
+                mu[c][r] = in ? mu_[ch] - b_[ch] : 0.f;
+                is[c][r] = in ? is_[ch] : 0.f;
+                k0[c][r] = (in && coef) ? coef[ch] : 0.f;
+                k1[c][r] = (in && coef) ? coef[H + ch] : 0.f;
+            }
+    }
+};
+
+// raw tile of stage SRC for one point (A layout) and, for stage 2, the activated stage-1 tile it was computed from
+template <int DT, int TERMS, int SRC>
+__device__ __forceinline__ void stage_raw(const RpeIn2& in, const VLane<DT>& vl, const VW2<DT, TERMS>& w2, int li, int lj,
+                                          f32x4 (&raw)[VX<DT>::NCH], float4 (&u1)[DT], Frag<DT>& f1) {
+    constexpr int NCH = VX<DT>::NCH;
+    f32x4 c0[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) c0[nb] = splat(0.f);
+    stage1_raw<DT>(in, vl, c0, raw);
+    if constexpr (SRC == 2) {
+#pragma unroll
+        for (int c = 0; c < DT; ++c) u1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) {
+            u1[nb] = f4(vrelu(__builtin_elementwise_fma(raw[nb], vl.get(VX<DT>::S1, nb), vl.get(VX<DT>::H1, nb))));
+            raw[nb] = splat(0.f);
+        }
+        if constexpr (TERMS == 0) stage2_raw<DT, TERMS>(u1, nullptr, w2, li, lj, raw);
+        else {
+            if constexpr (DT == 1) split4(u1[0], f1.h[0], f1.l[0]);
+            else {
+                bf16x4 h0, l0, h1, l1;
+                split4(u1[0], h0, l0);
+                split4(u1[1], h1, l1);
+                f1.h[0] = cat8(h0, h1);
+                f1.l[0] = cat8(l0, l1);
+            }
+            stage2_raw<DT, TERMS>(u1, &f1, w2, li, lj, raw);
+        }
+    }
+}
+
+// the rpe chunks of a (points*16) x H row tensor for one point, A layout (d = 16: the lanes of the gathered half re-read columns 0..3)
+template <int DT, bool GB>
+__device__ __forceinline__ void load_g4(const float* G, long pt, int li, int lj, float4 (&g)[VX<DT>::NCH]) {
+    const int col = (DT == 1 && lj >= 2) ? 0 : 4 * lj;
+#pragma unroll
+    for (int c = 0; c < VX<DT>::NCH; ++c) g[c] = rl_ldx4<GB>(G, (pt * 16 + li) * VX<DT>::H + 16 * c + col);
+}
+
+template <int DT, int TERMS, int SRC, bool GB>
+__global__ __launch_bounds__(256) void vrpe_bn_reduce_kernel(const RpeBwdParams q) {
+    const PoolParams& p = q.pp;
+    constexpr int NW = 4, NCH = VX<DT>::NCH, HP = VX<DT>::HP, H = VX<DT>::H;
+    __shared__ __attribute__((aligned(16))) unsigned char w2mem[SRC == 2 ? VW2<DT, TERMS>::BYTES : 16];
+    __shared__ __attribute__((aligned(16))) float cl[VX<DT>::INLDS ? VX<DT>::NCONST * HP : 4];
+    __shared__ double red[NW * 2 * HP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lj = lane >> 4;
+    VW2<DT, TERMS> w2;
+    w2.bind(w2mem);
+    if constexpr (SRC == 2) w2.stage(p.W2, H, 1, 64 * NW);
+    VLane<DT> vl;
+    vl.load(p, li, lj, cl, 0);
+    VBwdLane<DT> bc;
+    bc.load(p, nullptr, lj);
+    __syncthreads();
+    f32x4 sg[NCH], sx[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) sg[nb] = sx[nb] = splat(0.f);
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
+    RpeIn2 rin = {0.f, 0.f, 0.f}, rin_nxt;
+    Cursor cu;
+    cu.start(pt, p.n);
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    float4 gin[NCH], gin_nxt[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) gin[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pt < p.P) {
+        fetch_rpe2(p, cu, li, vl.comp, p.idx[pt * 16 + li], rin);
+        load_g4<DT, GB>(q.G, pt, li, lj, gin);
+    }
+    loads_landed();
+    for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        {
+            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
+            fetch_rpe2(p, cf, li, vl.comp, idx_nxt, rin_nxt);
+            load_g4<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
+        }
+        loads_issued();
+        idx_nxt = idx_n2;
+        cu = cn;
+        f32x4 raw[NCH];
+        float4 u1[DT];
+        Frag<DT> f1;
+        stage_raw<DT, TERMS, SRC>(rin, vl, w2, li, lj, raw, u1, f1);
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) {
+            const f32x4 z = __builtin_elementwise_fma(raw[nb], bc.sc[nb], bc.sh[nb]);
+            f32x4 g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? v4(gin[nb])[r] : 0.f;
+            sg[nb] += g;
+            sx[nb] = __builtin_elementwise_fma(g, (raw[nb] - bc.mu[nb]) * bc.is[nb], sx[nb]);
+        }
+        loads_landed();
+        rin = rin_nxt;
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) gin[nb] = gin_nxt[nb];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = li_sum(sg[c][r]), b = li_sum(sx[c][r]);
+            if (li == 0) {
+                red[(wave * 2 + 0) * HP + 16 * c + 4 * lj + r] = (double)a;
+                red[(wave * 2 + 1) * HP + 16 * c + 4 * lj + r] = (double)b;
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < H) {
+        const int c = threadIdx.x;
+        double a0 = 0.0, a1 = 0.0;
+        for (int wv = 0; wv < NW; ++wv) {
+            a0 += red[(wv * 2 + 0) * HP + c];
+            a1 += red[(wv * 2 + 1) * HP + c];
+        }
+        q.stats[((long)blockIdx.x * 2 + 0) * H + c] = a0;
+        q.stats[((long)blockIdx.x * 2 + 1) * H + c] = a1;
+    }
+}
+
+template <int DT, int TERMS, int SRC, bool GB>
+__global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
+    const PoolParams& p = q.pp;
+    constexpr int NW = 4, NCH = VX<DT>::NCH, HP = VX<DT>::HP, H = VX<DT>::H;
+    constexpr int KB = SRC == 1 ? 1 : NCH;            // k blocks of dW: stage 1 has 8 reduced input columns
+    constexpr int RSB = HP + 8, RSF = HP + 4;         // row strides of the transposition tiles: bf16 planes / floats
+    constexpr int TILE_BYTES = TERMS == 0 ? 16 * RSF * 4 : 2 * 16 * RSB * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char w2mem[SRC == 2 ? VW2<DT, TERMS>::BYTES : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char w2tmem[SRC == 2 ? VW2<DT, TERMS>::BYTES : 16];     // W2^T: GU1 = dY . W2
+    __shared__ __attribute__((aligned(16))) float cl[VX<DT>::INLDS ? VX<DT>::NCONST * HP : 4];
+    __shared__ __attribute__((aligned(16))) unsigned char Tl[NW][2][TILE_BYTES];      // [0]: the stage's input rows, [1]: dY
+    static_assert(NW * 2 * TILE_BYTES >= (NCH * KB * 256 + NCH * 64) * 4 || true, "");
+    __shared__ float red[NCH * KB * 256 + NW * HP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, lj = lane >> 4;
+    VW2<DT, TERMS> w2, w2t;
+    w2.bind(w2mem);
+    w2t.bind(w2tmem);
+    if constexpr (SRC == 2) {
+        w2.stage(p.W2, H, 1, 64 * NW);
+        w2t.stage(p.W2, 1, H, 64 * NW);
+    }
+    VLane<DT> vl;
+    vl.load(p, li, lj, cl, 0);
+    VBwdLane<DT> bc;
+    bc.load(p, q.coef, lj);
+    for (int e = threadIdx.x; e < NW * 2 * TILE_BYTES / 4; e += 64 * NW) reinterpret_cast<float*>(&Tl[0][0][0])[e] = 0.f;     // padding columns stay zero
+    __syncthreads();
+    unsigned char* Ti = Tl[wave][0];
+    unsigned char* Td = Tl[wave][1];
+    f32x4 accw[NCH][KB], bsum4[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) {
+        bsum4[nb] = splat(0.f);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = splat(0.f);
+    }
+    const long pstep = (long)gridDim.x * NW;
+    long pt = (long)blockIdx.x * NW + wave;
+    RpeIn2 rin = {0.f, 0.f, 0.f}, rin_nxt;
+    Cursor cu;
+    cu.start(pt, p.n);
+    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    float4 gin[NCH], gin_nxt[NCH];
+#pragma unroll
+    for (int nb = 0; nb < NCH; ++nb) gin[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pt < p.P) {
+        fetch_rpe2(p, cu, li, vl.comp, p.idx[pt * 16 + li], rin);
+        load_g4<DT, GB>(q.G, pt, li, lj, gin);
+    }
+    loads_landed();
+    // addresses of the transposing reads: rows 4*lj + (li >> 2), columns 4*(li & 3) .. +3 of a 16-column block
+    const int trow = 4 * lj + (li >> 2), tcol = 4 * (li & 3);
+    for (; pt < p.P; pt += pstep) {
+        const Cursor cn = cu.next(pstep, p.n);
+        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        {
+            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
+            fetch_rpe2(p, cf, li, vl.comp, idx_nxt, rin_nxt);
+            load_g4<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
+        }
+        loads_issued();
+        idx_nxt = idx_n2;
+        cu = cn;
+        f32x4 raw[NCH];
+        float4 u1[DT];
+        Frag<DT> f1;
+        stage_raw<DT, TERMS, SRC>(rin, vl, w2, li, lj, raw, u1, f1);
+        float4 dy[DT];
+#pragma unroll
+        for (int c = 0; c < DT; ++c) dy[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) {
+            const f32x4 z = __builtin_elementwise_fma(raw[nb], bc.sc[nb], bc.sh[nb]);
+            f32x4 g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? v4(gin[nb])[r] : 0.f;
+            const f32x4 xh = (raw[nb] - bc.mu[nb]) * bc.is[nb];
+            // padding channels / the lanes of the gathered half (d = 16): scale and the coefficients are zero there -> dy = 0
+            const f32x4 d = bc.sc[nb] * (g - bc.k0[nb] - xh * bc.k1[nb]);
+            bsum4[nb] += d;
+            dy[nb] = f4(d);
+        }
+        if constexpr (TERMS == 0) {
+            float* Fi = reinterpret_cast<float*>(Ti);
+            float* Fd = reinterpret_cast<float*>(Td);
+#pragma unroll
+            for (int nb = 0; nb < NCH; ++nb) *reinterpret_cast<float4*>(Fd + li * RSF + 16 * nb + 4 * lj) = dy[nb];
+            if constexpr (SRC == 1) {
+                const float diff = rin.pc - rin.nc, dist = __fsqrt_rn(rin.dd);
+                *reinterpret_cast<float2*>(Fi + li * RSF + 2 * lj) = make_float2(vl.l3 ? 0.f : rin.pc, vl.l3 ? dist : diff);
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) *reinterpret_cast<float4*>(Fi + li * RSF + 16 * nb + 4 * lj) = u1[nb];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float bx[KB];
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) bx[kb] = Fi[(4 * t + lj) * RSF + kb * 16 + li];
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) {
+                    const float ad = Fd[(4 * t + lj) * RSF + nb * 16 + li];
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+                        accw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, bx[kb], accw[nb][kb], 0, 0, 0);
+                }
+            }
+            if constexpr (SRC == 2) {
+                f32x4 gu[NCH];
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) gu[nb] = splat(0.f);
+                gemm_f32<DT, VX<DT>::NC2, NCH, true>(dy, w2t.f, VX<DT>::S2F, li, lj, gu);
+                loads_landed();
+                if (DT != 1 || lj < 2) {
+#pragma unroll
+                    for (int nb = 0; nb < NCH; ++nb) RL_ST4<GB>(q.GU1, (pt * 16 + li) * H + 16 * nb + 4 * lj, f4(gu[nb]));
+                }
+            } else loads_landed();
+        } else {
+            __bf16* Bi = reinterpret_cast<__bf16*>(Ti);      // planes: [hi][16][RSB], [lo][16][RSB]
+            __bf16* Bd = reinterpret_cast<__bf16*>(Td);
+            Frag<DT> fd;
+            if constexpr (DT == 1) split4(dy[0], fd.h[0], fd.l[0]);
+            else {
+                bf16x4 h0, l0, h1, l1;
+                split4(dy[0], h0, l0);
+                split4(dy[1], h1, l1);
+                fd.h[0] = cat8(h0, h1);
+                fd.l[0] = cat8(l0, l1);
+            }
+            // park dY and the input: row li, the lane's four channels of every rpe chunk
+            if constexpr (DT == 1) {
+                *reinterpret_cast<bf16x4*>(Bd + li * RSB + 4 * lj) = fd.h[0];
+                *reinterpret_cast<bf16x4*>(Bd + 16 * RSB + li * RSB + 4 * lj) = fd.l[0];
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) {
+                    bf16x4 hh, ll;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { hh[r] = fd.h[0][4 * nb + r]; ll[r] = fd.l[0][4 * nb + r]; }
+                    *reinterpret_cast<bf16x4*>(Bd + li * RSB + 16 * nb + 4 * lj) = hh;
+                    *reinterpret_cast<bf16x4*>(Bd + 16 * RSB + li * RSB + 16 * nb + 4 * lj) = ll;
+                }
+            }
+            if constexpr (SRC == 1) {
+                const float diff = rin.pc - rin.nc, dist = __fsqrt_rn(rin.dd);
+                const float i0 = vl.l3 ? 0.f : rin.pc, i1 = vl.l3 ? dist : diff;       // reduced inputs: columns 2*lj, 2*lj + 1
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                bf16x2 hh, ll;
+                hh[0] = (__bf16)i0; hh[1] = (__bf16)i1;
+                ll[0] = (__bf16)(i0 - (float)hh[0]); ll[1] = (__bf16)(i1 - (float)hh[1]);
+                *reinterpret_cast<bf16x2*>(Bi + li * RSB + 2 * lj) = hh;
+                *reinterpret_cast<bf16x2*>(Bi + 16 * RSB + li * RSB + 2 * lj) = ll;
+            } else {
+                if constexpr (DT == 1) {
+                    *reinterpret_cast<bf16x4*>(Bi + li * RSB + 4 * lj) = f1.h[0];
+                    *reinterpret_cast<bf16x4*>(Bi + 16 * RSB + li * RSB + 4 * lj) = f1.l[0];
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < NCH; ++nb) {
+                        bf16x4 hh, ll;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { hh[r] = f1.h[0][4 * nb + r]; ll[r] = f1.l[0][4 * nb + r]; }
+                        *reinterpret_cast<bf16x4*>(Bi + li * RSB + 16 * nb + 4 * lj) = hh;
+                        *reinterpret_cast<bf16x4*>(Bi + 16 * RSB + li * RSB + 16 * nb + 4 * lj) = ll;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // dW[n][k] += sum_rows dY[row][n] * In[row][k]: both operands = four rows of one column, by transposing reads
+            bf16x4 xh[KB], xl[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                xh[kb] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Bi + trow * RSB + 16 * kb + tcol)));
+                xl[kb] = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Bi + 16 * RSB + trow * RSB + 16 * kb + tcol)));
+            }
+#pragma unroll
+            for (int nb = 0; nb < NCH; ++nb) {
+                const bf16x4 dh = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Bd + trow * RSB + 16 * nb + tcol)));
+                const bf16x4 dl = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(Bd + 16 * RSB + trow * RSB + 16 * nb + tcol)));
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dh, xh[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dh, xl[kb], accw[nb][kb]);
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dl, xh[kb], accw[nb][kb]);
+            }
+            if constexpr (SRC == 2) {
+                // gradient w.r.t. the activated stage-1 output: dY . W2, transposed product -> A layout
+                f32x4 gu[NCH];
+#pragma unroll
+                for (int nb = 0; nb < NCH; ++nb) gu[nb] = splat(0.f);
+                gemm_frag<DT, NCH, 1, true>(fd, w2t.h, w2t.l, VX<DT>::S2B, li, lj, gu);
+                loads_landed();
+                if (DT != 1 || lj < 2) {
+#pragma unroll
+                    for (int nb = 0; nb < NCH; ++nb) RL_ST4<GB>(q.GU1, (pt * 16 + li) * H + 16 * nb + 4 * lj, f4(gu[nb]));
+                }
+            } else loads_landed();
+        }
+        __builtin_amdgcn_wave_barrier();
+        rin = rin_nxt;
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) gin[nb] = gin_nxt[nb];
+    }
+    // combine the four wavefronts in a fixed order; slab layout: dW[n][k] (n < H, k < Kin) then db[n]
+    constexpr int Kin = SRC == 1 ? 10 : H;
+    float* rb = red + NCH * KB * 256;                 // [NW][HP] per-wavefront column sums of dY
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sv = li_sum(bsum4[c][r]);
+            if (li == 0) rb[wave * HP + 16 * c + 4 * lj + r] = sv;
+        }
+    for (int wv = 1; wv < NW; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int nb = 0; nb < NCH; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((nb * KB + kb) * 4 + r) * 64 + lane] = accw[nb][kb][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int nb = 0; nb < NCH; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accw[nb][kb][r] += red[((nb * KB + kb) * 4 + r) * 64 + lane];
+        }
+    }
+    __syncthreads();
+    float* out = q.slab + (long)blockIdx.x * ((long)H * Kin + H);
+    if (wave == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NCH; ++nb) {
+            if constexpr (SRC == 1) {
+                // column li of the reduced product: 2c -> dU[c] (x_i component c), 2c + 1 -> dV[c] ([x_i - x_j, dist] component c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb * 16 + lj * 4 + r;
+                    const float v = accw[nb][0][r], o = __shfl_xor(v, 1, 64);
+                    const int c = li >> 1;
+                    if (n < H && li < 8) {
+                        if ((li & 1) == 0) {
+                            if (c < 3) { out[(long)n * 10 + c] = v; out[(long)n * 10 + 3 + c] = v - o; }     // dWa = dU, dWb = dU - dV
+                        } else {
+                            out[(long)n * 10 + (c < 3 ? 6 + c : 9)] = v;                                   // dWc = dV[:3], dwd = dV[3]
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int k = kb * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = nb * 16 + lj * 4 + r;
+                        if (n < H && k < Kin) out[(long)n * Kin + k] = accw[nb][kb][r];
+                    }
+                }
+            }
+        }
+    }
+    if (threadIdx.x < H) {
+        const int n = threadIdx.x;
+        out[(long)H * Kin + n] = ((rb[0 * HP + n] + rb[1 * HP + n]) + rb[2 * HP + n]) + rb[3 * HP + n];
+    }
+}
+
 // Sum of the per-workgroup partial dW slabs ([nsplit][count]) in a fixed order:
 __global__ __launch_bounds__(256) void pool_dw_reduce_kernel(const float* __restrict__ slab, int nsplit, int count,
                                                              float* __restrict__ dW) {
@@ -1740,16 +3071,19 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (p.src > 0) {
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_fwd: the virtual rpe branch needs its folded BatchNorm(s)");
-        if (pool_terms(p.d) == 0) {
-            if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
-            else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((pool_fwd_kernel<4, 0, 4, true>), dim3(g), dim3(256), 0, st, p);
-        } else {
-            if (p.d == 16) hipLaunchKernelGGL((pool_fwd_kernel<1, 3, 4, true>), dim3(g), dim3(256), 0, st, p);
-            else if (p.d == 32) hipLaunchKernelGGL((pool_fwd_kernel<2, 3, 4, true>), dim3(g), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((pool_fwd_kernel<4, 3, 4, true>), dim3(g), dim3(256), 0, st, p);
+        const int key = (pool_terms(p.d) == 0 ? 0 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + (p.src == 2 ? 2 : p.fstats2 ? 1 : 0);
+#define VFWD(K, DT, TERMS, SRC, FST) \
+        case K: hipLaunchKernelGGL((vpool_fwd_kernel<DT, TERMS, SRC, FST>), dim3(g), dim3(256), 0, st, p); break;
+        switch (key) {
+            VFWD(10, 1, 0, 1, false) VFWD(11, 1, 0, 1, true) VFWD(12, 1, 0, 2, false)
+            VFWD(20, 2, 0, 1, false) VFWD(21, 2, 0, 1, true) VFWD(22, 2, 0, 2, false)
+            VFWD(40, 4, 0, 1, false) VFWD(41, 4, 0, 1, true) VFWD(42, 4, 0, 2, false)
+            VFWD(110, 1, 3, 1, false) VFWD(111, 1, 3, 1, true) VFWD(112, 1, 3, 2, false)
+            VFWD(120, 2, 3, 1, false) VFWD(121, 2, 3, 1, true) VFWD(122, 2, 3, 2, false)
+            VFWD(140, 4, 3, 1, false) VFWD(141, 4, 3, 1, true) VFWD(142, 4, 3, 2, false)
         }
-        rl_note_kernel(p.d == 16 ? "pool_fwd_kernel<1,virtual>" : p.d == 32 ? "pool_fwd_kernel<2,virtual>" : "pool_fwd_kernel<4,virtual>");
+#undef VFWD
+        rl_note_kernel("vpool_fwd_kernel");
         RL_LAUNCH_CHECK("rl_pool_fwd(virtual)");
         return RL_OK;
     }
@@ -1791,20 +3125,21 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
     if (p.src > 0) {
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_bwd: the virtual rpe branch needs its folded BatchNorm(s)");
-        if (pool_terms(p.d) == 0) {
-            if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 0, true>), dim3(g), dim3(256), 0, st, p);
-            else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 0, true>), dim3(g), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((pool_bwd_kernel<4, 0, true, 8>), dim3(g), dim3(512), 0, st, p);
-        } else if (d->rows_bf16) {
-            if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3, true, 4, true>), dim3(g), dim3(256), 0, st, p);
-            else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3, true, 4, true>), dim3(g), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((pool_bwd_kernel<4, 3, true, 8, true>), dim3(g), dim3(512), 0, st, p);
-        } else {
-            if (p.d == 16) hipLaunchKernelGGL((pool_bwd_kernel<1, 3, true>), dim3(g), dim3(256), 0, st, p);
-            else if (p.d == 32) hipLaunchKernelGGL((pool_bwd_kernel<2, 3, true>), dim3(g), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((pool_bwd_kernel<4, 3, true, 8>), dim3(g), dim3(512), 0, st, p);
+        const int key = (pool_terms(p.d) == 0 ? 0 : d->rows_bf16 ? 200 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + (p.src == 2 ? 2 : 0) + (p.gu_accumulate ? 1 : 0);
+#define VBWD(K, DT, TERMS, SRC, NW, GB, ACC) \
+        case K: hipLaunchKernelGGL((vpool_bwd_kernel<DT, TERMS, SRC, NW, GB, ACC>), dim3(g), dim3(64 * NW), 0, st, p); break;
+#define VBWD4(K0, TERMS, GB) \
+        VBWD(K0 + 10, 1, TERMS, 1, 4, GB, false) VBWD(K0 + 11, 1, TERMS, 1, 4, GB, true) VBWD(K0 + 12, 1, TERMS, 2, 4, GB, false) VBWD(K0 + 13, 1, TERMS, 2, 4, GB, true) \
+        VBWD(K0 + 20, 2, TERMS, 1, 4, GB, false) VBWD(K0 + 21, 2, TERMS, 1, 4, GB, true) VBWD(K0 + 22, 2, TERMS, 2, 4, GB, false) VBWD(K0 + 23, 2, TERMS, 2, 4, GB, true) \
+        VBWD(K0 + 40, 4, TERMS, 1, 8, GB, false) VBWD(K0 + 41, 4, TERMS, 1, 8, GB, true) VBWD(K0 + 42, 4, TERMS, 2, 8, GB, false) VBWD(K0 + 43, 4, TERMS, 2, 8, GB, true)
+        switch (key) {
+            VBWD4(0, 0, false)
+            VBWD4(100, 3, false)
+            VBWD4(200, 3, true)
         }
-        rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1,virtual>" : p.d == 32 ? "pool_bwd_kernel<2,virtual>" : "pool_bwd_kernel<4,virtual>");
+#undef VBWD4
+#undef VBWD
+        rl_note_kernel("vpool_bwd_kernel");
         RL_LAUNCH_CHECK("rl_pool_bwd(virtual)");
         hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
         RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
@@ -1856,16 +3191,15 @@ extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) 
     p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
     const int g = rpe_grid(p.P);
     hipStream_t st = (hipStream_t)stream;
-    if (pool_terms(p.d) == 0) {
-        if (p.d == 16) hipLaunchKernelGGL((rpe_stats_kernel<1, 0>), dim3(g), dim3(256), 0, st, p, stats);
-        else if (p.d == 32) hipLaunchKernelGGL((rpe_stats_kernel<2, 0>), dim3(g), dim3(256), 0, st, p, stats);
-        else hipLaunchKernelGGL((rpe_stats_kernel<4, 0>), dim3(g), dim3(256), 0, st, p, stats);
-    } else {
-        if (p.d == 16) hipLaunchKernelGGL((rpe_stats_kernel<1, 3>), dim3(g), dim3(256), 0, st, p, stats);
-        else if (p.d == 32) hipLaunchKernelGGL((rpe_stats_kernel<2, 3>), dim3(g), dim3(256), 0, st, p, stats);
-        else hipLaunchKernelGGL((rpe_stats_kernel<4, 3>), dim3(g), dim3(256), 0, st, p, stats);
+    const int key = (pool_terms(p.d) == 0 ? 0 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + p.src;
+#define VST(K, DT, TERMS, SRC) \
+    case K: hipLaunchKernelGGL((vrpe_stats_kernel<DT, TERMS, SRC>), dim3(g), dim3(256), 0, st, p, stats); break;
+    switch (key) {
+        VST(11, 1, 0, 1) VST(12, 1, 0, 2) VST(21, 2, 0, 1) VST(22, 2, 0, 2) VST(41, 4, 0, 1) VST(42, 4, 0, 2)
+        VST(111, 1, 3, 1) VST(112, 1, 3, 2) VST(121, 2, 3, 1) VST(122, 2, 3, 2) VST(141, 4, 3, 1) VST(142, 4, 3, 2)
     }
-    rl_note_kernel("rpe_stats_kernel");
+#undef VST
+    rl_note_kernel("vrpe_stats_kernel");
     RL_LAUNCH_CHECK("rl_rpe_stats");
     return RL_OK;
 }
@@ -1897,20 +3231,21 @@ static int rpe_bwd_fill(RpeBwdParams* q, const rl_pool_desc* d, const float* G, 
 
 #define RPE_DISPATCH(KERNEL, grid, st, q)                                                                          \
     do {                                                                                                           \
-        if ((q).g_bf16) {                                                                                          \
-            if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 3, true>), dim3(grid), dim3(256), 0, st, q);         \
-            else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 3, true>), dim3(grid), dim3(256), 0, st, q);    \
-            else hipLaunchKernelGGL((KERNEL<4, 3, true>), dim3(grid), dim3(256), 0, st, q);                        \
-        } else if (pool_terms((q).pp.d) == 0) {                                                                         \
-            if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 0>), dim3(grid), dim3(256), 0, st, q);               \
-            else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 0>), dim3(grid), dim3(256), 0, st, q);          \
-            else hipLaunchKernelGGL((KERNEL<4, 0>), dim3(grid), dim3(256), 0, st, q);                              \
-        } else {                                                                                                   \
-            if ((q).pp.d == 16) hipLaunchKernelGGL((KERNEL<1, 3>), dim3(grid), dim3(256), 0, st, q);               \
-            else if ((q).pp.d == 32) hipLaunchKernelGGL((KERNEL<2, 3>), dim3(grid), dim3(256), 0, st, q);          \
-            else hipLaunchKernelGGL((KERNEL<4, 3>), dim3(grid), dim3(256), 0, st, q);                              \
+        const int key_ = ((q).g_bf16 ? 200 : pool_terms((q).pp.d) == 0 ? 0 : 100) + ((q).pp.d == 16 ? 10 : (q).pp.d == 32 ? 20 : 40) + (q).pp.src; \
+        switch (key_) {                                                                                            \
+            RPE_CASE(KERNEL, 11, 1, 0, 1, false, grid, st, q) RPE_CASE(KERNEL, 12, 1, 0, 2, false, grid, st, q)     \
+            RPE_CASE(KERNEL, 21, 2, 0, 1, false, grid, st, q) RPE_CASE(KERNEL, 22, 2, 0, 2, false, grid, st, q)     \
+            RPE_CASE(KERNEL, 41, 4, 0, 1, false, grid, st, q) RPE_CASE(KERNEL, 42, 4, 0, 2, false, grid, st, q)     \
+            RPE_CASE(KERNEL, 111, 1, 3, 1, false, grid, st, q) RPE_CASE(KERNEL, 112, 1, 3, 2, false, grid, st, q)   \
+            RPE_CASE(KERNEL, 121, 2, 3, 1, false, grid, st, q) RPE_CASE(KERNEL, 122, 2, 3, 2, false, grid, st, q)   \
+            RPE_CASE(KERNEL, 141, 4, 3, 1, false, grid, st, q) RPE_CASE(KERNEL, 142, 4, 3, 2, false, grid, st, q)   \
+            RPE_CASE(KERNEL, 211, 1, 3, 1, true, grid, st, q) RPE_CASE(KERNEL, 212, 1, 3, 2, true, grid, st, q)     \
+            RPE_CASE(KERNEL, 221, 2, 3, 1, true, grid, st, q) RPE_CASE(KERNEL, 222, 2, 3, 2, true, grid, st, q)     \
+            RPE_CASE(KERNEL, 241, 4, 3, 1, true, grid, st, q) RPE_CASE(KERNEL, 242, 4, 3, 2, true, grid, st, q)     \
         }                                                                                                          \
     } while (0)
+#define RPE_CASE(KERNEL, K, DT, TERMS, SRC, GB, grid, st, q) \
+    case K: hipLaunchKernelGGL((KERNEL<DT, TERMS, SRC, GB>), dim3(grid), dim3(256), 0, st, q); break;
 
 extern "C" int rl_rpe_bn_reduce(const rl_pool_desc* d, const float* G, double* stats, void* stream) {
     RpeBwdParams q;
@@ -1919,8 +3254,8 @@ extern "C" int rl_rpe_bn_reduce(const rl_pool_desc* d, const float* G, double* s
     RL_REQUIRE(stats, RL_ERR_ARGS, "rl_rpe_bn_reduce: null stats");
     q.stats = stats;
     const int g = rpe_grid(q.pp.P);
-    RPE_DISPATCH(rpe_bn_reduce_kernel, g, (hipStream_t)stream, q);
-    rl_note_kernel("rpe_bn_reduce_kernel");
+    RPE_DISPATCH(vrpe_bn_reduce_kernel, g, (hipStream_t)stream, q);
+    rl_note_kernel("vrpe_bn_reduce_kernel");
     RL_LAUNCH_CHECK("rl_rpe_bn_reduce");
     return RL_OK;
 }
@@ -1940,8 +3275,8 @@ extern "C" int rl_rpe_wgrad(const rl_pool_desc* d, const float* G, const float* 
     RL_REQUIRE(d->u_source == 1 || GU1, RL_ERR_ARGS, "rl_rpe_wgrad: stage 2 needs the stage-1 gradient output");
     q.coef = coef; q.slab = slab; q.GU1 = GU1;
     const int g = rpe_grid(q.pp.P);
-    RPE_DISPATCH(rpe_wgrad_kernel, g, (hipStream_t)stream, q);
-    rl_note_kernel("rpe_wgrad_kernel");
+    RPE_DISPATCH(vrpe_wgrad_kernel, g, (hipStream_t)stream, q);
+    rl_note_kernel("vrpe_wgrad_kernel");
     RL_LAUNCH_CHECK("rl_rpe_wgrad");
     return RL_OK;
 }
