@@ -1766,9 +1766,9 @@ struct RpeIn2 {
 // comp = lj < 3 ? lj : 0 (lane constant; lane group 3 supplies the distance, its coordinate loads are dummies)
 __device__ __forceinline__ void fetch_rpe2(const PoolParams& p, const Cursor& cu, int li, int comp, int nbr, RpeIn2& r) {
     const float* xb = p.xyz + (long)cu.b * p.xyz_bstride * p.xyz_w + comp;
+    r.dd = p.nbr_d2[cu.pt * 16 + li];      // (streaming loads before the gather: see the load groups of the kernels)
     r.pc = xb[(long)cu.i * p.xyz_w];
     r.nc = xb[(long)nbr * p.xyz_w];
-    r.dd = p.nbr_d2[cu.pt * 16 + li];
 }
 
 // LDS image of W2 (h x h, zero-padded to HP x KP2), [n][k]: the A operand of the transposed stage-2 product
@@ -1854,6 +1854,43 @@ struct VLane {
     }
 };
 
+// fold of every A-layout chunk of X for a virtual stage (lane_lazy with the stage's BatchNorm, bias folded, in the rpe half);
+// d = 64: read from LDS where used (32 registers otherwise - the 64-channel backward kernel has none to spare)
+template <int DT>
+struct XFold {
+    static constexpr int D = 16 * DT, H = VX<DT>::H;
+    static constexpr bool INLDS = DT >= 4;
+    static constexpr int LDS_FLOATS = INLDS ? 2 * D : 4;
+    f32x4 rsc[INLDS ? 1 : DT], rsh[INLDS ? 1 : DT];
+    const float* lds;
+    // all threads; `mem`: LDS_FLOATS floats, published by the caller's barrier
+    template <int SRC>
+    __device__ __forceinline__ void init(const PoolParams& p, int lj, float* mem) {
+        const float* s_ = SRC == 1 ? p.sc1 : p.sc2;
+        const float* h_ = SRC == 1 ? p.sh1 : p.sh2;
+        const float* b_ = SRC == 1 ? p.b1 : p.b2;
+        auto fsc = [&](int k) -> float { return k < H ? s_[k] : (p.glazy.scale ? p.glazy.scale[k - H] : 1.f); };
+        auto fsh = [&](int k) -> float { return k < H ? __builtin_fmaf(b_[k], s_[k], h_[k]) : (p.glazy.scale ? p.glazy.shift[k - H] : 0.f); };
+        if constexpr (INLDS) {
+            for (int k = threadIdx.x; k < D; k += blockDim.x) { mem[k] = fsc(k); mem[D + k] = fsh(k); }
+            lds = mem + 4 * lj;
+        } else {
+#pragma unroll
+            for (int c = 0; c < DT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rsc[c][r] = fsc(16 * c + 4 * lj + r); rsh[c][r] = fsh(16 * c + 4 * lj + r); }
+        }
+    }
+    __device__ __forceinline__ f32x4 sc(int c) const {
+        if constexpr (INLDS) return *reinterpret_cast<const f32x4*>(lds + 16 * c);
+        else return rsc[c];
+    }
+    __device__ __forceinline__ f32x4 sh(int c) const {
+        if constexpr (INLDS) return *reinterpret_cast<const f32x4*>(lds + D + 16 * c);
+        else return rsh[c];
+    }
+};
+
 // raw (bias-free) first-stage tile of one point, A layout: r[nb] = c0[nb] + U . x_i + [V | wd] . [x_i - x_j, dist]
 template <int DT>
 __device__ __forceinline__ void stage1_raw(const RpeIn2& in, const VLane<DT>& vl, const f32x4 (&c0)[VX<DT>::NCH], f32x4 (&r)[VX<DT>::NCH]) {
@@ -1882,7 +1919,7 @@ __device__ __forceinline__ void stage2_raw(const float4 (&u1)[DT], const Frag<DT
 // rawu: the raw tile of stage SRC (the backward's BatchNorm sums need it).  fr: split of xa when SPLIT (bf16 modes).
 template <int DT, int TERMS, int SRC>
 __device__ __forceinline__ void build_x(const RpeIn2& in, const float4 (&graw)[DT], const VLane<DT>& vl, const VW2<DT, TERMS>& w2,
-                                        const f32x4 (&xsc)[DT], const f32x4 (&xsh)[DT], float es_g, float e0, int li, int lj,
+                                        const XFold<DT>& xf, float es_g, float e0, int li, int lj,
                                         float4 (&xa)[DT], f32x4 (&rawu)[VX<DT>::NCH]) {
     constexpr int NCH = VX<DT>::NCH;
     f32x4 c0[NCH], r1[NCH];
@@ -1915,36 +1952,14 @@ __device__ __forceinline__ void build_x(const RpeIn2& in, const float4 (&graw)[D
         }
     }
     if constexpr (DT == 1) {
-        xa[0] = f4(vact(__builtin_elementwise_fma(rawu[0], xsc[0], xsh[0]), e0));
+        xa[0] = f4(vact(__builtin_elementwise_fma(rawu[0], xf.sc(0), xf.sh(0)), e0));
     } else {
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
-            if (c < NCH) xa[c] = f4(vrelu(__builtin_elementwise_fma(rawu[c], xsc[c], xsh[c])));
-            else xa[c] = f4(vact(__builtin_elementwise_fma(v4(graw[c]), xsc[c], xsh[c]), es_g));
+            if (c < NCH) xa[c] = f4(vrelu(__builtin_elementwise_fma(rawu[c], xf.sc(c), xf.sh(c))));
+            else xa[c] = f4(vact(__builtin_elementwise_fma(v4(graw[c]), xf.sc(c), xf.sh(c)), es_g));
         }
     }
-}
-
-// fold of every A-layout chunk of X for a virtual stage (lane_lazy with the stage's BatchNorm, bias folded, in the rpe half)
-template <int DT, int SRC>
-__device__ __forceinline__ void lane_fold(const PoolParams& p, int lj, f32x4 (&sc)[DT], f32x4 (&sh)[DT]) {
-    constexpr int H = VX<DT>::H;
-    const float* s_ = SRC == 1 ? p.sc1 : p.sc2;
-    const float* h_ = SRC == 1 ? p.sh1 : p.sh2;
-    const float* b_ = SRC == 1 ? p.b1 : p.b2;
-#pragma unroll
-    for (int c = 0; c < DT; ++c)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = 16 * c + 4 * lj + s;
-            if (k < H) {
-                sc[c][s] = s_[k];
-                sh[c][s] = __builtin_fmaf(b_[k], s_[k], h_[k]);
-            } else {
-                sc[c][s] = p.glazy.scale ? p.glazy.scale[k - H] : 1.f;
-                sh[c][s] = p.glazy.scale ? p.glazy.shift[k - H] : 0.f;
-            }
-        }
 }
 
 // the gathered chunks of a point (DT == 1: the mixed chunk through the per-lane base / stride)
@@ -2013,6 +2028,28 @@ __device__ __forceinline__ void write_moments(const f32x4 (&ssum)[VX<DT>::NCH], 
 // number of points a wavefront visits: pt0, pt0 + pstep, ... < P
 __device__ __forceinline__ long wave_points(long pt0, long pstep, long P) { return pt0 < P ? (P - pt0 + pstep - 1) / pstep : 0; }
 
+// one point's prefetched operands (virtual pooling kernels) + the neighbour index of the point that will take this buffer next
+template <int DT>
+struct PreF {
+    float4 graw[DT];
+    RpeIn2 rin;
+    int idx;
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int c = 0; c < DT; ++c) graw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rin.pc = rin.nc = rin.dd = 0.f;
+        idx = 0;
+    }
+};
+// wait until at most N vector-memory operations are outstanding (they complete in order: the N youngest stay in flight)
+template <int N>
+__device__ __forceinline__ void loads_landed_but() {
+    static_assert(N >= 0 && N < 16, "vmcnt immediate");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | N);
+    asm volatile("" ::: "memory");
+}
+
 template <int DT, int TERMS, int SRC, bool FST>      // SRC 1 / 2: the stage X's rpe half comes from; FST: leave the stage-2 statistics (SRC == 1)
 __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     constexpr int NW = 4;
@@ -2022,6 +2059,7 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     __shared__ __attribute__((aligned(16))) float Xt[NW][16 * XS];
     __shared__ __attribute__((aligned(16))) unsigned char w2mem[W2ON ? VW2<DT, TERMS>::BYTES : 16];
     __shared__ __attribute__((aligned(16))) float cl[VX<DT>::INLDS ? VX<DT>::NCONST * HP : 4];
+    __shared__ __attribute__((aligned(16))) float xfm[XFold<DT>::LDS_FLOATS];
     __shared__ double cnts[NW];
     float* Wt = reinterpret_cast<float*>(wmem);
     __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
@@ -2043,8 +2081,8 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     if constexpr (W2ON) w2.stage(p.W2, VX<DT>::H, 1, 64 * NW);
     VLane<DT> vl;
     vl.load(p, li, lj, cl, 0);
-    f32x4 xsc[DT], xsh[DT];
-    lane_fold<DT, SRC>(p, lj, xsc, xsh);
+    XFold<DT> xf;
+    xf.template init<SRC>(p, lj, xfm);
     const float es_g = eff_slope(p.glazy), e0 = lane_slope<DT>(lj, es_g);
     GatherG<DT> gg;
     gg.init(p, lj);
@@ -2056,36 +2094,44 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     const long pstep = (long)gridDim.x * NW;
     long pt = (long)blockIdx.x * NW + wave;
     const long npts = wave_points(pt, pstep, p.P);
-    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
-    float4 graw[DT];
-#pragma unroll
-    for (int c = 0; c < DT; ++c) graw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    RpeIn2 rin = {0.f, 0.f, 0.f};
-    Cursor cu;
-    cu.start(pt, p.n);
+    // Software pipeline TWO points deep (round 4: with ~160 instructions per point left, one point of prefetch is shorter than a
+    // gather's latency).  Two buffers alternate: while buffer U's point is computed, U is refilled for the point two further on
+    // and the other buffer's loads (issued one iteration ago) are awaited - loads_landed_but<NG> leaves this iteration's group
+    // of NG loads in flight.  A buffer carries the neighbour index of ITS NEXT point (loaded two iterations before it is used).
+    constexpr int NG = (DT == 4 ? 2 : 1) + 3 + 1;      // loads of one group: gathered chunks, two coordinates + distance, index
+    PreF<DT> A, B;
+    A.zero(); B.zero();
+    Cursor c0, c1, c2;
+    c0.start(pt, p.n);
+    c1 = c0.next(pstep, p.n);
+    c2 = c1.next(pstep, p.n);
     if (pt < p.P) {
-        gg.fetch(p, cu, idx_cur, graw);
-        fetch_rpe2(p, cu, li, vl.comp, idx_cur, rin);
+        const bool v1 = pt + pstep < p.P;
+        const int i0 = p.idx[pt * 16 + li];
+        const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
+        A.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
+        B.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+        gg.fetch(p, c0, i0, A.graw);
+        fetch_rpe2(p, c0, li, vl.comp, i0, A.rin);
+        gg.fetch(p, v1 ? c1 : c0, i1, B.graw);
+        fetch_rpe2(p, v1 ? c1 : c0, li, vl.comp, i1, B.rin);
     }
     loads_landed();
-    for (; pt < p.P; pt += pstep) {
-        const Cursor cn = cu.next(pstep, p.n);
+    auto body = [&](PreF<DT>& U) {
         float4 xa[DT];
         f32x4 rawu[NCH];
-        build_x<DT, TERMS, SRC>(rin, graw, vl, w2, xsc, xsh, es_g, e0, li, lj, xa, rawu);
+        build_x<DT, TERMS, SRC>(U.rin, U.graw, vl, w2, xf, es_g, e0, li, lj, xa, rawu);
 #pragma unroll
         for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(Xs + li * XS + 16 * c + 4 * lj) = xa[c];
-        // the next point's loads, one group, no branch around it (past the last point the current one is read again)
-        const bool more = pt + pstep < p.P;
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        const Cursor cf = more ? cn : cu;
-        const int nbr_f = more ? idx_nxt : idx_cur;
-        gg.fetch(p, cf, nbr_f, graw);
-        fetch_rpe2(p, cf, li, vl.comp, nbr_f, rin);
+        // refill U for the point two further on - one group, no branch around it (past the last point the current one is read again)
+        {
+            const Cursor cf = pt + 2 * pstep < p.P ? c2 : c0;
+            fetch_rpe2(p, cf, li, vl.comp, U.idx, U.rin);
+            gg.fetch(p, cf, U.idx, U.graw);
+            U.idx = p.idx[(pt + 4 * pstep < p.P ? pt + 4 * pstep : pt) * 16 + li];
+        }
         loads_issued();
-        cu = cn;
-        idx_cur = idx_nxt; idx_nxt = idx_n2;
+        c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
         f32x4 s[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) s[nb] = splat(0.f);
@@ -2131,7 +2177,7 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
             const float den = lg_sum(sum4(e)), num = lg_sum(sum4(e * xc));
             outv[nb] = num * __builtin_amdgcn_rcpf(den);
         }
-        loads_landed();
+        loads_landed_but<NG>();
         if constexpr (DT == 4) {
             // every lane holds all four results: lane group q stores column block q - one 256-byte store per point
             const float v = lj == 0 ? outv[0] : lj == 1 ? outv[1] : lj == 2 ? outv[2] : outv[3];
@@ -2142,7 +2188,16 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
                 if (lj == nb) p.Pout[pt * D + nb * 16 + li] = outv[nb];
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    // ONE exit from the loop: with a break after either half the two exits are merged into one block that (as far as the
+    // waitcnt pass can tell) also leads back to the loop header - it then waits for the loads just issued at the top of the loop
+    for (long k = npts >> 1; k > 0; --k) {
+        body(A);
+        pt += pstep;
+        body(B);
+        pt += pstep;
     }
+    if (npts & 1) body(A);
     if constexpr (FST) {
         __syncthreads();                                                    // the X tiles are free now
         double* redd = reinterpret_cast<double*>(&Xt[0][0]);                // [NW][2][HP] doubles
@@ -2173,23 +2228,36 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
     const long pstep = (long)gridDim.x * NW;
     long pt = (long)blockIdx.x * NW + wave;
     const long npts = wave_points(pt, pstep, p.P);
-    RpeIn2 rin = {0.f, 0.f, 0.f}, rin_nxt;
-    Cursor cu;
-    cu.start(pt, p.n);
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
-    if (pt < p.P) fetch_rpe2(p, cu, li, vl.comp, p.idx[pt * 16 + li], rin);
+    // two points deep, two alternating buffers (see vpool_fwd_kernel): coordinates + distance of a point, and the neighbour
+    // index of the point that takes the buffer next
+    constexpr int NG = 3 + 1;
+    struct Buf { RpeIn2 rin; int idx; } A = {{0.f, 0.f, 0.f}, 0}, B = {{0.f, 0.f, 0.f}, 0};
+    Cursor c0, c1, c2;
+    c0.start(pt, p.n);
+    c1 = c0.next(pstep, p.n);
+    c2 = c1.next(pstep, p.n);
+    if (pt < p.P) {
+        const bool v1 = pt + pstep < p.P;
+        const int i0 = p.idx[pt * 16 + li];
+        const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
+        A.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
+        B.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+        fetch_rpe2(p, c0, li, vl.comp, i0, A.rin);
+        fetch_rpe2(p, v1 ? c1 : c0, li, vl.comp, i1, B.rin);
+    }
     loads_landed();
-    for (; pt < p.P; pt += pstep) {
-        const Cursor cn = cu.next(pstep, p.n);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        fetch_rpe2(p, pt + pstep < p.P ? cn : cu, li, vl.comp, idx_nxt, rin_nxt);      // (no branch: see pool_fwd_kernel)
-        loads_issued();
-        idx_nxt = idx_n2;
-        cu = cn;
-        f32x4 c0[NCH], raw[NCH];
+    auto body = [&](Buf& U) {
+        f32x4 c0v[NCH], raw[NCH];
 #pragma unroll
-        for (int nb = 0; nb < NCH; ++nb) c0[nb] = splat(0.f);
-        stage1_raw<DT>(rin, vl, c0, raw);
+        for (int nb = 0; nb < NCH; ++nb) c0v[nb] = splat(0.f);
+        stage1_raw<DT>(U.rin, vl, c0v, raw);
+        {
+            const Cursor cf = pt + 2 * pstep < p.P ? c2 : c0;      // (no branch: see pool_fwd_kernel)
+            fetch_rpe2(p, cf, li, vl.comp, U.idx, U.rin);
+            U.idx = p.idx[(pt + 4 * pstep < p.P ? pt + 4 * pstep : pt) * 16 + li];
+        }
+        loads_issued();
+        c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
         if constexpr (SRC == 2) {
             float4 u1[DT];
 #pragma unroll
@@ -2218,12 +2286,33 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
             ssum[nb] += raw[nb];
             ssq[nb] = __builtin_elementwise_fma(raw[nb], raw[nb], ssq[nb]);
         }
-        loads_landed();
-        rin = rin_nxt;
+        loads_landed_but<NG>();
+    };
+    for (long k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
+        body(A);
+        pt += pstep;
+        body(B);
+        pt += pstep;
     }
+    if (npts & 1) body(A);
     write_moments<DT, NW>(ssum, ssq, SRC == 1 ? p.b1 : p.b2, npts * 16, wave, lane, red, cnts, stats);
 }
 
+
+// the backward's buffer: + dP of the point and its GU rows when the launch accumulates
+template <int DT, bool ACC>
+struct PreB {
+    PreF<DT> f;
+    float gp[DT];
+    float4 gacc[ACC ? VX<DT>::NCH : 1];
+    __device__ __forceinline__ void zero() {
+        f.zero();
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) gp[nb] = 0.f;
+#pragma unroll
+        for (int c = 0; c < (ACC ? VX<DT>::NCH : 1); ++c) gacc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
 
 // Backward of the fused pooling block with a virtual rpe stage (pool_bwd_kernel's VIRT case, transposed orientation).
 // ACC: this launch adds to GU; p.bstats: it completes GU and leaves the BatchNorm-backward sums of stage SRC; GB: GU / DG are bf16.
@@ -2235,6 +2324,7 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB, NCH = VX<DT>::NCH, HP = VX<DT>::HP;
     __shared__ __attribute__((aligned(16))) unsigned char w2mem[SRC == 2 ? VW2<DT, TERMS>::BYTES : 16];
     __shared__ __attribute__((aligned(16))) float cl[VX<DT>::INLDS ? VX<DT>::NCONST * HP : 4];
+    __shared__ __attribute__((aligned(16))) float xfm[XFold<DT>::LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Wmem[TERMS == 0 ? 2 * D * XS : 2 * D * XSB];   // bf16: 4 arrays of D*XSB
     __shared__ __attribute__((aligned(16))) float Tiles[NW][2][16 * XS];
     float* Wt = Wmem;
@@ -2261,8 +2351,8 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
     if constexpr (SRC == 2) w2.stage(p.W2, VX<DT>::H, 1, 64 * NW);
     VLane<DT> vl;
     vl.load(p, li, lj, cl, BST ? SRC : 0);
-    f32x4 xsc[DT], xsh[DT];
-    lane_fold<DT, SRC>(p, lj, xsc, xsh);
+    XFold<DT> xf;
+    xf.template init<SRC>(p, lj, xfm);
     const float es_g = eff_slope(p.glazy), e0 = lane_slope<DT>(lj, es_g);
     GatherG<DT> gg;
     gg.init(p, lj);
@@ -2287,49 +2377,72 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
 
     const long pstep = (long)gridDim.x * NW;
     long pt = (long)blockIdx.x * NW + wave;
-    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
-    float4 graw[DT];
+    const long npts = wave_points(pt, pstep, p.P);
+    // Software pipeline two points deep (see vpool_fwd_kernel): a buffer holds a point's gathered rows, coordinates, dP and - when
+    // this launch adds to GU - its GU rows, plus the neighbour index of the point that takes the buffer next.
+    constexpr int NG = (DT == 4 ? 2 : 1) + 3 + 1 + DT + (ACC ? NCH : 0);      // loads of one group
+    constexpr int AHEAD = DT >= 4 ? 1 : 2;      // d = 64: no registers for a second buffer (256 per lane with 8 wavefronts per workgroup) - one point ahead
+    PreB<DT, ACC> A, B;
+    A.zero(); B.zero();
+    Cursor c0, c1, c2;
+    c0.start(pt, p.n);
+    c1 = c0.next(pstep, p.n);
+    c2 = c1.next(pstep, p.n);
+    auto fill = [&](PreB<DT, ACC>& U, const Cursor& cf, int nbr) {
+        // (dP first: should the register allocator rotate a buffer register with a copy at the back edge, the copy waits for the
+        // OLDEST load of the group - a streaming one - not for the gathers)
 #pragma unroll
-    for (int c = 0; c < DT; ++c) graw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    RpeIn2 rin = {0.f, 0.f, 0.f};
-    Cursor cu;
-    cu.start(pt, p.n);
-    float gp[DT], gp_nxt[DT];          // dP of the current / next point
-#pragma unroll
-    for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb] = 0.f;
-    if (pt < p.P) {
-        gg.fetch(p, cu, idx_cur, graw);
-        fetch_rpe2(p, cu, li, vl.comp, idx_cur, rin);
-#pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
-    }
-    loads_landed();
-    for (; pt < p.P; pt += pstep) {
-        const Cursor cn = cu.next(pstep, p.n);
-        float4 xa[DT];
-        f32x4 rawu[NCH];
-        build_x<DT, TERMS, SRC>(rin, graw, vl, w2, xsc, xsh, es_g, e0, li, lj, xa, rawu);
-#pragma unroll
-        for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(Xs + li * XS + 16 * c + 4 * lj) = xa[c];
-        // ONE load group per iteration (see pool_bwd_kernel): the next point's rows, coordinates and dP, the index two points
-        // ahead, this point's GU when accumulating; the only vector-memory wait is loads_landed() before the stores
-        const bool more = pt + pstep < p.P;
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        const Cursor cf = more ? cn : cu;
-        const int nbr_f = more ? idx_nxt : idx_cur;
-        gg.fetch(p, cf, nbr_f, graw);
-        fetch_rpe2(p, cf, li, vl.comp, nbr_f, rin);
-#pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
-        float4 gacc[NCH];
+        for (int nb = 0; nb < DT; ++nb) U.gp[nb] = p.dP[cf.pt * D + nb * 16 + li];
         if constexpr (ACC) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) gacc[c] = rl_ldx4<GB>(abase, ((pt * 16 + li) * H) * amul + 16 * c + acol);
+            for (int c = 0; c < NCH; ++c) U.gacc[c] = rl_ldx4<GB>(abase, ((cf.pt * 16 + li) * H) * amul + 16 * c + acol);
+        }
+        fetch_rpe2(p, cf, li, vl.comp, nbr, U.f.rin);
+        gg.fetch(p, cf, nbr, U.f.graw);
+    };
+    if (pt < p.P) {
+        const int i0 = p.idx[pt * 16 + li];
+        if constexpr (AHEAD == 2) {
+            const bool v1 = pt + pstep < p.P;
+            const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
+            A.f.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
+            B.f.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+            fill(A, c0, i0);
+            fill(B, v1 ? c1 : c0, i1);
+        } else {
+            A.f.idx = p.idx[(pt + pstep < p.P ? pt + pstep : pt) * 16 + li];
+            fill(A, c0, i0);
+        }
+    }
+    loads_landed();
+    auto body = [&](PreB<DT, ACC>& U) {
+        float4 xa[DT];
+        f32x4 rawu[NCH];
+        build_x<DT, TERMS, SRC>(U.f.rin, U.f.graw, vl, w2, xf, es_g, e0, li, lj, xa, rawu);
+#pragma unroll
+        for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(Xs + li * XS + 16 * c + 4 * lj) = xa[c];
+        // dP and the GU rows are used AFTER the refill below: real copies, made here (the empty asm "redefines" each one), so
+        // that the buffer's registers are dead when its loads are issued and the loads can land in them - otherwise the
+        // loop-carried copies are made at the back edge, with a wait for the loads just issued
+        float gpv[DT];
+#pragma unroll
+        for (int nb = 0; nb < DT; ++nb) { gpv[nb] = U.gp[nb]; asm volatile("" : "+v"(gpv[nb])); }
+        float4 gaccv[NCH];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                gaccv[c] = U.gacc[c];
+                asm volatile("" : "+v"(gaccv[c].x), "+v"(gaccv[c].y), "+v"(gaccv[c].z), "+v"(gaccv[c].w));
+            }
+        }
+        // refill U for the point two further on - one group, no branch around it (past the last point the current one is read again)
+        {
+            const Cursor cf = pt + AHEAD * pstep < p.P ? (AHEAD == 2 ? c2 : c1) : c0;
+            fill(U, cf, U.f.idx);
+            U.f.idx = p.idx[(pt + 2 * AHEAD * pstep < p.P ? pt + 2 * AHEAD * pstep : pt) * 16 + li];
         }
         loads_issued();
-        cu = cn;
-        idx_cur = idx_nxt; idx_nxt = idx_n2;
+        c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = splat(0.f);
@@ -2358,7 +2471,7 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
             const float den = lg_sum(sum4(e)), num = lg_sum(sum4(e * xc));
             const float inv = __builtin_amdgcn_rcpf(den);
             const float pool = num * inv;
-            dx[nb] = e * splat(inv * gp[nb]);                        // direct path dP*A
+            dx[nb] = e * splat(inv * gpv[nb]);                        // direct path dP*A
             dsr[nb] = dx[nb] * (xc - splat(pool));                   // dS = A*dP*(X-P)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + col] = dsr[nb][r];
@@ -2412,18 +2525,18 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + nb * 16 + li] = dx[nb][r];
         __builtin_amdgcn_wave_barrier();
-        loads_landed();
+        loads_landed_but<AHEAD == 2 ? NG : 0>();
         const long orow = (pt * 16 + li) * H;
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
             f32x4 v = *reinterpret_cast<const f32x4*>(Ds + li * XS + 16 * c + 4 * lj);
             if (c < NCH) {
-                if constexpr (ACC) v += v4(gacc[c]);
+                if constexpr (ACC) v += v4(gaccv[c]);
                 if (BST) {
                     // this launch completes the gradient of the stage's activated output: the batch-statistics sums of its
                     // BatchNorm backward come for free (the raw tile is in registers; d = 16: the lanes of the gathered half
                     // compute along, their sums are never written)
-                    const f32x4 z = __builtin_elementwise_fma(rawu[c], xsc[c], xsh[c]);      // = build_x
+                    const f32x4 z = __builtin_elementwise_fma(rawu[c], xf.sc(c), xf.sh(c));      // = build_x
                     f32x4 g;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? v[r] : 0.f;
@@ -2435,9 +2548,21 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
             else if (c < NCH) RL_ST4<GB>(p.GU, orow + 16 * c + 4 * lj, f4(v));
             else RL_ST4<GB>(p.DG, orow + 16 * c + 4 * lj - H, f4(v));
         }
-#pragma unroll
-        for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb];
         __builtin_amdgcn_wave_barrier();
+    };
+    if constexpr (AHEAD == 2) {
+        for (long k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
+            body(A);
+            pt += pstep;
+            body(B);
+            pt += pstep;
+        }
+        if (npts & 1) body(A);
+    } else {
+        for (long k = npts; k > 0; --k) {
+            body(A);
+            pt += pstep;
+        }
     }
     if (BST) {
         // (Tiles is free: every wavefront is past its last point once the barrier below is reached)
@@ -2699,35 +2824,44 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
     }
     const long pstep = (long)gridDim.x * NW;
     long pt = (long)blockIdx.x * NW + wave;
-    RpeIn2 rin = {0.f, 0.f, 0.f}, rin_nxt;
-    Cursor cu;
-    cu.start(pt, p.n);
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
-    float4 gin[NCH], gin_nxt[NCH];
+    // two points deep, two alternating buffers (see vpool_fwd_kernel)
+    constexpr int NG = 3 + NCH + 1;
+    struct Buf { RpeIn2 rin; float4 gin[NCH]; int idx; } A, B;
+    A.rin.pc = A.rin.nc = A.rin.dd = B.rin.pc = B.rin.nc = B.rin.dd = 0.f;
+    A.idx = B.idx = 0;
 #pragma unroll
-    for (int nb = 0; nb < NCH; ++nb) gin[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int nb = 0; nb < NCH; ++nb) A.gin[nb] = B.gin[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long npts = wave_points(pt, pstep, p.P);
+    Cursor c0, c1, c2;
+    c0.start(pt, p.n);
+    c1 = c0.next(pstep, p.n);
+    c2 = c1.next(pstep, p.n);
     if (pt < p.P) {
-        fetch_rpe2(p, cu, li, vl.comp, p.idx[pt * 16 + li], rin);
-        load_g4<DT, GB>(q.G, pt, li, lj, gin);
+        const bool v1 = pt + pstep < p.P;
+        const int i0 = p.idx[pt * 16 + li];
+        const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
+        A.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
+        B.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+        fetch_rpe2(p, c0, li, vl.comp, i0, A.rin);
+        load_g4<DT, GB>(q.G, pt, li, lj, A.gin);
+        fetch_rpe2(p, v1 ? c1 : c0, li, vl.comp, i1, B.rin);
+        load_g4<DT, GB>(q.G, v1 ? pt + pstep : pt, li, lj, B.gin);
     }
     loads_landed();
     // addresses of the transposing reads: rows 4*lj + (li >> 2), columns 4*(li & 3) .. +3 of a 16-column block
     const int trow = 4 * lj + (li >> 2), tcol = 4 * (li & 3);
-    for (; pt < p.P; pt += pstep) {
-        const Cursor cn = cu.next(pstep, p.n);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        {
-            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
-            fetch_rpe2(p, cf, li, vl.comp, idx_nxt, rin_nxt);
-            load_g4<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
-        }
-        loads_issued();
-        idx_nxt = idx_n2;
-        cu = cn;
+    auto body = [&](Buf& U) {
         f32x4 raw[NCH];
         float4 u1[DT];
         Frag<DT> f1;
-        stage_raw<DT, TERMS, SRC>(rin, vl, w2, li, lj, raw, u1, f1);
+        stage_raw<DT, TERMS, SRC>(U.rin, vl, w2, li, lj, raw, u1, f1);
+        // stage 1: the reduced inputs (columns 2*lj, 2*lj + 1 of the input tile), taken before the buffer is refilled
+        float in0 = 0.f, in1 = 0.f;
+        if constexpr (SRC == 1) {
+            const float diff = U.rin.pc - U.rin.nc, dist = __fsqrt_rn(U.rin.dd);
+            in0 = vl.l3 ? 0.f : U.rin.pc;
+            in1 = vl.l3 ? dist : diff;
+        }
         float4 dy[DT];
 #pragma unroll
         for (int c = 0; c < DT; ++c) dy[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2736,21 +2870,30 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
             const f32x4 z = __builtin_elementwise_fma(raw[nb], bc.sc[nb], bc.sh[nb]);
             f32x4 g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? v4(gin[nb])[r] : 0.f;
+            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? v4(U.gin[nb])[r] : 0.f;
             const f32x4 xh = (raw[nb] - bc.mu[nb]) * bc.is[nb];
             // padding channels / the lanes of the gathered half (d = 16): scale and the coefficients are zero there -> dy = 0
             const f32x4 d = bc.sc[nb] * (g - bc.k0[nb] - xh * bc.k1[nb]);
             bsum4[nb] += d;
             dy[nb] = f4(d);
         }
+        {
+            const Cursor cf = pt + 2 * pstep < p.P ? c2 : c0;      // (no branch: see pool_fwd_kernel)
+            // (the streaming rows first: should the register allocator rotate a buffer register with a copy at the back edge,
+            // the copy then waits for the oldest loads of the group, not for the gathers)
+            load_g4<DT, GB>(q.G, cf.pt, li, lj, U.gin);
+            fetch_rpe2(p, cf, li, vl.comp, U.idx, U.rin);
+            U.idx = p.idx[(pt + 4 * pstep < p.P ? pt + 4 * pstep : pt) * 16 + li];
+        }
+        loads_issued();
+        c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
         if constexpr (TERMS == 0) {
             float* Fi = reinterpret_cast<float*>(Ti);
             float* Fd = reinterpret_cast<float*>(Td);
 #pragma unroll
             for (int nb = 0; nb < NCH; ++nb) *reinterpret_cast<float4*>(Fd + li * RSF + 16 * nb + 4 * lj) = dy[nb];
             if constexpr (SRC == 1) {
-                const float diff = rin.pc - rin.nc, dist = __fsqrt_rn(rin.dd);
-                *reinterpret_cast<float2*>(Fi + li * RSF + 2 * lj) = make_float2(vl.l3 ? 0.f : rin.pc, vl.l3 ? dist : diff);
+                *reinterpret_cast<float2*>(Fi + li * RSF + 2 * lj) = make_float2(in0, in1);
             } else {
 #pragma unroll
                 for (int nb = 0; nb < NCH; ++nb) *reinterpret_cast<float4*>(Fi + li * RSF + 16 * nb + 4 * lj) = u1[nb];
@@ -2774,12 +2917,12 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
 #pragma unroll
                 for (int nb = 0; nb < NCH; ++nb) gu[nb] = splat(0.f);
                 gemm_f32<DT, VX<DT>::NC2, NCH, true>(dy, w2t.f, VX<DT>::S2F, li, lj, gu);
-                loads_landed();
+                loads_landed_but<NG>();
                 if (DT != 1 || lj < 2) {
 #pragma unroll
                     for (int nb = 0; nb < NCH; ++nb) RL_ST4<GB>(q.GU1, (pt * 16 + li) * H + 16 * nb + 4 * lj, f4(gu[nb]));
                 }
-            } else loads_landed();
+            } else loads_landed_but<NG>();
         } else {
             __bf16* Bi = reinterpret_cast<__bf16*>(Ti);      // planes: [hi][16][RSB], [lo][16][RSB]
             __bf16* Bd = reinterpret_cast<__bf16*>(Td);
@@ -2807,8 +2950,7 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
                 }
             }
             if constexpr (SRC == 1) {
-                const float diff = rin.pc - rin.nc, dist = __fsqrt_rn(rin.dd);
-                const float i0 = vl.l3 ? 0.f : rin.pc, i1 = vl.l3 ? dist : diff;       // reduced inputs: columns 2*lj, 2*lj + 1
+                const float i0 = in0, i1 = in1;
                 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
                 bf16x2 hh, ll;
                 hh[0] = (__bf16)i0; hh[1] = (__bf16)i1;
@@ -2859,18 +3001,22 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
 #pragma unroll
                 for (int nb = 0; nb < NCH; ++nb) gu[nb] = splat(0.f);
                 gemm_frag<DT, NCH, 1, true>(fd, w2t.h, w2t.l, VX<DT>::S2B, li, lj, gu);
-                loads_landed();
+                loads_landed_but<NG>();
                 if (DT != 1 || lj < 2) {
 #pragma unroll
                     for (int nb = 0; nb < NCH; ++nb) RL_ST4<GB>(q.GU1, (pt * 16 + li) * H + 16 * nb + 4 * lj, f4(gu[nb]));
                 }
-            } else loads_landed();
+            } else loads_landed_but<NG>();
         }
         __builtin_amdgcn_wave_barrier();
-        rin = rin_nxt;
-#pragma unroll
-        for (int nb = 0; nb < NCH; ++nb) gin[nb] = gin_nxt[nb];
+    };
+    for (long k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
+        body(A);
+        pt += pstep;
+        body(B);
+        pt += pstep;
     }
+    if (npts & 1) body(A);
     // combine the four wavefronts in a fixed order; slab layout: dW[n][k] (n < H, k < Kin) then db[n]
     constexpr int Kin = SRC == 1 ? 10 : H;
     float* rb = red + NCH * KB * 256;                 // [NW][HP] per-wavefront column sums of dY

@@ -29,6 +29,16 @@ void rl_note_kernel(const char* name);
         }                                                                            \
     } while (0)
 
+// every kernel launch of the library goes through hipLaunchKernelGGL: count them (rl_launch_count: what a rocprofv3 kernel
+// trace would count for the same calls - bench.py reports launches per step from it)
+void rl_count_launch();
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                         \
+    do {                                                                                                         \
+        rl_count_launch();                                                                                       \
+        kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                       \
+    } while (0)
+
 // arithmetic mode of the MFMA-heavy kernels (gemm.hip owns it, rl_set_wide_gemm): 0 fp32, 3 bf16x3, 1 bf16
 int rl_wide_terms();
 

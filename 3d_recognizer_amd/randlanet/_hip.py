@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 # diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
 _LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
+ABI_VERSION = 104      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -184,6 +185,7 @@ _SIGNATURES = {
     "rl_last_error": (C.c_char_p, []),
     "rl_last_kernel": (C.c_char_p, []),
     "rl_version": (_i, []),
+    "rl_launch_count": (_l, []),
     "rl_row_blocks": (_i, [_l, _i]),
     "rl_knn_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "rl_knn_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
@@ -271,6 +273,11 @@ def lib() -> C.CDLL:
                 f"{_LIB_PATH} not found: build it with `make -C 3d_recognizer_amd/csrc` "
                 "(or __graft_entry__.build()); there is no fallback path for the HIP kernels")
         handle = C.CDLL(_LIB_PATH)
+        handle.rl_version.restype = C.c_int
+        have = handle.rl_version()
+        if have != ABI_VERSION:      # a stale build (or an RL_HIP_LIB override from another revision): the argument lists differ
+            raise HipKernelError(f"{_LIB_PATH} reports C-ABI version {have}, these bindings were written for {ABI_VERSION}: "
+                                 "rebuild it (`make -C 3d_recognizer_amd/csrc`)")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res

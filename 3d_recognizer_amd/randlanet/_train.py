@@ -241,7 +241,6 @@ class TrainStep:
     def last_metrics(self) -> Dict[str, float]:
         """Synchronises and unpacks the record of the last step (reference metrics.py:8-59).  With several
         ranks the counts are summed and the loss averaged over the ranks first."""
-        from .utils.metrics import accuracy_from_counts, iou_from_counts
         if self.world > 1 and self.sync is None:
             import torch.distributed as dist
             rec_dev = self.out.clone()
@@ -251,11 +250,44 @@ class TrainStep:
         else:
             torch.cuda.current_stream(self.dev).synchronize()
             rec = self.out_host.numpy().copy()
-        cnt = rec[1:1 + 3 * self.C].reshape(3, self.C)
-        oa, pca = accuracy_from_counts(cnt)
-        miou, pci = iou_from_counts(cnt)
-        return dict(loss=float(rec[0]), OA=oa, mAcc=float(np.mean(pca)), mIoU=miou, per_class_iou=pci,
-                    per_class_acc=pca)
+        return unpack_record(rec, self.C)
+
+
+def unpack_record(rec: np.ndarray, C: int) -> Dict[str, float]:
+    """Loss and metrics of one step from its packed record [loss, 3 x C class counts, ...] (reference metrics.py:8-59)."""
+    from .utils.metrics import accuracy_from_counts, iou_from_counts
+    cnt = rec[1:1 + 3 * C].reshape(3, C)
+    oa, pca = accuracy_from_counts(cnt)
+    miou, pci = iou_from_counts(cnt)
+    return dict(loss=float(rec[0]), OA=oa, mAcc=float(np.mean(pca)), mIoU=miou, per_class_iou=pci, per_class_acc=pca)
+
+
+class RecordTable:
+    """The packed records of an epoch's steps, kept on the device: the training loop appends a row per step (one tiny
+    device-to-device copy, no synchronisation - the host runs ahead of the GPU like bench.py does) and reads the whole
+    table back ONCE at the end of the epoch; with several ranks the table is all-reduced once, not per step."""
+
+    def __init__(self, device, width: int, rows: int = 64):
+        self.table = torch.zeros((max(1, rows), width), dtype=torch.float64, device=device)
+        self.k = 0
+
+    def append(self, rec: torch.Tensor) -> None:
+        if self.k >= self.table.shape[0]:
+            self.table = torch.cat([self.table, torch.zeros_like(self.table)])
+        self.table[self.k].copy_(rec, non_blocking=True)
+        self.k += 1
+
+    def read(self, world: int = 1, group=None) -> np.ndarray:
+        """(steps, width) on the host, in step order; counts summed and the loss averaged over the ranks."""
+        t = self.table[:self.k]
+        if world > 1 and self.k:
+            import torch.distributed as dist
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            t[:, 0] /= world
+        host = t.cpu().numpy()
+        self.k = 0
+        return host
 
 
 class InferStep:

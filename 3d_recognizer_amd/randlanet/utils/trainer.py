@@ -123,6 +123,7 @@ class Trainer:
         full_batch = self._train_dataloader.batch_size
         lr = settings.learning_rate
         warned_short = False
+        table = None                 # the epoch's step records, on the device (RecordTable)
         for epoch in range(1, settings.epochs + 1):
             collected = MetricCollector(self._class_names)
             if world > 1:
@@ -152,9 +153,23 @@ class Trainer:
                 stepper = steppers[key]
                 stepper.set_batch(batch.to(model.device, torch.float32), labels.to(model.device))
                 stepper.step(np.random.permutation(key[1]))      # the forward's permutation (modules.py:571)
-                m = stepper.last_metrics()                       # ONE packed read-back per step
-                pca_count = m["per_class_acc"]
-                collected.push(m["loss"], m["OA"], pca_count, m["mIoU"], m["per_class_iou"])
+                if getattr(stepper, "out", None) is not None and getattr(stepper, "sync", None) is None:
+                    # the step's packed record stays on the device: no synchronisation here, the host runs ahead of the GPU
+                    # (the pinned permutation ring of the stepper bounds how far); read back once per epoch, below
+                    if table is None:
+                        from .._train import RecordTable
+                        table = RecordTable(model.device, stepper.out.numel(), len(self._train_dataloader) + 1)
+                    table.append(stepper.out)
+                else:                                            # (stand-in steppers of the CPU tests, the equivalence mode)
+                    m = stepper.last_metrics()
+                    collected.push(m["loss"], m["OA"], m["per_class_acc"], m["mIoU"], m["per_class_iou"])
+            if table is not None and table.k:
+                # ONE read-back (and, with ranks, ONE all-reduce) per epoch; the metrics are pushed in step order, exactly
+                # what the per-step loop pushed (reference trainer.py:121-131)
+                from .._train import unpack_record
+                for rec in table.read(world, getattr(state, "pg", None)):
+                    m = unpack_record(rec, model.settings.n_classes)
+                    collected.push(m["loss"], m["OA"], m["per_class_acc"], m["mIoU"], m["per_class_iou"])
             if epoch % 10 == 0:                                  # StepLR(step_size=10, gamma) (trainer.py:81-83)
                 lr *= settings.learning_rate_decay
                 state.set_lr(lr)

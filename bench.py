@@ -127,6 +127,7 @@ def cpu_baseline(steps=3, B=2):
                        "+ single-threaded exact C KNN (oracle/knn_oracle.c)")
 
 
+MIN_WARMUP_S = 0.4      # untimed steps run for at least this long before a timed window (clock ramp)
 METRIC = "training clouds/sec, N=40960 pts, bs=8, at 1/2/4/8 GPUs; mIoU parity"     # BASELINE.json `metric`, verbatim
 
 
@@ -148,7 +149,38 @@ def fused_min_bytes_per_cloud(N, K, layers, C, e, dec=4):
 
 
 MFMA_KERNELS = ("wgemm_kernel", "wgemm2_kernel", "pgemm_kernel", "pwgrad", "wgrad_kernel", "sgemm_kernel", "swgrad_kernel", "gemm_kernel",
-                "pool_fwd_kernel", "pool_bwd_kernel", "pool128_bwd_kernel", "rpe_wgrad_kernel", "rpe_stats_kernel")
+                "pool_fwd_kernel", "pool_bwd_kernel", "pool128_bwd_kernel", "rpe_wgrad_kernel", "rpe_stats_kernel",
+                "vpool_fwd_kernel", "vpool_bwd_kernel", "vrpe_wgrad_kernel", "vrpe_stats_kernel")
+# the fused tile kernels: bf16x3 products on the bf16 MFMAs like the wide kernels, but bound by neither roof - by instruction
+# issue and the latency of their gathers; the line says so next to the two fractions
+TILE_KERNELS = ("vpool_fwd_kernel", "vpool_bwd_kernel", "vrpe_wgrad_kernel", "vrpe_stats_kernel", "vrpe_bn_reduce_kernel",
+                "pool_fwd_kernel", "pool_bwd_kernel", "pool128_bwd_kernel", "attpool_fwd16_kernel", "attpool_bwd16_kernel")
+
+
+def function_name(kernel: str) -> str:
+    """Kernel FUNCTION of a launch: the name without its template arguments - every instantiation of a function is summed,
+    the way `rocprofv3 --stats` rows are summed per function when the dominant one is picked."""
+    return kernel.split("<")[0].strip()
+
+
+def function_roofline(name, f):
+    """bound / achieved / peak / frac of one kernel function from its algorithmic bytes and flops per step and its time."""
+    secs = max(f["ms"], 1e-9) * 1e-3
+    ai = f["flops"] / max(f["bytes"], 1)
+    if (name.startswith(WIDE_KERNELS) or name.startswith(TILE_KERNELS)) and WIDE_GEMM != "fp32":
+        mfma_peak, spent = BF16_MFMA_PEAK_TFLOPS, (1 if WIDE_GEMM == "bf16" else 3)
+    else:
+        mfma_peak, spent = F32_MFMA_PEAK_TFLOPS, 1
+    if name.startswith(MFMA_KERNELS) and spent * ai > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
+        achieved, peak, unit, bound = f["flops"] / secs / 1e12, mfma_peak, "TFLOP/s", "mfma"
+    else:
+        achieved, peak, unit, bound = f["bytes"] / secs / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+    out = dict(bound=bound, achieved=round(achieved, 2), peak=peak, unit=unit, frac=round(achieved / peak, 5),
+               hbm_frac=round(f["bytes"] / secs / 1e9 / HBM_PEAK_GBS, 5),
+               mfma_frac=round(spent * f["flops"] / secs / 1e12 / mfma_peak, 5))
+    if name.startswith(TILE_KERNELS):
+        out["limited_by"] = "instruction issue / gather latency (neither roof): see DESIGN.md section 5"
+    return out
 
 
 def roofline_pass(stepper, eager_steps=3):
@@ -165,10 +197,13 @@ def roofline_pass(stepper, eager_steps=3):
     ops.TIMER = ops.KernelTimer()
     g_main, g_adam = stepper._g_main, stepper._g_adam
     stepper._g_main = stepper._g_adam = None
+    from randlanet import _hip as _H
     try:
+        n0 = _H.lib().rl_launch_count()
         for _ in range(eager_steps):
             stepper.step(np.random.permutation(stepper.N))
         torch.cuda.synchronize()
+        kernel_launches = (_H.lib().rl_launch_count() - n0) / eager_steps
         records = ops.TIMER.records
     finally:
         ops.TIMER = None
@@ -187,40 +222,41 @@ def roofline_pass(stepper, eager_steps=3):
     total_ms = sum(r["ms_per_step"] for r in rows)
     funcs = {}
     for r in rows:
-        f = funcs.setdefault(r["kernel"], dict(ms=0.0, launches=0.0, bytes=0.0, flops=0.0))
+        f = funcs.setdefault(function_name(r["kernel"]), dict(ms=0.0, launches=0.0, bytes=0.0, flops=0.0))
         f["ms"] += r["ms_per_step"]; f["launches"] += r["launches_per_step"]
         f["bytes"] += r["bytes"] * r["launches_per_step"]; f["flops"] += r["flops"] * r["launches_per_step"]
     name, top = max(funcs.items(), key=lambda kv: kv[1]["ms"])
-    secs = top["ms"] * 1e-3
-    ai = top["flops"] / max(top["bytes"], 1)
-    # the matrix unit a kernel really runs on, and how many MFMA flops it spends per algorithmic flop
-    if name.startswith(WIDE_KERNELS) and WIDE_GEMM != "fp32":
-        mfma_peak, spent = BF16_MFMA_PEAK_TFLOPS, (1 if WIDE_GEMM == "bf16" else 3)
-    else:
-        mfma_peak, spent = F32_MFMA_PEAK_TFLOPS, 1
-    if name.startswith(MFMA_KERNELS) and spent * ai > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9):
-        achieved, peak, unit, bound = top["flops"] / secs / 1e12, mfma_peak, "TFLOP/s", "mfma"
-    else:
-        achieved, peak, unit, bound = top["bytes"] / secs / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-    big = max((r for r in rows if r["kernel"] == name), key=lambda r: r["ms_per_step"])
-    roof = dict(bound=bound, kernel=name, achieved=round(achieved, 2), peak=peak, unit=unit,
-                frac=round(achieved / peak, 5), traffic=None,
+    fr = function_roofline(name, top)
+    big = max((r for r in rows if function_name(r["kernel"]) == name), key=lambda r: r["ms_per_step"])
+    roof = dict(bound=fr["bound"], kernel=name, achieved=fr["achieved"], peak=fr["peak"], unit=fr["unit"],
+                frac=fr["frac"], traffic=None,
                 avg_launch_us=round(1e3 * top["ms"] / top["launches"], 2), launches_per_step=round(top["launches"], 1),
                 bytes_per_launch=int(top["bytes"] / top["launches"]), flops_per_launch=int(top["flops"] / top["launches"]),
                 share_of_step=round(top["ms"] / total_ms, 3),
                 largest_shape=dict(op=f"{big['category']}{list(big['shape'])}", us_per_launch=round(1e3 * big["ms_per_launch"], 1),
                                    TFLOPs=round(big["flops"] / max(big["ms_per_launch"], 1e-9) / 1e9, 2),
                                    GBps=round(big["bytes"] / max(big["ms_per_launch"], 1e-9) / 1e6, 1)))
+    for k in ("hbm_frac", "mfma_frac", "limited_by"):
+        if k in fr:
+            roof[k] = fr[k]
+    # the five largest kernel functions of the step, each against its own roof
+    roof["by_function"] = []
+    for fname, f in sorted(funcs.items(), key=lambda kv: -kv[1]["ms"])[:5]:
+        e = dict(kernel=fname, ms_per_step=round(f["ms"], 4), share=round(f["ms"] / total_ms, 4),
+                 launches_per_step=round(f["launches"], 1))
+        e.update(function_roofline(fname, f))
+        roof["by_function"].append(e)
     pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            t = json.load(open(pmc)).get(roof["largest_shape"]["op"])
+            t = json.load(open(pmc)).get(roof["largest_shape"]["op"]) or json.load(open(pmc)).get(name)
             if t is not None:
                 roof["traffic"] = t
                 roof["traffic_shape"] = roof["largest_shape"]["op"]
         except Exception:
             pass
-    breakdown = dict(step_kernel_ms=round(total_ms, 3),
+    roof["kernel_launches_per_step"] = round(kernel_launches, 1)
+    breakdown = dict(step_kernel_ms=round(total_ms, 3), kernel_launches_per_step=round(kernel_launches, 1),
                      kernels={k: dict(ms_per_step=round(v["ms"], 3), launches_per_step=round(v["launches"], 1),
                                       avg_launch_us=round(1e3 * v["ms"] / max(v["launches"], 1e-9), 1),
                                       GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
@@ -281,8 +317,24 @@ def launch_ranks(args) -> int:
 
 def timed_steps(stepper, N, steps, warmup, barrier, world, dist, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.  Returns seconds."""
+    tw = time.perf_counter()
     for _ in range(warmup):
         stepper.step(np.random.permutation(N))
+    # ... and at least MIN_WARMUP_S seconds of it whatever --warmup says: a 20-step window right after a cold start was seen
+    # 8 % low (clocks still ramping)
+    extra = 0
+    while True:
+        barrier()
+        el = time.perf_counter() - tw
+        if world > 1:      # one decision for all ranks (every step contains a collective)
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            el = float(t.item())
+        if el >= MIN_WARMUP_S or extra >= 2000:
+            break
+        for _ in range(10):
+            stepper.step(np.random.permutation(N))
+        extra += 10
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -312,7 +364,9 @@ def step_rooflines(breakdown, B, value, world):
     HBM traffic, the neighbour search two ways, and the matrix work per encoder level."""
     layers = CFG["layer_sizes"]
     ws = whole_step_roofline(CFG, value / world)
-    ws["launches_per_step"] = round(sum(k["launches_per_step"] for k in breakdown["kernels"].values()), 1)
+    # every kernel the library launches in a step (its own counter: what a rocprofv3 kernel trace counts for the same step,
+    # without the runtime's few copy kernels) - not just the launches the event timer brackets
+    ws["launches_per_step"] = breakdown["kernel_launches_per_step"]
     out = {"whole_step": ws}
     rows = breakdown["all_shapes"]
     knn = [r for r in rows if r["op"].startswith("knn")]
@@ -339,6 +393,71 @@ def step_rooflines(breakdown, B, value, world):
     return out
 
 
+def trainer_e2e(dev, clouds=200, batch=4):
+    """Clouds/s through the callers' side of the path: Model.train -> Trainer.train -> device data loader
+    (one rl_batch_assemble launch per batch) -> TrainStep graph replay, config A shape (4 clouds of 40960 points per step),
+    default augmentation, one timed epoch of clouds/batch steps after a warm-up epoch (graph capture, allocator).  The epoch
+    is timed between the Trainer's per-epoch callbacks, so it contains that epoch's validation (one batch x 10 passes).
+    Two random-number modes of the loader: "numpy" (the reference's streams, drawn on the host: ~3.5 ms of numpy per cloud
+    bounds it) and "device" (sample indices and jitter noise from a device generator)."""
+    import logging
+    from randlanet import Model, RandLANetSettings, TrainingSettings
+    logging.getLogger("trainer").setLevel(logging.WARNING)
+    N, C = CFG["n_points"], CFG["n_classes"]
+    rs = np.random.RandomState(7)
+    n_raw = N + 4096
+
+    def cloud():
+        xyz = rs.uniform(0.0, 1.0, (n_raw, 3)).astype(np.float32)
+        lab = (np.linalg.norm(xyz - 0.5, axis=-1) < 0.25).astype(np.int64)
+        return xyz, np.zeros((n_raw, 0), np.float32), lab
+    train = [cloud() for _ in range(clouds)]
+    val = train[:batch]
+    out = {"workload": f"Model.train, {clouds} clouds of {n_raw} points sampled to {N}, bs={batch}, default augmentation, "
+                       f"one epoch = {clouds // batch} steps + validation (1 batch x 10 passes); device data loader", "unit": "clouds/s"}
+    for mode in ("numpy", "device"):
+        os.environ["RL_PIPELINE_RNG"] = mode
+        try:
+            torch.manual_seed(0)
+            np.random.seed(0)
+            model = Model(RandLANetSettings(n_classes=C, n_points=N, n_neighbors=CFG["n_neighbors"],
+                                            layer_sizes=list(CFG["layer_sizes"])))
+            stamps = []
+            settings = TrainingSettings(epochs=2, batch_size=batch, early_stopping=False)
+            model.train(train, val, settings, class_names=[f"c{i}" for i in range(C)],
+                        callbacks=[lambda e, m: (torch.cuda.synchronize(dev), stamps.append(time.perf_counter()))])
+            dt = stamps[1] - stamps[0]
+            out[f"rng_{mode}"] = {"value": round(clouds / dt, 2), "ms_per_step": round(1e3 * dt / (clouds // batch), 3)}
+            del model
+        finally:
+            os.environ.pop("RL_PIPELINE_RNG", None)
+        torch.cuda.empty_cache()
+    return out
+
+
+def predict_latency(reps=20, n_cloud=120000):
+    """Config P (BASELINE.json configs[0], reference predict.py:22-31 / the UI's 250 ms timer main.py:49): ms per Model.predict
+    on one mock-shaped cloud - seed-0 down-sample to 2500 points, forward (K = 32, 4 layers), full-resolution nearest-neighbour
+    up-sampling ("nni"), softmax confidences back on the host."""
+    from randlanet import Model, RandLANetSettings
+    rs = np.random.RandomState(0)
+    cloud = rs.rand(n_cloud, 3).astype(np.float32)
+    model = Model(RandLANetSettings(n_classes=2, n_points=2500, n_neighbors=32, upsampling="nni"))
+    for _ in range(3):
+        conf = model.predict(cloud)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        conf = model.predict(cloud)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    if conf.shape != (2, n_cloud) or not np.isfinite(conf).all():
+        raise SystemExit("bench.py: Model.predict returned a malformed result")
+    return {"workload": f"Model.predict: one cloud of {n_cloud} points -> 2500 sampled, K=32, 4 layers, nni up-sampling to every "
+                        "input point, confidences on the host", "value": round(1e3 * dt, 3), "unit": "ms per cloud", "reps": reps,
+            "higher_is_better": False}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +471,7 @@ def main():
     ap.add_argument("--no-inference", action="store_true", help="skip the secondary eval-forward measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config_A / strong_bs8 / bf16_operands / fp32_exact objects")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the config_S / config_Kt_shard objects")
+    ap.add_argument("--no-callers", action="store_true", help="skip the trainer_e2e / predict_P objects (the callers' side of the path)")
     ap.add_argument("--batch", type=int, default=CFG["per_gpu_batch"], help="clouds per GPU (the metric's bs=8)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank control flow on a one-GPU box)")
@@ -415,10 +535,21 @@ def main():
         return {"workload": what, "value": round(per_gpu * world * args.steps / el, 3), "unit": "clouds/s",
                 "per_gpu_batch": per_gpu, "global_batch": per_gpu * world, "scaling": scaling,
                 "ms_per_step": round(1e3 * el / args.steps, 3), "final_loss": round(m["loss"], 5)}
-    config_a = strong = None
+    config_a = strong = sweep = None
     if not args.no_secondary:
         if B != 4:
             config_a = secondary(4, "weak", "BASELINE.json config A (1 GPU) / B (8 GPUs): 4 clouds per GPU")
+        if world == 1 and B == CFG["per_gpu_batch"]:
+            # the compute side of the metric's "bs=8 at 1/2/4/8 GPUs" read as strong scaling: the step of ONE GPU's shard
+            sweep = {"what": "ms per step of one GPU at per-GPU batch 1, 2, 4, 8 (one MI355X; no collective)", "ms_per_step": {}}
+            for b in (1, 2):
+                sweep["ms_per_step"][str(b)] = secondary(b, "weak", "")["ms_per_step"]
+            sweep["ms_per_step"]["4"] = config_a["ms_per_step"] if config_a else None
+            sweep["ms_per_step"]["8"] = round(1e3 * elapsed / args.steps, 3)
+            a, b8 = sweep["ms_per_step"]["4"], sweep["ms_per_step"]["8"]
+            if a:
+                sweep["marginal_ms_per_cloud"] = round((b8 - a) / 4.0, 4)
+                sweep["fixed_ms_per_step"] = round(b8 - 8 * (b8 - a) / 4.0, 4)
         if world > 1 and 8 % world == 0 and 8 // world != B:
             strong = secondary(8 // world, "strong", "the metric's global batch of 8 clouds split over the ranks")
     # BASELINE config A names "bf16": the same step with plain bf16 operands in the wide GEMMs / weight gradients
@@ -510,6 +641,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()             # every collective is done: the other ranks leave, rank 0 times the host path
+    callers_train = callers_predict = None
+    if rank == 0 and not args.no_callers:
+        callers_train = trainer_e2e(dev)
+        callers_predict = predict_latency()
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
@@ -549,6 +684,9 @@ def main():
             "config_S": config_s,
             "config_Kt_shard": config_kt,
             "strong_bs8": strong,
+            "per_gpu_batch_sweep": sweep,
+            "trainer_e2e": callers_train,
+            "predict_P": callers_predict,
             "inference": infer,
         }
         if breakdown is not None:

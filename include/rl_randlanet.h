@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 100
+#define RL_VERSION 104     /* round 4: rl_launch_count; round-3 signature changes (rl_bn_finalize folded_bias, rl_dropout_* first_row, descriptor fields) */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -69,6 +69,9 @@ const char* rl_last_error(void);
  * matches the kernel names of a rocprofv3 trace) */
 const char* rl_last_kernel(void);
 int rl_version(void);
+/* kernel launches issued by this library in the calling process so far (every entry point counts the kernels it launches;
+ * a measurement aid: the difference around an eager step = the kernels a rocprofv3 trace shows for it) */
+int64_t rl_launch_count(void);
 
 /* Number of partial-statistics slots a row-streaming kernel writes for `rows` rows:
  * rl_gemm uses rows_per_tile = 128, rl_loss 256; rl_bn_bwd_reduce has its own rl_bn_bwd_slots. */
