@@ -42,10 +42,25 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // fp32 -> bf16 head + bf16 tail (value = hi + lo up to 2^-17 relative); the products of the score / gradient GEMMs are
 // then a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMAs with fp32 accumulation ("bf16x3", as in gemm.hip)
+// (written on pairs so that it compiles to ten instructions per four values: two v_cvt_pk_bf16_f32 for the heads, a shift and a
+// mask per pair to widen them again, two v_pk_add_f32 for the remainders, two v_cvt_pk_bf16_f32 for the tails - the
+// element-wise form came out at fourteen to fifteen)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ void split2(const f32x2 x, unsigned& hi, unsigned& lo) {
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+    const f32x2 hf = {__uint_as_float(hb << 16), __uint_as_float(hb & 0xffff0000u)};
+    const f32x2 l = x - hf;
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+    hi = hb;
+}
 __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
-    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+    unsigned h0, h1, l0, l1;
+    split2((f32x2){v.x, v.y}, h0, l0);
+    split2((f32x2){v.z, v.w}, h1, l1);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(bf16x4, (u2){h0, h1});
+    lo = __builtin_bit_cast(bf16x4, (u2){l0, l1});
 }
 __device__ __forceinline__ bf16x8 cat8(const bf16x4 a, const bf16x4 b) {
     bf16x8 r;
@@ -551,6 +566,45 @@ __device__ __forceinline__ void finish_x_virtual(const PoolParams& p, int li, in
     }
 }
 
+// ---- reductions over the four lane groups (the 16 rows of a C-layout tile): v_permlane16_swap / v_permlane32_swap (gfx950) instead
+// of ds_bpermute round trips through the LDS pipe; the same operand pairs as __shfl_xor(v, 16) / (v, 32), so the same bits ----
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// sqrt of a squared neighbour distance: the hardware instruction alone (sqrtf wraps it in a range scaling for denormal
+// arguments - a compare, two selects, two ldexp - that a d2 below 1e-38 would need; such a distance is 0 to everything it
+// meets).  One expression in every kernel of the branch.
+__device__ __forceinline__ float vsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// all-reduce over the four lane groups (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float lg_sum(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// two sums at once, seven instructions instead of twelve: the first swap pairs a's upper half with b's lower half, so that one
+// add reduces BOTH over l ^ 32 (a's result in lanes 0..31, b's in lanes 32..63); one more swap + add over l ^ 16; the last swap
+// hands every lane both totals.  (Pairs (l, l^32) before (l, l^16): the other order than lg_sum - sums of four positive
+// softmax terms either way.)
+__device__ __forceinline__ void lg_sum2(float& a, float& b) {
+    u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float z = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+    z = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// max(a, b) of finite values as med3(a, b, FLT_MAX): fmaxf (and med3 against +inf, which the compiler folds back into it)
+// canonicalises every operand first (a v_max_f32 v, v, v each - MFMA results could be signalling NaNs for all it knows), and
+// an inline-asm v_max hides the MFMA -> VALU read hazard from the hazard recogniser (no s_nop: it read accumulators before
+// they were written)
+__device__ __forceinline__ float vmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 0x1.fffffep127f); }
+__device__ __forceinline__ float lg_max(float v) {
+    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 // softmax over the 16 rows of a C-layout tile, in place: s -> A
 template <int DT>
 __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
@@ -561,17 +615,14 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[DT]) {
     constexpr float LOG2E = 1.44269504088896340736f;
 #pragma unroll
     for (int nb = 0; nb < DT; ++nb) {
-        float m = fmaxf(fmaxf(s[nb][0], s[nb][1]), fmaxf(s[nb][2], s[nb][3]));
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float m = lg_max(vmax2(vmax2(s[nb][0], s[nb][1]), vmax2(s[nb][2], s[nb][3])));
         float den = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             s[nb][r] = __builtin_amdgcn_exp2f((s[nb][r] - m) * LOG2E);
             den += s[nb][r];
         }
-        den += __shfl_xor(den, 16, 64);
-        den += __shfl_xor(den, 32, 64);
+        den = lg_sum(den);
         const float inv = __builtin_amdgcn_rcpf(den);
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[nb][r] *= inv;
@@ -691,8 +742,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + nb * 16 + li];
             float acc = sum4(s[nb] * xc);
-            acc += __shfl_xor(acc, 16, 64);
-            acc += __shfl_xor(acc, 32, 64);
+            acc = lg_sum(acc);
             if (lj == 0) p.Pout[pt * D + nb * 16 + li] = acc;
         }
         __builtin_amdgcn_wave_barrier();
@@ -941,8 +991,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + col];
             float pool = sum4(a[nb] * xc);
-            pool += __shfl_xor(pool, 16, 64);
-            pool += __shfl_xor(pool, 32, 64);
+            pool = lg_sum(pool);
             dx[nb] = a[nb] * splat(gp[nb]);                          // direct path dP*A
             dsr[nb] = dx[nb] * (xc - splat(pool));                   // dS = A*dP*(X-P)
 #pragma unroll
@@ -1028,7 +1077,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         }
         if constexpr (DT <= 2) {
             __builtin_amdgcn_wave_barrier();
-            const long orow = (pt * 16 + li) * H;
+                const long orow = (pt * 16 + li) * H;
 #pragma unroll
             for (int c = 0; c < DT; ++c) {
                 const int k = 16 * c + 4 * lj;
@@ -1188,8 +1237,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) xc[r] = Xs[(lj * 4 + r) * XS + col];
             float pool = sum4(a[nb] * xc);
-            pool += __shfl_xor(pool, 16, 64);
-            pool += __shfl_xor(pool, 32, 64);
+            pool = lg_sum(pool);
             dx[nb] = a[nb] * splat(gp[nb]);                          // direct path dP*A
             const f32x4 ds = dx[nb] * (xc - splat(pool));            // dS = A*dP*(X-P)
 #pragma unroll
@@ -1628,27 +1676,6 @@ __global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
 // The softmax / pooling reductions over the four lane groups use v_permlane16_swap / v_permlane32_swap (gfx950) instead of
 // ds_bpermute round trips.
 // ===============================================================================================================
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-
-// all-reduce over the four lane groups (lanes l, l^16, l^32, l^48)
-__device__ __forceinline__ float lg_sum(float v) {
-    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// max(a, b) of finite values as med3(a, b, FLT_MAX): fmaxf (and med3 against +inf, which the compiler folds back into it)
-// canonicalises every operand first (a v_max_f32 v, v, v each - MFMA results could be signalling NaNs for all it knows), and
-// an inline-asm v_max hides the MFMA -> VALU read hazard from the hazard recogniser (no s_nop: it read accumulators before
-// they were written)
-__device__ __forceinline__ float vmax2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 0x1.fffffep127f); }
-__device__ __forceinline__ float lg_max(float v) {
-    u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
 // sum over the 16 lanes of a lane group (end-of-kernel reductions of the A-layout accumulators)
 __device__ __forceinline__ float li_sum(float v) {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
@@ -1763,12 +1790,86 @@ struct RpeIn2 {
     float pc, nc, dd;
     __device__ __forceinline__ void pin() { asm volatile("" : "+v"(pc), "+v"(nc), "+v"(dd)); }
 };
+// ---- addressing of the per-point operands: buffer loads / stores -----------------------------------------------------------------
+// The tile kernels are bound by vector-instruction issue (profiles/r04_pmc_sq_tiles.md: the vector ALU busy in ~80 % of a
+// SIMD's cycles), and a fifth of that was 64-bit address arithmetic (v_lshl_add_u64 / v_mad_u64_u32: half / quarter rate).  Every
+// per-point operand is therefore addressed as  descriptor (SGPRs, from the kernel arguments) + wavefront-uniform byte offset
+// (SGPR, scalar unit) + per-lane byte offset (ONE 32-bit VGPR, mostly a lane constant): no vector instruction for most
+// addresses, one v_lshl_add_u32 / v_mad_u32_u24 for a gather.  A lane that must not take part in an access gets a per-lane
+// offset beyond the descriptor's 2 GB extent: the hardware returns zeros for such a load and drops such a store - the d = 16
+// tile's "zeros in the rpe lanes, gathered rows in the others" and its GU / DG split need no exec masking.
+// (Every tensor addressed this way must be smaller than 2 GB: checked on the host.)
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+constexpr unsigned RL_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* ptr) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// four consecutive elements of a row tensor stored as fp32 or bf16 (offsets in BYTES of that storage)
+template <bool BF>
+__device__ __forceinline__ float4 bldrow4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (BF) {
+        const rl_bf16x4 h = __builtin_bit_cast(rl_bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else return bld4(r, voff, soff);
+}
+// ... stored, non-temporal (read once, by a later kernel: see RL_ST4) unless RL_POOL_PLAIN_STORES.  The wavefront-uniform byte
+// offset goes into the descriptor's BASE (scalar adds), not into the instruction's SGPR offset: a 16-byte buffer store with an
+// SGPR offset, followed at once by a vector instruction that rewrites its data registers, stored the NEW values on this
+// hardware (seen as wrong DG rows in a few hundred of 8192 points, different ones every run, when two workgroups shared a CU) -
+// hipcc 7.2 inserts the wait state this needs only for stores WITHOUT an SGPR offset (its hazard recogniser follows the
+// older ISA manuals' exception for "BUFFER_STORE that use an SGPR for offset").
+template <bool BF>
+__device__ __forceinline__ void bstrow4(const float4 v, const float* base, unsigned voff, unsigned soff_bytes) {
+#ifdef RL_POOL_PLAIN_STORES
+    constexpr int AUX = 0;
+#else
+    constexpr int AUX = 2;      // nt
+#endif
+    const __amdgpu_buffer_rsrc_t r = rsrc_of(reinterpret_cast<const char*>(base) + soff_bytes);
+    if constexpr (BF) {
+        rl_bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, h), r, voff, 0, AUX);
+    } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, 0, AUX);
+}
+// neighbour index of slot li of point pt
+__device__ __forceinline__ int ld_idx(const PoolParams& p, long pt, int li) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc_of(p.idx), (unsigned)li * 4u, (unsigned)(pt * 64), 0);
+}
 // comp = lj < 3 ? lj : 0 (lane constant; lane group 3 supplies the distance, its coordinate loads are dummies)
 __device__ __forceinline__ void fetch_rpe2(const PoolParams& p, const Cursor& cu, int li, int comp, int nbr, RpeIn2& r) {
-    const float* xb = p.xyz + (long)cu.b * p.xyz_bstride * p.xyz_w + comp;
-    r.dd = p.nbr_d2[cu.pt * 16 + li];      // (streaming loads before the gather: see the load groups of the kernels)
-    r.pc = xb[(long)cu.i * p.xyz_w];
-    r.nc = xb[(long)nbr * p.xyz_w];
+    const unsigned w4 = (unsigned)p.xyz_w * 4u;
+    const unsigned cloud = (unsigned)((long)cu.b * p.xyz_bstride) * w4;     // byte offset of the cloud: scalar unit
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(p.xyz);
+    r.dd = bld1(rsrc_of(p.nbr_d2), (unsigned)li * 4u, (unsigned)(cu.pt * 64));      // (streaming loads before the gather: see the load groups of the kernels)
+    r.pc = bld1(rx, (unsigned)comp * 4u, cloud + (unsigned)cu.i * w4);
+    r.nc = bld1(rx, __umul24((unsigned)nbr, w4) + (unsigned)comp * 4u, cloud);      // points per cloud < 2^24 (checked on the host)
+}
+
+// per-lane byte offset of a lane's four channels inside the 16 rows x H block of one point of a (points*16) x H row tensor
+// (chunk 0; chunk c adds 16*c elements), and the wavefront-uniform offset of the point; d = 16: RL_OOB in the lanes of the
+// gathered half (loads give zeros there, stores are dropped)
+template <int DT, bool GB>
+__device__ __forceinline__ unsigned row_voff(int li, int lj) {
+    constexpr unsigned ES = GB ? 2 : 4;
+    return (DT == 1 && lj >= 2) ? RL_OOB : ((unsigned)li * VX<DT>::H + 4u * lj) * ES;
+}
+template <int DT, bool GB>
+__device__ __forceinline__ unsigned row_soff(long pt) { return (unsigned)(pt * (16 * VX<DT>::H * (GB ? 2 : 4))); }
+// the rpe chunks of such a tensor for one point, A layout
+template <int DT, bool GB>
+__device__ __forceinline__ void load_g4(const float* G, long pt, int li, int lj, float4 (&g)[VX<DT>::NCH]) {
+    const __amdgpu_buffer_rsrc_t rg = rsrc_of(G);
+    const unsigned vo = row_voff<DT, GB>(li, lj), so = row_soff<DT, GB>(pt);
+#pragma unroll
+    for (int c = 0; c < VX<DT>::NCH; ++c) g[c] = bldrow4<GB>(rg, vo + 16u * c * (GB ? 2 : 4), so);
 }
 
 // LDS image of W2 (h x h, zero-padded to HP x KP2), [n][k]: the A operand of the transposed stage-2 product
@@ -1894,7 +1995,7 @@ struct XFold {
 // raw (bias-free) first-stage tile of one point, A layout: r[nb] = c0[nb] + U . x_i + [V | wd] . [x_i - x_j, dist]
 template <int DT>
 __device__ __forceinline__ void stage1_raw(const RpeIn2& in, const VLane<DT>& vl, const f32x4 (&c0)[VX<DT>::NCH], f32x4 (&r)[VX<DT>::NCH]) {
-    float diff = in.pc - in.nc, dist = __fsqrt_rn(in.dd), pc = in.pc;
+    float diff = in.pc - in.nc, dist = vsqrt(in.dd), pc = in.pc;
     asm volatile("" : "+v"(diff), "+v"(dist), "+v"(pc));      // selects, not exec-masked branches (see rpe_gemm)
     const float a1 = vl.l3 ? dist : diff;
     const float a2 = vl.l3 ? 0.f : pc;
@@ -1962,28 +2063,25 @@ __device__ __forceinline__ void build_x(const RpeIn2& in, const float4 (&graw)[D
     }
 }
 
-// the gathered chunks of a point (DT == 1: the mixed chunk through the per-lane base / stride)
+// the gathered chunks of a point (d = 16: the mixed chunk - the rpe lanes read beyond the descriptor and get zeros)
 template <int DT>
 struct GatherG {
-    const float* base;      // DT == 1: lanes lj < 2 -> 16 bytes of zeros, stride 0
-    unsigned mul;
+    unsigned vcol;      // per-lane byte offset inside a gathered row (+ RL_OOB in the rpe lanes of the mixed chunk)
     __device__ __forceinline__ void init(const PoolParams& p, int lj) {
         constexpr int H = VX<DT>::H;
-        if constexpr (DT == 1) {
-            base = lj < 2 ? g_zero16 : p.G + (4 * lj - H);
-            mul = lj < 2 ? 0u : (unsigned)H;
-        } else {
-            base = p.G + 4 * lj;
-            mul = (unsigned)H;
-        }
+        if constexpr (DT == 1) vcol = lj < 2 ? RL_OOB : (unsigned)(4 * lj - H) * 4u;
+        else vcol = (unsigned)(4 * lj) * 4u;
     }
     __device__ __forceinline__ void fetch(const PoolParams& p, const Cursor& cu, int nbr, float4 (&raw)[DT]) const {
-        const unsigned row = (unsigned)((long)cu.b * p.g_bstride) + (unsigned)nbr;     // rows of G < 2^31 (checked on the host)
-        const float* r = base + (unsigned long)row * mul;
-        if constexpr (DT == 1) raw[0] = *reinterpret_cast<const float4*>(r);
+        constexpr int H = VX<DT>::H;
+        constexpr unsigned ROWB = H * 4;                                            // bytes of a row of G: 32 / 64 / 128
+        const __amdgpu_buffer_rsrc_t rg = rsrc_of(p.G);
+        const unsigned cloud = (unsigned)((long)cu.b * p.g_bstride) * ROWB;         // scalar unit
+        const unsigned vo = (unsigned)nbr * ROWB + vcol;                            // one v_lshl_add_u32
+        if constexpr (DT == 1) raw[0] = bld4(rg, vo, cloud);
         else {
 #pragma unroll
-            for (int c = VX<DT>::NCH; c < DT; ++c) raw[c] = *reinterpret_cast<const float4*>(r + (16 * c - VX<DT>::H));
+            for (int c = VX<DT>::NCH; c < DT; ++c) raw[c] = bld4(rg, vo + (unsigned)(16 * c - H) * 4u, cloud);
         }
     }
 };
@@ -2091,9 +2189,10 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     for (int nb = 0; nb < NCH; ++nb) fs2[nb] = fq2[nb] = splat(0.f);
     __syncthreads();
     float* Xs = Xt[wave];
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
-    const long npts = wave_points(pt, pstep, p.P);
+    // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
+    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
+    int pt = (int)blockIdx.x * NW + wave;
+    const int npts = (int)wave_points(pt, pstep, P);
     // Software pipeline TWO points deep (round 4: with ~160 instructions per point left, one point of prefetch is shorter than a
     // gather's latency).  Two buffers alternate: while buffer U's point is computed, U is refilled for the point two further on
     // and the other buffer's loads (issued one iteration ago) are awaited - loads_landed_but<NG> leaves this iteration's group
@@ -2105,12 +2204,12 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     c0.start(pt, p.n);
     c1 = c0.next(pstep, p.n);
     c2 = c1.next(pstep, p.n);
-    if (pt < p.P) {
-        const bool v1 = pt + pstep < p.P;
-        const int i0 = p.idx[pt * 16 + li];
-        const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
-        A.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
-        B.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+    if (pt < P) {
+        const bool v1 = pt + pstep < P;
+        const int i0 = ld_idx(p, pt, li);
+        const int i1 = ld_idx(p, v1 ? pt + pstep : pt, li);
+        A.idx = ld_idx(p, pt + 2 * pstep < P ? pt + 2 * pstep : pt, li);
+        B.idx = ld_idx(p, pt + 3 * pstep < P ? pt + 3 * pstep : pt, li);
         gg.fetch(p, c0, i0, A.graw);
         fetch_rpe2(p, c0, li, vl.comp, i0, A.rin);
         gg.fetch(p, v1 ? c1 : c0, i1, B.graw);
@@ -2125,10 +2224,10 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
         for (int c = 0; c < DT; ++c) *reinterpret_cast<float4*>(Xs + li * XS + 16 * c + 4 * lj) = xa[c];
         // refill U for the point two further on - one group, no branch around it (past the last point the current one is read again)
         {
-            const Cursor cf = pt + 2 * pstep < p.P ? c2 : c0;
+            const Cursor cf = pt + 2 * pstep < P ? c2 : c0;
             fetch_rpe2(p, cf, li, vl.comp, U.idx, U.rin);
             gg.fetch(p, cf, U.idx, U.graw);
-            U.idx = p.idx[(pt + 4 * pstep < p.P ? pt + 4 * pstep : pt) * 16 + li];
+            U.idx = ld_idx(p, pt + 4 * pstep < P ? pt + 4 * pstep : pt, li);
         }
         loads_issued();
         c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
@@ -2174,24 +2273,27 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
             f32x4 e;
 #pragma unroll
             for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
-            const float den = lg_sum(sum4(e)), num = lg_sum(sum4(e * xc));
+            float den = sum4(e), num = sum4(e * xc);
+            lg_sum2(den, num);
             outv[nb] = num * __builtin_amdgcn_rcpf(den);
         }
         loads_landed_but<NG>();
         if constexpr (DT == 4) {
             // every lane holds all four results: lane group q stores column block q - one 256-byte store per point
             const float v = lj == 0 ? outv[0] : lj == 1 ? outv[1] : lj == 2 ? outv[2] : outv[3];
-            p.Pout[pt * D + lane] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc_of(p.Pout), (unsigned)lane * 4u, (unsigned)(pt * (D * 4)), 0);
         } else {
+            // lane group nb stores column block nb (the others' offsets lie beyond the descriptor: dropped)
 #pragma unroll
             for (int nb = 0; nb < DT; ++nb)
-                if (lj == nb) p.Pout[pt * D + nb * 16 + li] = outv[nb];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv[nb]), rsrc_of(p.Pout),
+                                                      lj == nb ? (unsigned)(nb * 16 + li) * 4u : RL_OOB, (unsigned)(pt * (D * 4)), 0);
         }
         __builtin_amdgcn_wave_barrier();
     };
     // ONE exit from the loop: with a break after either half the two exits are merged into one block that (as far as the
     // waitcnt pass can tell) also leads back to the loop header - it then waits for the loads just issued at the top of the loop
-    for (long k = npts >> 1; k > 0; --k) {
+    for (int k = npts >> 1; k > 0; --k) {
         body(A);
         pt += pstep;
         body(B);
@@ -2225,9 +2327,10 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
     f32x4 ssum[NCH], ssq[NCH];
 #pragma unroll
     for (int nb = 0; nb < NCH; ++nb) ssum[nb] = ssq[nb] = splat(0.f);
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
-    const long npts = wave_points(pt, pstep, p.P);
+    // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
+    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
+    int pt = (int)blockIdx.x * NW + wave;
+    const int npts = (int)wave_points(pt, pstep, P);
     // two points deep, two alternating buffers (see vpool_fwd_kernel): coordinates + distance of a point, and the neighbour
     // index of the point that takes the buffer next
     constexpr int NG = 3 + 1;
@@ -2236,12 +2339,12 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
     c0.start(pt, p.n);
     c1 = c0.next(pstep, p.n);
     c2 = c1.next(pstep, p.n);
-    if (pt < p.P) {
-        const bool v1 = pt + pstep < p.P;
-        const int i0 = p.idx[pt * 16 + li];
-        const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
-        A.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
-        B.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+    if (pt < P) {
+        const bool v1 = pt + pstep < P;
+        const int i0 = ld_idx(p, pt, li);
+        const int i1 = ld_idx(p, v1 ? pt + pstep : pt, li);
+        A.idx = ld_idx(p, pt + 2 * pstep < P ? pt + 2 * pstep : pt, li);
+        B.idx = ld_idx(p, pt + 3 * pstep < P ? pt + 3 * pstep : pt, li);
         fetch_rpe2(p, c0, li, vl.comp, i0, A.rin);
         fetch_rpe2(p, v1 ? c1 : c0, li, vl.comp, i1, B.rin);
     }
@@ -2252,9 +2355,9 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
         for (int nb = 0; nb < NCH; ++nb) c0v[nb] = splat(0.f);
         stage1_raw<DT>(U.rin, vl, c0v, raw);
         {
-            const Cursor cf = pt + 2 * pstep < p.P ? c2 : c0;      // (no branch: see pool_fwd_kernel)
+            const Cursor cf = pt + 2 * pstep < P ? c2 : c0;      // (no branch: see pool_fwd_kernel)
             fetch_rpe2(p, cf, li, vl.comp, U.idx, U.rin);
-            U.idx = p.idx[(pt + 4 * pstep < p.P ? pt + 4 * pstep : pt) * 16 + li];
+            U.idx = ld_idx(p, pt + 4 * pstep < P ? pt + 4 * pstep : pt, li);
         }
         loads_issued();
         c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
@@ -2288,7 +2391,7 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
         }
         loads_landed_but<NG>();
     };
-    for (long k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
+    for (int k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
         body(A);
         pt += pstep;
         body(B);
@@ -2358,11 +2461,10 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
     gg.init(p, lj);
     // d = 16: the one output chunk is GU in lanes lj < 2 and DG in the others - per-lane base pointer and column; the GU
     // this launch adds to is read the same way (the other lanes read 16 bytes of zeros)
-    float* obase = (DT == 1 && lj >= 2) ? p.DG : p.GU;
-    const int ocol = DT == 1 ? (lj < 2 ? 4 * lj : 4 * lj - H) : 0;
-    const float* abase = (DT == 1 && lj >= 2) ? g_zero16 : p.GU;
-    const long amul = (DT == 1 && lj >= 2) ? 0 : 1;
-    const int acol = (DT == 1 && lj >= 2) ? 0 : 4 * lj;
+    constexpr unsigned ES = GB ? 2 : 4;
+    const unsigned v_gu = row_voff<DT, GB>(li, lj);                                                   // rpe lanes / chunks -> GU
+    const unsigned v_dg = DT == 1 ? (lj >= 2 ? ((unsigned)li * H + 4u * lj - H) * ES : RL_OOB)        // gathered lanes / chunks -> DG
+                                  : ((unsigned)li * H + 4u * lj) * ES;
     f32x4 bsg[NCH], bsx[NCH];
 #pragma unroll
     for (int nb = 0; nb < NCH; ++nb) bsg[nb] = bsx[nb] = splat(0.f);
@@ -2375,13 +2477,17 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
 #pragma unroll
         for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = splat(0.f);
 
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
-    const long npts = wave_points(pt, pstep, p.P);
+    // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
+    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
+    int pt = (int)blockIdx.x * NW + wave;
+    const int npts = (int)wave_points(pt, pstep, P);
     // Software pipeline two points deep (see vpool_fwd_kernel): a buffer holds a point's gathered rows, coordinates, dP and - when
     // this launch adds to GU - its GU rows, plus the neighbour index of the point that takes the buffer next.
     constexpr int NG = (DT == 4 ? 2 : 1) + 3 + 1 + DT + (ACC ? NCH : 0);      // loads of one group
-    constexpr int AHEAD = DT >= 4 ? 1 : 2;      // d = 64: no registers for a second buffer (256 per lane with 8 wavefronts per workgroup) - one point ahead
+#ifndef RL_BWD_AHEAD16
+#define RL_BWD_AHEAD16 2
+#endif
+    constexpr int AHEAD = DT >= 4 ? 1 : RL_BWD_AHEAD16;      // d = 64: no registers for a second buffer (256 per lane with 8 wavefronts per workgroup) - one point ahead
     PreB<DT, ACC> A, B;
     A.zero(); B.zero();
     Cursor c0, c1, c2;
@@ -2392,25 +2498,25 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
         // (dP first: should the register allocator rotate a buffer register with a copy at the back edge, the copy waits for the
         // OLDEST load of the group - a streaming one - not for the gathers)
 #pragma unroll
-        for (int nb = 0; nb < DT; ++nb) U.gp[nb] = p.dP[cf.pt * D + nb * 16 + li];
+        for (int nb = 0; nb < DT; ++nb) U.gp[nb] = bld1(rsrc_of(p.dP), (unsigned)(nb * 16 + li) * 4u, (unsigned)(cf.pt * (D * 4)));
         if constexpr (ACC) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) U.gacc[c] = rl_ldx4<GB>(abase, ((cf.pt * 16 + li) * H) * amul + 16 * c + acol);
+            for (int c = 0; c < NCH; ++c) U.gacc[c] = bldrow4<GB>(rsrc_of(p.GU), v_gu + 16u * c * ES, row_soff<DT, GB>(cf.pt));
         }
         fetch_rpe2(p, cf, li, vl.comp, nbr, U.f.rin);
         gg.fetch(p, cf, nbr, U.f.graw);
     };
-    if (pt < p.P) {
-        const int i0 = p.idx[pt * 16 + li];
+    if (pt < P) {
+        const int i0 = ld_idx(p, pt, li);
         if constexpr (AHEAD == 2) {
-            const bool v1 = pt + pstep < p.P;
-            const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
-            A.f.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
-            B.f.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+            const bool v1 = pt + pstep < P;
+            const int i1 = ld_idx(p, v1 ? pt + pstep : pt, li);
+            A.f.idx = ld_idx(p, pt + 2 * pstep < P ? pt + 2 * pstep : pt, li);
+            B.f.idx = ld_idx(p, pt + 3 * pstep < P ? pt + 3 * pstep : pt, li);
             fill(A, c0, i0);
             fill(B, v1 ? c1 : c0, i1);
         } else {
-            A.f.idx = p.idx[(pt + pstep < p.P ? pt + pstep : pt) * 16 + li];
+            A.f.idx = ld_idx(p, pt + pstep < P ? pt + pstep : pt, li);
             fill(A, c0, i0);
         }
     }
@@ -2437,9 +2543,9 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
         }
         // refill U for the point two further on - one group, no branch around it (past the last point the current one is read again)
         {
-            const Cursor cf = pt + AHEAD * pstep < p.P ? (AHEAD == 2 ? c2 : c1) : c0;
+            const Cursor cf = pt + AHEAD * pstep < P ? (AHEAD == 2 ? c2 : c1) : c0;
             fill(U, cf, U.f.idx);
-            U.f.idx = p.idx[(pt + 2 * AHEAD * pstep < p.P ? pt + 2 * AHEAD * pstep : pt) * 16 + li];
+            U.f.idx = ld_idx(p, pt + 2 * AHEAD * pstep < P ? pt + 2 * AHEAD * pstep : pt, li);
         }
         loads_issued();
         c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
@@ -2468,7 +2574,8 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
             f32x4 e;
 #pragma unroll
             for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(t[r]);
-            const float den = lg_sum(sum4(e)), num = lg_sum(sum4(e * xc));
+            float den = sum4(e), num = sum4(e * xc);
+            lg_sum2(den, num);
             const float inv = __builtin_amdgcn_rcpf(den);
             const float pool = num * inv;
             dx[nb] = e * splat(inv * gpv[nb]);                        // direct path dP*A
@@ -2526,7 +2633,7 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
             for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + nb * 16 + li] = dx[nb][r];
         __builtin_amdgcn_wave_barrier();
         loads_landed_but<AHEAD == 2 ? NG : 0>();
-        const long orow = (pt * 16 + li) * H;
+        const unsigned orow = row_soff<DT, GB>(pt);
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
             f32x4 v = *reinterpret_cast<const f32x4*>(Ds + li * XS + 16 * c + 4 * lj);
@@ -2544,14 +2651,16 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
                     bsx[c] = __builtin_elementwise_fma(g, (rawu[c] - vl.get(VX<DT>::MU, c)) * vl.get(VX<DT>::IS, c), bsx[c]);
                 }
             }
-            if constexpr (DT == 1) RL_ST4<GB>(obase, orow + ocol, f4(v));
-            else if (c < NCH) RL_ST4<GB>(p.GU, orow + 16 * c + 4 * lj, f4(v));
-            else RL_ST4<GB>(p.DG, orow + 16 * c + 4 * lj - H, f4(v));
+            if constexpr (DT == 1) {
+                bstrow4<GB>(f4(v), p.GU, v_gu, orow);      // (each lane takes part in one of the two)
+                bstrow4<GB>(f4(v), p.DG, v_dg, orow);
+            } else if (c < NCH) bstrow4<GB>(f4(v), p.GU, v_gu + 16u * c * ES, orow);
+            else bstrow4<GB>(f4(v), p.DG, v_dg + (16u * c - H) * ES, orow);
         }
         __builtin_amdgcn_wave_barrier();
     };
     if constexpr (AHEAD == 2) {
-        for (long k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
+        for (int k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
             body(A);
             pt += pstep;
             body(B);
@@ -2559,7 +2668,7 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
         }
         if (npts & 1) body(A);
     } else {
-        for (long k = npts; k > 0; --k) {
+        for (int k = npts; k > 0; --k) {
             body(A);
             pt += pstep;
         }
@@ -2691,14 +2800,6 @@ __device__ __forceinline__ void stage_raw(const RpeIn2& in, const VLane<DT>& vl,
     }
 }
 
-// the rpe chunks of a (points*16) x H row tensor for one point, A layout (d = 16: the lanes of the gathered half re-read columns 0..3)
-template <int DT, bool GB>
-__device__ __forceinline__ void load_g4(const float* G, long pt, int li, int lj, float4 (&g)[VX<DT>::NCH]) {
-    const int col = (DT == 1 && lj >= 2) ? 0 : 4 * lj;
-#pragma unroll
-    for (int c = 0; c < VX<DT>::NCH; ++c) g[c] = rl_ldx4<GB>(G, (pt * 16 + li) * VX<DT>::H + 16 * c + col);
-}
-
 template <int DT, int TERMS, int SRC, bool GB>
 __global__ __launch_bounds__(256) void vrpe_bn_reduce_kernel(const RpeBwdParams q) {
     const PoolParams& p = q.pp;
@@ -2719,25 +2820,26 @@ __global__ __launch_bounds__(256) void vrpe_bn_reduce_kernel(const RpeBwdParams 
     f32x4 sg[NCH], sx[NCH];
 #pragma unroll
     for (int nb = 0; nb < NCH; ++nb) sg[nb] = sx[nb] = splat(0.f);
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
+    // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
+    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
+    int pt = (int)blockIdx.x * NW + wave;
     RpeIn2 rin = {0.f, 0.f, 0.f}, rin_nxt;
     Cursor cu;
     cu.start(pt, p.n);
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    int idx_nxt = pt + pstep < P ? ld_idx(p, pt + pstep, li) : 0;
     float4 gin[NCH], gin_nxt[NCH];
 #pragma unroll
     for (int nb = 0; nb < NCH; ++nb) gin[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pt < p.P) {
-        fetch_rpe2(p, cu, li, vl.comp, p.idx[pt * 16 + li], rin);
+    if (pt < P) {
+        fetch_rpe2(p, cu, li, vl.comp, ld_idx(p, pt, li), rin);
         load_g4<DT, GB>(q.G, pt, li, lj, gin);
     }
     loads_landed();
-    for (; pt < p.P; pt += pstep) {
+    for (; pt < P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        const int idx_n2 = pt + 2 * pstep < P ? ld_idx(p, pt + 2 * pstep, li) : 0;
         {
-            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
+            const Cursor cf = pt + pstep < P ? cn : cu;      // (no branch: see pool_fwd_kernel)
             fetch_rpe2(p, cf, li, vl.comp, idx_nxt, rin_nxt);
             load_g4<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
         }
@@ -2822,8 +2924,9 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = splat(0.f);
     }
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
+    // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
+    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
+    int pt = (int)blockIdx.x * NW + wave;
     // two points deep, two alternating buffers (see vpool_fwd_kernel)
     constexpr int NG = 3 + NCH + 1;
     struct Buf { RpeIn2 rin; float4 gin[NCH]; int idx; } A, B;
@@ -2831,17 +2934,17 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
     A.idx = B.idx = 0;
 #pragma unroll
     for (int nb = 0; nb < NCH; ++nb) A.gin[nb] = B.gin[nb] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long npts = wave_points(pt, pstep, p.P);
+    const int npts = (int)wave_points(pt, pstep, P);
     Cursor c0, c1, c2;
     c0.start(pt, p.n);
     c1 = c0.next(pstep, p.n);
     c2 = c1.next(pstep, p.n);
-    if (pt < p.P) {
-        const bool v1 = pt + pstep < p.P;
-        const int i0 = p.idx[pt * 16 + li];
-        const int i1 = p.idx[(v1 ? pt + pstep : pt) * 16 + li];
-        A.idx = p.idx[(pt + 2 * pstep < p.P ? pt + 2 * pstep : pt) * 16 + li];
-        B.idx = p.idx[(pt + 3 * pstep < p.P ? pt + 3 * pstep : pt) * 16 + li];
+    if (pt < P) {
+        const bool v1 = pt + pstep < P;
+        const int i0 = ld_idx(p, pt, li);
+        const int i1 = ld_idx(p, v1 ? pt + pstep : pt, li);
+        A.idx = ld_idx(p, pt + 2 * pstep < P ? pt + 2 * pstep : pt, li);
+        B.idx = ld_idx(p, pt + 3 * pstep < P ? pt + 3 * pstep : pt, li);
         fetch_rpe2(p, c0, li, vl.comp, i0, A.rin);
         load_g4<DT, GB>(q.G, pt, li, lj, A.gin);
         fetch_rpe2(p, v1 ? c1 : c0, li, vl.comp, i1, B.rin);
@@ -2858,7 +2961,7 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
         // stage 1: the reduced inputs (columns 2*lj, 2*lj + 1 of the input tile), taken before the buffer is refilled
         float in0 = 0.f, in1 = 0.f;
         if constexpr (SRC == 1) {
-            const float diff = U.rin.pc - U.rin.nc, dist = __fsqrt_rn(U.rin.dd);
+            const float diff = U.rin.pc - U.rin.nc, dist = vsqrt(U.rin.dd);
             in0 = vl.l3 ? 0.f : U.rin.pc;
             in1 = vl.l3 ? dist : diff;
         }
@@ -2878,12 +2981,12 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
             dy[nb] = f4(d);
         }
         {
-            const Cursor cf = pt + 2 * pstep < p.P ? c2 : c0;      // (no branch: see pool_fwd_kernel)
+            const Cursor cf = pt + 2 * pstep < P ? c2 : c0;      // (no branch: see pool_fwd_kernel)
             // (the streaming rows first: should the register allocator rotate a buffer register with a copy at the back edge,
             // the copy then waits for the oldest loads of the group, not for the gathers)
             load_g4<DT, GB>(q.G, cf.pt, li, lj, U.gin);
             fetch_rpe2(p, cf, li, vl.comp, U.idx, U.rin);
-            U.idx = p.idx[(pt + 4 * pstep < p.P ? pt + 4 * pstep : pt) * 16 + li];
+            U.idx = ld_idx(p, pt + 4 * pstep < P ? pt + 4 * pstep : pt, li);
         }
         loads_issued();
         c0 = c1; c1 = c2; c2 = c2.next(pstep, p.n);
@@ -2918,10 +3021,9 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
                 for (int nb = 0; nb < NCH; ++nb) gu[nb] = splat(0.f);
                 gemm_f32<DT, VX<DT>::NC2, NCH, true>(dy, w2t.f, VX<DT>::S2F, li, lj, gu);
                 loads_landed_but<NG>();
-                if (DT != 1 || lj < 2) {
 #pragma unroll
-                    for (int nb = 0; nb < NCH; ++nb) RL_ST4<GB>(q.GU1, (pt * 16 + li) * H + 16 * nb + 4 * lj, f4(gu[nb]));
-                }
+                for (int nb = 0; nb < NCH; ++nb)
+                    bstrow4<GB>(f4(gu[nb]), q.GU1, row_voff<DT, GB>(li, lj) + 16u * nb * (GB ? 2 : 4), row_soff<DT, GB>(pt));
             } else loads_landed_but<NG>();
         } else {
             __bf16* Bi = reinterpret_cast<__bf16*>(Ti);      // planes: [hi][16][RSB], [lo][16][RSB]
@@ -3002,15 +3104,14 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
                 for (int nb = 0; nb < NCH; ++nb) gu[nb] = splat(0.f);
                 gemm_frag<DT, NCH, 1, true>(fd, w2t.h, w2t.l, VX<DT>::S2B, li, lj, gu);
                 loads_landed_but<NG>();
-                if (DT != 1 || lj < 2) {
 #pragma unroll
-                    for (int nb = 0; nb < NCH; ++nb) RL_ST4<GB>(q.GU1, (pt * 16 + li) * H + 16 * nb + 4 * lj, f4(gu[nb]));
-                }
+                for (int nb = 0; nb < NCH; ++nb)
+                    bstrow4<GB>(f4(gu[nb]), q.GU1, row_voff<DT, GB>(li, lj) + 16u * nb * (GB ? 2 : 4), row_soff<DT, GB>(pt));
             } else loads_landed_but<NG>();
         }
         __builtin_amdgcn_wave_barrier();
     };
-    for (long k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
+    for (int k = npts >> 1; k > 0; --k) {      // (one exit: see vpool_fwd_kernel)
         body(A);
         pt += pstep;
         body(B);
@@ -3130,7 +3231,14 @@ int pool_grid(long P, int d, bool backward, bool virt = false) {
         if (g8 < 1) g8 = 1;
         return (int)(g8 < 256 ? g8 : 256);
     }
-    const long cap = (!backward && d <= 16) ? 1280 : (!backward && d == 64) ? 768 : 1024;
+    // (RL_GRID_FWD16 / RL_GRID_BWD16 / RL_GRID_FWD64: measurement overrides of the caps, tools/pool_bench.py)
+    static const long env_f16 = getenv("RL_GRID_FWD16") ? atol(getenv("RL_GRID_FWD16")) : 0;
+    static const long env_b16 = getenv("RL_GRID_BWD16") ? atol(getenv("RL_GRID_BWD16")) : 0;
+    static const long env_f64 = getenv("RL_GRID_FWD64") ? atol(getenv("RL_GRID_FWD64")) : 0;
+    long cap = (!backward && d <= 16) ? 1280 : (!backward && d == 64) ? 768 : 1024;
+    if (!backward && d <= 16 && env_f16 > 0) cap = env_f16;
+    if (backward && d <= 16 && env_b16 > 0) cap = env_b16;
+    if (!backward && d == 64 && env_f64 > 0) cap = env_f64;
     long g = (P + 15) / 16;  // >= 4 points per wavefront
     if (d == 128) g = (P + 31) / 32 < 256 ? (P + 31) / 32 : 256;   // 8 wavefronts per workgroup, one workgroup per CU
     if (g < 1) g = 1;
@@ -3148,6 +3256,18 @@ static int pool_terms(int d) {
     }
     if (d <= max_d) return 0;
     return rl_wide_terms();
+}
+
+// The kernels of a virtual rpe branch address their operands through 32-bit byte offsets (buffer descriptors, see "addressing of
+// the per-point operands"): every tensor they touch must stay below 2 GB, and a cloud below 2^24 points.
+int virtual_extents_ok(const rl_pool_desc* d, const char* who) {
+    const int64_t B = d->n > 0 ? d->points / d->n : 0, h = d->d / 2, lim = (int64_t)1 << 31;
+    RL_REQUIRE(d->n < (1 << 24), RL_ERR_UNSUPPORTED, "%s: a virtual rpe branch needs fewer than 2^24 points per cloud", who);
+    RL_REQUIRE((int64_t)d->points * 16 * h * 4 < lim && (int64_t)d->points * d->d * 4 < lim, RL_ERR_UNSUPPORTED,
+               "%s: a virtual rpe branch needs (points*16) x d/2 row tensors below 2 GB", who);
+    RL_REQUIRE(B * d->xyz_bstride * 16 < lim && (d->g_bstride == 0 || B * d->g_bstride * h * 4 < lim), RL_ERR_UNSUPPORTED,
+               "%s: a virtual rpe branch needs coordinate / feature tables below 2 GB", who);
+    return RL_OK;
 }
 
 int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
@@ -3178,6 +3298,7 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->xyz = d->xyz; p->xyz_bstride = d->xyz_bstride; p->nbr_d2 = d->nbr_d2;
     p->xyz_w = d->xyz_width == 4 ? 4 : 3;
     if (d->u_source > 0) {
+        { int rc2 = virtual_extents_ok(d, who); if (rc2) return rc2; }
         RL_REQUIRE(d->xyz_width == 0 || d->xyz_width == 3 || d->xyz_width == 4, RL_ERR_ARGS, "%s: xyz_width must be 3 or 4", who);
         RL_REQUIRE(d->xyz_width != 4 || ((uintptr_t)d->xyz & 15) == 0, RL_ERR_ARGS, "%s: padded xyz must be 16-byte aligned", who);
     }
@@ -3328,6 +3449,7 @@ extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) 
     RL_REQUIRE(d->xyz && d->nbr_d2 && d->xyz_bstride >= d->n && d->W1 && d->b1, RL_ERR_ARGS, "rl_rpe_stats: incomplete rpe branch");
     RL_REQUIRE(d->u_source < 2 || (d->W2 && d->b2 && d->scale1 && d->shift1), RL_ERR_ARGS, "rl_rpe_stats: stage 2 needs W2 / b2 and BatchNorm 1");
     RL_REQUIRE((int64_t)d->points * 16 < (1l << 31), RL_ERR_ARGS, "rl_rpe_stats: too many neighbourhood rows");
+    { int rc2 = virtual_extents_ok(d, "rl_rpe_stats"); if (rc2) return rc2; }
     PoolParams p = {};
     p.idx = d->idx; p.P = d->points; p.n = d->n; p.d = d->d; p.src = d->u_source;
     p.xyz = d->xyz; p.xyz_bstride = d->xyz_bstride; p.nbr_d2 = d->nbr_d2;
@@ -3360,6 +3482,7 @@ static int rpe_bwd_fill(RpeBwdParams* q, const rl_pool_desc* d, const float* G, 
     RL_REQUIRE(d->u_source < 2 || (d->W2 && d->b2 && d->scale2 && d->shift2 && d->mean2 && d->invstd2), RL_ERR_ARGS,
                "%s: stage 2 needs W2 / b2 and its BatchNorm records", who);
     RL_REQUIRE((int64_t)d->points * 16 < (1l << 31), RL_ERR_ARGS, "%s: too many neighbourhood rows", who);
+    { int rc2 = virtual_extents_ok(d, who); if (rc2) return rc2; }
     PoolParams& p = q->pp;
     p = PoolParams{};
     p.idx = d->idx; p.P = d->points; p.n = d->n; p.d = d->d; p.src = d->u_source;

@@ -180,7 +180,7 @@ class Engine:
         ctx.bn_defer = [] if self.sync is None else None
         f0 = self._mlp(ctx, xin, f"{e}.mlp1", h, H.ACT_LRELU, 0.2)
         sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
-        if ops.virtual_rpe_supported(d, K):
+        if ops.virtual_rpe_supported(d, K, B * n, n):
             # the outputs of mlp_rpe1 / mlp_rpe2 are never stored: their consumers recompute them from the coordinates
             vr = ops.VirtualRpe(ctx.xyz4 if getattr(ctx, "xyz4", None) is not None else xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
                                 self.P[f"{e}.mlp_rpe2.conv.weight"], self.P[f"{e}.mlp_rpe2.conv.bias"])
@@ -272,7 +272,7 @@ class Engine:
         searches = ops.knn_multi(xyz, tasks)
         # coordinates padded to 16 bytes for the kernels that gather them per neighbour (virtual rpe branch)
         xyz4 = None
-        if any(ops.virtual_rpe_supported(d, self.K) for d in self.layers):
+        if any(ops.virtual_rpe_supported(d, self.K, B * (N // dec ** l), N // dec ** l) for l, d in enumerate(self.layers)):
             xyz4 = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
             ops.copy_rows(xyz.view(B * N, 3), (0, 3), N, xyz4.view(B * N, 4), (0, 3), B * N, N)
             ctx.keep.append(xyz4)

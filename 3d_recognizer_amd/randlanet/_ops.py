@@ -401,6 +401,9 @@ def _slab(device, floats: int) -> torch.Tensor:
 NO_WGRAD_BATCH = bool(int(__import__("os").environ.get("RL_NO_WGRAD_BATCH", "0")))      # diagnostics: one launch per layer
 
 
+WGRAD_BATCH_BYTES = int(__import__("os").environ.get("RL_WGRAD_BATCH_BYTES", str(3 << 30)))   # operands a queued group may pin
+
+
 def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: int, w_ns: int,
           dbias: Optional[torch.Tensor] = None, pending: Optional[list] = None, batch: Optional[list] = None) -> None:
     """dW / dbias of a layer.  With `pending` (a list) only the per-workgroup partial slabs are produced, in a
@@ -427,8 +430,12 @@ def wgrad(a, dY: torch.Tensor, dy_bstride: int, N: int, dW: torch.Tensor, w_ks: 
     nbytes, flops = es * (M * (K if not isinstance(a, Rpe) else 6) + M * N) + 4 * K * N, 2 * M * K * N
     kind = H.lib().rl_wgrad_batchable(C.byref(d)) if (batch is not None and pending is not None and not NO_WGRAD_BATCH) else 0
     if kind:
-        # (the operands stay referenced by the queue entry until the grouped launch has been issued)
+        # (the operands stay referenced by the queue entry until the grouped launch has been issued: the queue is flushed
+        # early once it holds WGRAD_BATCH_BYTES of them, so that a large configuration does not keep every layer's A / dY
+        # alive until the end of backward - a handful of grouped launches still remove most of the launch overhead)
         batch.append((d, nbytes, flops, a, dY, slab, kind))
+        if sum(b[1] for b in batch) > WGRAD_BATCH_BYTES:
+            wgrad_batch_flush(batch)
     else:
         with _rec("wgrad_rpe" if isinstance(a, Rpe) else "wgrad", (M, K, N), nbytes, flops):
             H.check(H.lib().rl_wgrad(C.byref(d), _st()), "rl_wgrad")
@@ -796,7 +803,11 @@ class VirtualRpe:
         return self.B * self.n * 16
 
 
-def virtual_rpe_supported(d: int, K: int) -> bool:
+def virtual_rpe_supported(d: int, K: int, points: int = 0, n: int = 0) -> bool:
+    """points / n (when given): the kernels of a virtual branch address through 32-bit byte offsets - (points*16) x d/2 row
+    tensors below 2 GB, clouds below 2^24 points; larger levels take the stored path."""
+    if points * 16 * (d // 2) * 4 >= 2 ** 31 or n >= 2 ** 24:
+        return False
     return VIRTUAL_RPE and K == 16 and d in (16, 32, 64) and pool_supported(d, K)
 
 

@@ -377,6 +377,8 @@ class RandLANet(nn.Module):
             self._engine_key = key
         return self._engine
 
+    _MAX_INFER_STEPS = 4
+
     def infer_step(self, B: int, N: int):
         """The eval forward for one batch shape as a replayable hipGraph (`_train.InferStep`), captured on first use and
         kept while the parameters stay where they are (Trainer.evaluate's passes run through these)."""
@@ -389,6 +391,12 @@ class RandLANet(nn.Module):
             step.capture()
             self.train(was_training)
             self._infer_steps[(B, N)] = step
+            # a captured graph + its static buffers per batch shape: keep the few most recent ones (a loader's full batch and
+            # its ragged last batch are two shapes; a sweep over shapes must not pile graphs up)
+            while len(self._infer_steps) > self._MAX_INFER_STEPS:
+                self._infer_steps.pop(next(iter(self._infer_steps)))
+        else:
+            self._infer_steps[(B, N)] = self._infer_steps.pop((B, N))       # most recently used last
         return step
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:

@@ -156,6 +156,7 @@ def _check_gradient(ctx, name, g, r, bound):
     ("S", 13, 65536, 16, [16, 64, 128, 256, 512], 1),
     ("S", 13, 65536, 16, [16, 64, 128, 256, 512], 8),    # BASELINE configs[3]: S at bs=8
     ("Kt", 20, 122880, 16, [16, 64, 128, 256], 1),
+    ("Kt", 20, 122880, 16, [16, 64, 128, 256], 2),        # the per-GPU shard of BASELINE configs[4] that bench.py times
 ])
 def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, layers, B):
     """The path bench.py times, at its own size: _train.TrainStep's forward + dice + backward (fused pooling incl.
@@ -178,7 +179,8 @@ def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, laye
     if (tag, B) == ("A", 4):
         g64 = _oracle_step(sd, x, y, perm, layers, K, torch.float64)[2]
         gyard = {"fp32": g32, "bf16x3": _noisy_yard(sd, x, y, perm, layers, K, g64)}
-    modes = ["bf16x3", "fp32"] if tag == "A" else ["bf16x3"]
+    # exact fp32 products: config A, and once on the 5-layer / d = 512 shapes of S
+    modes = ["bf16x3", "fp32"] if (tag == "A" or (tag, B) == ("S", 1)) else ["bf16x3"]
     default = ops.get_wide_gemm()
     try:
         for mode in modes:

@@ -768,6 +768,97 @@ def test_virtual_rpe_branch_forward(ops, d, B, n_parent, n):
     assert float((t2b[3] - t2[3]).abs().max()) < 1e-5 * max(1.0, float(t2[3].abs().max()))
 
 
+@pytest.mark.parametrize("d,B,n_parent,n", [(16, 2, 900, 500), (32, 1, 300, 300), (64, 2, 400, 257), (16, 4, 2048, 2048)])
+def test_virtual_rpe_branch_backward(ops, d, B, n_parent, n):
+    """rl_pool_bwd with a virtual rpe stage (u_source 1 / 2; its BatchNorm-backward sums) and rl_rpe_wgrad against the same
+    block with the mlp_rpe1 / mlp_rpe2 outputs STORED (rl_gemm + the non-virtual rl_pool_bwd + rl_bn_backward + rl_wgrad): the
+    gradient of the gathered rows (DG), of the rpe half (GU), of the score weight, the BatchNorm sums, and the weight / bias
+    gradients of both rpe layers."""
+    from randlanet import _hip as H
+    torch.manual_seed(d + n)
+    K, h = 16, d // 2
+    xyz = torch.rand(B, n_parent, 3, device=DEV)
+    idx, d2 = ops.knn_i32(xyz, xyz, n, n, K)
+    W1, b1 = torch.randn(h, 10, device=DEV) * 0.5, torch.randn(h, device=DEV) * 0.1
+    W2, b2 = torch.randn(h, h, device=DEV) / h ** 0.5, torch.randn(h, device=DEV) * 0.1
+    g1w, g1b = torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.2
+    g2w, g2b = torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.2
+    Gf = torch.randn(B * n_parent, h, device=DEV)
+    g = ops.Lazy(Gf, B, n, n_parent, h, torch.rand(h, device=DEV) + 0.5, torch.randn(h, device=DEV) * 0.3, 2, 0.2)
+    Ws = torch.randn(d, d, device=DEV) / d ** 0.5
+    rows, P = B * n * K, B * n
+    dP = torch.randn(P, d, device=DEV)
+
+    def bn(stats, nslots, gamma, beta, c):
+        rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+        return ops.bn_finalize(stats, rows, 128, c, gamma, beta, rm, rv, None, 0.99, 1e-6, True, nslots=nslots)
+
+    # stored path: Y1 = mlp_rpe1(rpe), Y2 = mlp_rpe2(u1)
+    rpe = ops.rpe_build(ops.Rpe(xyz, idx, d2, B, n, K))
+    st1 = ops.new_stats(DEV, h)
+    Y1 = ops.gemm(rpe, W1, 1, 10, h, b1, stats=st1)
+    s1 = bn(st1, H.row_blocks(rows, 128), g1w, g1b, h)
+    u1 = ops.Lazy(Y1, B, n * K, n * K, h, s1[0], s1[1], 1, 0.0, s1[2], s1[3])
+    st2 = ops.new_stats(DEV, h)
+    Y2 = ops.gemm(u1, W2, 1, h, h, b2, stats=st2)
+    s2 = bn(st2, H.row_blocks(rows, 128), g2w, g2b, h)
+    u2 = ops.Lazy(Y2, B, n * K, n * K, h, s2[0], s2[1], 1, 0.0, s2[2], s2[3])
+    # virtual path with the SAME folded BatchNorms
+    vr = ops.VirtualRpe(xyz, idx, d2, B, n, h, W1, b1, W2, b2)
+    vr.bn1 = ops.Lazy(d2, B, n * K, n * K, h, s1[0], s1[1], 1, 0.0, s1[2], s1[3])
+    vr.bn2 = ops.Lazy(d2, B, n * K, n * K, h, s2[0], s2[1], 1, 0.0, s2[2], s2[3])
+    tol = 2e-5 if ops.get_wide_gemm() == "fp32" else 2e-4
+
+    def close(a, b_, what, t=tol):
+        sc = max(1.0, float(b_.abs().max()))
+        assert float((a - b_).abs().max()) < t * sc, (what, float((a - b_).abs().max()), sc)
+
+    for stage, u in ((2, u2), (1, u1)):
+        GUs = torch.full((rows, h), 0.25, device=DEV)
+        dWs = torch.empty(d, d, device=DEV)
+        DGs = ops.pool_bwd(u, g, idx, Ws, n, d, dP, GUs, True, dWs)
+        GUv = torch.full((rows, h), 0.25, device=DEV)
+        dWv = torch.empty(d, d, device=DEV)
+        nslots = H.lib().rl_pool_bwd_slots(P, d)
+        bst = torch.empty((nslots, 2, h), dtype=torch.float64, device=DEV)
+        DGv = ops.pool_bwd(vr, g, idx, Ws, n, d, dP, GUv, True, dWv, stage=stage, bn_bwd_stats=bst)
+        close(DGv, DGs, f"DG stage {stage}")
+        close(GUv, GUs, f"GU stage {stage}")
+        close(dWv, dWs, f"dW stage {stage}", 10 * tol)
+        # the stage's own backward: BatchNorm sums from the pooling kernel, then the weight / bias / input gradients
+        bnl = vr.bn2 if stage == 2 else vr.bn1
+        dg_v, db_v = torch.empty(h, device=DEV), torch.empty(h, device=DEV)
+        coef = ops.rpe_bn_backward(vr, stage, GUv, dg_v, db_v, stats=bst, nslots=nslots)
+        dg_s, db_s = torch.empty(h, device=DEV), torch.empty(h, device=DEV)
+        Gs = GUs.clone()
+        ops.bn_backward(Gs, u, dg_s, db_s, True)                 # Gs <- gradient w.r.t. the raw stage output
+        close(dg_v, dg_s, f"dgamma stage {stage}", 10 * tol)
+        close(db_v, db_s, f"dbeta stage {stage}", 10 * tol)
+        Kin = 10 if stage == 1 else h
+        dWl_v, dbl_v = torch.empty(h, Kin, device=DEV), torch.empty(h, device=DEV)
+        pend = []
+        GU1 = torch.empty_like(GUv) if stage == 2 else None
+        ops.rpe_wgrad(vr, stage, GUv, coef, dWl_v, dbl_v, pend, GU1)
+        ops.wgrad_flush(pend)
+        dWl_s, dbl_s = torch.empty(h, Kin, device=DEV), torch.empty(h, device=DEV)
+        a_in = rpe if stage == 1 else u1
+        ops.wgrad(a_in, Gs, n * K, h, dWl_s, 1, Kin, dbl_s)
+        close(dWl_v, dWl_s, f"layer dW stage {stage}", 20 * tol)
+        # (a bias in front of a BatchNorm: its true gradient is 0 - both sides hold rounding noise of a sum over all rows, and
+        # here the virtual side differentiates against the STORED path's batch mean, which differs from the mean of its own
+        # recomputed tile by the rounding of a different summation order: a per-row offset of ~1e-7 that the sum multiplies)
+        close(dbl_v, dbl_s, f"layer db stage {stage}", max(200 * tol, 3e-6 * rows))
+        if stage == 2:
+            gl = ops.Lazy(Gs, B, n * K, n * K, h)
+            GU1s = torch.empty(rows, h, device=DEV)
+            ops.gemm(gl, W2, h, 1, h, None, out=GU1s, out_bstride=n * K)
+            # the mask z > 0 of the stage's ReLU is a step: where the two paths' raw values (equal to ~1e-7) straddle 0, a whole
+            # row of dY . W2 differs - a handful of the rows x h elements at most
+            e1 = (GU1 - GU1s).abs().max(1).values
+            sc1 = max(1.0, float(GU1s.abs().max()))
+            assert float((e1 > 10 * tol * sc1).float().mean()) < 2e-4, ("GU1", float(e1.max()), sc1)
+
+
 def test_knn_multi_and_csr_replay_from_a_captured_graph(ops):
     """The neighbour searches of a forward (rl_knn_multi: grid reset, bounding box, counting sort, ring walk) and the
     graph transposes (rl_csr_build) captured into ONE hipGraph and replayed on new coordinates give exactly the eager

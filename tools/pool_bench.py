@@ -34,7 +34,13 @@ def level(l, B=8, N=40960):
     n, h = N // 4 ** l, d // 2
     torch.manual_seed(l)
     xyz = torch.rand((B, n, 4), device=DEV)
-    idx = torch.randint(0, n, (B, n, 16), dtype=torch.int32, device=DEV)
+    # RL_BENCH_LOCAL=w: neighbours within +-w of the point's own index (gathers that stay in L1 / L2) instead of uniformly random
+    # ones (what the network sees: its points are randomly permuted) - the kernels' time without their gather misses
+    w = int(os.environ.get("RL_BENCH_LOCAL", "0"))
+    if w:
+        idx = ((torch.arange(n, device=DEV).view(1, n, 1) + torch.randint(-w, w + 1, (B, n, 16), device=DEV)) % n).to(torch.int32)
+    else:
+        idx = torch.randint(0, n, (B, n, 16), dtype=torch.int32, device=DEV)
     d2 = torch.rand((B, n, 16), device=DEV) * 0.01
     r = lambda *s: torch.randn(*s, device=DEV) * 0.3
     vr = ops.VirtualRpe(xyz, idx, d2, B, n, h, r(h, 10), r(h), r(h, h), r(h))
