@@ -124,7 +124,8 @@ struct PoolParams {
     float* GU;             // (P*16) x h
     int gu_accumulate;
     float* DG;             // (P*16) x h: gradient of the gathered row of every neighbourhood slot
-    float* slab;           // per-workgroup partial dW: [grid][d*d]
+    float* slab;           // per-workgroup partial dW: [grid][slab_stride], d*d used
+    long slab_stride;      // d*d, or d*d + d when the caller sums the slabs with rl_wgrad_reduce_batch (its slab layout: dW then db)
     float* X_out;          // d = 128 backward: X and dS leave the kernel ((P*16) x d each); dW = dS^T.X is the caller's
     float* dS_out;         //   weight-gradient GEMM (64 accumulator tiles do not fit one wavefront)
     // u_source 1 / 2: the rpe-branch half of X is not a tensor but a function of the coordinates, recomputed per point:
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         }
     }
     if (wave == 0) {
-        float* out = p.slab + (long)blockIdx.x * D * D;
+        float* out = p.slab + (long)blockIdx.x * p.slab_stride;
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb)
 #pragma unroll
@@ -2723,7 +2724,7 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
         }
     }
     if (wave == 0) {
-        float* out = p.slab + (long)blockIdx.x * D * D;
+        float* out = p.slab + (long)blockIdx.x * p.slab_stride;
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb)
 #pragma unroll
@@ -3285,6 +3286,7 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->glazy.scale = d->g_scale; p->glazy.shift = d->g_shift; p->glazy.act = d->g_act; p->glazy.slope = d->g_slope;
     p->idx = d->idx; p->W = d->W; p->P = d->points; p->n = d->n; p->d = d->d;
     p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->DG = d->DG; p->slab = d->slab;
+    p->slab_stride = (long)d->d * d->d + (d->dW ? 0 : d->d);
     p->X_out = nullptr; p->dS_out = nullptr;
     p->src = d->u_source;
     RL_REQUIRE(d->u_source >= 0 && d->u_source <= 2, RL_ERR_ARGS, "%s: u_source must be 0, 1 or 2", who);
@@ -3326,8 +3328,9 @@ extern "C" int rl_pool_supported(int d, int nbr_k) {
     return (d == 128 && rl_wide_terms() != 0) ? 1 : 0;
 }
 
-extern "C" int64_t rl_pool_slab_floats(int64_t points, int d) { return (int64_t)pool_grid(points, d, true) * d * d; }
+extern "C" int64_t rl_pool_slab_floats(int64_t points, int d) { return (int64_t)pool_grid(points, d, true) * (d * d + d); }
 extern "C" int rl_pool_bwd_slots(int64_t points, int d) { return pool_grid(points, d, true, true); }
+extern "C" int rl_pool_bwd_grid(int64_t points, int d, int virt) { return pool_grid(points, d, true, virt != 0); }
 extern "C" int rl_pool_fwd_slots(int64_t points, int d) { return pool_grid(points, d, false); }
 
 extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
@@ -3386,10 +3389,12 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
         RL_LAUNCH_CHECK("rl_pool_bwd(128)");
         return RL_OK;
     }
-    RL_REQUIRE(d->dW && d->slab, RL_ERR_ARGS, "rl_pool_bwd: null gradient buffers");
+    // dW == NULL: the caller sums the partial slabs itself (rl_wgrad_reduce_batch: nsplit = rl_pool_bwd_slots / the launch's
+    // workgroups, N = K = d, slab stride d*d + d) - one reduction launch for a whole backward pass instead of one per block
+    RL_REQUIRE(d->slab, RL_ERR_ARGS, "rl_pool_bwd: null gradient buffers");
     RL_REQUIRE(!d->rows_bf16 || pool_terms(p.d) == 3, RL_ERR_UNSUPPORTED, "rl_pool_bwd: bf16 gradient rows need the bf16x3 arithmetic mode");
     const int g = pool_grid(p.P, p.d, true, p.src > 0);
-    RL_REQUIRE(d->slab_floats >= (int64_t)g * p.d * p.d, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
+    RL_REQUIRE(d->slab_floats >= (int64_t)g * p.slab_stride, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
     if (p.src > 0) {
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_bwd: the virtual rpe branch needs its folded BatchNorm(s)");
         const int key = (pool_terms(p.d) == 0 ? 0 : d->rows_bf16 ? 200 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + (p.src == 2 ? 2 : 0) + (p.gu_accumulate ? 1 : 0);
@@ -3408,7 +3413,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
 #undef VBWD
         rl_note_kernel("vpool_bwd_kernel");
         RL_LAUNCH_CHECK("rl_pool_bwd(virtual)");
-        hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
+        if (d->dW) hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
         RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
         return RL_OK;
     }
@@ -3427,7 +3432,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     }
     rl_note_kernel(p.d == 16 ? "pool_bwd_kernel<1>" : p.d == 32 ? "pool_bwd_kernel<2>" : "pool_bwd_kernel<4>");
     RL_LAUNCH_CHECK("rl_pool_bwd");
-    hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
+    if (d->dW) hipLaunchKernelGGL(pool_dw_reduce_kernel, dim3(rl_cdiv(p.d * p.d, 16)), dim3(256), 0, st, p.slab, g, p.d * p.d, d->dW);
     RL_LAUNCH_CHECK("rl_pool_bwd(reduce)");
     return RL_OK;
 }

@@ -225,6 +225,7 @@ _SIGNATURES = {
     "rl_pool_supported": (_i, [_i, _i]),
     "rl_pool_slab_floats": (_l, [_l, _i]),
     "rl_pool_bwd_slots": (_i, [_l, _i]),
+    "rl_pool_bwd_grid": (_i, [_l, _i, _i]),
     "rl_pool_fwd_slots": (_i, [_l, _i]),
     "rl_pool_fwd": (_i, [C.POINTER(PoolDesc), _vp]),
     "rl_rpe_stats_slots": (_i, [_l]),

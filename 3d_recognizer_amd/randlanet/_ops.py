@@ -967,10 +967,20 @@ def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP:
         wgrad(plain(X, u.B, n * 16), dS, n * 16, d, dW, 1, d, None, pending=pending, batch=batch)
         return DG
     floats = H.lib().rl_pool_slab_floats(P, d)
-    slab = _slab(W.device, floats)
+    if pending is not None:
+        # the partial dW slabs join the backward pass's ONE slab reduction (wgrad_flush) instead of a launch of their own
+        slab = torch.empty(floats, dtype=F32, device=W.device)
+        pd.dW = None
+    else:
+        slab = _slab(W.device, floats)
     pd.slab, pd.slab_floats = slab.data_ptr(), slab.numel()
     with _rec("pool_bwd", (P, 16, d), nbytes, 6 * P * 16 * d * d):
         H.check(H.lib().rl_pool_bwd(C.byref(pd), _st()), "rl_pool_bwd")
+    if pending is not None:
+        it = H.WgradReduceItem()
+        it.slab, it.dW, it.dbias, it.w_ks, it.w_ns = slab.data_ptr(), dW.data_ptr(), None, 1, d
+        it.nsplit, it.N, it.K = H.lib().rl_pool_bwd_grid(P, d, int(virt)), d, d
+        pending.append((it, slab, dW, None))
     return DG
 
 

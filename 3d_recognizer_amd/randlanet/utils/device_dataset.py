@@ -50,6 +50,7 @@ class DeviceDataLoader:
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)) if rng == "device" else 0)
         self._consistent_idx = {}
+        self._ring = None            # pinned host staging (see _staging)
         # the whole dataset moves to HBM once
         self._xyz: List[torch.Tensor] = []
         self._feat: List[torch.Tensor] = []
@@ -83,7 +84,9 @@ class DeviceDataLoader:
         g.manual_seed(seed)
         return torch.randperm(len(self._xyz), generator=g).tolist()
 
-    def _sample(self, n_src: int) -> torch.Tensor:
+    def _sample(self, n_src: int, host_row: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Sample indices of one cloud on the device - or, numpy mode with `host_row` (a row of the pinned staging buffer):
+        written there and None returned (the batch's rows go over in one asynchronous copy)."""
         n = self._n
         if self._consistent:
             key = n_src
@@ -92,14 +95,19 @@ class DeviceDataLoader:
                 self._consistent_idx[key] = torch.from_numpy(idx.astype(np.int64)).to(self.device)
             return self._consistent_idx[key]
         if self.rng == "numpy":
-            return torch.from_numpy(preprocessing.sample_points(n_src, n, consistent=False).astype(np.int64)).to(self.device)
+            idx = preprocessing.sample_points(n_src, n, consistent=False)
+            if host_row is not None:
+                host_row.numpy()[:] = idx
+                return None
+            return torch.from_numpy(idx.astype(np.int64)).to(self.device)
         idx = torch.randperm(n_src, device=self.device, generator=self._gen)[:min(n, n_src)]
         if n > n_src:
             idx = torch.cat([idx, torch.randint(0, n_src, (n - n_src,), device=self.device, generator=self._gen)])
         return idx
 
-    def _job(self, cloud: int, job: H.CloudJob) -> Optional[torch.Tensor]:
-        """Fill the job record of one cloud; returns its jitter noise (n,3) float64 on the device, or None."""
+    def _job(self, cloud: int, job: H.CloudJob, host_noise: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Fill the job record of one cloud; returns its jitter noise (n,3) float64 on the device, or None (no augmentation,
+        or numpy mode with `host_noise`, a slice of the pinned staging buffer: the draw is written there)."""
         x = self._xyz[cloud]
         job.xyz, job.features, job.labels = x.data_ptr(), self._feat[cloud].data_ptr(), self._lab[cloud].data_ptr()
         job.n_points, job.xyz_f64 = x.shape[0], int(x.dtype == torch.float64)
@@ -111,7 +119,12 @@ class DeviceDataLoader:
         job.jitter_variance, job.jitter_limit = a.jitter_variance, a.jitter_limit
         # the reference's order of draws: jitter noise, scale, three angles, three shifts (augmentation.py:147-167)
         if self.rng == "numpy":
-            noise = torch.from_numpy(np.random.randn(self._n, 3)).to(self.device)
+            draw = np.random.randn(self._n, 3)
+            if host_noise is not None:
+                host_noise.numpy()[:] = draw
+                noise = None
+            else:
+                noise = torch.from_numpy(draw).to(self.device)
         else:
             noise = torch.randn((self._n, 3), dtype=torch.float64, device=self.device, generator=self._gen)
         job.scale = np.random.uniform(1 - a.scale_limit, 1 + a.scale_limit)
@@ -128,6 +141,25 @@ class DeviceDataLoader:
         return noise
 
     # ------------------------------------------------------------------------------ iteration
+    def _staging(self, B: int):
+        """Pinned host staging for one batch (job records; in the numpy mode also sample indices and jitter noise), from a
+        small ring: everything the host draws reaches the device through asynchronous copies, so the host never waits for
+        the GPU here (a pageable `.to(device)` is a synchronous copy - it stalled the training loop once per batch behind
+        all the work queued on the stream).  A slot is reused only after the copies that last read it have executed."""
+        if self._ring is None:
+            n, Bmax = self._n, self.batch_size
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
+            self._ring = [dict(jobs=mk((Bmax * C.sizeof(H.CloudJob),), torch.uint8),
+                               idx=mk((Bmax, n), torch.int64) if self.rng == "numpy" or self._consistent else None,
+                               noise=mk((Bmax, n, 3), torch.float64) if (self.rng == "numpy" and self._aug) else None,
+                               event=None) for _ in range(4)]
+            self._slot = 0
+        st = self._ring[self._slot]
+        self._slot = (self._slot + 1) % len(self._ring)
+        if st["event"] is not None:
+            st["event"].synchronize()
+        return st
+
     def __iter__(self):
         order = self._order()
         n, F, dev = self._n, self._F, self.device
@@ -135,14 +167,28 @@ class DeviceDataLoader:
             ids = order[start:start + self.batch_size]
             B = len(ids)
             jobs = (H.CloudJob * B)()
+            st = self._staging(B)
+            host_idx = st["idx"] is not None and not self._consistent and self.rng == "numpy"
+            host_noise = st["noise"] is not None
             indices = torch.empty((B, n), dtype=torch.int64, device=dev)
             noise = torch.empty((B, n, 3), dtype=torch.float64, device=dev) if self._aug else None
             for b, cloud in enumerate(ids):            # item by item, like DataLoader(num_workers=0)
-                indices[b] = self._sample(self._xyz[cloud].shape[0])
-                nz = self._job(cloud, jobs[b])
+                smp = self._sample(self._xyz[cloud].shape[0], st["idx"][b] if host_idx else None)
+                if smp is not None:
+                    indices[b] = smp
+                nz = self._job(cloud, jobs[b], st["noise"][b] if host_noise else None)
                 if nz is not None:
                     noise[b] = nz
-            jobs_dev = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+            if host_idx:
+                indices.copy_(st["idx"][:B], non_blocking=True)
+            if host_noise:
+                noise.copy_(st["noise"][:B], non_blocking=True)
+            nbytes = B * C.sizeof(H.CloudJob)
+            st["jobs"].numpy()[:nbytes] = np.frombuffer(bytes(jobs), dtype=np.uint8)
+            jobs_dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            jobs_dev.copy_(st["jobs"][:nbytes], non_blocking=True)
+            st["event"] = torch.cuda.Event()
+            st["event"].record(torch.cuda.current_stream(dev))
             scratch = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
             inp = torch.empty((B, n, 3 + F), dtype=torch.float32, device=dev)
             lab = torch.empty((B, n), dtype=torch.int64, device=dev)

@@ -543,6 +543,9 @@ typedef struct rl_pool_desc {
 int rl_pool_supported(int d, int nbr_k);
 int64_t rl_pool_slab_floats(int64_t points, int d);
 int rl_pool_bwd_slots(int64_t points, int d);   /* workgroups (= partial slots) of an rl_pool_bwd launch with a virtual stage */
+/* workgroups of an rl_pool_bwd launch = partial dW slabs it leaves.  With rl_pool_desc.dW == NULL the call does not sum them: the
+ * caller queues (slab, nsplit = this, N = K = d, stride d*d + d) for rl_wgrad_reduce_batch.  rl_pool_slab_floats covers both. */
+int rl_pool_bwd_grid(int64_t points, int d, int virtual_stage);
 int rl_pool_fwd_slots(int64_t points, int d);   /* workgroups (= partial slots) of an rl_pool_fwd launch */
 int rl_pool_fwd(const rl_pool_desc* d, void* stream);
 int rl_pool_bwd(const rl_pool_desc* d, void* stream);
