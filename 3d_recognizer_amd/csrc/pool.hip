@@ -297,276 +297,6 @@ __device__ __forceinline__ void tile_gemm_bf(const float4 (&a)[DT], const __bf16
 }
 
 
-// ===============================================================================================================
-// The rpe branch as a virtual tensor.  mlp_rpe1 / mlp_rpe2 (reference modules.py:287-291, 313-320) act on the
-// (points*K) x 10 relative position encoding - a pure function of the coordinates and the neighbour indices - with tiny
-// weights (10 x h, h x h).  Storing their outputs costs (points*K) x h floats per tensor and every consumer streams
-// them back; recomputing a point's 16 x h tile inside the consumer costs two small MFMA GEMMs and no HBM traffic.
-//   rpe tile  (A layout, K = 10 padded to 16): lane (i, j) holds channels 4j..4j+3 of neighbour slot i
-//   u1raw = rpe . W1^T + b1            (C layout)      u1 = relu(u1raw*sc1 + sh1)
-//   u2raw = u1  . W2^T + b2            (C layout)      u2 = relu(u2raw*sc2 + sh2)
-// The activated tile lands in the wavefront's X tile (columns < H), exactly where a loaded U would have gone.
-// ===============================================================================================================
-template <int DT>
-struct VT {
-    static constexpr int H = 8 * DT;                 // width of the rpe branch
-    static constexpr int DTH = (H + 15) / 16;        // its 16-column blocks
-    static constexpr int HP = 16 * DTH;
-    static constexpr int S1 = 20;                    // fp32 row stride of the staged W1 ([n][16 k] + pad, 16-byte aligned)
-};
-
-// LDS image of the two small weights.  W1 (10 x h, applied to raw coordinates) is ALWAYS kept in fp32 and multiplied with
-// the exact fp32 MFMA: its inputs are coordinates of magnitude ~1 whose differences carry the signal, a bf16x3 product
-// error of 2^-16 relative to the LARGEST term would be felt in the logits (train-mode logits error 1.4e-4 -> 3e-4 when it
-// was bf16x3), and the matrix pipe is idle in these kernels anyway.  W2 (h x h): TERMS == 0 floats, else bf16 head + tail.
-template <int DT, int TERMS>
-struct VWeights {
-    static constexpr int HP = VT<DT>::HP, DTH = VT<DT>::DTH;
-    static constexpr int XS2 = Tile<DTH>::XS, XSB2 = Tile<DTH>::XSB;
-    static constexpr int BYTES = HP * VT<DT>::S1 * 4 + (TERMS == 0 ? HP * XS2 * 4 : HP * XSB2 * 2 * 2);
-    float* w1f; float* w2f;
-    __bf16 *w2h, *w2l;
-    __device__ __forceinline__ void bind(unsigned char* mem) {
-        w1f = reinterpret_cast<float*>(mem);
-        if constexpr (TERMS == 0) {
-            w2f = w1f + HP * VT<DT>::S1;
-        } else {
-            w2h = reinterpret_cast<__bf16*>(w1f + HP * VT<DT>::S1);
-            w2l = w2h + HP * XSB2;
-        }
-    }
-    // all threads of the workgroup; a barrier must follow
-    __device__ __forceinline__ void stage(const PoolParams& p, int nthreads) {
-        constexpr int H = VT<DT>::H;
-        // The first stage in the form rpe_gemm uses it.  With the channels [x_i, x_j, x_i - x_j, dist] and x_j = x_i - (x_i - x_j):
-        //   W1 . rpe = (Wa + Wb) . x_i  +  (Wc - Wb) . (x_i - x_j)  +  wd * dist
-        // - the first term is the same for the 16 neighbours of a point, the rest has FOUR inputs: one exact fp32 MFMA
-        // (16 x 16 x 4) per column block instead of four dependent ones.  Row n: [V0 V1 V2 wd | U0 U1 U2 0], V = Wc - Wb,
-        // U = Wa + Wb (the weights are combined in fp32: one rounding each, like any other fp32 evaluation order).
-        for (int e = threadIdx.x; e < HP * 8; e += nthreads) {
-            const int n = e >> 3, k = e & 7;
-            float v = 0.f;
-            if (n < H) {
-                const float* w = p.W1 + n * 10;
-                if (k < 3) v = w[6 + k] - w[3 + k];
-                else if (k == 3) v = w[9];
-                else if (k < 7) v = w[k - 4] + w[3 + k - 4];
-            }
-            w1f[n * VT<DT>::S1 + k] = v;
-        }
-        if (p.src >= 2 || p.fstats2) {
-            for (int e = threadIdx.x; e < HP * HP; e += nthreads) {
-                const int n = e / HP, k = e - n * HP;
-                const float w = (n < H && k < H) ? p.W2[n * H + k] : 0.f;
-                if constexpr (TERMS == 0) w2f[n * XS2 + k] = w;
-                else {
-                    const __bf16 h = (__bf16)w;
-                    w2h[n * XSB2 + k] = h;
-                    w2l[n * XSB2 + k] = (__bf16)(w - (float)h);
-                }
-            }
-        }
-    }
-};
-
-// per-lane constants of the C-layout epilogues: column nb*16 + li of each stage.  d >= 64 (two column blocks): the twelve
-// values live in LDS and are read where they are used - the 64-channel backward kernel has no registers to spare (it ran
-// 33 dwords into scratch with them).  `lds` = NCONST * HP floats of the kernel's LDS; the caller's barrier after the
-// staging makes them visible.
-template <int DT>
-struct VCols {
-    static constexpr int DTH = VT<DT>::DTH, HP = VT<DT>::HP;
-    static constexpr bool INLDS = DT >= 4;
-    static constexpr int NCONST = 10;            // b1 s1 h1 b2 s2 h2 + the four BatchNorm-backward constants of pool_bwd
-    float rb1[INLDS ? 1 : DTH], rs1[INLDS ? 1 : DTH], rh1[INLDS ? 1 : DTH], rb2[INLDS ? 1 : DTH], rs2[INLDS ? 1 : DTH], rh2[INLDS ? 1 : DTH];
-    const float* lc;                               // lds + li
-    __device__ __forceinline__ void load(const PoolParams& p, int li, float* lds) {
-        lc = lds + li;
-        if constexpr (INLDS) {
-            for (int c = threadIdx.x; c < HP; c += blockDim.x) {
-                const bool in = c < VT<DT>::H;
-                lds[0 * HP + c] = in ? p.b1[c] : 0.f;
-                lds[1 * HP + c] = (in && p.sc1) ? p.sc1[c] : 0.f;
-                lds[2 * HP + c] = (in && p.sh1) ? p.sh1[c] : 0.f;
-                lds[3 * HP + c] = (in && (p.src >= 2 || p.fstats2)) ? p.b2[c] : 0.f;
-                lds[4 * HP + c] = (in && p.src >= 2 && p.sc2) ? p.sc2[c] : 0.f;
-                lds[5 * HP + c] = (in && p.src >= 2 && p.sh2) ? p.sh2[c] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int nb = 0; nb < DTH; ++nb) {
-                const int c = nb * 16 + li;
-                const bool in = c < VT<DT>::H;
-                rb1[nb] = in ? p.b1[c] : 0.f;
-                rs1[nb] = (in && p.sc1) ? p.sc1[c] : 0.f;
-                rh1[nb] = (in && p.sh1) ? p.sh1[c] : 0.f;
-                rb2[nb] = (in && (p.src >= 2 || p.fstats2)) ? p.b2[c] : 0.f;
-                rs2[nb] = (in && p.src >= 2 && p.sc2) ? p.sc2[c] : 0.f;
-                rh2[nb] = (in && p.src >= 2 && p.sh2) ? p.sh2[c] : 0.f;
-            }
-        }
-    }
-    __device__ __forceinline__ float cst(int which, int nb, const float (&r)[INLDS ? 1 : DTH]) const {
-        if constexpr (INLDS) return lc[which * HP + nb * 16];
-        else return r[nb];
-    }
-    __device__ __forceinline__ float b1(int nb) const { return cst(0, nb, rb1); }
-    __device__ __forceinline__ float s1(int nb) const { return cst(1, nb, rs1); }
-    __device__ __forceinline__ float h1(int nb) const { return cst(2, nb, rh1); }
-    __device__ __forceinline__ float b2(int nb) const { return cst(3, nb, rb2); }
-    __device__ __forceinline__ float s2(int nb) const { return cst(4, nb, rs2); }
-    __device__ __forceinline__ float h2(int nb) const { return cst(5, nb, rh2); }
-};
-
-// what a lane needs of one point to build the relative position encoding of its neighbour slot li
-// (the two coordinate loads stay whole 4-vectors: a loop-carried value that is the load's own register tuple needs no
-// copy - with separate floats the compiler copied them out right behind the load, i.e. waited for it on the spot)
-struct RpeIn {
-    float4 a, c;      // the point, its neighbour (w unused; three-float coordinates are widened on load)
-    float dd;
-    // Called right after loads_landed() by the kernels that refill `rin` in place: the loop-carried copies of the
-    // loaded registers are made HERE (an empty asm "redefines" every field), not right behind the loads - where the
-    // compiler otherwise puts them, with a wait for the loads it has just issued.
-    __device__ __forceinline__ void pin() {
-        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(dd));
-    }
-};
-__device__ __forceinline__ void fetch_rpe(const PoolParams& p, const Cursor& cu, int li, int nbr, RpeIn& r) {
-    const long pt = cu.pt, b = cu.b, i = cu.i;
-    if (p.xyz_w == 4) {
-        // padded coordinates: one 16-byte gather per point instead of three 4-byte ones (the texture path pays per
-        // distinct line and per instruction)
-        const float4* xb = reinterpret_cast<const float4*>(p.xyz) + b * p.xyz_bstride;
-        r.a = xb[i];
-        r.c = xb[nbr];
-    } else {
-        const float* xb = p.xyz + b * p.xyz_bstride * 3;
-        r.a = make_float4(xb[i * 3 + 0], xb[i * 3 + 1], xb[i * 3 + 2], 0.f);
-        r.c = make_float4(xb[(long)nbr * 3 + 0], xb[(long)nbr * 3 + 1], xb[(long)nbr * 3 + 2], 0.f);
-    }
-    r.dd = p.nbr_d2[pt * 16 + li];
-}
-// channels [x_i, x_nbr, x_i - x_nbr, dist, 0...] (modules.py:173-186): this lane's float4 = channels 4*lj .. 4*lj+3
-__device__ __forceinline__ float4 rpe_frag(const RpeIn& r, int lj) {
-    // every lane computes all ten channels and selects its four (lane-constant masks): no divergent branches in the loops
-    const float dx = r.a.x - r.c.x, dy = r.a.y - r.c.y, dz = r.a.z - r.c.z, dist = __fsqrt_rn(r.dd);
-    const bool l0 = lj == 0, l1 = lj == 1, l2 = lj == 2;
-    float4 o;
-    o.x = l0 ? r.a.x : l1 ? r.c.y : l2 ? dz : 0.f;
-    o.y = l0 ? r.a.y : l1 ? r.c.z : l2 ? dist : 0.f;
-    o.z = l0 ? r.a.z : l1 ? dx : 0.f;
-    o.w = l0 ? r.c.x : l1 ? dy : 0.f;
-    return o;
-}
-
-// acc[nb] (C layout) = rpe rows (10 channels) . W1^T for the 16 neighbours of one point, exact fp32 products in every
-// arithmetic mode, in the reduced form staged by VWeights::stage: U . x_i + [V | wd] . [x_i - x_j, dist] - two 16 x 16 x 4
-// MFMAs (lane (li, lj) supplies input lj of neighbour li and weight lj of column li) instead of four over the ten channels
-template <int DT, int TERMS>
-__device__ __forceinline__ void rpe_gemm(const RpeIn& r, const VWeights<DT, TERMS>& w, int li, int lj, f32x4 (&acc)[VT<DT>::DTH]) {
-    float dx = r.a.x - r.c.x, dy = r.a.y - r.c.y, dz = r.a.z - r.c.z, dist = __fsqrt_rn(r.dd);
-    float px = r.a.x, py = r.a.y, pz = r.a.z;
-    // every lane computes all candidates and SELECTS (v_cndmask on lane-constant masks).  Without the pin hipcc sinks the
-    // square root and the differences into exec-masked branches per lj - ~35 instructions and 8 branches for two selects.
-    asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz), "+v"(dist), "+v"(px), "+v"(py), "+v"(pz));
-    const float a1 = lj == 0 ? dx : lj == 1 ? dy : lj == 2 ? dz : dist;        // [x_i - x_j, dist] of neighbour li, input lj
-    const float a2 = lj == 0 ? px : lj == 1 ? py : lj == 2 ? pz : 0.f;         // x_i (the same for every neighbour)
-#pragma unroll
-    for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
-        const float* wr = w.w1f + (nb * 16 + li) * VT<DT>::S1;
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, wr[4 + lj], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, wr[lj], acc[nb], 0, 0, 0);
-    }
-}
-
-// The raw (pre-BatchNorm) tile of stage `stage` (1 or 2) of the rpe branch for one point, C layout, and - when
-// `Xs` is given - the ACTIVATED tile of the last stage written to columns < H of the wavefront's X tile.
-// `scratch` is a wavefront-private 16 x XS tile used to turn u1 from C into A layout for stage 2 (may alias Xs).
-template <int DT, int TERMS>
-__device__ __forceinline__ void rpe_branch(const PoolParams& p, const RpeIn& in, int stage, const VWeights<DT, TERMS>& w,
-                                           const VCols<DT>& vc, int li, int lj, float* scratch, int XS,
-                                           f32x4 (&raw)[VT<DT>::DTH], float* Xs) {
-    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH;
-    rpe_gemm<DT, TERMS>(in, w, li, lj, raw);
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b1(nb));
-    if (stage == 1) {
-        if (Xs) {
-#pragma unroll
-            for (int nb = 0; nb < DTH; ++nb) {
-                const int col = nb * 16 + li;
-                const f32x4 u = vrelu(vbn(raw[nb], vc.s1(nb), vc.h1(nb)));
-                if (col < H) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = u[r];
-                }
-            }
-        }
-        return;
-    }
-    // stage 2: u1 (activated) through the scratch tile into A layout, then the h x h GEMM
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) {
-        const int col = nb * 16 + li;
-        const f32x4 u = vrelu(vbn(raw[nb], vc.s1(nb), vc.h1(nb)));
-        if (col < H) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) scratch[(4 * lj + r) * XS + col] = u[r];
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    float4 a1[DTH];
-#pragma unroll
-    for (int c = 0; c < DTH; ++c) {
-        a1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (16 * c + 4 * lj < H) a1[c] = *reinterpret_cast<const float4*>(scratch + li * XS + 16 * c + 4 * lj);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) raw[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (TERMS == 0) tile_gemm<DTH>(a1, w.w2f, li, lj, raw);
-    else tile_gemm_bf<DTH>(a1, w.w2h, w.w2l, li, lj, raw);
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) raw[nb] += splat(vc.b2(nb));
-    if (Xs) {
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) {
-            const int col = nb * 16 + li;
-            const f32x4 u = vrelu(vbn(raw[nb], vc.s2(nb), vc.h2(nb)));
-            if (col < H) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Xs[(4 * lj + r) * XS + col] = u[r];
-            }
-        }
-    }
-}
-
-// The X tile of a point whose rpe half is virtual: the gathered half comes from `graw` (fetch_x loaded only those
-// chunks), the rpe half is computed; xa (A layout) is read back from the tile.
-template <int DT, int TERMS>
-__device__ __forceinline__ void finish_x_virtual(const PoolParams& p, int li, int lj, const float4 (&graw)[DT], const RpeIn& in,
-                                                 const f32x4 (&sc)[DT], const f32x4 (&sh)[DT], const VWeights<DT, TERMS>& w,
-                                                 const VCols<DT>& vc, float4 (&xa)[DT], float* Xs, f32x4 (&rawu)[VT<DT>::DTH]) {
-    constexpr int H = Tile<DT>::H, XS = Tile<DT>::XS;
-    rpe_branch<DT, TERMS>(p, in, p.src, w, vc, li, lj, Xs, XS, rawu, Xs);
-    const float es_g = eff_slope(p.glazy);
-#pragma unroll
-    for (int c = 0; c < DT; ++c) {
-        const int k = 16 * c + 4 * lj;
-        if (k >= H) {
-            const float4 v = f4(vact(v4(graw[c]) * sc[c] + sh[c], es_g));
-            xa[c] = v;
-            *reinterpret_cast<float4*>(Xs + li * XS + k) = v;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < DT; ++c) {
-        const int k = 16 * c + 4 * lj;
-        if (k < H) xa[c] = *reinterpret_cast<const float4*>(Xs + li * XS + k);
-    }
-}
-
 // ---- reductions over the four lane groups (the 16 rows of a C-layout tile): v_permlane16_swap / v_permlane32_swap (gfx950) instead
 // of ds_bpermute round trips through the LDS pipe; the same operand pairs as __shfl_xor(v, 16) / (v, 32), so the same bits ----
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -642,13 +372,11 @@ __device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* W
     }
 }
 
-template <int DT, int TERMS, int NW = 4, bool VIRT = false>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product); NW wavefronts; VIRT: rpe half recomputed (PoolParams::src)
+template <int DT, int TERMS, int NW = 4>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product); NW wavefronts.  (A virtual rpe half: vpool_fwd_kernel.)
 __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     __shared__ __attribute__((aligned(16))) unsigned char wmem[TERMS == 0 ? D * XS * 4 : 2 * D * XSB * 2];
     __shared__ __attribute__((aligned(16))) float Xt[NW][16 * XS];
-    __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
-    __shared__ float vcl[(VIRT && VCols<DT>::INLDS) ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
     float* Wt = reinterpret_cast<float*>(wmem);
     __bf16* Wh = reinterpret_cast<__bf16*>(wmem);
     __bf16* Wl = Wh + D * XSB;
@@ -665,16 +393,6 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
             Wl[o * XSB + i] = (__bf16)(w - (float)h);
         }
     }
-    VWeights<DT, TERMS> vw;
-    VCols<DT> vc;
-    f32x4 fs2[VIRT ? VT<DT>::DTH : 1], fq2[VIRT ? VT<DT>::DTH : 1];   // per-lane partials of its four rows
-    if constexpr (VIRT) {
-        vw.bind(vmem);
-        vw.stage(p, 64 * NW);
-        vc.load(p, li, vcl);
-#pragma unroll
-        for (int nb = 0; nb < VT<DT>::DTH; ++nb) fs2[nb] = fq2[nb] = splat(0.f);
-    }
     __syncthreads();
     f32x4 sc[DT], sh[DT];
     lane_lazy<DT>(p, lj, sc, sh);
@@ -685,47 +403,20 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
-    RpeIn rin;      // consumed at the top of an iteration, refilled for the next point right after
     Cursor cu;
     cu.start(pt, p.n);
-    if (pt < p.P) {
-        fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
-        if constexpr (VIRT) fetch_rpe(p, cu, li, idx_cur, rin);
-    }
+    if (pt < p.P) fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
                          // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
-        if constexpr (VIRT) {
-            f32x4 rawu[VT<DT>::DTH];
-            finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs, rawu);
-            if (p.fstats2) {
-                // the next stage's raw output (mlp_rpe2 on this tile) only for its BatchNorm batch statistics
-                constexpr int DTH = VT<DT>::DTH, H = VT<DT>::H;
-                float4 a1[DTH];
-                f32x4 r2[DTH];
-#pragma unroll
-                for (int c = 0; c < DTH; ++c) {
-                    a1[c] = (16 * c + 4 * lj < H) ? xa[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    r2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                if constexpr (TERMS == 0) tile_gemm<DTH>(a1, vw.w2f, li, lj, r2);
-                else tile_gemm_bf<DTH>(a1, vw.w2h, vw.w2l, li, lj, r2);
-#pragma unroll
-                for (int nb = 0; nb < DTH; ++nb) {
-                    const f32x4 v = r2[nb] + splat(vc.b2(nb));
-                    fs2[nb] += v;
-                    fq2[nb] = __builtin_elementwise_fma(v, v, fq2[nb]);
-                }
-            }
-        } else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
         const Cursor cf = pt + pstep < p.P ? cn : cu;
         fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
-        if constexpr (VIRT) fetch_rpe(p, cf, li, pt + pstep < p.P ? idx_nxt : idx_cur, rin);
         loads_issued();
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
@@ -748,112 +439,16 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (VIRT) {
-        if (p.fstats2) {
-            constexpr int H = VT<DT>::H, HP = VT<DT>::HP;
-            __syncthreads();                                                    // the X tiles are free now
-            double* redd = reinterpret_cast<double*>(&Xt[0][0]);                // [NW][2][HP] doubles
-            static_assert(NW * 2 * VT<DT>::HP * 2 <= NW * 16 * XS, "statistics scratch does not fit the X tiles");
-#pragma unroll
-            for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
-                float a = sum4(fs2[nb]), b = sum4(fq2[nb]);
-                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-                if (lane < 16) {
-                    redd[(wave * 2 + 0) * HP + nb * 16 + lane] = (double)a;
-                    redd[(wave * 2 + 1) * HP + nb * 16 + lane] = (double)b;
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x < H) {
-                const int c = threadIdx.x;
-                double a0 = 0.0, a1 = 0.0;
-                for (int wv = 0; wv < NW; ++wv) {
-                    a0 += redd[(wv * 2 + 0) * HP + c];
-                    a1 += redd[(wv * 2 + 1) * HP + c];
-                }
-                p.fstats2[((long)blockIdx.x * 2 + 0) * H + c] = a0;
-                p.fstats2[((long)blockIdx.x * 2 + 1) * H + c] = a1;
-            }
-        }
-    }
 }
 
-// BatchNorm batch statistics of the raw stage-1 / stage-2 tile of the rpe branch (PoolParams::src) over all rows:
-// the reduction that mlp_rpe1 / mlp_rpe2's GEMM epilogue would have produced, without the tensor.  One partial
-// (sum, sum of squares; doubles) per workgroup and channel, [grid][2][H], for rl_bn_finalize.
-template <int DT, int TERMS>
-__global__ __launch_bounds__(256) void rpe_stats_kernel(const PoolParams p, double* __restrict__ stats) {
-    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, XS = Tile<VT<DT>::DTH>::XS;
-    __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
-    __shared__ float vcl[VCols<DT>::INLDS ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
-    __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
-    __shared__ double red[4][2][VT<DT>::HP];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
-    const int li = lane & 15, lj = lane >> 4;
-    VWeights<DT, TERMS> vw;
-    VCols<DT> vc;
-    vw.bind(vmem);
-    vw.stage(p, 256);
-    vc.load(p, li, vcl);
-    __syncthreads();
-    f32x4 ssum[DTH], ssq[DTH];
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) ssum[nb] = ssq[nb] = splat(0.f);
-    const long pstep = (long)gridDim.x * 4;
-    long pt = (long)blockIdx.x * 4 + wave;
-    // software pipeline as in the pooling kernels: neighbour index two points ahead, coordinates (and G) one point ahead,
-    // every load of an iteration issued in one group at its top
-    RpeIn rin, rin_nxt;
-    Cursor cu;
-    cu.start(pt, p.n);
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
-    if (pt < p.P) fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
-    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
-                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
-    for (; pt < p.P; pt += pstep) {
-        const Cursor cn = cu.next(pstep, p.n);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        fetch_rpe(p, pt + pstep < p.P ? cn : cu, li, idx_nxt, rin_nxt);      // (no branch: see pool_fwd_kernel)
-        loads_issued();
-        idx_nxt = idx_n2;
-        cu = cn;
-        f32x4 raw[DTH];
-        rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) {
-            ssum[nb] += raw[nb];
-            ssq[nb] = __builtin_elementwise_fma(raw[nb], raw[nb], ssq[nb]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        rin = rin_nxt;
-    }
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) {
-        float sm = sum4(ssum[nb]), q = sum4(ssq[nb]);
-        sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-        if (lane < 16) {
-            red[wave][0][nb * 16 + lane] = (double)sm;
-            red[wave][1][nb * 16 + lane] = (double)q;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < H) {
-        const int c = threadIdx.x;
-        stats[((long)blockIdx.x * 2 + 0) * H + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-        stats[((long)blockIdx.x * 2 + 1) * H + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
-    }
-}
-
-// GB: the neighbourhood-row gradient tensors are stored as bf16 (the bf16-storage mode): DG always, GU when the rpe branch
-// is virtual (a real U tensor's gradient goes on into the fp32 GEMM chain)
+// The rpe half of X is a real tensor U here (a virtual one: vpool_bwd_kernel).  GB: DG is stored as bf16 (the bf16-storage
+// mode); GU - a real tensor's gradient, it goes on into the fp32 GEMM chain - stays fp32.  `VIRT` is kept in the template list as
+// `false` only (the instantiations name it).
 template <int DT, int TERMS, bool VIRT = false, int NW = 4, bool GB = false>   // NW wavefronts share the staged weights
 __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
-    constexpr bool GUB = GB && VIRT;
+    static_assert(!VIRT, "a virtual rpe stage runs vpool_bwd_kernel");
+    constexpr bool GUB = false;
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
-    __shared__ __attribute__((aligned(16))) unsigned char vmem[VIRT ? VWeights<DT, TERMS>::BYTES : 16];
-    __shared__ float vcl[(VIRT && VCols<DT>::INLDS) ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
     // LDS: W^T, W, and per wavefront an X tile and a dS tile; after the main loop the W region is
     // reused to combine the four wavefronts' dW tiles
     __shared__ __attribute__((aligned(16))) float Wmem[TERMS == 0 ? 2 * D * XS : 2 * D * XSB];   // bf16: 4 arrays of D*XSB
@@ -877,43 +472,6 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
             Wth[i * XSB + o] = h; Wtl[i * XSB + o] = l;
         }
     }
-    VWeights<DT, TERMS> vw;
-    VCols<DT> vc;
-    constexpr int BDTH = VIRT ? VT<DT>::DTH : 1;
-    constexpr bool CL = VIRT && VCols<DT>::INLDS;       // BatchNorm-backward constants in LDS beside vc's (rows 6..9)
-    constexpr int BREG = CL ? 1 : BDTH;
-    float bsg[BDTH], bsx[BDTH], bstat_sc[BREG], bstat_sh[BREG], bstat_mu[BREG], bstat_is[BREG];
-    if constexpr (VIRT) {
-        vw.bind(vmem);
-        vw.stage(p, 64 * NW);
-        vc.load(p, li, vcl);
-#pragma unroll
-        for (int nb = 0; nb < BDTH; ++nb) bsg[nb] = bsx[nb] = 0.f;
-        if constexpr (CL) {
-            constexpr int HP = VCols<DT>::HP;
-            for (int c = threadIdx.x; c < HP; c += 64 * NW) {
-                const bool in = c < H && p.bstats != nullptr;
-                vcl[6 * HP + c] = in ? (p.src == 1 ? p.sc1[c] : p.sc2[c]) : 0.f;
-                vcl[7 * HP + c] = in ? (p.src == 1 ? p.sh1[c] : p.sh2[c]) : 0.f;
-                vcl[8 * HP + c] = in ? (p.src == 1 ? p.mu1[c] : p.mu2[c]) : 0.f;
-                vcl[9 * HP + c] = in ? (p.src == 1 ? p.is1[c] : p.is2[c]) : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int nb = 0; nb < BDTH; ++nb) {
-                const int c = nb * 16 + li;
-                const bool in = c < H && p.bstats != nullptr;
-                bstat_sc[nb] = in ? (p.src == 1 ? p.sc1[c] : p.sc2[c]) : 0.f;
-                bstat_sh[nb] = in ? (p.src == 1 ? p.sh1[c] : p.sh2[c]) : 0.f;
-                bstat_mu[nb] = in ? (p.src == 1 ? p.mu1[c] : p.mu2[c]) : 0.f;
-                bstat_is[nb] = in ? (p.src == 1 ? p.is1[c] : p.is2[c]) : 0.f;
-            }
-        }
-    }
-    auto bcst = [&](int which, int nb, const float (&r)[BREG]) -> float {
-        if constexpr (CL) return vcl[(6 + which) * VCols<DT>::HP + nb * 16 + li];
-        else return r[nb];
-    };
     __syncthreads();
     f32x4 sc[DT], sh[DT];
     lane_lazy<DT>(p, lj, sc, sh);
@@ -931,7 +489,6 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
     int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
-    RpeIn rin;      // consumed at the top of an iteration, refilled for the next point right after
     Cursor cu;
     cu.start(pt, p.n);
     // Every load of an iteration belongs to ONE group issued at its top - the next point's rows, coordinates and dP, the
@@ -943,7 +500,6 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb] = 0.f;
     if (pt < p.P) {
         fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
-        if constexpr (VIRT) fetch_rpe(p, cu, li, idx_cur, rin);
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
     }
@@ -953,15 +509,12 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
-        f32x4 rawu[VIRT ? VT<DT>::DTH : 1];
-        if constexpr (VIRT) finish_x_virtual<DT, TERMS>(p, li, lj, raw, rin, sc, sh, vw, vc, xa, Xs, rawu);
-        else finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
         const Cursor cf = pt + pstep < p.P ? cn : cu;
         fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
-        if constexpr (VIRT) fetch_rpe(p, cf, li, pt + pstep < p.P ? idx_nxt : idx_cur, rin);
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
         f32x4 gacc[NGU];                 // GU of this point when this launch adds to it
@@ -1057,16 +610,6 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
                 float v = dx[nb][r];
                 if (col < H) {
                     if (nb < NGU) v += gacc[nb][r];
-                    if constexpr (VIRT) {
-                        // this launch completes the gradient of the stage's activated output: the batch-statistics sums
-                        // of its BatchNorm backward come for free (the raw tile is in registers)
-                        if (p.bstats && nb < VT<DT>::DTH) {
-                            const float z = __builtin_fmaf(rawu[nb][r], bcst(0, nb, bstat_sc), bcst(1, nb, bstat_sh));   // = vbn
-                            const float g = z > 0.f ? v : 0.f;
-                            bsg[nb] += g;
-                            bsx[nb] += g * ((rawu[nb][r] - bcst(2, nb, bstat_mu)) * bcst(3, nb, bstat_is));
-                        }
-                    }
                 }
                 if constexpr (DT <= 2) Ds[rowi * XS + col] = v;
                 else {                      // d = 64: measured better with the element stores (11 us per step)
@@ -1078,7 +621,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         }
         if constexpr (DT <= 2) {
             __builtin_amdgcn_wave_barrier();
-                const long orow = (pt * 16 + li) * H;
+            const long orow = (pt * 16 + li) * H;
 #pragma unroll
             for (int c = 0; c < DT; ++c) {
                 const int k = 16 * c + 4 * lj;
@@ -1090,35 +633,6 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb];
         __builtin_amdgcn_wave_barrier();
-    }
-    if constexpr (VIRT) {
-        if (p.bstats) {
-            // (Tiles is free: every wavefront is past its last point once the barrier below is reached)
-            __syncthreads();
-            double* redd = reinterpret_cast<double*>(&Tiles[0][0][0]);      // [NW][2][HP] doubles
-            constexpr int HP = VT<DT>::HP;
-#pragma unroll
-            for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
-                float a = bsg[nb], b = bsx[nb];
-                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-                b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-                if (lane < 16) {
-                    redd[(wave * 2 + 0) * HP + nb * 16 + lane] = (double)a;
-                    redd[(wave * 2 + 1) * HP + nb * 16 + lane] = (double)b;
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x < H) {
-                const int c = threadIdx.x;
-                double a0 = 0.0, a1 = 0.0;
-                for (int wv = 0; wv < NW; ++wv) {
-                    a0 += redd[(wv * 2 + 0) * HP + c];
-                    a1 += redd[(wv * 2 + 1) * HP + c];
-                }
-                p.bstats[((long)blockIdx.x * 2 + 0) * H + c] = a0;
-                p.bstats[((long)blockIdx.x * 2 + 1) * H + c] = a1;
-            }
-        }
     }
     // combine the four wavefronts' dW tiles in a fixed order (W region is free now)
     __syncthreads();
@@ -1303,27 +817,11 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// the lane's C-layout elements of G for one point (zero in the padding columns)
-template <int DT, bool GB = false>
-__device__ __forceinline__ void load_gin(const float* __restrict__ G, long pt, int li, int lj, f32x4 (&g)[VT<DT>::DTH]) {
-    constexpr int H = VT<DT>::H;
-#pragma unroll
-    for (int nb = 0; nb < VT<DT>::DTH; ++nb) {
-        const int col = nb * 16 + li;
-        g[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (col < H) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[nb][r] = rl_ldx<GB>(G, (pt * 16 + 4 * lj + r) * H + col);
-        }
-    }
-}
-
 // Backward of a virtual rpe stage (mlp_rpe1 / mlp_rpe2 + BatchNorm + ReLU whose output was never stored).  G holds the
 // gradient w.r.t. the ACTIVATED stage output ((points*16) x H, written by the pooling backward kernels); the raw tile
 // is recomputed per point.  With g = G*[act > 0] and xhat = (raw - mean)*invstd:
-//   rpe_bn_reduce_kernel : per-workgroup partials of sum g and sum g*xhat (doubles)            -> rl_bn_bwd_finalize
-//   rpe_wgrad_kernel     : dY = scale*(g - coef0 - xhat*coef1);  dW += dY^T . input (rpe rows / activated stage 1),
+//   vrpe_bn_reduce_kernel : per-workgroup partials of sum g and sum g*xhat (doubles)            -> rl_bn_bwd_finalize
+//   vrpe_wgrad_kernel     : dY = scale*(g - coef0 - xhat*coef1);  dW += dY^T . input (rpe rows / activated stage 1),
 //                          db += sum dY (one partial slab per workgroup, the layout rl_wgrad_reduce_batch sums);
 //                          stage 2 also stores dY . W2 = the gradient w.r.t. the activated stage-1 output (GU1).
 // ---------------------------------------------------------------------------------------------------------------
@@ -1336,328 +834,6 @@ struct RpeBwdParams {
     float* GU1;           // wgrad stage 2: (P*16, H) out
     int g_bf16;           // G and GU1 are stored as bf16
 };
-
-template <int DT>
-struct VBwdCols {
-    static constexpr int DTH = VT<DT>::DTH;
-    float mu[DTH], is[DTH], scl[DTH], sft[DTH], k0[DTH], k1[DTH];
-    __device__ __forceinline__ void load(const PoolParams& p, const float* coef, int li) {
-        const float* mu_ = p.src == 1 ? p.mu1 : p.mu2;
-        const float* is_ = p.src == 1 ? p.is1 : p.is2;
-        const float* sc_ = p.src == 1 ? p.sc1 : p.sc2;
-        const float* sh_ = p.src == 1 ? p.sh1 : p.sh2;
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) {
-            const int c = nb * 16 + li;
-            const bool in = c < VT<DT>::H;
-            mu[nb] = in ? mu_[c] : 0.f;
-            is[nb] = in ? is_[c] : 0.f;
-            scl[nb] = in ? sc_[c] : 0.f;
-            sft[nb] = in ? sh_[c] : 0.f;
-            k0[nb] = (in && coef) ? coef[c] : 0.f;
-            k1[nb] = (in && coef) ? coef[VT<DT>::H + c] : 0.f;
-        }
-    }
-};
-
-template <int DT, int TERMS, bool GB = false>
-__global__ __launch_bounds__(256) void rpe_bn_reduce_kernel(const RpeBwdParams q) {
-    const PoolParams& p = q.pp;
-    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, XS = Tile<VT<DT>::DTH>::XS;
-    __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
-    __shared__ float vcl[VCols<DT>::INLDS ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
-    __shared__ __attribute__((aligned(16))) float Sc[4][16 * XS];
-    __shared__ double red[4][2][VT<DT>::HP];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
-    const int li = lane & 15, lj = lane >> 4;
-    VWeights<DT, TERMS> vw;
-    VCols<DT> vc;
-    VBwdCols<DT> bc;
-    vw.bind(vmem);
-    vw.stage(p, 256);
-    vc.load(p, li, vcl);
-    bc.load(p, nullptr, li);
-    __syncthreads();
-    f32x4 sg[DTH], sx[DTH];
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) sg[nb] = sx[nb] = splat(0.f);
-    const long pstep = (long)gridDim.x * 4;
-    long pt = (long)blockIdx.x * 4 + wave;
-    // software pipeline as in the pooling kernels: neighbour index two points ahead, coordinates (and G) one point ahead,
-    // every load of an iteration issued in one group at its top
-    RpeIn rin, rin_nxt;
-    Cursor cu;
-    cu.start(pt, p.n);
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
-    f32x4 gin[DTH], gin_nxt[DTH];
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb] = splat(0.f);
-    if (pt < p.P) {
-        fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
-        load_gin<DT, GB>(q.G, pt, li, lj, gin);
-    }
-    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
-                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
-    for (; pt < p.P; pt += pstep) {
-        const Cursor cn = cu.next(pstep, p.n);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        {
-            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
-            fetch_rpe(p, cf, li, idx_nxt, rin_nxt);
-            load_gin<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
-        }
-        loads_issued();
-        idx_nxt = idx_n2;
-        cu = cn;
-        f32x4 raw[DTH];
-        rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Sc[wave], XS, raw, nullptr);
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) {
-            const f32x4 z = vbn(raw[nb], bc.scl[nb], bc.sft[nb]);
-            f32x4 g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? gin[nb][r] : 0.f;
-            sg[nb] += g;
-            sx[nb] = __builtin_elementwise_fma(g, (raw[nb] - splat(bc.mu[nb])) * splat(bc.is[nb]), sx[nb]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        rin = rin_nxt;
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb];
-    }
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) {
-        float a = sum4(sg[nb]), b = sum4(sx[nb]);
-        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-        if (lane < 16) {
-            red[wave][0][nb * 16 + lane] = (double)a;
-            red[wave][1][nb * 16 + lane] = (double)b;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < H) {
-        const int c = threadIdx.x;
-        q.stats[((long)blockIdx.x * 2 + 0) * H + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-        q.stats[((long)blockIdx.x * 2 + 1) * H + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
-    }
-}
-
-template <int DT, int TERMS, bool GB = false>
-__global__ __launch_bounds__(256) void rpe_wgrad_kernel(const RpeBwdParams q) {
-    const PoolParams& p = q.pp;
-    constexpr int H = VT<DT>::H, DTH = VT<DT>::DTH, HP = VT<DT>::HP, XS = Tile<VT<DT>::DTH>::XS, XSB = Tile<VT<DT>::DTH>::XSB;
-    constexpr int KB = DTH;                           // k blocks of dW: stage 1 uses block 0 only (10 of its 16 columns)
-    __shared__ __attribute__((aligned(16))) unsigned char vmem[VWeights<DT, TERMS>::BYTES];
-    __shared__ float vcl[VCols<DT>::INLDS ? VCols<DT>::NCONST * VCols<DT>::HP : 1];
-    __shared__ __attribute__((aligned(16))) unsigned char w2t_mem[TERMS == 0 ? HP * XS * 4 : HP * XSB * 2 * 2];   // W2^T image for dY . W2
-    // [0]: the stage's input rows [row][k] (rpe rows for stage 1, the activated stage-1 tile for stage 2); [1]: dY [row][n]
-    __shared__ __attribute__((aligned(16))) float Tl[2][4][16 * XS];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave: an SGPR
-    const int li = lane & 15, lj = lane >> 4;
-    VWeights<DT, TERMS> vw;
-    VCols<DT> vc;
-    VBwdCols<DT> bc;
-    vw.bind(vmem);
-    vw.stage(p, 256);
-    vc.load(p, li, vcl);
-    bc.load(p, q.coef, li);
-    float* w2tf = reinterpret_cast<float*>(w2t_mem);
-    __bf16* w2th = reinterpret_cast<__bf16*>(w2t_mem);
-    __bf16* w2tl = w2th + HP * XSB;
-    if (p.src == 2) {
-        // transposed-B image of W2^T for dA[row][k] = sum_n dY[row][n] W2[n][k]:  Bt[k][n] = W2[n][k]
-        for (int e = threadIdx.x; e < HP * HP; e += 256) {
-            const int k = e / HP, n = e - k * HP;
-            const float w = (n < H && k < H) ? p.W2[n * H + k] : 0.f;
-            if constexpr (TERMS == 0) w2tf[k * XS + n] = w;
-            else {
-                const __bf16 hh = (__bf16)w;
-                w2th[k * XSB + n] = hh;
-                w2tl[k * XSB + n] = (__bf16)(w - (float)hh);
-            }
-        }
-    }
-    for (int e = threadIdx.x; e < 2 * 4 * 16 * XS; e += 256) (&Tl[0][0][0])[e] = 0.f;     // padding columns stay zero
-    __syncthreads();
-    float* Is = Tl[0][wave];
-    float* Ds = Tl[1][wave];
-    f32x4 accw[DTH][KB];
-    f32x4 bsum4[DTH];
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) {
-        bsum4[nb] = splat(0.f);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const long pstep = (long)gridDim.x * 4;
-    long pt = (long)blockIdx.x * 4 + wave;
-    // software pipeline as in the pooling kernels: neighbour index two points ahead, coordinates (and G) one point ahead,
-    // every load of an iteration issued in one group at its top
-    RpeIn rin, rin_nxt;
-    Cursor cu;
-    cu.start(pt, p.n);
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
-    f32x4 gin[DTH], gin_nxt[DTH];
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb] = splat(0.f);
-    if (pt < p.P) {
-        fetch_rpe(p, cu, li, p.idx[pt * 16 + li], rin);
-        load_gin<DT, GB>(q.G, pt, li, lj, gin);
-    }
-    loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
-                         // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
-    for (; pt < p.P; pt += pstep) {
-        const Cursor cn = cu.next(pstep, p.n);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
-        {
-            const Cursor cf = pt + pstep < p.P ? cn : cu;      // (no branch: see pool_fwd_kernel)
-            fetch_rpe(p, cf, li, idx_nxt, rin_nxt);
-            load_gin<DT, GB>(q.G, cf.pt, li, lj, gin_nxt);
-        }
-        loads_issued();
-        idx_nxt = idx_n2;
-        cu = cn;
-        f32x4 raw[DTH];
-        // stage 2 leaves the activated stage-1 tile in Is (its scratch); stage 1's input is the rpe tile itself
-        rpe_branch<DT, TERMS>(p, rin, p.src, vw, vc, li, lj, Is, XS, raw, nullptr);
-        if (p.src == 1) *reinterpret_cast<float4*>(Is + li * XS + 4 * lj) = rpe_frag(rin, lj);
-        // dY, C layout -> Ds
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) {
-            const int col = nb * 16 + li;
-            const f32x4 z = vbn(raw[nb], bc.scl[nb], bc.sft[nb]);
-            f32x4 g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) g[r] = z[r] > 0.f ? gin[nb][r] : 0.f;
-            const f32x4 xh = (raw[nb] - splat(bc.mu[nb])) * splat(bc.is[nb]);
-            // padding columns (col >= H): scale, the coefficients and the incoming gradient are all zero there -> dy = 0
-            const f32x4 dy = splat(bc.scl[nb]) * (g - splat(bc.k0[nb]) - xh * splat(bc.k1[nb]));
-            bsum4[nb] += dy;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ds[(4 * lj + r) * XS + col] = dy[r];
-        }
-        __builtin_amdgcn_wave_barrier();
-        // dW[n][k] += sum_rows dY[row][n] * In[row][k]   (rows are the MFMA reduction index)
-        if constexpr (TERMS == 0) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float bx[KB];
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) bx[kb] = Is[(4 * t + lj) * XS + kb * 16 + li];
-#pragma unroll
-                for (int nb = 0; nb < DTH; ++nb) {
-                    const float ad = Ds[(4 * t + lj) * XS + nb * 16 + li];
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
-                        accw[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, bx[kb], accw[nb][kb], 0, 0, 0);
-                }
-            }
-        } else {
-            bf16x4 xh[KB], xl[KB];
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                float4 v;
-                v.x = Is[(4 * lj + 0) * XS + kb * 16 + li]; v.y = Is[(4 * lj + 1) * XS + kb * 16 + li];
-                v.z = Is[(4 * lj + 2) * XS + kb * 16 + li]; v.w = Is[(4 * lj + 3) * XS + kb * 16 + li];
-                split4(v, xh[kb], xl[kb]);
-            }
-#pragma unroll
-            for (int nb = 0; nb < DTH; ++nb) {
-                float4 v;
-                v.x = Ds[(4 * lj + 0) * XS + nb * 16 + li]; v.y = Ds[(4 * lj + 1) * XS + nb * 16 + li];
-                v.z = Ds[(4 * lj + 2) * XS + nb * 16 + li]; v.w = Ds[(4 * lj + 3) * XS + nb * 16 + li];
-                bf16x4 dh, dl;
-                split4(v, dh, dl);
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dh, xh[kb], accw[nb][kb]);
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dh, xl[kb], accw[nb][kb]);
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = mfma16(dl, xh[kb], accw[nb][kb]);
-            }
-        }
-        if (p.src == 2) {
-            // gradient w.r.t. the activated stage-1 output: dY . W2  (dY re-read in A layout)
-            float4 da[DTH];
-#pragma unroll
-            for (int c = 0; c < DTH; ++c) da[c] = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
-            f32x4 gu[DTH];
-#pragma unroll
-            for (int nb = 0; nb < DTH; ++nb) gu[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (TERMS == 0) tile_gemm<DTH>(da, w2tf, li, lj, gu);
-            else tile_gemm_bf<DTH>(da, w2th, w2tl, li, lj, gu);
-            loads_landed();
-#pragma unroll
-            for (int nb = 0; nb < DTH; ++nb) {
-                const int col = nb * 16 + li;
-                if (col < H) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) RL_ST1<GB>(q.GU1, (pt * 16 + 4 * lj + r) * H + col, gu[nb][r]);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        rin = rin_nxt;
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) gin[nb] = gin_nxt[nb];
-    }
-    // combine the four wavefronts in a fixed order; slab layout: dW[n][k] (n < H, k < Kin) then db[n]
-    const int Kin = p.src == 1 ? 10 : H;
-    float bsum[DTH];
-#pragma unroll
-    for (int nb = 0; nb < DTH; ++nb) {
-        bsum[nb] = sum4(bsum4[nb]);
-        bsum[nb] += __shfl_xor(bsum[nb], 16, 64);
-        bsum[nb] += __shfl_xor(bsum[nb], 32, 64);
-    }
-    __syncthreads();
-    float* red = &Tl[0][0][0];       // DTH*KB*256 + DTH*64 floats <= 2 * 4*16*XS: checked by the static_assert below
-    static_assert(DTH * KB * 256 + DTH * 64 <= 2 * 4 * 16 * XS, "reduction scratch does not fit");
-    float* rb = red + DTH * KB * 256;
-    for (int wv = 1; wv < 4; ++wv) {
-        __syncthreads();
-        if (wave == wv) {
-#pragma unroll
-            for (int nb = 0; nb < DTH; ++nb) {
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[((nb * KB + kb) * 4 + r) * 64 + lane] = accw[nb][kb][r];
-                rb[nb * 64 + lane] = bsum[nb];
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int nb = 0; nb < DTH; ++nb) {
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) accw[nb][kb][r] += red[((nb * KB + kb) * 4 + r) * 64 + lane];
-                bsum[nb] += rb[nb * 64 + lane];
-            }
-        }
-    }
-    if (wave == 0) {
-        float* out = q.slab + (long)blockIdx.x * ((long)H * Kin + H);
-#pragma unroll
-        for (int nb = 0; nb < DTH; ++nb) {
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                const int k = kb * 16 + li;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = nb * 16 + lj * 4 + r;
-                    if (n < H && k < Kin) out[(long)n * Kin + k] = accw[nb][kb][r];
-                }
-            }
-            const int n = nb * 16 + li;
-            if (lj == 0 && n < H) out[(long)H * Kin + n] = bsum[nb];
-        }
-    }
-}
-
 
 // ===============================================================================================================
 // The virtual rpe branch in the TRANSPOSED orientation (round 4).  The kernels above build a point's rpe tile in C layout
@@ -1906,7 +1082,7 @@ template <int DT>
 struct VLane {
     static constexpr int H = VX<DT>::H, NCH = VX<DT>::NCH, HP = VX<DT>::HP;
     static constexpr bool INLDS = VX<DT>::INLDS;
-    float w1a[NCH], w1b[NCH];        // first stage in reduced form (VWeights::stage): U = Wa + Wb against x_i, [Wc - Wb | wd] against [x_i - x_j, dist]
+    float w1a[NCH], w1b[NCH];        // first stage in reduced form: W1.rpe = (Wa + Wb).x_i + (Wc - Wb).(x_i - x_j) + wd.dist (the channels are [x_i, x_j, x_i - x_j, dist] and x_j = x_i - (x_i - x_j)): U = Wa + Wb against x_i, [Wc - Wb | wd] against [x_i - x_j, dist]
     int comp;
     bool l3;
     f32x4 reg[INLDS ? 1 : VX<DT>::NCONST][NCH];
@@ -1997,7 +1173,7 @@ struct XFold {
 template <int DT>
 __device__ __forceinline__ void stage1_raw(const RpeIn2& in, const VLane<DT>& vl, const f32x4 (&c0)[VX<DT>::NCH], f32x4 (&r)[VX<DT>::NCH]) {
     float diff = in.pc - in.nc, dist = vsqrt(in.dd), pc = in.pc;
-    asm volatile("" : "+v"(diff), "+v"(dist), "+v"(pc));      // selects, not exec-masked branches (see rpe_gemm)
+    asm volatile("" : "+v"(diff), "+v"(dist), "+v"(pc));      // selects on lane-constant masks: without the pin hipcc sinks the square root and the difference into exec-masked branches
     const float a1 = vl.l3 ? dist : diff;
     const float a2 = vl.l3 ? 0.f : pc;
 #pragma unroll
@@ -2309,7 +1485,7 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     }
 }
 
-// BatchNorm batch statistics of the raw stage-1 / stage-2 tile of the branch (see rpe_stats_kernel above), transposed orientation
+// BatchNorm batch statistics of the raw stage-1 / stage-2 tile of the branch (what the GEMM epilogue of mlp_rpe1 / mlp_rpe2 would have left for rl_bn_finalize), transposed orientation
 template <int DT, int TERMS, int SRC>
 __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, double* __restrict__ stats) {
     constexpr int NW = 4, NCH = VX<DT>::NCH, HP = VX<DT>::HP;
@@ -2735,7 +1911,7 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
 }
 
 
-// ---- backward of a virtual stage (rpe_bn_reduce_kernel / rpe_wgrad_kernel above), transposed orientation -------------------
+// ---- backward of a virtual stage, transposed orientation ------------------------------------------------------------------
 // G arrives as A-layout float4s (one 16-byte load per lane and chunk instead of four 4-byte ones), the raw tile, the mask,
 // xhat and dY = scale*(g - coef0 - xhat*coef1) live in the A layout; GU1 = dY . W2 is one more transposed product and leaves
 // as 16-byte stores.  Only dW = dY^T . In needs the neighbourhood rows as the MFMA reduction index: dY and the stage's

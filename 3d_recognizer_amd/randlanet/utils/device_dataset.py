@@ -160,42 +160,48 @@ class DeviceDataLoader:
             st["event"].synchronize()
         return st
 
-    def __iter__(self):
-        order = self._order()
+    def _assemble(self, ids):
+        """One batch on the CURRENT stream: the draws (in the reference's order), the staging copies, rl_batch_assemble."""
         n, F, dev = self._n, self._F, self.device
+        B = len(ids)
+        jobs = (H.CloudJob * B)()
+        st = self._staging(B)
+        host_idx = st["idx"] is not None and not self._consistent and self.rng == "numpy"
+        host_noise = st["noise"] is not None
+        indices = torch.empty((B, n), dtype=torch.int64, device=dev)
+        noise = torch.empty((B, n, 3), dtype=torch.float64, device=dev) if self._aug else None
+        for b, cloud in enumerate(ids):            # item by item, like DataLoader(num_workers=0)
+            smp = self._sample(self._xyz[cloud].shape[0], st["idx"][b] if host_idx else None)
+            if smp is not None:
+                indices[b] = smp
+            nz = self._job(cloud, jobs[b], st["noise"][b] if host_noise else None)
+            if nz is not None:
+                noise[b] = nz
+        if host_idx:
+            indices.copy_(st["idx"][:B], non_blocking=True)
+        if host_noise:
+            noise.copy_(st["noise"][:B], non_blocking=True)
+        nbytes = B * C.sizeof(H.CloudJob)
+        st["jobs"].numpy()[:nbytes] = np.frombuffer(bytes(jobs), dtype=np.uint8)
+        jobs_dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        jobs_dev.copy_(st["jobs"][:nbytes], non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record(torch.cuda.current_stream(dev))
+        scratch = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
+        inp = torch.empty((B, n, 3 + F), dtype=torch.float32, device=dev)
+        lab = torch.empty((B, n), dtype=torch.int64, device=dev)
+        H.check(H.lib().rl_batch_assemble(jobs_dev.data_ptr(), B, n, F, indices.data_ptr(), H.ptr(noise),
+                                          scratch.data_ptr(), inp.data_ptr(), lab.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "rl_batch_assemble")
+        return inp, lab, torch.tensor(ids, dtype=torch.int64)
+
+    def __iter__(self):
+        # (Assembling batches one ahead on a stream of the loader's own, beside the training step, was built and measured in
+        # the device-rng mode: 762 vs 770 clouds/s through Model.train - the loader's sort / fill kernels, ~0.45 ms of GPU time per
+        # step of four clouds, do not find room beside a replayed step graph.  Not kept.)
+        order = self._order()
         for start in range(0, len(order), self.batch_size):
-            ids = order[start:start + self.batch_size]
-            B = len(ids)
-            jobs = (H.CloudJob * B)()
-            st = self._staging(B)
-            host_idx = st["idx"] is not None and not self._consistent and self.rng == "numpy"
-            host_noise = st["noise"] is not None
-            indices = torch.empty((B, n), dtype=torch.int64, device=dev)
-            noise = torch.empty((B, n, 3), dtype=torch.float64, device=dev) if self._aug else None
-            for b, cloud in enumerate(ids):            # item by item, like DataLoader(num_workers=0)
-                smp = self._sample(self._xyz[cloud].shape[0], st["idx"][b] if host_idx else None)
-                if smp is not None:
-                    indices[b] = smp
-                nz = self._job(cloud, jobs[b], st["noise"][b] if host_noise else None)
-                if nz is not None:
-                    noise[b] = nz
-            if host_idx:
-                indices.copy_(st["idx"][:B], non_blocking=True)
-            if host_noise:
-                noise.copy_(st["noise"][:B], non_blocking=True)
-            nbytes = B * C.sizeof(H.CloudJob)
-            st["jobs"].numpy()[:nbytes] = np.frombuffer(bytes(jobs), dtype=np.uint8)
-            jobs_dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            jobs_dev.copy_(st["jobs"][:nbytes], non_blocking=True)
-            st["event"] = torch.cuda.Event()
-            st["event"].record(torch.cuda.current_stream(dev))
-            scratch = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
-            inp = torch.empty((B, n, 3 + F), dtype=torch.float32, device=dev)
-            lab = torch.empty((B, n), dtype=torch.int64, device=dev)
-            H.check(H.lib().rl_batch_assemble(jobs_dev.data_ptr(), B, n, F, indices.data_ptr(), H.ptr(noise),
-                                              scratch.data_ptr(), inp.data_ptr(), lab.data_ptr(),
-                                              torch.cuda.current_stream(dev).cuda_stream), "rl_batch_assemble")
-            yield inp, lab, torch.tensor(ids, dtype=torch.int64)
+            yield self._assemble(order[start:start + self.batch_size])
 
 
 def get_device_data_loader(dataset: Sequence[Sample], n_sample_points: int, batch_size: int, shuffle: bool = False,

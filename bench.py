@@ -393,7 +393,7 @@ def step_rooflines(breakdown, B, value, world):
     return out
 
 
-def trainer_e2e(dev, clouds=200, batch=4):
+def trainer_e2e(dev, clouds=400, batch=4):
     """Clouds/s through the callers' side of the path: Model.train -> Trainer.train -> device data loader
     (one rl_batch_assemble launch per batch) -> TrainStep graph replay, config A shape (4 clouds of 40960 points per step),
     default augmentation, one timed epoch of clouds/batch steps after a warm-up epoch (graph capture, allocator).  The epoch
