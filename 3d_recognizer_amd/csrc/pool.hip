@@ -176,6 +176,36 @@ __device__ __forceinline__ float chunk_slope(int c, int lj, float es_u, float es
     else return 16 * c < Tile<DT>::H ? es_u : es_g;
 }
 
+// The per-chunk lazy parameters as the kernels read them: registers up to d = 64; at d = 128 (sixteen float4s = 64 registers in
+// kernels that sit at the 256-register limit) from an LDS image, 16 bytes per use.  `mem`: 2*D floats, published by the caller's barrier.
+template <int DT>
+struct LFold {
+    static constexpr int D = 16 * DT;
+    static constexpr bool INLDS = DT >= 8;
+    static constexpr int LDS_FLOATS = INLDS ? 2 * D : 4;
+    f32x4 rsc[INLDS ? 1 : DT], rsh[INLDS ? 1 : DT];
+    const float* lds;
+    __device__ __forceinline__ void init(const PoolParams& p, int lj, float* mem) {
+        if constexpr (INLDS) {
+            constexpr int H = D / 2;
+            for (int k = threadIdx.x; k < D; k += blockDim.x) {
+                const RlLazy& t = k < H ? p.ulazy : p.glazy;
+                mem[k] = t.scale ? t.scale[k < H ? k : k - H] : 1.f;
+                mem[D + k] = t.scale ? t.shift[k < H ? k : k - H] : 0.f;
+            }
+            lds = mem + 4 * lj;
+        } else lane_lazy<DT>(p, lj, rsc, rsh);
+    }
+    __device__ __forceinline__ f32x4 sc(int c) const {
+        if constexpr (INLDS) return *reinterpret_cast<const f32x4*>(lds + 16 * c);
+        else return rsc[c];
+    }
+    __device__ __forceinline__ f32x4 sh(int c) const {
+        if constexpr (INLDS) return *reinterpret_cast<const f32x4*>(lds + D + 16 * c);
+        else return rsh[c];
+    }
+};
+
 // Position of a wavefront in its sequence of points: the point, its cloud and its index inside the cloud.  All three are
 // wavefront-uniform (the wave number is read through readfirstlane), so this arithmetic - and every address built from
 // it - runs on the scalar unit; the cloud is tracked incrementally instead of dividing by n per point.
@@ -215,13 +245,13 @@ __device__ __forceinline__ void fetch_x(const PoolParams& p, const Cursor& cu, i
 }
 template <int DT>
 __device__ __forceinline__ void finish_x(const PoolParams& p, int li, int lj, const float4 (&raw)[DT],
-                                         const f32x4 (&sc)[DT], const f32x4 (&sh)[DT], float4 (&xa)[DT], float* Xs) {
+                                         const LFold<DT>& lf, float4 (&xa)[DT], float* Xs) {
     constexpr int XS = Tile<DT>::XS;
     const float es_u = eff_slope(p.ulazy), es_g = eff_slope(p.glazy);
 #pragma unroll
     for (int c = 0; c < DT; ++c) {
         const int k = 16 * c + 4 * lj;
-        const float4 v = f4(vact(v4(raw[c]) * sc[c] + sh[c], chunk_slope<DT>(c, lj, es_u, es_g)));
+        const float4 v = f4(vact(v4(raw[c]) * lf.sc(c) + lf.sh(c), chunk_slope<DT>(c, lj, es_u, es_g)));
         xa[c] = v;
         *reinterpret_cast<float4*>(Xs + li * XS + k) = v;
     }
@@ -375,6 +405,7 @@ __device__ __forceinline__ void stage_w(const PoolParams& p, float* Wt, float* W
 template <int DT, int TERMS, int NW = 4>   // TERMS 0: fp32 MFMA; 3: bf16x3 (head + tail operands, three bf16 MFMAs per product); NW wavefronts.  (A virtual rpe half: vpool_fwd_kernel.)
 __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     constexpr int D = Tile<DT>::D, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
+    __shared__ __attribute__((aligned(16))) float lfm[LFold<DT>::LDS_FLOATS];
     __shared__ __attribute__((aligned(16))) unsigned char wmem[TERMS == 0 ? D * XS * 4 : 2 * D * XSB * 2];
     __shared__ __attribute__((aligned(16))) float Xt[NW][16 * XS];
     float* Wt = reinterpret_cast<float*>(wmem);
@@ -393,9 +424,9 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
             Wl[o * XSB + i] = (__bf16)(w - (float)h);
         }
     }
+    LFold<DT> lf;
+    lf.init(p, lj, lfm);
     __syncthreads();
-    f32x4 sc[DT], sh[DT];
-    lane_lazy<DT>(p, lj, sc, sh);
     float* Xs = Xt[wave];
     // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
     const long pstep = (long)gridDim.x * NW;
@@ -411,7 +442,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
-        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        finish_x<DT>(p, li, lj, raw, lf, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
@@ -447,6 +478,7 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
 template <int DT, int TERMS, bool VIRT = false, int NW = 4, bool GB = false>   // NW wavefronts share the staged weights
 __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     static_assert(!VIRT, "a virtual rpe stage runs vpool_bwd_kernel");
+    __shared__ __attribute__((aligned(16))) float lfm[LFold<DT>::LDS_FLOATS];
     constexpr bool GUB = false;
     constexpr int D = Tile<DT>::D, H = Tile<DT>::H, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
     // LDS: W^T, W, and per wavefront an X tile and a dS tile; after the main loop the W region is
@@ -472,9 +504,9 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
             Wth[i * XSB + o] = h; Wtl[i * XSB + o] = l;
         }
     }
+    LFold<DT> lf;
+    lf.init(p, lj, lfm);
     __syncthreads();
-    f32x4 sc[DT], sh[DT];
-    lane_lazy<DT>(p, lj, sc, sh);
     float* Xs = Tiles[wave][0];
     float* Ds = Tiles[wave][1];
     f32x4 accw[DT][DT];
@@ -509,7 +541,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
-        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        finish_x<DT>(p, li, lj, raw, lf, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
@@ -681,6 +713,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 template <bool GB>      // X_out, dS_out and DG stored as bf16 (GU is a real tensor's gradient: fp32)
 __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
+    __shared__ __attribute__((aligned(16))) float lfm[LFold<8>::LDS_FLOATS];
     constexpr int NW = 8;    // 70 KB of W in LDS: one workgroup per CU, so it brings eight wavefronts
     constexpr int TERMS = 3;
     constexpr int DT = 8, D = 128, H = 64, XS = Tile<DT>::XS, XSB = Tile<DT>::XSB;
@@ -696,9 +729,9 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
         Wh[o * XSB + i] = h;
         if constexpr (TERMS == 3) Wl[o * XSB + i] = (__bf16)(w - (float)h);
     }
+    LFold<DT> lf;
+    lf.init(p, lj, lfm);
     __syncthreads();
-    f32x4 sc[DT], sh[DT];
-    lane_lazy<DT>(p, lj, sc, sh);
     // one tile per wavefront: X in C layout is read and dS written by the SAME lane at the same element, so dS
     // replaces X in place (nothing needs X afterwards - the weight gradient is external)
     float* Xs = Tiles[wave];
@@ -724,7 +757,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     for (; pt < p.P; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
-        finish_x<DT>(p, li, lj, raw, sc, sh, xa, Xs);
+        finish_x<DT>(p, li, lj, raw, lf, xa, Xs);
         const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
@@ -793,23 +826,32 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
                 }
             }
         }
-        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row
+        // outputs of dX: columns < H -> rpe-branch gradient, columns >= H -> gradient of this slot's gathered row.  The finished
+        // tile (C layout: a lane holds four ROWS of one column) goes through the wavefront's tile - dS is dead by now - and
+        // leaves in A layout: 16-byte stores, 256 contiguous bytes per row and tensor (round 4; the element form - 32 4-byte
+        // stores per lane and point, and 16 4-byte read-modify-writes when the launch adds to GU - made the accumulating
+        // launch 212 us against 145)
         loads_landed();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rowi = lj * 4 + r;
-            const long urow = (pt * 16 + rowi) * H;
+        for (int nb = 0; nb < DT; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < DT; ++nb) {
-                const int col = nb * 16 + li;
-                const float v = dx[nb][r];
-                if (col < H) {
-                    if (p.gu_accumulate) p.GU[urow + col] += v;
-                    else p.GU[urow + col] = v;
-                } else {
-                    rl_stx<GB>(p.DG, urow + (col - H), v);
-                }
-            }
+            for (int r = 0; r < 4; ++r) Ds[(lj * 4 + r) * XS + nb * 16 + li] = dx[nb][r];
+        __builtin_amdgcn_wave_barrier();
+        const long orow = (pt * 16 + li) * H;
+        float4 gold[DT / 2];
+        if (p.gu_accumulate) {
+#pragma unroll
+            for (int c = 0; c < DT / 2; ++c) gold[c] = *reinterpret_cast<const float4*>(p.GU + orow + 16 * c + 4 * lj);
+        }
+#pragma unroll
+        for (int c = DT / 2; c < DT; ++c)      // (the gathered half first: its stores go out while the GU rows arrive)
+            rl_stx4<GB>(p.DG, orow + 16 * c + 4 * lj - H, *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj));
+#pragma unroll
+        for (int c = 0; c < DT / 2; ++c) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ds + li * XS + 16 * c + 4 * lj);
+            if (p.gu_accumulate) v += v4(gold[c]);
+            *reinterpret_cast<float4*>(p.GU + orow + 16 * c + 4 * lj) = f4(v);
         }
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb];
