@@ -1527,6 +1527,86 @@ __global__ __launch_bounds__(512, 4) void wgemm_kernel(const GemmParams p) {
 }
 
 // ===========================================================================================
+// The same epilogue for a TRANSPOSED accumulator (the MFMA operands exchanged, round 4): acc[nb][j] = element (row lr, column
+// col0 + nb * 16 + lq * 4 + j) - a lane owns four consecutive columns of ITS row, so a block leaves (and its addend / old Y
+// arrive) in 16-byte pieces: 8 stores per lane and 128-column block instead of 32.  No statistics here (a launch that wants them
+// keeps the column-per-lane layout, whose column sums are two shuffles).  `vec`: N, ldy and the pointers allow 16-byte accesses.
+template <int NT>
+__device__ __forceinline__ void tile_rows_epilogue_t(const GemmParams& p, const f32x4 (&acc)[NT], long Rb, int col0, int lr, int lq, bool vec) {
+    constexpr int BN = 16 * NT;
+    const int N = p.N;
+    const long R = Rb + lr;
+    if (R >= p.a.M) return;
+    const bool to_y = !p.out2 || col0 + BN <= p.split_col;
+    const bool to_out2 = p.out2 && !p.out2_index && col0 >= p.split_col;
+    long yoff;
+    if (p.y_contig) yoff = R * p.ldy;
+    else {
+        const int b = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+        const int i = (int)(R - (long)b * p.rows_per_batch);
+        yoff = ((long)b * p.y_bstride + i) * p.ldy;
+    }
+    const int c0 = col0 + 4 * lq;                   // this lane's first column of block 0
+    if (vec && (to_y || to_out2)) {
+        float* y = to_y ? p.Y + yoff + c0 : p.out2 + R * (N - p.split_col) - p.split_col + c0;
+        const bool full = col0 + BN <= N;
+        const bool accumulate = to_y && p.accumulate;
+        f32x4 v[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) v[nb] = acc[nb];
+        if (p.bias) {
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb)
+                if (full || c0 + nb * 16 < N) v[nb] += *reinterpret_cast<const f32x4*>(p.bias + c0 + nb * 16);
+        }
+        if (p.addend) {
+            const float* ad = p.addend + R * N + c0;
+            f32x4 o[NT];
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) o[nb] = (full || c0 + nb * 16 < N) ? *reinterpret_cast<const f32x4*>(ad + nb * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) v[nb] += o[nb];
+        }
+        if (accumulate) {
+            f32x4 o[NT];
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) o[nb] = (full || c0 + nb * 16 < N) ? *reinterpret_cast<const f32x4*>(y + nb * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) v[nb] += o[nb];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb)
+            if (full || c0 + nb * 16 < N) *reinterpret_cast<f32x4*>(y + nb * 16) = v[nb];
+        return;
+    }
+    // element by element: a tile that straddles split_col, the indexed (atomic) out2, or operands that rule out 16-byte accesses
+    long o2 = 0;
+    if (p.out2) {
+        if (p.out2_index) {
+            const int b2 = (int)((unsigned)R / (unsigned)p.rows_per_batch);
+            o2 = ((long)b2 * p.out2_bstride + p.out2_index[R]) * (N - p.split_col) - p.split_col;
+        } else o2 = R * (N - p.split_col) - p.split_col;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + nb * 16 + j;
+            if (c < N) {
+                float t = acc[nb][j];
+                if (p.bias) t += p.bias[c];
+                if (p.addend) t += p.addend[R * N + c];
+                if (p.out2 && c >= p.split_col) {
+                    if (p.out2_index) atomicAdd(p.out2 + o2 + c, t);
+                    else p.out2[o2 + c] = t;
+                } else {
+                    if (p.accumulate) t += p.Y[yoff + c];
+                    p.Y[yoff + c] = t;
+                }
+            }
+        }
+}
+
 // wgemm2_kernel: wgemm_kernel's tile and arithmetic as a PERSISTENT workgroup per CU whose operands arrive by LDS-DMA
 // (global_load_lds_dwordx4) from dedicated loader wavefronts.
 // wgemm_kernel keeps one 32-deep chunk of loads in flight per workgroup, in registers, behind two barriers per chunk; its
@@ -1594,6 +1674,7 @@ template <int TERMS, bool STATS, int AS, int WS>
 __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) {
     static_assert(AS >= 3 && AS <= 6 && WS >= 2 && WS <= 6, "ring depths vs the wait table");
     constexpr int BN = 128, NT = 8;
+    constexpr bool TR = !STATS;                 // transposed accumulator (16-byte epilogue) where no column statistics are wanted
     constexpr int A_STAGE = 128 * 128;          // bytes: 128 rows x 32 fp32
     constexpr int W_PLANE = 128 * 64;           // bytes: 128 columns x 32 bf16
     constexpr int W_STAGE = 2 * W_PLANE;
@@ -1631,6 +1712,10 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
     const int k_begin = (p.ksplit > 1) ? blockIdx.z * p.kchunk : 0;
     const int k_end = (p.ksplit > 1) ? min(K, k_begin + p.kchunk) : K;
     const int nch = (k_end - k_begin) / PG_BK;
+    // 16-byte accesses of the transposed epilogue: every row start and column group 16-byte aligned in all tensors it touches
+    const bool vec_t = (N % 4 == 0) && (p.ldy % 4 == 0) && (p.split_col % 4 == 0) &&
+                       (((reinterpret_cast<uintptr_t>(p.Y) | reinterpret_cast<uintptr_t>(p.out2) | reinterpret_cast<uintptr_t>(p.addend) |
+                          reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.kslab)) & 15) == 0);
     const int my_tiles = bx < ntiles ? (int)((ntiles - 1 - bx) / p.gx) + 1 : 0;
     const int T = my_tiles * nch;                                  // chunk steps of this workgroup = barriers every wavefront passes
 
@@ -1746,13 +1831,18 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
 #pragma unroll
             for (int nb = 0; nb < NT; ++nb) { acc[nb][0] += (float)b_h[nb][0] * (float)a_h[0]; acc[nb][1] += (float)b_l[nb][1] * (float)a_l[1]; }
 #else
+            // TR (launches without statistics): operands exchanged - the tile comes out transposed, a lane owns four consecutive
+            // columns of its row (tile_rows_epilogue_t); the same products in the same order, the same bits
 #pragma unroll
-            for (int nb = 0; nb < NT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[nb], acc[nb], 0, 0, 0);
+            for (int nb = 0; nb < NT; ++nb) acc[nb] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_h[nb], a_h, acc[nb], 0, 0, 0)
+                                                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[nb], acc[nb], 0, 0, 0);
             if constexpr (TERMS == 3) {
 #pragma unroll
-                for (int nb = 0; nb < NT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l[nb], acc[nb], 0, 0, 0);
+                for (int nb = 0; nb < NT; ++nb) acc[nb] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_l[nb], a_h, acc[nb], 0, 0, 0)
+                                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l[nb], acc[nb], 0, 0, 0);
 #pragma unroll
-                for (int nb = 0; nb < NT; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h[nb], acc[nb], 0, 0, 0);
+                for (int nb = 0; nb < NT; ++nb) acc[nb] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_h[nb], a_l, acc[nb], 0, 0, 0)
+                                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h[nb], acc[nb], 0, 0, 0);
             }
 #endif
             if (++c < nch) continue;
@@ -1768,6 +1858,22 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
             if (p.ksplit > 1) {
 #endif
                 float* slab = p.kslab + (long)blockIdx.z * M * N;
+                if constexpr (TR) {
+                    const long R = row0 + wave * 16 + lr;
+                    if (R < M) {
+#pragma unroll
+                        for (int nb = 0; nb < NT; ++nb) {
+                            const int cc = col0 + nb * 16 + lq * 4;
+                            if (vec_t) {
+                                if (cc < N) *reinterpret_cast<f32x4*>(slab + R * N + cc) = acc[nb];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (cc + j < N) slab[R * N + cc + j] = acc[nb][j];
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long R = row0 + wave * 16 + lq * 4 + r;
@@ -1779,6 +1885,7 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
                         }
                     }
                 }
+                }
 #if W2_ABLATE == 4
             } else if (p.ksplit > 1000) {
 #else
@@ -1787,7 +1894,8 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
                 float ssum[NT], ssq[NT];
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
-                tile_rows_epilogue<NT, STATS>(p, acc, row0 + wave * 16, col0, lr, lq, ssum, ssq);
+                if constexpr (TR) tile_rows_epilogue_t<NT>(p, acc, row0 + wave * 16, col0, lr, lq, vec_t);
+                else tile_rows_epilogue<NT, STATS>(p, acc, row0 + wave * 16, col0, lr, lq, ssum, ssq);
                 if constexpr (STATS) if (p.stats) {
                     // this wavefront's own slice of the scratch: no other wavefront touches it before the final barrier
 #pragma unroll
