@@ -485,6 +485,160 @@ __global__ __launch_bounds__(256) void resid_bn_bwd_apply_kernel(const ResidPara
     }
 }
 
+// ---- small tensors: the whole BatchNorm backward in ONE launch ------------------------------------------------------------
+// reduce -> finalize -> apply is three dependent launches of ~5 us each on a tensor of a few thousand rows (level 3, the
+// summit, the first decoder stage): 15 us for a microsecond of work.  With SM_R (1 or 2) rows per lane a workgroup of 1024
+// lanes can own ONE channel quad and ALL its rows: the rows stay in registers, the batch sums never leave the workgroup
+// (a fixed butterfly per wavefront, then the 16 wavefronts in a fixed order, in double), and the result is written by the
+// lanes that loaded the operands.  Same expressions per element as the three kernels; the sums group differently (another
+// fixed order of the same terms).
+constexpr int SM_T = 1024;
+// Workgroup -> channel quad.  A workgroup uses 16 bytes of every 128-byte line it touches; the other quads of the line belong
+// to other workgroups - which must sit on the SAME XCD, or every XCD's L2 fetches the line for itself (measured: 33 us for
+// 5120 x 256, eight times the tensor over the fabric).  Workgroup ids go to the XCDs round-robin (id % 8): XCD x takes the
+// contiguous quads [x * per, (x + 1) * per), per = ceil(quads / 8).
+__device__ __forceinline__ int small_quad(int C) {
+    const int nq = C >> 2, per = (nq + 7) >> 3;
+    const int q = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    return ((int)(blockIdx.x >> 3) < per && q < nq) ? q : -1;
+}
+static inline unsigned small_grid(int C) { return (unsigned)(8 * (((C >> 2) + 7) >> 3)); }
+template <int SM_R>
+__global__ __launch_bounds__(SM_T) void bn_bwd_small_kernel(const BwdParams p, const double count, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ coef_out) {
+    __shared__ float red[SM_T / 64][8];
+    const int C = p.C, c = small_quad(C) * 4;
+    if (c < 0) return;
+    BnQuad k;
+    k.load(p, c, true);
+    bnf4 d[SM_R], xh[SM_R];
+    long off[SM_R];
+    bnf4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    {
+        bnf4 y[SM_R], g[SM_R];
+#pragma unroll
+        for (int j = 0; j < SM_R; ++j) {
+            const long R = (long)j * SM_T + threadIdx.x;
+            const bool in = R < p.M;
+            off[j] = in ? row_off(p, R) + c : -1;
+            y[j] = in ? *reinterpret_cast<const bnf4*>(p.Y + off[j]) : (bnf4){0.f, 0.f, 0.f, 0.f};
+            g[j] = in ? *reinterpret_cast<const bnf4*>(p.G + off[j]) : (bnf4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < SM_R; ++j) {
+            d[j] = k.grad(y[j], g[j]);
+            xh[j] = k.xhat(y[j]);
+            a0 += d[j];
+            a1 += d[j] * xh[j];
+        }
+    }
+    float acc[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = rl_wave_sum(acc[j]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x >> 6][j] = acc[j];
+    }
+    __syncthreads();
+    // eight lanes finish the eight sums (the wavefronts in a fixed order, in double - and ONE fp64 division each, not 8192)
+    __shared__ __attribute__((aligned(16))) float kk[8];
+    if (threadIdx.x < 8) {
+        const int j = threadIdx.x;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_T / 64; ++w) s += (double)red[w][j];
+        const float m = (float)(s / count);
+        kk[j] = m;
+        float* tot = j < 4 ? dbeta : dgamma;
+        if (tot) tot[c + (j & 3)] = (float)s;
+        if (coef_out) coef_out[(j < 4 ? 0 : C) + c + (j & 3)] = m;
+    }
+    __syncthreads();
+    const bnf4 k0 = *reinterpret_cast<const bnf4*>(kk), k1 = *reinterpret_cast<const bnf4*>(kk + 4);
+    const bnf4 osc = p.scale ? k.sc : (bnf4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < SM_R; ++j)
+        if (off[j] >= 0) *reinterpret_cast<bnf4*>(p.G + off[j]) = (d[j] - k0 - xh[j] * k1) * osc;
+}
+
+// the same for the residual junction (one gradient, two BatchNorms: resid_bn_bwd_reduce / _apply)
+template <int SM_R>
+__global__ __launch_bounds__(SM_T) void resid_bn_bwd_small_kernel(const ResidParams p, const double count, float* __restrict__ dgamma1,
+                                                                  float* __restrict__ dbeta1, float* __restrict__ dgamma2,
+                                                                  float* __restrict__ dbeta2) {
+    __shared__ float red[SM_T / 64][12];
+    const int C = p.C, c = small_quad(C) * 4;
+    if (c < 0) return;
+    const bnf4 mu1 = *reinterpret_cast<const bnf4*>(p.mu1 + c), is1 = *reinterpret_cast<const bnf4*>(p.is1 + c);
+    const bnf4 mu2 = *reinterpret_cast<const bnf4*>(p.mu2 + c), is2 = *reinterpret_cast<const bnf4*>(p.is2 + c);
+    bnf4 g[SM_R], x1[SM_R], x2[SM_R];
+    bnf4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+    {
+        bnf4 gi[SM_R], o[SM_R], y1[SM_R], y2[SM_R];
+#pragma unroll
+        for (int j = 0; j < SM_R; ++j) {
+            const long R = (long)j * SM_T + threadIdx.x;
+            const bool in = R < p.M;
+            const long off = in ? R * C + c : 0;
+            const bnf4 z = {0.f, 0.f, 0.f, 0.f};
+            gi[j] = in ? *reinterpret_cast<const bnf4*>(p.G + off) : z;
+            o[j] = in ? *reinterpret_cast<const bnf4*>(p.O + off) : z;
+            y1[j] = in ? *reinterpret_cast<const bnf4*>(p.Y1 + off) : z;
+            y2[j] = in ? *reinterpret_cast<const bnf4*>(p.Y2 + off) : z;
+        }
+#pragma unroll
+        for (int j = 0; j < SM_R; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[j][e] = o[j][e] > 0.f ? gi[j][e] : gi[j][e] * p.slope;
+            x1[j] = (y1[j] - mu1) * is1;
+            x2[j] = (y2[j] - mu2) * is2;
+            a0 += g[j];
+            a1 += g[j] * x1[j];
+            a2 += g[j] * x2[j];
+        }
+    }
+    float acc[12] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0], a2[1], a2[2], a2[3]};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = rl_wave_sum(acc[j]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) red[threadIdx.x >> 6][j] = acc[j];
+    }
+    __syncthreads();
+    __shared__ __attribute__((aligned(16))) float kk[12];      // mean g, mean g*xhat1, mean g*xhat2
+    if (threadIdx.x < 12) {
+        const int j = threadIdx.x, e = j & 3;
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_T / 64; ++w) s += (double)red[w][j];
+        kk[j] = (float)(s / count);
+        if (j < 4) {
+            if (dbeta1) dbeta1[c + e] = (float)s;
+            if (dbeta2) dbeta2[c + e] = (float)s;
+        } else if (j < 8) {
+            if (dgamma1) dgamma1[c + e] = (float)s;
+        } else if (dgamma2) dgamma2[c + e] = (float)s;
+    }
+    __syncthreads();
+    const bnf4 k0 = *reinterpret_cast<const bnf4*>(kk), k1 = *reinterpret_cast<const bnf4*>(kk + 4), k2 = *reinterpret_cast<const bnf4*>(kk + 8);
+    const bnf4 s1 = *reinterpret_cast<const bnf4*>(p.sc1 + c), s2 = *reinterpret_cast<const bnf4*>(p.sc2 + c);
+#pragma unroll
+    for (int j = 0; j < SM_R; ++j) {
+        const long R = (long)j * SM_T + threadIdx.x;
+        if (R < p.M) {
+            const long off = R * C + c;
+            *reinterpret_cast<bnf4*>(p.G + off) = (g[j] - k0 - x1[j] * k1) * s1;
+            *reinterpret_cast<bnf4*>(p.G2 + off) = (g[j] - k0 - x2[j] * k2) * s2;
+        }
+    }
+}
+// Where it pays: each lane-row costs a 64-byte sector for 16 bytes used, so L2 -> L1 moves four times the tensor; measured inside
+// the benchmark's step (5 plain tensors of 1280 - 5120 rows, one junction of 5120 x 512) the one-launch form took 25 us / 61 us
+// against 15 us / 35 us for the three launches with 5 rows per lane - it is used up to TWO rows per lane (2048 rows: the
+// summit at any batch size, levels 2 - 3 at small per-GPU batches), where the launch floor is all there is to save.
+constexpr int SM_ROWS = 2 * SM_T;
+constexpr int SM_ROWS_RESID = 2 * SM_T;
+
 int resid_fill(ResidParams* p, const rl_resid_bn_bwd_desc* d, const char* who) {
     RL_REQUIRE(d && d->G && d->O && d->Y1 && d->Y2 && d->rows > 0 && d->C > 0, RL_ERR_ARGS, "%s: bad descriptor", who);
     RL_REQUIRE(d->scale1 && d->mean1 && d->invstd1 && d->scale2 && d->mean2 && d->invstd2, RL_ERR_ARGS, "%s: needs both BatchNorms' scale / mean / invstd", who);
@@ -611,6 +765,45 @@ extern "C" int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream) {
                            (hipStream_t)stream, p);
     rl_note_kernel(vec_ok(p) ? "bn_bwd_apply_vec_kernel" : "bn_bwd_apply_kernel");
     RL_LAUNCH_CHECK("rl_bn_bwd_apply");
+    return RL_OK;
+}
+
+extern "C" int rl_bn_bwd_fused_supported(int64_t rows, int C, int64_t ld) {
+    return (rows > 0 && rows <= SM_ROWS && C > 0 && C % 4 == 0 && ld % 4 == 0 && getenv("RL_NO_BN_SMALL") == nullptr) ? 1 : 0;
+}
+
+extern "C" int rl_bn_bwd_fused(const rl_bn_bwd_desc* d, int64_t count, float* dgamma, float* dbeta, float* coef_out, void* stream) {
+    BwdParams p;
+    int rc = fill(&p, d, "rl_bn_bwd_fused");
+    if (rc) return rc;
+    RL_REQUIRE(p.mean && p.invstd && count > 0, RL_ERR_ARGS, "rl_bn_bwd_fused: needs mean / invstd and the row count");
+    RL_REQUIRE(rl_bn_bwd_fused_supported(p.M, p.C, p.ld) && (((uintptr_t)p.G | (uintptr_t)p.Y) & 15) == 0, RL_ERR_UNSUPPORTED,
+               "rl_bn_bwd_fused: %ld rows x %d channels (ld %ld) is not a small 16-byte-aligned tensor - use reduce / finalize / apply", p.M, p.C, p.ld);
+    const uintptr_t al = (uintptr_t)p.scale | (uintptr_t)p.shift | (uintptr_t)p.mean | (uintptr_t)p.invstd;
+    RL_REQUIRE((al & 15) == 0, RL_ERR_ARGS, "rl_bn_bwd_fused: per-channel vectors must be 16-byte aligned");
+    const dim3 grid(small_grid(p.C));
+    if (p.M <= SM_T) hipLaunchKernelGGL(bn_bwd_small_kernel<1>, grid, dim3(SM_T), 0, (hipStream_t)stream, p, (double)count, dgamma, dbeta, coef_out);
+    else hipLaunchKernelGGL(bn_bwd_small_kernel<2>, grid, dim3(SM_T), 0, (hipStream_t)stream, p, (double)count, dgamma, dbeta, coef_out);
+    rl_note_kernel("bn_bwd_small_kernel");
+    RL_LAUNCH_CHECK("rl_bn_bwd_fused");
+    return RL_OK;
+}
+
+extern "C" int rl_resid_bn_bwd_fused_supported(int64_t rows, int C) {
+    return (rl_resid_bn_bwd_supported(rows, C) && rows <= SM_ROWS_RESID && getenv("RL_NO_BN_SMALL") == nullptr) ? 1 : 0;
+}
+
+extern "C" int rl_resid_bn_bwd_fused(const rl_resid_bn_bwd_desc* d, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream) {
+    ResidParams p;
+    int rc = resid_fill(&p, d, "rl_resid_bn_bwd_fused");
+    if (rc) return rc;
+    RL_REQUIRE(p.G2, RL_ERR_ARGS, "rl_resid_bn_bwd_fused: needs G2");
+    RL_REQUIRE(rl_resid_bn_bwd_fused_supported(p.M, p.C), RL_ERR_UNSUPPORTED, "rl_resid_bn_bwd_fused: %ld rows is not a small tensor", p.M);
+    const dim3 grid(small_grid(p.C));
+    if (p.M <= SM_T) hipLaunchKernelGGL(resid_bn_bwd_small_kernel<1>, grid, dim3(SM_T), 0, (hipStream_t)stream, p, (double)p.M, dgamma1, dbeta1, dgamma2, dbeta2);
+    else hipLaunchKernelGGL(resid_bn_bwd_small_kernel<2>, grid, dim3(SM_T), 0, (hipStream_t)stream, p, (double)p.M, dgamma1, dbeta1, dgamma2, dbeta2);
+    rl_note_kernel("resid_bn_bwd_small_kernel");
+    RL_LAUNCH_CHECK("rl_resid_bn_bwd_fused");
     return RL_OK;
 }
 

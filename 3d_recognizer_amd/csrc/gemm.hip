@@ -2648,6 +2648,7 @@ struct WBItem {
     int N, K, n, rows_per_batch, act;
     float slope;
     int first_block;           // of this layer in the launch
+    int nsplit;                // its row blocks (slabs)
     unsigned short gy, gz;     // its column-tile / k-tile counts
     unsigned char a_contig, dy_contig, has_bias, pad;
 };
@@ -2663,8 +2664,19 @@ __global__ __launch_bounds__(512, 4) void pwgrad128w_batch_kernel(const WgradBat
     const WBItem& it = b.item[i];
     const int local = (int)blockIdx.x - it.first_block;
     const int per = (int)it.gy * (int)it.gz;
-    const int bx = local / per, rem = local - bx * per;
-    const int by = rem / (int)it.gz, bz = rem - by * (int)it.gz;
+    // Workgroup -> (row block, tile).  A layer wider than one 128 x 128 tile reads each row block once per tile of the other
+    // operand's direction (81920 x 256 x 256: both operands twice); workgroups go to the eight XCDs round-robin (id % 8), each
+    // with an L2 of its own, so the tiles of ONE row block are given ids 8 apart: same XCD, dispatched back to back, streaming
+    // the same rows at the same time - the second reader of a row finds it in that L2.  (Layer starts are multiples of 8;
+    // ids past the layer's last row block have nothing to do.)
+    int bx, t = 0;
+    if (per > 1) {
+        const int grp = local / (8 * per), rem = local - grp * 8 * per;
+        t = rem >> 3;
+        bx = grp * 8 + (rem & 7);
+    } else bx = local;
+    if (bx >= it.nsplit) return;
+    const int by = t / (int)it.gz, bz = t - by * (int)it.gz;
     WgradParams p;
     p.a.A = it.A; p.a.lda = it.lda; p.a.a_bstride = it.a_bstride; p.a.a_mode = 0;
     p.a.lazy.scale = it.sc; p.a.lazy.shift = it.sh; p.a.lazy.act = it.act; p.a.lazy.slope = it.slope;
@@ -2691,6 +2703,7 @@ __global__ __launch_bounds__(256) void swgrad_batch_kernel(const WgradBatch b) {
     p.N = it.N; p.dY = it.dY; p.lddy = it.lddy; p.dy_bstride = it.dy_bstride; p.rows_per_batch = it.rows_per_batch;
     p.dy_contig = it.dy_contig; p.slab = it.slab; p.rows_per_block = it.rows_per_block; p.has_bias = it.has_bias;
     const int bx = (int)blockIdx.x - it.first_block;
+    if (bx >= it.nsplit) return;
     switch (it.gy) {
         case 0: swgrad_body<1, 1>(p, bx, red); break;
         case 1: swgrad_body<1, 2>(p, bx, red); break;
@@ -2950,14 +2963,18 @@ extern "C" int rl_wgrad_batch(const rl_wgrad_desc* descs, int count, void* strea
             it.lda = p.a.lda; it.a_bstride = p.a.a_bstride; it.lddy = p.lddy; it.dy_bstride = p.dy_bstride;
             it.rows_per_block = p.rows_per_block; it.M = p.a.M;
             it.N = p.N; it.K = p.a.K; it.n = p.a.n; it.rows_per_batch = p.rows_per_batch; it.act = p.a.lazy.act; it.slope = p.a.lazy.slope;
-            it.first_block = (int)blocks;
+            it.nsplit = nsplit;
             if (streaming) {
                 const int kt = d->K <= 16 ? 0 : d->K <= 32 ? 1 : 2, nt = d->N <= 16 ? 0 : d->N <= 32 ? 1 : d->N <= 64 ? 2 : 3;
                 it.gy = (unsigned short)(4 * kt + nt); it.gz = 1;
+                it.first_block = (int)blocks;
                 blocks += nsplit;
             } else {
                 it.gy = (unsigned short)rl_cdiv(d->N, 128); it.gz = (unsigned short)rl_cdiv(d->K, 128);
-                blocks += (long)nsplit * it.gy * it.gz;
+                const int per = (int)it.gy * (int)it.gz;
+                if (per > 1) blocks = (blocks + 7) / 8 * 8;          // (see the kernel: tiles of a row block share an XCD)
+                it.first_block = (int)blocks;
+                blocks += per > 1 ? (long)((nsplit + 7) / 8 * 8) * per : (long)nsplit;
             }
             it.a_contig = (unsigned char)p.a.contig; it.dy_contig = (unsigned char)p.dy_contig; it.has_bias = (unsigned char)p.has_bias; it.pad = 0;
             RL_REQUIRE(blocks < (1l << 30), RL_ERR_ARGS, "rl_wgrad_batch: too many workgroups");

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 # diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
 _LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
-ABI_VERSION = 104      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
+ABI_VERSION = 105      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -213,9 +213,13 @@ _SIGNATURES = {
     "rl_bn_bwd_reduce": (_i, [C.POINTER(BnBwdDesc), _vp]),
     "rl_bn_bwd_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp]),
     "rl_bn_bwd_apply": (_i, [C.POINTER(BnBwdDesc), _vp]),
+    "rl_bn_bwd_fused_supported": (_i, [_l, _i, _l]),
+    "rl_bn_bwd_fused": (_i, [C.POINTER(BnBwdDesc), _l, _vp, _vp, _vp, _vp]),
     "rl_resid_bn_bwd_supported": (_i, [_l, _i]),
     "rl_resid_bn_bwd_reduce": (_i, [C.POINTER(ResidBnBwdDesc), _vp]),
     "rl_resid_bn_bwd_apply": (_i, [C.POINTER(ResidBnBwdDesc), _vp]),
+    "rl_resid_bn_bwd_fused_supported": (_i, [_l, _i]),
+    "rl_resid_bn_bwd_fused": (_i, [C.POINTER(ResidBnBwdDesc), _vp, _vp, _vp, _vp, _vp]),
     "rl_copy_rows": (_i, [C.POINTER(RowsDesc), _vp]),
     "rl_copy_rows_pair": (_i, [C.POINTER(RowsDesc), C.POINTER(RowsDesc), _vp]),
     "rl_scatter_add_rows": (_i, [C.POINTER(RowsDesc), _vp]),

@@ -117,6 +117,7 @@ TIMER: Optional[KernelTimer] = None
 LEVEL = -1      # encoder level the engine is working on (-1: outside the encoder) - a tag on the timer's records only
 # Weight gradients on a second stream beside the dY->dX chain: measured 11.2 -> 19-21 ms per step under
 # hipGraph replay (every fork/join becomes a cross-branch dependency in the graph), so OFF by default.
+NO_BN_SMALL = bool(int(__import__("os").environ.get("RL_NO_BN_SMALL", "0")))      # A/B: small tensors take the three-launch path too
 SIDE_STREAM_WGRAD = bool(int(__import__("os").environ.get("RL_SIDE_STREAM", "0")))
 NO_FUSED_POOL = bool(int(__import__("os").environ.get("RL_NO_FUSED_POOL", "0")))         # diagnostics only
 NO_DEFERRED_WGRAD = bool(int(__import__("os").environ.get("RL_NO_DEFERRED_WGRAD", "0")))  # diagnostics only
@@ -601,6 +602,12 @@ def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta:
                 training: bool, sync: Optional[SyncGroup] = None) -> None:
     """In place: G (gradient w.r.t. the activated value of `y`) becomes the gradient w.r.t. y.raw."""
     d = _bn_bwd_desc(G, y.bstride, y)
+    if (training and y.mean is not None and sync is None and not NO_BN_SMALL and G.data_ptr() % 16 == 0 and y.raw.data_ptr() % 16 == 0
+            and H.lib().rl_bn_bwd_fused_supported(y.rows, y.C, y.raw.shape[1])):
+        # a small tensor: reduce, finalize and apply in one launch (a workgroup owns a channel quad and all its rows)
+        with _rec("bn_bwd_fused", (y.rows, y.C), 12 * y.rows * y.C, 0):
+            H.check(H.lib().rl_bn_bwd_fused(C.byref(d), y.rows, H.ptr(dgamma), H.ptr(dbeta), None, _st()), "rl_bn_bwd_fused")
+        return
     if training and y.mean is not None:
         stats = new_stats(G.device, y.C)
         coef = torch.empty(2 * y.C, dtype=F32, device=G.device)
@@ -627,12 +634,17 @@ def resid_bn_backward(G: torch.Tensor, O: torch.Tensor, slope: float, y1: Lazy, 
     assert G.shape == O.shape == (rows, Cc)
     d = H.ResidBnBwdDesc()
     G2 = torch.empty_like(G)
-    st1, st2 = new_stats(G.device, Cc), new_stats(G.device, Cc)
-    c1 = torch.empty(2 * Cc, dtype=F32, device=G.device)
-    c2 = torch.empty(2 * Cc, dtype=F32, device=G.device)
     d.G, d.G2, d.O, d.slope, d.rows, d.C = G.data_ptr(), G2.data_ptr(), O.data_ptr(), slope, rows, Cc
     d.Y1, d.scale1, d.mean1, d.invstd1 = y1.raw.data_ptr(), y1.scale.data_ptr(), y1.mean.data_ptr(), y1.invstd.data_ptr()
     d.Y2, d.scale2, d.mean2, d.invstd2 = y2.raw.data_ptr(), y2.scale.data_ptr(), y2.mean.data_ptr(), y2.invstd.data_ptr()
+    if sync is None and not NO_BN_SMALL and H.lib().rl_resid_bn_bwd_fused_supported(rows, Cc):
+        with _rec("resid_bn_bwd_fused", (rows, Cc), 24 * rows * Cc, 0):
+            H.check(H.lib().rl_resid_bn_bwd_fused(C.byref(d), H.ptr(dgamma1), H.ptr(dbeta1), H.ptr(dgamma2), H.ptr(dbeta2), _st()),
+                    "rl_resid_bn_bwd_fused")
+        return G2
+    st1, st2 = new_stats(G.device, Cc), new_stats(G.device, Cc)
+    c1 = torch.empty(2 * Cc, dtype=F32, device=G.device)
+    c2 = torch.empty(2 * Cc, dtype=F32, device=G.device)
     d.stats1, d.stats2, d.coef1, d.coef2 = st1.data_ptr(), st2.data_ptr(), c1.data_ptr(), c2.data_ptr()
     with _rec("resid_bn_bwd_reduce", (rows, Cc), 16 * rows * Cc, 0):
         H.check(H.lib().rl_resid_bn_bwd_reduce(C.byref(d), _st()), "rl_resid_bn_bwd_reduce")

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 104     /* round 4: rl_launch_count; round-3 signature changes (rl_bn_finalize folded_bias, rl_dropout_* first_row, descriptor fields) */
+#define RL_VERSION 105     /* round 4: rl_launch_count; round-3 signature changes (rl_bn_finalize folded_bias, rl_dropout_* first_row, descriptor fields) */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -349,6 +349,13 @@ int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, fl
 int rl_bn_bwd_finalize_pair(const double* stats0, const double* stats1, int nslots, int64_t count, int C, float* dgamma0,
                             float* dbeta0, float* coef0, float* dgamma1, float* dbeta1, float* coef1, void* stream);
 int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream);
+/* The three steps in ONE launch for a small tensor (rows <= 2048, C % 4 == 0, ld % 4 == 0, 16-byte aligned; ask
+ * rl_bn_bwd_fused_supported): a workgroup owns a channel quad and all its rows, so the batch sums never leave it.  G becomes
+ * the gradient w.r.t. Y in place, dgamma / dbeta (and, when coef_out != NULL, the 2*C means rl_bn_bwd_finalize would
+ * leave) are written.  Same expressions per element; the sums are grouped per wavefront (another fixed order).
+ * Replaces the same reference lines as the three (BatchNorm2d backward of modules.py:85-89).                          */
+int rl_bn_bwd_fused_supported(int64_t rows, int C, int64_t ld);
+int rl_bn_bwd_fused(const rl_bn_bwd_desc* d, int64_t count, float* dgamma, float* dbeta, float* coef_out, void* stream);
 
 /* Backward of the residual junction of LocalFeatureAggregation (modules.py:325):
  *     O = LeakyReLU_slope( BN1(Y1) + BN2(Y2) ),   Y1 = mlp2 output, Y2 = shortcut output, no activation of their own.
@@ -374,6 +381,9 @@ typedef struct rl_resid_bn_bwd_desc {
 int rl_resid_bn_bwd_supported(int64_t rows, int C);
 int rl_resid_bn_bwd_reduce(const rl_resid_bn_bwd_desc* d, void* stream);
 int rl_resid_bn_bwd_apply(const rl_resid_bn_bwd_desc* d, void* stream);
+/* ... and the junction's two sweeps + rl_bn_bwd_finalize_pair as ONE launch for rows <= 2048 (stats / coef fields unused). */
+int rl_resid_bn_bwd_fused_supported(int64_t rows, int C);
+int rl_resid_bn_bwd_fused(const rl_resid_bn_bwd_desc* d, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row movement.  dst row r of `rows` rows (r = b*rows_per_batch + i) receives `C` channels:

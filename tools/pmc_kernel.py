@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE kernel shape of the training step a few times on random data so that
 `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) can read its HBM traffic.
-usage: python3 tools/pmc_kernel.py gemm|wgrad M K N [reps]"""
+usage: python3 tools/pmc_kernel.py gemm|wgrad|wgradb M K N [reps]      (wgradb: through the grouped launch, rl_wgrad_batch)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "3d_recognizer_amd"))
@@ -24,6 +24,11 @@ for _ in range(reps):
     big.fill_(1.0)
     if kind == "gemm":
         ops.gemm(a, W, 1, K, N, None, stats=stats if use_stats else None, wsplit=ws)
+    elif kind == "wgradb":
+        pend, batch = [], []
+        ops.wgrad(a, dY, M, N, dW, 1, K, None, pending=pend, batch=batch)
+        ops.wgrad_batch_flush(batch)
+        ops.wgrad_flush(pend)
     else:
         ops.wgrad(a, dY, M, N, dW, 1, K, None)
 torch.cuda.synchronize()
