@@ -2474,16 +2474,21 @@ __global__ __launch_bounds__(256, 2) void pwgrad128_kernel(const WgradParams p) 
 // wavefronts per SIMD, twice the loads in flight (pwgrad128_kernel<3>: 240 VGPRs, two per SIMD, 39 % of its wavefront
 // cycles parked on memory).  bf16 arithmetic modes only; same operands and MFMA sequence per accumulator -> same bits.
 // RB: A and dY are stored as bf16 rows (bf16-storage mode; then TERMS = 1 is exact - the tails would be zero)
+typedef __attribute__((ext_vector_type(4))) short s16x4g;
 template <int TERMS, bool RB = false>   // 3: bf16x3; 1: bf16
 __device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int bx, const int by, const int bz) {
-    constexpr int BS = 40;
+    // bf16 planes ROW-MAJOR: [32 rows][RP], RP = 128 + 16 (288 B: the four rows of a transposing read fall on disjoint bank
+    // groups).  A lane's four converted columns of a row leave as ONE ds_write_b64 per plane - 8 LDS writes per lane and chunk
+    // where the column-major image took 32 ds_write_b16 - and the MFMA fragments (8 consecutive ROWS of one column per lane)
+    // come back through ds_read_b64_tr_b16, four rows per read.
+    constexpr int RP = 144;
     constexpr int NSPL = TERMS == 3 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) __bf16 lds_d[PW2_T * BS * NSPL];
-    __shared__ __attribute__((aligned(16))) __bf16 lds_a[PW2_T * BS * NSPL];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_d[PW2_RB * RP * NSPL];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[PW2_RB * RP * NSPL];
     __bf16* Dh = lds_d;
-    __bf16* Dl = Dh + PW2_T * BS;
+    __bf16* Dl = Dh + PW2_RB * RP;
     __bf16* Xh = lds_a;
-    __bf16* Xl = Xh + PW2_T * BS;
+    __bf16* Xl = Xh + PW2_RB * RP;
     // the lazy BatchNorm scale / shift of this workgroup's 128 k-columns: 1 KB of LDS read in the staging step instead of
     // 16 registers per lane (the kernel sat 2 dwords over its 128-VGPR budget, i.e. in scratch)
     __shared__ __attribute__((aligned(16))) float lz[2][PW2_T];
@@ -2515,10 +2520,17 @@ __device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int 
         lz[1][tid] = in ? p.a.lazy.shift[k0 + tid] : 0.f;
     }
     // (the first barrier of the row loop makes lz visible before its first use in commit)
-    f32x4 acc[8];
+    // wavefront (nh, kw) owns n columns nh*64 .. +63 x k columns kw*32 .. +31 of the dW tile: 12 fragment reads per chunk (8 of dY,
+    // 4 of A) instead of the 18 of a 16 x 128 strip (2 + 16) - the LDS pipe is this kernel's bound (profiles/r04_pmc_sq_step.md:
+    // 5.8 % of the wavefront cycles x 16 wavefronts per CU; halving its L2 misses changed nothing)
+    const int nh = wave >> 2, kw = wave & 3;
+    f32x4 acc[4][2];
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) acc[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};          // (wavefronts kw == 0: the dY column sums of their four n blocks, replicated over lq)
+    const bool want_bias = p.has_bias && bz == 0 && kw == 0;
     float4 rd[2], ra[2];
 
     auto fetch = [&](long r0) {
@@ -2557,79 +2569,89 @@ __device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int 
             bf16x4 dh, dl, xh, xl;
             split_bf16(rd[i], dh, dl);
             split_bf16(v, xh, xl);
-            const int o = ucol[i] * BS + urow[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                Dh[o + j * BS] = dh[j];
-                Xh[o + j * BS] = xh[j];
-                if constexpr (TERMS == 3) {
-                    Dl[o + j * BS] = dl[j];
-                    Xl[o + j * BS] = xl[j];
-                }
+            const int o = urow[i] * RP + ucol[i];
+            *reinterpret_cast<bf16x4*>(Dh + o) = dh;
+            *reinterpret_cast<bf16x4*>(Xh + o) = xh;
+            if constexpr (TERMS == 3) {
+                *reinterpret_cast<bf16x4*>(Dl + o) = dl;
+                *reinterpret_cast<bf16x4*>(Xl + o) = xl;
             }
         }
     };
 
-    const __bf16* dh_frag = Dh + (wave * 16 + lr) * BS + lq * 8;
-    const __bf16* xh_frag = Xh + lr * BS + lq * 8;
-    constexpr int LO = PW2_T * BS;
+    // transposing read: lane 4q + p of a 16-lane group gives the address of row q, columns 4p .. 4p+3 of a 4-row x 16-column
+    // block and receives column (its index in the group) of the four rows
+    const int tr_off = (lq * 8 + (lr >> 2)) * RP + 4 * (lr & 3);
+    const __bf16* dh_frag = Dh + tr_off + nh * 64;
+    const __bf16* xh_frag = Xh + tr_off + kw * 32;
+    constexpr int LO = PW2_RB * RP;
+    auto frag = [&](const __bf16* q) {      // rows 8*lq .. 8*lq+7 of column (block start + lr)
+        const bf16x4 r0 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g*)q));
+        const bf16x4 r1 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g*)(q + 4 * RP)));
+        return __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     if (r_begin < r_end) fetch(r_begin);
     for (long r0 = r_begin; r0 < r_end; r0 += PW2_RB) {
         __syncthreads();
         commit(r0);
         __syncthreads();
         if (r0 + PW2_RB < r_end) fetch(r0 + PW2_RB);
-        if (p.has_bias && bz == 0 && tid < PW2_T) {
+        bf16x8 b_h[2], b_l[2];
 #pragma unroll
-            for (int j = 0; j < PW2_RB / 8; ++j) {
-                const bf16x8 h = *reinterpret_cast<const bf16x8*>(Dh + tid * BS + j * 8);
+        for (int kb = 0; kb < 2; ++kb) {
+            b_h[kb] = frag(xh_frag + kb * 16);
+            if constexpr (TERMS == 3) b_l[kb] = frag(xh_frag + LO + kb * 16);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            bf16x8 a_h, a_l;
+            a_h = frag(dh_frag + nb * 16);
+            if constexpr (TERMS == 3) a_l = frag(dh_frag + LO + nb * 16);
+            if (want_bias) {
+                // per 8-row group t = (the 8 heads in row order) + the 8 tails one by one; the groups are added in row order
                 float t = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t += (float)h[e];
+                for (int e = 0; e < 8; ++e) t += (float)a_h[e];
                 if constexpr (TERMS == 3) {
-                    const bf16x8 l = *reinterpret_cast<const bf16x8*>(Dl + tid * BS + j * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) t += (float)l[e];
+                    for (int e = 0; e < 8; ++e) t += (float)a_l[e];
                 }
-                bsum += t;
-            }
-        }
-        bf16x8 a_h, a_l;
-        a_h = *reinterpret_cast<const bf16x8*>(dh_frag);
-        if constexpr (TERMS == 3) a_l = *reinterpret_cast<const bf16x8*>(dh_frag + LO);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int kb0 = g * 2;
-            bf16x8 b_h[2], b_l[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                b_h[j] = *reinterpret_cast<const bf16x8*>(xh_frag + (kb0 + j) * 16 * BS);
-                if constexpr (TERMS == 3) b_l[j] = *reinterpret_cast<const bf16x8*>(xh_frag + LO + (kb0 + j) * 16 * BS);
+                for (int g = 0; g < PW2_RB / 8; ++g) bsum[nb] += __shfl(t, lr + 16 * g, 64);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[j], acc[kb0 + j], 0, 0, 0);
+            for (int kb = 0; kb < 2; ++kb)
+                acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[kb], acc[nb][kb], 0, 0, 0);
             if constexpr (TERMS == 3) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l[j], acc[kb0 + j], 0, 0, 0);
+                for (int kb = 0; kb < 2; ++kb)
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_l[kb], acc[nb][kb], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[kb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h[j], acc[kb0 + j], 0, 0, 0);
+                for (int kb = 0; kb < 2; ++kb)
+                    acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l, b_h[kb], acc[nb][kb], 0, 0, 0);
             }
         }
     }
     float* out = p.slab + (long)bx * ((long)N * K + N);
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-        const int k = k0 + kb * 16 + lr;
+    for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wave * 16 + lq * 4 + r;
-            if (n < N && k < K) out[(long)n * K + k] = acc[kb][r];
+        for (int kb = 0; kb < 2; ++kb) {
+            const int k = k0 + kw * 32 + kb * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + nh * 64 + nb * 16 + lq * 4 + r;
+                if (n < N && k < K) out[(long)n * K + k] = acc[nb][kb][r];
+            }
         }
     }
-    if (p.has_bias && bz == 0 && tid < nvalid) out[(long)N * K + n0 + tid] = bsum;
+    if (want_bias && lq == 0) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int n = nh * 64 + nb * 16 + lr;
+            if (n < nvalid) out[(long)N * K + n0 + n] = bsum[nb];
+        }
+    }
 }
 
 template <int TERMS, bool RB = false>
