@@ -2529,8 +2529,12 @@ __device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int 
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) acc[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};          // (wavefronts kw == 0: the dY column sums of their four n blocks, replicated over lq)
-    const bool want_bias = p.has_bias && bz == 0 && kw == 0;
+    // db = column sums of dY: every lane adds the fp32 values it stages (its four columns, its rows of every chunk) - 8 additions per
+    // chunk; the 16 lanes of a wavefront that share the columns are combined once, at the end.  (The sums used to be rebuilt from
+    // the bf16 heads and tails of the planes: 32 conversions + 36 additions + 16 cross-lane reads per chunk in two of the eight
+    // wavefronts - the two every barrier then waited for.  SQ counters: 188 vector instructions per wavefront and chunk.)
+    const bool want_bias = p.has_bias && bz == 0;
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
     float4 rd[2], ra[2];
 
     auto fetch = [&](long r0) {
@@ -2567,6 +2571,7 @@ __device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int 
                 v.w = actf(v.w * sc.w + sh.w);
             }
             bf16x4 dh, dl, xh, xl;
+            if (want_bias) bs += (f32x4){rd[i].x, rd[i].y, rd[i].z, rd[i].w};
             split_bf16(rd[i], dh, dl);
             split_bf16(v, xh, xl);
             const int o = urow[i] * RP + ucol[i];
@@ -2607,18 +2612,6 @@ __device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int 
             bf16x8 a_h, a_l;
             a_h = frag(dh_frag + nb * 16);
             if constexpr (TERMS == 3) a_l = frag(dh_frag + LO + nb * 16);
-            if (want_bias) {
-                // per 8-row group t = (the 8 heads in row order) + the 8 tails one by one; the groups are added in row order
-                float t = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) t += (float)a_h[e];
-                if constexpr (TERMS == 3) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t += (float)a_l[e];
-                }
-#pragma unroll
-                for (int g = 0; g < PW2_RB / 8; ++g) bsum[nb] += __shfl(t, lr + 16 * g, 64);
-            }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
                 acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h, b_h[kb], acc[nb][kb], 0, 0, 0);
@@ -2645,11 +2638,15 @@ __device__ __forceinline__ void pwgrad128w_body(const WgradParams& p, const int 
             }
         }
     }
-    if (want_bias && lq == 0) {
+    if (want_bias) {
+        // lanes l, l + 4, ... , l + 60 staged the same four columns (rows l >> 2 and 16 + (l >> 2) of every chunk)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int n = nh * 64 + nb * 16 + lr;
-            if (n < nvalid) out[(long)N * K + n0 + n] = bsum[nb];
+        for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bs[j] += __shfl_xor(bs[j], o, 64);
+        if (lane < 4 && ucol[0] < nvalid) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(long)N * K + n0 + ucol[0] + j] = bs[j];
         }
     }
 }
