@@ -770,7 +770,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
         idx_cur = idx_nxt; idx_nxt = idx_n2;
         // X leaves the kernel for the weight-gradient GEMM: row li, 16 bytes per 16-column chunk
 #pragma unroll
-        for (int c = 0; c < DT; ++c) rl_stx4_nt<GB>(p.X_out, (pt * 16 + li) * D + 16 * c + 4 * lj, xa[c]);      // (read again by the weight gradient at the end of the step: past the L2)
+        for (int c = 0; c < DT; ++c) rl_stx4<GB>(p.X_out, (pt * 16 + li) * D + 16 * c + 4 * lj, xa[c]);      // (non-temporal stores here: measured, rejected - DESIGN.md section 5)
         f32x4 a[DT];
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) a[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
 #pragma unroll
         for (int c = 0; c < DT; ++c) {
             const float4 da = *reinterpret_cast<const float4*>(Ds + li * XS + 16 * c + 4 * lj);
-            rl_stx4_nt<GB>(p.dS_out, (pt * 16 + li) * D + 16 * c + 4 * lj, da);
+            rl_stx4<GB>(p.dS_out, (pt * 16 + li) * D + 16 * c + 4 * lj, da);
             bf16x4 ah, al;
             split4(da, ah, al);
             // B fragment of column block nb: W[o = 16c + 4lj + j][nb*16 + li], j = 0..3 - four rows of one column.
