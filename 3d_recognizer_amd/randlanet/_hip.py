@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 # diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
 _LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
-ABI_VERSION = 105      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
+ABI_VERSION = 106      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -245,6 +245,7 @@ _SIGNATURES = {
     "rl_rpe_build": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_rpe_build_dist": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_batch_assemble": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rl_batch_draw": (_i, [_vp, _i, _i, C.c_uint64, _vp, _vp, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
     "rl_dropout_tick": (_i, [_vp, _vp, _vp]),
     "rl_dropout_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _l, _l, _i, _vp, C.c_uint64, _f, _vp]),

@@ -47,8 +47,10 @@ class DeviceDataLoader:
         self._consistent = bool(consistent_sampling)
         self._aug = augmentation_settings
         self._norm = _NORMALIZATION.get(normalization, 4)        # any other string: centre only (dataset.py:92)
-        self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)) if rng == "device" else 0)
+        # device mode: ONE launch (rl_batch_draw) draws a batch's sample indices and jitter noise, a counter-based generator
+        # keyed by (seed of this loader, batch number)
+        self._seed = int(np.random.randint(0, 2 ** 31 - 1)) if rng == "device" else 0
+        self._draws = 0
         self._consistent_idx = {}
         self._ring = None            # pinned host staging (see _staging)
         # the whole dataset moves to HBM once
@@ -100,10 +102,7 @@ class DeviceDataLoader:
                 host_row.numpy()[:] = idx
                 return None
             return torch.from_numpy(idx.astype(np.int64)).to(self.device)
-        idx = torch.randperm(n_src, device=self.device, generator=self._gen)[:min(n, n_src)]
-        if n > n_src:
-            idx = torch.cat([idx, torch.randint(0, n_src, (n - n_src,), device=self.device, generator=self._gen)])
-        return idx
+        return None        # device mode: rl_batch_draw fills the batch's rows (see _assemble)
 
     def _job(self, cloud: int, job: H.CloudJob, host_noise: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """Fill the job record of one cloud; returns its jitter noise (n,3) float64 on the device, or None (no augmentation,
@@ -126,7 +125,7 @@ class DeviceDataLoader:
             else:
                 noise = torch.from_numpy(draw).to(self.device)
         else:
-            noise = torch.randn((self._n, 3), dtype=torch.float64, device=self.device, generator=self._gen)
+            noise = None           # device mode: rl_batch_draw
         job.scale = np.random.uniform(1 - a.scale_limit, 1 + a.scale_limit)
         assert len(a.rotation_angle_variances) == 3, "angle_sigmas should have length 3"
         assert len(a.rotation_angle_limits) == 3, "angle_clips should have length 3"
@@ -187,6 +186,13 @@ class DeviceDataLoader:
         jobs_dev.copy_(st["jobs"][:nbytes], non_blocking=True)
         st["event"] = torch.cuda.Event()
         st["event"].record(torch.cuda.current_stream(dev))
+        if self.rng == "device":
+            want_idx = not self._consistent
+            if want_idx or noise is not None:
+                self._draws += 1
+                H.check(H.lib().rl_batch_draw(jobs_dev.data_ptr(), B, n, (self._seed << 32) | (self._draws & 0xFFFFFFFF),
+                                              indices.data_ptr() if want_idx else None, H.ptr(noise),
+                                              torch.cuda.current_stream(dev).cuda_stream), "rl_batch_draw")
         scratch = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
         inp = torch.empty((B, n, 3 + F), dtype=torch.float32, device=dev)
         lab = torch.empty((B, n), dtype=torch.int64, device=dev)

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 105     /* round 4: rl_launch_count; round-3 signature changes (rl_bn_finalize folded_bias, rl_dropout_* first_row, descriptor fields) */
+#define RL_VERSION 106     /* round 4: rl_launch_count; round-3 signature changes (rl_bn_finalize folded_bias, rl_dropout_* first_row, descriptor fields) */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -628,6 +628,12 @@ typedef struct rl_cloud_job {
 int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int F, const int64_t* indices,
                       const double* noise, double* scratch, float* out_input, int64_t* out_labels,
                       void* stream);
+/* The random draws rl_batch_assemble consumes, made on the device in ONE launch (the device loader's fast mode; the
+ * reference draws them from numpy's global stream - preprocessing.py:35-62 np.random.choice, augmentation.py:147 np.random.randn -
+ * which is the loader's "numpy" mode): indices (B,n) = n rows of each cloud without replacement (a keyed permutation of
+ * [0, n_points), no sort; with replacement past n_points), noise (B,n,3) = standard-normal float64; either may be NULL.  Pure
+ * functions of (seed, cloud, position). */
+int rl_batch_draw(const rl_cloud_job* jobs_dev, int B, int n, uint64_t seed, int64_t* indices, double* noise, void* stream);
 
 /* Dropout (fc_end, modules.py:528) with a keep-mask drawn by the caller (uint8, 1 = keep):
  * x[i] = mask[i] ? x[i]*scale : 0, in place; the same call is its own backward.             */

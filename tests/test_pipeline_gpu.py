@@ -140,6 +140,49 @@ def test_device_rng_mode_is_deterministic_and_well_formed():
     assert len(np.unique(lab[0].cpu().numpy())) == 3000
 
 
+def test_batch_draw_statistics():
+    """rl_batch_draw (the device-rng loader's one launch): without replacement, every row equally likely at every position,
+    standard-normal noise, a pure function of (seed, cloud, position)."""
+    import ctypes as C
+    from randlanet import _hip as H
+    B, n, n_src = 3, 5000, 6007
+    jobs = (H.CloudJob * B)()
+    for b in range(B):
+        jobs[b].n_points = n_src - b          # clouds of different sizes
+    jd = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).cuda()
+    idx = torch.empty((B, n), dtype=torch.int64, device="cuda")
+    nz = torch.empty((B, n, 3), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    incl = np.zeros(n_src)
+    first = []
+    for seed in range(200):
+        H.check(H.lib().rl_batch_draw(jd.data_ptr(), B, n, seed, idx.data_ptr(), nz.data_ptr(), st), "rl_batch_draw")
+        i = idx.cpu().numpy()
+        for b in range(B):
+            assert i[b].min() >= 0 and i[b].max() < n_src - b and len(np.unique(i[b])) == n
+        incl[i[0]] += 1
+        first.append(int(i[0, 0]))
+        if seed == 0:
+            i0, z0 = i.copy(), nz.cpu().numpy().copy()
+            assert not np.array_equal(i[0, :100], i[1, :100])           # clouds of one batch draw differently
+    # inclusion frequency of a row of cloud 0: n / n_src, binomial scatter
+    p = n / n_src
+    z = (incl - 200 * p) / np.sqrt(200 * p * (1 - p))
+    assert abs(z.mean()) < 0.1 and 0.8 < z.std() < 1.2 and np.abs(z).max() < 5.5
+    assert len(set(first)) > 190                                        # the first position is not stuck
+    H.check(H.lib().rl_batch_draw(jd.data_ptr(), B, n, 0, idx.data_ptr(), nz.data_ptr(), st), "rl_batch_draw")
+    assert np.array_equal(idx.cpu().numpy(), i0) and np.array_equal(nz.cpu().numpy(), z0)      # same seed, same draws
+    v = z0.reshape(-1)
+    assert abs(v.mean()) < 0.02 and abs(v.var() - 1) < 0.03 and abs((v ** 4).mean() - 3) < 0.15 and np.abs(v).max() < 6.5
+    assert abs(np.corrcoef(z0[0, :, 0], z0[0, :, 1])[0, 1]) < 0.05 and abs(np.corrcoef(z0[0, :-1, 2], z0[0, 1:, 2])[0, 1]) < 0.05
+    # more rows wanted than the cloud has: every row once, then draws with replacement
+    jobs[0].n_points = 1000
+    jd = torch.from_numpy(np.frombuffer(bytes(jobs), dtype=np.uint8).copy()).cuda()
+    H.check(H.lib().rl_batch_draw(jd.data_ptr(), 1, n, 7, idx.data_ptr(), None, st), "rl_batch_draw")
+    i = idx[0].cpu().numpy()
+    assert len(np.unique(i[:1000])) == 1000 and i.max() < 1000 and len(np.unique(i[1000:])) > 900
+
+
 def test_bad_arguments_fail_loudly():
     from randlanet import _hip as H
     from randlanet.utils.device_dataset import DeviceDataLoader
