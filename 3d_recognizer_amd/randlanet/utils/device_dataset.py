@@ -10,9 +10,11 @@ rng="numpy" (default): every random number is drawn on the host from numpy's and
     the reference's order (the sampler's permutation like torch's RandomSampler, then per item: sample indices,
     jitter noise, scale, three angles, three shifts), so that a run seeded like a reference run sees the same
     batches (to float32 rounding) and leaves both generators where the reference leaves them.
-rng="device": sample indices and jitter noise come from a torch generator on the GPU (the host cost of numpy's
-    permutation + 3n normal draws, ~3.5 ms per 40960-point cloud, caps the numpy mode near 300 clouds/s); the
-    seven per-cloud scalars still come from numpy.  Same distribution, different stream.
+rng="device": sample indices and jitter noise of a whole batch are drawn on the GPU by ONE launch (rl_batch_draw: a keyed
+    permutation for the sample without replacement, Philox normals; a pure function of this loader's seed, the batch
+    number, the cloud and the position) - the host cost of numpy's permutation + 3n normal draws, ~1.7 ms per
+    40960-point cloud, caps the numpy mode near 580 clouds/s where this one feeds 870 (bench.py trainer_e2e); the seven
+    per-cloud scalars still come from numpy.  Same distributions, different stream.
 """
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
