@@ -359,7 +359,13 @@ extern "C" int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int
     RL_REQUIRE(jobs_dev && indices && scratch && out_input && out_labels, RL_ERR_ARGS, "rl_batch_assemble: null pointer");
     RL_REQUIRE(B > 0 && n > 0 && F >= 0, RL_ERR_ARGS, "rl_batch_assemble: bad sizes (B %d, n %d, F %d)", B, n, F);
     // workgroups per cloud: up to 16, all gw * B of a launch resident at once (one of 1024 lanes per CU: 256 on an MI355X)
-    int gw = 256 / B;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 64;
+    }
+    int gw = cus / B;
     gw = gw > 16 ? 16 : (gw < 1 ? 1 : gw);
     while (gw > 1 && (long)(gw - 1) * 1024 >= n) --gw;        // (no workgroup without points)
     if (getenv("RL_ASSEMBLE_ONE_WG")) gw = 1;
