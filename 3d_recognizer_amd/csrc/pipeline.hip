@@ -78,22 +78,29 @@ __device__ __forceinline__ void cloud_reduce(double (&v)[NV], CloudSync& cs, dou
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = MAX ? wg_max(v[k], red) : wg_sum(v[k], red);
     if (cs.gw == 1) return;
-    // (the records of the previous reduction have been read by everyone: a barrier separates two reductions - the one below)
+    // ONE barrier per reduction: the records alternate between two sets, and set s is written again two reductions later - behind
+    // the next reduction's barrier, which nobody passes before everybody has read this one's records
+    double* part = cs.part + (cs.passed & 1u) * 64;
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) cs.part[cs.w * 4 + k] = v[k];
+        for (int k = 0; k < NV; ++k) part[cs.w * 4 + k] = v[k];
     }
     cloud_barrier(cs);
+    // (plain loads, all in flight at once: the barrier's acquire fence has emptied this CU's vector cache; an agent-scope atomic load
+    // per record would be gw dependent round trips)
+    double rec[16][NV];
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) rec[w][k] = w < cs.gw ? part[w * 4 + k] : 0.0;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        double s = __hip_atomic_load(cs.part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int w = 1; w < cs.gw; ++w) {
-            const double t = __hip_atomic_load(cs.part + w * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s = MAX ? fmax(s, t) : s + t;
-        }
+        double s = rec[0][k];
+#pragma unroll
+        for (int w = 1; w < 16; ++w)
+            if (w < cs.gw) s = MAX ? fmax(s, rec[w][k]) : s + rec[w][k];
         v[k] = s;
     }
-    cloud_barrier(cs);              // nobody overwrites the records before everybody has read them
 }
 
 // this workgroup's points: [i0, i1)
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(1024) void batch_assemble_kernel(const rl_cloud_job
     const int b = blockIdx.y, gw = gridDim.x;
     CloudSync cs;
     cs.gw = gw; cs.w = blockIdx.x; cs.passed = 0u;
-    cs.part = sync_part + (long)b * gw * 4;
+    cs.part = sync_part + (long)b * 128;          // two sets of 16 records of 4 doubles
     cs.arrive = sync_count + 2 * b;
     const rl_cloud_job job = jobs[b];
     const int64_t* idx = indices + (long)b * n;
@@ -332,7 +339,7 @@ extern "C" int rl_batch_draw(const rl_cloud_job* jobs_dev, int B, int n, uint64_
     return RL_OK;
 }
 
-// scratch for the cloud-wide sums of rl_batch_assemble: per cloud 64 records of 4 doubles and two counters (zero at first use,
+// scratch for the cloud-wide sums of rl_batch_assemble: per cloud two sets of 16 records of 4 doubles and two counters (zero at first use,
 // zero again after every launch); owned by the library, one per device
 static int assemble_sync(int B, double** part, unsigned** count) {
     static double* s_part[16] = {nullptr};
@@ -343,7 +350,7 @@ static int assemble_sync(int B, double** part, unsigned** count) {
     if (s_cap[dev] < B) {
         // (the old buffers are not freed: a launch that still uses them may be in flight; a few KB, a handful of times)
         const int cap = B < 64 ? 64 : B;
-        if (hipMalloc((void**)&s_part[dev], (size_t)cap * 64 * 4 * sizeof(double)) != hipSuccess) return RL_ERR_LAUNCH;
+        if (hipMalloc((void**)&s_part[dev], (size_t)cap * 128 * sizeof(double)) != hipSuccess) return RL_ERR_LAUNCH;
         if (hipMalloc((void**)&s_count[dev], (size_t)cap * 2 * sizeof(unsigned)) != hipSuccess) return RL_ERR_LAUNCH;
         if (hipMemset(s_count[dev], 0, (size_t)cap * 2 * sizeof(unsigned)) != hipSuccess) return RL_ERR_LAUNCH;
         s_cap[dev] = cap;
