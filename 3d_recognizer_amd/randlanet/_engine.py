@@ -322,6 +322,7 @@ class Engine:
             ops.copy_rows_pair(((x.raw, (0, x.C), x.bstride, cat, (0, x.C), B * n_f, n_f), dict(index=nn, lazy=x)),
                                ((skip.raw, (0, skip.C), skip.bstride, cat, (x.C, skip.C), B * n_f, n_f), {}))
             catl = ops.plain(cat, B, n_f)
+            catl.concat = (x, skip)            # (backward: its gradient may leave the dgrad GEMM in two pieces, see _bwd_linear)
             ctx.tape.append(("interp_concat", x, skip, csrs[L + j], catl))
             n_out = 8 if j == L - 1 else 2 * self.layers[L - 2 - j]
             x = self._mlp(ctx, catl, f"decoder.{j}", n_out, H.ACT_RELU, transposed=True)
@@ -427,9 +428,10 @@ class Engine:
                 gp = self._gbuf(ctx, prev)
                 ops.segment_sum_rows(G, (0, prev.C), catl.n, csr, gp[0], prev.bstride, accumulate=gp[1])
                 gp[1] = True
-                gs = self._gbuf(ctx, skip)
-                ops.copy_rows(G, (prev.C, skip.C), catl.n, gs[0], (0, skip.C), catl.rows, catl.n, accumulate=gs[1])
-                gs[1] = True
+                if init != "split":              # (else: the skip half went to its gradient directly, _bwd_linear)
+                    gs = self._gbuf(ctx, skip)
+                    ops.copy_rows(G, (prev.C, skip.C), catl.n, gs[0], (0, skip.C), catl.rows, catl.n, accumulate=gs[1])
+                    gs[1] = True
             elif kind == "dropout_philox":
                 _, src, dropped, key, p_drop, seed, first_row = rec
                 G, init = self._gbuf(ctx, dropped)
@@ -474,6 +476,22 @@ class Engine:
         n_out = out.C
         self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,
                                             grads[bname] if bname else None, pending=ctx.pending, batch=ctx.wbatch), G)
+        halves = getattr(a, "concat", None) if (a_grad and isinstance(a, Lazy)) else None
+        if (halves is not None and not ops.NO_SPLIT_SCATTER and (n_out > 64 or a.C > 64) and id(a.raw) not in ctx.grads
+                and halves[1].bstride == halves[1].n and halves[1].raw.shape[0] == a.rows and not self._gbuf(ctx, halves[1])[1]):
+            # the decoder's concat [interpolated | skip] (modules.py:362): its gradient leaves the dgrad GEMM in two pieces - the
+            # interpolated half to a dense tensor (summed per coarse point by the record behind this one), the skip half
+            # straight into the skip tensor's gradient, whose FIRST writer this is (the encoder's own contributions follow) -
+            # instead of one (rows, C1 + C2) tensor and a strided copy of its right half
+            prev, skip = halves
+            gs = self._gbuf(ctx, skip)
+            Gp = torch.empty((a.rows, prev.C), dtype=torch.float32, device=G.device)
+            gl = Lazy(G, out.B, out.n, out.bstride, n_out)
+            ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=Gp, out_bstride=a.bstride, out2=gs[0], split_col=prev.C,
+                     wsplit=getattr(ctx, "wsplit", None))
+            gs[1] = True
+            ctx.grads[id(a.raw)] = [Gp, "split"]
+            return
         if a_grad and isinstance(a, Lazy):
             ga = self._gbuf(ctx, a)
             if not ga[1]:
