@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 // Several independent layers' folds in ONE launch (blockIdx.y = layer, blockIdx.x = channel): a fold is a 5 us launch that
 // does 0.5 us of work, and the folds of layers at one dependency depth (mlp1 / shortcut / mlp_rpe1 of an encoder level,
 // pool1.mlp / mlp_rpe2) are all wanted at the same moment.
-constexpr int BNF_MAX = 8;
+constexpr int BNF_MAX = 24;      // (24 x 120 B of kernel arguments; an eval forward folds its ~45 layers in two launches)
 struct BnFoldBatch {
     rl_bn_finalize_item it[BNF_MAX];
 };
