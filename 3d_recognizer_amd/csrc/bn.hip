@@ -58,23 +58,27 @@ __device__ __forceinline__ void bn_finalize_body(
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-    const float* __restrict__ folded_bias, const int c, double (*red)[2]) {
-    double mean, var;
-    if (training) {
-        double s, q;
-        slot_sums_wg(stats, nslots, C, c, red, s, q);
-        mean = s / count;
-        var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-    } else {
-        mean = (double)rmean[c];
-        var = (double)rvar[c];
-    }
-    // folded_bias: the producer left the layer's bias OUT of the tensor (it cancels in y - mean): the statistics above are
+    const float* __restrict__ folded_bias, const int pivoted, const int c, double (*red)[2]) {
+    double s = 0.0, q = 0.0;
+    if (training) slot_sums_wg(stats, nslots, C, c, red, s, q);
+    if (threadIdx.x != 0) return;         // (only this lane reads the running mean below - and rewrites it at the end)
+    // folded_bias: the producer left the layer's bias OUT of the tensor (it cancels in y - mean): the statistics are
     // those of y - bias, and so is the tensor the (scale, shift) pair will be applied to; only the RUNNING mean is that of y
     const float fb = folded_bias ? folded_bias[c] : 0.f;
-    if (!training) mean -= (double)fb;
-    if (threadIdx.x != 0) return;
+    double mean, var;
+    if (training) {
+        // pivoted: the sums are those of (t - pivot), (t - pivot)^2 around pivot = running mean - folded bias (the producer
+        // subtracted the same fp32 value per element before squaring): a channel whose spread is tiny against its mean keeps
+        // its variance, which E[t^2] - E[t]^2 on fp32 partial sums loses (the reference's ATen BatchNorm is two-pass)
+        const double pivot = pivoted ? (double)(rmean[c] - fb) : 0.0;
+        const double ms = s / count;
+        mean = pivot + ms;
+        var = q / count - ms * ms;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = (double)rmean[c] - (double)fb;
+        var = (double)rvar[c];
+    }
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = g * invstd;
@@ -94,10 +98,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-    const float* __restrict__ folded_bias) {
+    const float* __restrict__ folded_bias, int pivoted) {
     __shared__ double red[4][2];
     bn_finalize_body(stats, nslots, count, C, gamma, beta, rmean, rvar, nbt, momentum, eps, training, scale, shift, save_mean,
-                     save_invstd, folded_bias, (int)blockIdx.x, red);
+                     save_invstd, folded_bias, pivoted, (int)blockIdx.x, red);
 }
 // Several independent layers' folds in ONE launch (blockIdx.y = layer, blockIdx.x = channel): a fold is a 5 us launch that
 // does 0.5 us of work, and the folds of layers at one dependency depth (mlp1 / shortcut / mlp_rpe1 of an encoder level,
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void bn_finalize_batch_kernel(const BnFoldBatc
     const rl_bn_finalize_item& t = b.it[blockIdx.y];
     if ((int)blockIdx.x >= t.C) return;
     bn_finalize_body(t.stats, t.nslots, (double)t.count, t.C, t.gamma, t.beta, t.running_mean, t.running_var, t.num_batches_tracked,
-                     t.momentum, t.eps, t.training, t.scale, t.shift, t.save_mean, t.save_invstd, t.folded_bias, (int)blockIdx.x, red);
+                     t.momentum, t.eps, t.training, t.scale, t.shift, t.save_mean, t.save_invstd, t.folded_bias, t.pivoted, (int)blockIdx.x, red);
 }
 
 // (nslots, 2, C) partials -> (2, C) totals, one wavefront per channel, fixed order: the piece a data-parallel caller
@@ -678,13 +682,14 @@ int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
 extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                               float momentum, float eps, int training, float* scale, float* shift,
-                              float* save_mean, float* save_invstd, const float* folded_bias, void* stream) {
+                              float* save_mean, float* save_invstd, const float* folded_bias, int pivoted, void* stream) {
     RL_REQUIRE(C > 0 && scale && shift, RL_ERR_ARGS, "rl_bn_finalize: bad arguments");
+    RL_REQUIRE(!pivoted || (training && running_mean), RL_ERR_ARGS, "rl_bn_finalize: pivoted statistics need training mode and the running mean");
     if (training) RL_REQUIRE(stats && nslots > 0 && count > 0, RL_ERR_ARGS, "rl_bn_finalize: training needs partial statistics");
     else RL_REQUIRE(running_mean && running_var, RL_ERR_ARGS, "rl_bn_finalize: eval needs running statistics");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslots,
                        (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, training,
-                       scale, shift, save_mean, save_invstd, folded_bias);
+                       scale, shift, save_mean, save_invstd, folded_bias, pivoted);
     RL_LAUNCH_CHECK("rl_bn_finalize");
     return RL_OK;
 }
@@ -700,6 +705,7 @@ extern "C" int rl_bn_finalize_batch(const rl_bn_finalize_item* items, int count,
             RL_REQUIRE(t.C > 0 && t.scale && t.shift, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: bad arguments", base + i);
             if (t.training) RL_REQUIRE(t.stats && t.nslots > 0 && t.count > 0, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: training needs partial statistics", base + i);
             else RL_REQUIRE(t.running_mean && t.running_var, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: eval needs running statistics", base + i);
+            RL_REQUIRE(!t.pivoted || (t.training && t.running_mean), RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: pivoted statistics need training mode and the running mean", base + i);
             b.it[i] = t;
             maxc = t.C > maxc ? t.C : maxc;
         }

@@ -126,6 +126,11 @@ struct GemmParams {
     int y_contig;
     int accumulate;
     double* stats;
+    // shifted statistics (round 5): the sums are those of (y - pivot) and (y - pivot)^2, pivot[c] = piv_mean[c] - piv_bias[c]
+    // (the layer's running mean, minus the conv bias this GEMM leaves out): a channel whose spread is small against its mean
+    // keeps its variance in fp32 partial sums.  NULL = pivot 0.  rl_bn_finalize(pivoted) adds the pivot back.
+    const float* piv_mean;
+    const float* piv_bias;
     int ksplit;        // > 1: blockIdx.z owns a K range and writes raw partial tiles to kslab
     int kchunk;        // K range per split (multiple of 32)
     float* kslab;      // [ksplit][M][N]
@@ -138,6 +143,11 @@ struct GemmParams {
     int split_col;
     const __bf16* wsplit;      // wgemm: head plane [N][K] (k contiguous), tail plane follows at + N*K
 };
+
+__device__ __forceinline__ float stat_pivot(const GemmParams& p, int c) {
+    if (!p.stats || !p.piv_mean || c >= p.N) return 0.f;
+    return p.piv_mean[c] - (p.piv_bias ? p.piv_bias[c] : 0.f);
+}
 
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
@@ -154,9 +164,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const long M = p.a.M;
     const long ntiles = (M + GM_BM - 1) / GM_BM;
 
-    float ssum[NT], ssq[NT];
+    float ssum[NT], ssq[NT], piv[NT];
 #pragma unroll
-    for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
+    for (int nb = 0; nb < NT; ++nb) {
+        ssum[nb] = ssq[nb] = 0.f;
+        piv[nb] = stat_pivot(p, col0 + nb * 16 + lr);
+    }
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row0 = tile * GM_BM;
@@ -216,8 +229,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                             if (p.bias) v += p.bias[c];
                             if (p.accumulate) v += p.Y[yoff + c];
                             p.Y[yoff + c] = v;
-                            ssum[nb] += v;
-                            ssq[nb] += v * v;
+                            const float dv = v - piv[nb];
+                            ssum[nb] += dv;
+                            ssq[nb] += dv * dv;
                         }
                     }
                 }
@@ -501,12 +515,13 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
     // the statistics changed with it, and two tests that sit on nearly degenerate BatchNorm channels - the 1029-point ragged
     // configuration, the two-rank equivalence step - moved from 1e-4 to 0.5 - 3 % gradient differences: mean / variance come out of
     // sum and sum of squares by subtraction.  Reverted: nothing was gained.)
-    float bias[NT], ssum[NT], ssq[NT];
+    float bias[NT], ssum[NT], ssq[NT], piv[NT];
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) {
         const int n = nb * 16 + li;
         bias[nb] = (p.bias && n < N) ? p.bias[n] : 0.f;
         ssum[nb] = ssq[nb] = 0.f;
+        piv[nb] = stat_pivot(p, n);
     }
     const bool lazy = p.a.lazy.scale != nullptr;
     const float es = (!lazy || p.a.lazy.act == RL_ACT_NONE) ? 1.f : (p.a.lazy.act == RL_ACT_RELU ? 0.f : p.a.lazy.slope);
@@ -582,8 +597,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
                 for (int nb = 0; nb < NT; ++nb) {
                     if (full || nb * 16 + li < N) {
                         y[nb * 16] = v[nb];
-                        ssum[nb] += v[nb];
-                        ssq[nb] += v[nb] * v[nb];
+                        const float dv = v[nb] - piv[nb];
+                        ssum[nb] += dv;
+                        ssq[nb] += dv * dv;
                     }
                 }
             }
@@ -864,6 +880,11 @@ __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f3
             const int c = col0 + nb * 16 + lr;
             bv[nb] = (has_bias && c < N) ? p.bias[c] : 0.f;
         }
+        float pv[STATS ? NT : 1];             // shifted statistics: sums of (y - pivot), see GemmParams
+        if constexpr (STATS) {
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) pv[nb] = stat_pivot(p, col0 + nb * 16 + lr);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long R = Rb + lq * 4 + r;
@@ -908,8 +929,9 @@ __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f3
                     for (int nb = 0; nb < NT; ++nb) {
                         y[nb * 16] = v[nb];
                         if constexpr (STATS) {
-                            ssum[nb] += v[nb];
-                            ssq[nb] += v[nb] * v[nb];
+                            const float dv = v[nb] - pv[nb];
+                            ssum[nb] += dv;
+                            ssq[nb] += dv * dv;
                         }
                     }
                 } else {
@@ -918,8 +940,9 @@ __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f3
                         if (col0 + nb * 16 + lr < N) {
                             y[nb * 16] = v[nb];
                             if constexpr (STATS) {
-                                ssum[nb] += v[nb];
-                                ssq[nb] += v[nb] * v[nb];
+                                const float dv = v[nb] - pv[nb];
+                                ssum[nb] += dv;
+                                ssq[nb] += dv * dv;
                             }
                         }
                     }
@@ -963,8 +986,9 @@ __device__ __forceinline__ void tile_rows_epilogue(const GemmParams& p, const f3
                         if (p.accumulate) v += p.Y[yoff + c];
                         p.Y[yoff + c] = v;
                         if constexpr (STATS) {
-                            ssum[nb] += v;
-                            ssq[nb] += v * v;
+                            const float dv = v - stat_pivot(p, c);
+                            ssum[nb] += dv;
+                            ssq[nb] += dv * dv;
                         }
                     }
                 }
@@ -1945,6 +1969,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && cvalid) bias = make_float4(p.bias[c], p.bias[c + 1], p.bias[c + 2], p.bias[c + 3]);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 piv = make_float4(0.f, 0.f, 0.f, 0.f);        // shifted statistics, see GemmParams
+    if (cvalid) piv = make_float4(stat_pivot(p, c), stat_pivot(p, c + 1), stat_pivot(p, c + 2), stat_pivot(p, c + 3));
     if (cvalid) {
         for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const long rend = min(M, (tile + 1) * GM_BM);
@@ -1964,6 +1990,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
                 float* y = p.Y + yoff + c;
                 if (p.accumulate) { v.x += y[0]; v.y += y[1]; v.z += y[2]; v.w += y[3]; }
                 y[0] = v.x; y[1] = v.y; y[2] = v.z; y[3] = v.w;
+                v.x -= piv.x; v.y -= piv.y; v.z -= piv.z; v.w -= piv.w;
                 acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
                 acc[4] += v.x * v.x; acc[5] += v.y * v.y; acc[6] += v.z * v.z; acc[7] += v.w * v.w;
             }
@@ -2752,6 +2779,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     RL_REQUIRE(d->y_bstride >= p.rows_per_batch, RL_ERR_ARGS, "rl_gemm: y_bstride smaller than rows per cloud");
     p.y_contig = (d->y_bstride == p.rows_per_batch);
     p.accumulate = d->accumulate; p.stats = d->stats;
+    p.piv_mean = d->stats ? d->stats_pivot_mean : nullptr; p.piv_bias = d->stats ? d->stats_pivot_bias : nullptr;
     p.addend = d->addend; p.out2 = d->out2; p.out2_index = d->out2_index; p.out2_bstride = d->out2_bstride;
     RL_REQUIRE(!d->out2_index || rl_float_atomics_allowed(), RL_ERR_UNSUPPORTED,
                "rl_gemm: out2_index scatters with fp32 atomics (order-dependent); the deterministic path is a dense out2 + "

@@ -139,6 +139,7 @@ struct PoolParams {
     const float* W1; const float* b1; const float* sc1; const float* sh1;   // mlp_rpe1 (h x 10) + folded BatchNorm
     const float* W2; const float* b2; const float* sc2; const float* sh2;   // mlp_rpe2 (h x h)
     const float* mu1; const float* is1; const float* mu2; const float* is2; // saved mean / invstd (backward kernels)
+    const float* piv1; const float* piv2;      // shifted statistics: running mean of stage 1 / 2 (forward statistics only), or null
     double* fstats2;       // pool_fwd with virtual stage 1: [grid][2][H] partial (sum, sum of squares) of the RAW stage-2 output
     double* bstats;        // pool_bwd with a virtual stage: [grid][2][H] partial sums of g and g*xhat of that stage's BatchNorm
 };
@@ -1130,7 +1131,7 @@ struct VLane {
     f32x4 reg[INLDS ? 1 : VX<DT>::NCONST][NCH];
     const float* lds;                // + 4*lj
     // `cl`: NCONST * HP floats of LDS (INLDS only); the caller's barrier after this publishes them.  `stage`: the stage whose
-    // mean' / invstd are wanted (backward kernels; 0: none)
+    // mean' / invstd are wanted (backward kernels; 0: none; -1 / -2: the MU slot carries the statistics pivot of stage 1 / 2)
     __device__ __forceinline__ void load(const PoolParams& p, int li, int lj, float* cl, int stage) {
         comp = lj < 3 ? lj : 0;
         l3 = lj == 3;
@@ -1152,7 +1153,9 @@ struct VLane {
             case VX<DT>::H1: return p.sc1 ? __builtin_fmaf(p.b1[ch], p.sc1[ch], p.sh1[ch]) : 0.f;
             case VX<DT>::S2: return (p.sc2 && p.b2) ? p.sc2[ch] : 0.f;
             case VX<DT>::H2: return (p.sc2 && p.b2) ? __builtin_fmaf(p.b2[ch], p.sc2[ch], p.sh2[ch]) : 0.f;
-            case VX<DT>::MU: return stage == 1 ? p.mu1[ch] - p.b1[ch] : stage == 2 ? p.mu2[ch] - p.b2[ch] : 0.f;
+            // forward statistics kernels (stage -1 / -2): the PIVOT of the shifted sums in the bias-free raw tile's terms
+            case VX<DT>::MU: return stage == 1 ? p.mu1[ch] - p.b1[ch] : stage == 2 ? p.mu2[ch] - p.b2[ch]
+                                  : stage == -1 ? (p.piv1 ? p.piv1[ch] - p.b1[ch] : 0.f) : stage == -2 ? (p.piv2 ? p.piv2[ch] - p.b2[ch] : 0.f) : 0.f;
             default: return stage == 1 ? p.is1[ch] : stage == 2 ? p.is2[ch] : 0.f;
             }
         };
@@ -1397,7 +1400,7 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     w2.bind(w2mem);
     if constexpr (W2ON) w2.stage(p.W2, VX<DT>::H, 1, 64 * NW);
     VLane<DT> vl;
-    vl.load(p, li, lj, cl, 0);
+    vl.load(p, li, lj, cl, FST ? -2 : 0);
     XFold<DT> xf;
     xf.template init<SRC>(p, lj, xfm);
     const float es_g = eff_slope(p.glazy), e0 = lane_slope<DT>(lj, es_g);
@@ -1455,9 +1458,9 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
         for (int nb = 0; nb < DT; ++nb) s[nb] = splat(0.f);
         if constexpr (TERMS == 0) {
             if constexpr (FST) {
-                f32x4 r2[NCH];
+                f32x4 r2[NCH];        // (the accumulator starts at -pivot: the shifted sums cost nothing)
 #pragma unroll
-                for (int nb = 0; nb < NCH; ++nb) r2[nb] = splat(0.f);
+                for (int nb = 0; nb < NCH; ++nb) r2[nb] = -vl.get(VX<DT>::MU, nb);
                 gemm_f32<DT, VX<DT>::NC2, NCH, true>(xa, w2.f, VX<DT>::S2F, li, lj, r2);
 #pragma unroll
                 for (int nb = 0; nb < NCH; ++nb) { fs2[nb] += r2[nb]; fq2[nb] = __builtin_elementwise_fma(r2[nb], r2[nb], fq2[nb]); }
@@ -1469,9 +1472,9 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
             if constexpr (FST) {
                 // the next stage's raw output (mlp_rpe2 on this tile) only for its BatchNorm batch statistics; the gathered
                 // lanes / chunks of X meet zero rows of the padded W2
-                f32x4 r2[NCH];
+                f32x4 r2[NCH];        // (the accumulator starts at -pivot: the shifted sums cost nothing)
 #pragma unroll
-                for (int nb = 0; nb < NCH; ++nb) r2[nb] = splat(0.f);
+                for (int nb = 0; nb < NCH; ++nb) r2[nb] = -vl.get(VX<DT>::MU, nb);
                 gemm_frag<DT, NCH, 1, true>(fx, w2.h, w2.l, VX<DT>::S2B, li, lj, r2);
 #pragma unroll
                 for (int nb = 0; nb < NCH; ++nb) { fs2[nb] += r2[nb]; fq2[nb] = __builtin_elementwise_fma(r2[nb], r2[nb], fq2[nb]); }
@@ -1523,7 +1526,7 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
         __syncthreads();                                                    // the X tiles are free now
         double* redd = reinterpret_cast<double*>(&Xt[0][0]);                // [NW][2][HP] doubles
         static_assert(NW * 2 * HP * 2 <= NW * 16 * XS, "statistics scratch does not fit the X tiles");
-        write_moments<DT, NW>(fs2, fq2, p.b2, npts * 16, wave, lane, redd, cnts, p.fstats2);
+        write_moments<DT, NW>(fs2, fq2, p.piv2 ? nullptr : p.b2, npts * 16, wave, lane, redd, cnts, p.fstats2);
     }
 }
 
@@ -1541,7 +1544,7 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
     w2.bind(w2mem);
     if constexpr (SRC == 2) w2.stage(p.W2, VX<DT>::H, 1, 64 * NW);
     VLane<DT> vl;
-    vl.load(p, li, lj, cl, 0);
+    vl.load(p, li, lj, cl, SRC == 1 ? -1 : -2);       // MU slot: the pivot of the shifted sums (0 without one)
     __syncthreads();
     f32x4 ssum[NCH], ssq[NCH];
 #pragma unroll
@@ -1569,9 +1572,9 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
     }
     loads_landed();
     auto body = [&](Buf& U) {
-        f32x4 c0v[NCH], raw[NCH];
+        f32x4 c0v[NCH], raw[NCH];       // the product's accumulator starts at -pivot (stage 1 here, stage 2 below)
 #pragma unroll
-        for (int nb = 0; nb < NCH; ++nb) c0v[nb] = splat(0.f);
+        for (int nb = 0; nb < NCH; ++nb) c0v[nb] = SRC == 1 ? -vl.get(VX<DT>::MU, nb) : splat(0.f);
         stage1_raw<DT>(U.rin, vl, c0v, raw);
         {
             const Cursor cf = pt + 2 * pstep < P ? c2 : c0;      // (no branch: see pool_fwd_kernel)
@@ -1587,7 +1590,7 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
 #pragma unroll
             for (int nb = 0; nb < NCH; ++nb) {
                 u1[nb] = f4(vrelu(__builtin_elementwise_fma(raw[nb], vl.get(VX<DT>::S1, nb), vl.get(VX<DT>::H1, nb))));
-                raw[nb] = splat(0.f);
+                raw[nb] = -vl.get(VX<DT>::MU, nb);
             }
             if constexpr (TERMS == 0) stage2_raw<DT, TERMS>(u1, nullptr, w2, li, lj, raw);
             else {
@@ -1617,7 +1620,7 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
         pt += pstep;
     }
     if (npts & 1) body(A);
-    write_moments<DT, NW>(ssum, ssq, SRC == 1 ? p.b1 : p.b2, npts * 16, wave, lane, red, cnts, stats);
+    write_moments<DT, NW>(ssum, ssq, (SRC == 1 ? p.piv1 : p.piv2) ? nullptr : (SRC == 1 ? p.b1 : p.b2), npts * 16, wave, lane, red, cnts, stats);
 }
 
 
@@ -2525,6 +2528,7 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->W1 = d->W1; p->b1 = d->b1; p->sc1 = d->scale1; p->sh1 = d->shift1;
     p->W2 = d->W2; p->b2 = d->b2; p->sc2 = d->scale2; p->sh2 = d->shift2;
     p->mu1 = d->mean1; p->is1 = d->invstd1; p->mu2 = d->mean2; p->is2 = d->invstd2;
+    p->piv1 = backward ? nullptr : d->pivot_mean1; p->piv2 = backward ? nullptr : d->pivot_mean2;
     p->fstats2 = backward ? nullptr : d->bn_fwd_stats2;
     if (p->fstats2) RL_REQUIRE(d->u_source == 1 && d->W2 && d->b2, RL_ERR_ARGS, "%s: bn_fwd_stats2 needs virtual stage 1 and W2 / b2", who);
     p->bstats = backward ? d->bn_bwd_stats : nullptr;

@@ -33,6 +33,9 @@ BN_MOMENTUM = 0.99
 # in the replayed graph - measured 7.96 -> 8.12 ms per step (a cross-stream edge costs more than the 0.3 ms it could hide), so OFF
 CSR_SIDE_STREAM = bool(int(__import__("os").environ.get("RL_CSR_SIDE_STREAM", "0")))
 FOLD_BIAS = not bool(int(__import__("os").environ.get("RL_NO_FOLD_BIAS", "0")))     # diagnostics: keep the bias in the GEMM
+# BatchNorm batch statistics as SHIFTED sums around the running mean (round 5): var = E[(y-c)^2] - E[y-c]^2 keeps the variance
+# of a channel whose spread is tiny against its mean, which E[y^2] - E[y]^2 on fp32 partial sums loses.  A/B: RL_NO_BN_PIVOT=1
+BN_PIVOT = not bool(int(__import__("os").environ.get("RL_NO_BN_PIVOT", "0")))
 
 
 class _Tape(list):
@@ -96,6 +99,10 @@ class Engine:
         w = self.P[name]
         return w.view(w.shape[0], w.shape[1])
 
+    def _pivot(self, ctx: Context, bn_name: str):
+        """The pivot of a layer's shifted batch statistics: its running mean (training only)."""
+        return self.Bf[f"{bn_name}.running_mean"] if (ctx.training and BN_PIVOT) else None
+
     def _fold(self, ctx: Context, bn_name: str, stats, rows: int, C: int, folded_bias=None, nslots=None):
         """The BatchNorm fold of one layer (rl_bn_finalize).  Eval mode: the fold depends on nothing the forward computes (running
         statistics, gamma, beta), so the folds of ALL layers are issued in front of the network as grouped launches
@@ -112,7 +119,7 @@ class Engine:
             stats, rows, 128, C, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
             self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
             nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, folded_bias=folded_bias,
-            nslots=nslots, defer=getattr(ctx, "bn_defer", None))
+            nslots=nslots, defer=getattr(ctx, "bn_defer", None), pivoted=ctx.training and BN_PIVOT)
 
     def _eval_folds(self):
         """(scale, shift) of every BatchNorm layer from the running statistics, as grouped launches."""
@@ -140,8 +147,9 @@ class Engine:
         # a bias in front of a BatchNorm cancels in (y - mean): the GEMM epilogue leaves it out (a bias costs a wide GEMM
         # launch +18 %) and the BatchNorm fold accounts for it where it shows - the running mean (rl_bn_finalize)
         fold = FOLD_BIAS and bn is not None and bname is not None
+        piv = self._pivot(ctx, bn) if stats is not None else None
         Y = ops.gemm(a, W, ks, ns, n_out, self.P[bname] if (bname and not fold) else None, stats=stats,
-                     wsplit=getattr(ctx, "wsplit", None))
+                     wsplit=getattr(ctx, "wsplit", None), pivot=(piv, self.P[bname] if fold else None) if piv is not None else None)
         rpb = a.n * a.K if isinstance(a, Rpe) else a.n
         out = Lazy(Y, a.B, rpb, rpb, n_out)
         if bn:
@@ -205,6 +213,7 @@ class Engine:
             # the outputs of mlp_rpe1 / mlp_rpe2 are never stored: their consumers recompute them from the coordinates
             vr = ops.VirtualRpe(ctx.xyz4 if getattr(ctx, "xyz4", None) is not None else xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
                                 self.P[f"{e}.mlp_rpe2.conv.weight"], self.P[f"{e}.mlp_rpe2.conv.bias"])
+            vr.piv1, vr.piv2 = self._pivot(ctx, f"{e}.mlp_rpe1.batch_norm"), self._pivot(ctx, f"{e}.mlp_rpe2.batch_norm")
             vr.bn1 = self._virtual_bn(ctx, vr, 1, f"{e}.mlp_rpe1.batch_norm")
             ops.bn_finalize_flush(ctx.bn_defer)
             # in training pool1's kernel also leaves the batch statistics of mlp_rpe2's raw output (it has the tile)

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 # diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
 _LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
-ABI_VERSION = 106      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
+ABI_VERSION = 107      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -46,6 +46,7 @@ class GemmDesc(C.Structure):
         ("addend", C.c_void_p), ("out2", C.c_void_p), ("out2_index", C.c_void_p), ("out2_bstride", C.c_int64),
         ("split_col", C.c_int32),
         ("W_split", C.c_void_p),
+        ("stats_pivot_mean", C.c_void_p), ("stats_pivot_bias", C.c_void_p),
     ]
 
 
@@ -125,6 +126,7 @@ class PoolDesc(C.Structure):
         ("mean1", C.c_void_p), ("invstd1", C.c_void_p), ("mean2", C.c_void_p), ("invstd2", C.c_void_p),
         ("xyz_width", C.c_int32), ("bn_bwd_stats", C.c_void_p), ("bn_fwd_stats2", C.c_void_p),
         ("rows_bf16", C.c_int32),
+        ("pivot_mean1", C.c_void_p), ("pivot_mean2", C.c_void_p),
     ]
 
 
@@ -153,7 +155,7 @@ class BnFinalizeItem(C.Structure):
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
         ("folded_bias", C.c_void_p), ("nslots", C.c_int32), ("C", C.c_int32), ("training", C.c_int32),
-        ("momentum", C.c_float), ("eps", C.c_float), ("reserved", C.c_int32),
+        ("momentum", C.c_float), ("eps", C.c_float), ("pivoted", C.c_int32),
     ]
 
 
@@ -205,7 +207,7 @@ _SIGNATURES = {
     "rl_wgrad_batchable": (_i, [C.POINTER(WgradDesc)]),
     "rl_wgrad_batch": (_i, [C.POINTER(WgradDesc), _i, _vp]),
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
-    "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "rl_bn_finalize_batch": (_i, [C.POINTER(BnFinalizeItem), _i, _vp]),
     "rl_bn_bwd_finalize_pair": (_i, [_vp, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_bn_reduce_slots": (_i, [_vp, _i, _i, _vp, _vp]),

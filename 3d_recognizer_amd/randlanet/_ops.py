@@ -337,10 +337,12 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
          accumulate: bool = False, stats: Optional[torch.Tensor] = None,
          addend: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
          out2_index: Optional[torch.Tensor] = None, out2_bstride: int = 0, split_col: int = 0,
-         wsplit: Optional[dict] = None) -> torch.Tensor:
+         wsplit: Optional[dict] = None, pivot: Optional[tuple] = None) -> torch.Tensor:
     """Y = A'.W (+ bias).  With `out2` (split epilogue, wide layers only): v = A'.W + addend; columns < split_col go to
     `out` (which then has split_col columns), the others to the dense (M, N - split_col) tensor `out2` (or, with
-    `out2_index`, atomically to the rows it names) - the two halves of a concat's gradient in one pass."""
+    `out2_index`, atomically to the rows it names) - the two halves of a concat's gradient in one pass.
+    pivot (with stats): (running_mean, conv bias left out of this product or None) - the statistics are SHIFTED sums around
+    running_mean - bias (rl_gemm_desc.stats_pivot_*); the matching bn_finalize call must say pivoted=True."""
     d = H.GemmDesc()
     M, K = _fill_a(d, a)
     assert isinstance(a, Rpe) or a.raw.dtype == F32, "rl_gemm reads fp32 rows"
@@ -364,6 +366,10 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
         d.W_split = planes.data_ptr()
     d.Y, d.ldy, d.y_bstride, d.accumulate = out.data_ptr(), out.shape[1], out_bstride, int(accumulate)
     d.stats = H.ptr(stats)
+    if pivot is not None:
+        assert stats is not None and pivot[0].numel() == N and (pivot[1] is None or pivot[1].numel() == N)
+        _dev_check(*pivot)
+        d.stats_pivot_mean, d.stats_pivot_bias = pivot[0].data_ptr(), H.ptr(pivot[1])
     if addend is not None or out2 is not None:
         _dev_check(addend, out2, out2_index)
         assert addend is None or (addend.dtype == F32 and addend.shape == (M, N))
@@ -535,8 +541,9 @@ NO_BN_BATCH = bool(int(__import__("os").environ.get("RL_NO_BN_BATCH", "0")))    
 
 def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, nbt, momentum: float,
                 eps: float, training: bool, sync: Optional[SyncGroup] = None, nslots: Optional[int] = None,
-                folded_bias: Optional[torch.Tensor] = None, defer: Optional[list] = None):
+                folded_bias: Optional[torch.Tensor] = None, defer: Optional[list] = None, pivoted: bool = False):
     """folded_bias: the layer's conv bias when the producing GEMM did NOT add it (rl_bn_finalize in rl_randlanet.h).
+    pivoted: the partial sums are shifted around (running_mean - folded_bias), see gemm(pivot=...).
     defer (a list): the fold is only queued - the returned tensors are filled by `bn_finalize_flush(defer)`, which runs all
     queued folds as ONE launch; the caller flushes before anything reads them."""
     dev = gamma.device
@@ -557,11 +564,13 @@ def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, n
         it.running_mean, it.running_var, it.num_batches_tracked = H.ptr(rmean), H.ptr(rvar), H.ptr(nbt)
         it.scale, it.shift, it.save_mean, it.save_invstd = scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd)
         it.folded_bias, it.nslots, it.C, it.training, it.momentum, it.eps = H.ptr(folded_bias), nslots, C, int(training), momentum, eps
+        it.pivoted = int(bool(pivoted and training))
         defer.append((it, stats, scale, shift, mean, invstd))       # (the tensors stay referenced until the launch is issued)
         return scale, shift, mean, invstd
     H.check(H.lib().rl_bn_finalize(H.ptr(stats), nslots, rows, C, H.ptr(gamma), H.ptr(beta),
                                    H.ptr(rmean), H.ptr(rvar), H.ptr(nbt), momentum, eps, int(training),
-                                   scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), H.ptr(folded_bias), _st()),
+                                   scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), H.ptr(folded_bias),
+                                   int(bool(pivoted and training)), _st()),
             "rl_bn_finalize")
     return scale, shift, mean, invstd
 
@@ -809,6 +818,9 @@ class VirtualRpe:
     b2: torch.Tensor
     bn1: Optional[Lazy] = None
     bn2: Optional[Lazy] = None
+    # training: the running means of the two BatchNorms - pivots of the shifted batch statistics (rl_pool_desc.pivot_mean*)
+    piv1: Optional[torch.Tensor] = None
+    piv2: Optional[torch.Tensor] = None
 
     @property
     def rows(self) -> int:
@@ -832,6 +844,8 @@ def _fill_virtual(pd: "H.PoolDesc", v: VirtualRpe, stage: int) -> None:
     pd.u_source, pd.xyz, pd.xyz_bstride, pd.nbr_d2 = stage, v.xyz.data_ptr(), v.xyz.shape[1], v.d2.data_ptr()
     pd.W1, pd.b1, pd.W2, pd.b2 = v.W1.data_ptr(), v.b1.data_ptr(), v.W2.data_ptr(), v.b2.data_ptr()
     pd.idx, pd.points, pd.n, pd.d, pd.nbr_k = v.idx.data_ptr(), v.B * v.n, v.n, 2 * v.h, 16
+    _dev_check(v.piv1, v.piv2)
+    pd.pivot_mean1, pd.pivot_mean2 = H.ptr(v.piv1), H.ptr(v.piv2)
     for tag, bn in (("1", v.bn1), ("2", v.bn2)):
         if bn is not None:
             _dev_check(bn.scale, bn.shift, bn.mean, bn.invstd)

@@ -101,13 +101,14 @@ class _SharedMLPRows(torch.autograd.Function):
         train_stats = bn is not None and mod.training
         stats = ops.new_stats(rows.device, n_out) if train_stats else None
         a = ops.plain(rows.detach(), 1, M)
-        Y = ops.gemm(a, W2, ks, ns, n_out, bias.detach(), stats=stats)
+        # batch statistics as shifted sums around the running mean (rl_gemm_desc.stats_pivot_*)
+        Y = ops.gemm(a, W2, ks, ns, n_out, bias.detach(), stats=stats, pivot=(bn.running_mean, None) if train_stats else None)
         act, slope = _act_code(mod.activation)
         y = ops.Lazy(Y, 1, M, M, n_out, None, None, act, slope)
         if bn is not None:
             y.scale, y.shift, y.mean, y.invstd = ops.bn_finalize(
                 stats, M, 128, n_out, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
-                bn.num_batches_tracked if train_stats else None, 0.99, 1e-6, train_stats)
+                bn.num_batches_tracked if train_stats else None, 0.99, 1e-6, train_stats, pivoted=train_stats)
             if not train_stats:      # eval mode: the "batch" statistics of the backward formulas are the running ones
                 y.mean, y.invstd = bn.running_mean.clone(), torch.rsqrt(bn.running_var + 1e-6)
         elif act != H.ACT_NONE:
@@ -166,12 +167,13 @@ class SharedMLP(nn.Module):
         bn = self.batch_norm
         train_stats = bn is not None and self.training
         stats = ops.new_stats(rows.device, n_out) if train_stats else None
-        Y = ops.gemm(ops.plain(rows, 1, M), W2, ks, ns, n_out, self.conv.bias.detach(), stats=stats)
+        Y = ops.gemm(ops.plain(rows, 1, M), W2, ks, ns, n_out, self.conv.bias.detach(), stats=stats,
+                     pivot=(bn.running_mean, None) if train_stats else None)
         act, slope = _act_code(self.activation)
         if bn is not None:
             scale, shift, _, _ = ops.bn_finalize(stats, M, 128, n_out, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                  bn.running_var, bn.num_batches_tracked if train_stats else None,
-                                                 0.99, 1e-6, train_stats)
+                                                 0.99, 1e-6, train_stats, pivoted=train_stats)
         elif act != H.ACT_NONE:
             scale, shift = torch.ones(n_out, device=rows.device), torch.zeros(n_out, device=rows.device)
         else:

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 106     /* round 4: rl_launch_count; round-3 signature changes (rl_bn_finalize folded_bias, rl_dropout_* first_row, descriptor fields) */
+#define RL_VERSION 107     /* round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted); round 4: rl_launch_count */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -179,6 +179,14 @@ typedef struct rl_gemm_desc {
      * 16-byte aligned, K % 8 == 0).  Selects the 8-wavefront kernel: no conversion of the weight per tile, four
      * wavefronts per SIMD instead of two.  Same arithmetic, same results as without it. */
     const void* W_split;
+    /* optional, with stats: SHIFTED statistics.  The partial sums are those of (y - pivot) and (y - pivot)^2 with
+     * pivot[c] = stats_pivot_mean[c] - (stats_pivot_bias ? stats_pivot_bias[c] : 0) - the layer's running mean (what torch's
+     * BatchNorm2d keeps, modules.py:85-89), minus the conv bias this product leaves out (rl_bn_finalize folded_bias) -
+     * subtracted per element BEFORE squaring, so that a channel whose spread is a few 1e-4 of its mean keeps its variance
+     * (the reference's ATen BatchNorm is two-pass; E[y^2] - E[y]^2 on fp32 partial sums is not).  rl_bn_finalize must then be
+     * told `pivoted`.  NULL = plain sums (pivot 0). */
+    const float* stats_pivot_mean;
+    const float* stats_pivot_bias;
 } rl_gemm_desc;
 
 /* Splits weights for rl_gemm_desc.W_split: out (2*N*K bf16) <- heads, then tails, of W(k, n) = W[k*w_ks + n*w_ns].
@@ -287,11 +295,15 @@ int rl_wgrad_reduce_batch(const rl_wgrad_reduce_item* items, int count, void* st
  * folded_bias (C floats or NULL): the bias of the layer in front (SharedMLP's conv bias, modules.py:93-104), when the
  *   producer left it OUT of the tensor - it cancels in (y - mean), so the GEMM epilogue need not add it.  The statistics
  *   and the saved mean are then those of (y - bias), (scale, shift) apply to that tensor, and the running mean is kept
- *   as the reference keeps it: that of y (mean + bias); in eval mode the running mean is read as (running_mean - bias). */
+ *   as the reference keeps it: that of y (mean + bias); in eval mode the running mean is read as (running_mean - bias).
+ * pivoted != 0 (training): the partial sums are SHIFTED - those of (t - pivot) and (t - pivot)^2 of the stored tensor t,
+ *   pivot[c] = running_mean[c] (as it stands BEFORE this call's update) - folded_bias[c]: mean = pivot + S/n,
+ *   var = Q/n - (S/n)^2.  The producer must have been given the same two vectors (rl_gemm_desc.stats_pivot_*,
+ *   rl_pool_desc.pivot_mean*). */
 int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                    float momentum, float eps, int training, float* scale, float* shift,
-                   float* save_mean, float* save_invstd, const float* folded_bias, void* stream);
+                   float* save_mean, float* save_invstd, const float* folded_bias, int pivoted, void* stream);
 
 /* Several independent layers' folds in one launch (same arithmetic per layer as rl_bn_finalize: same results).  The folds of
  * the layers at one dependency depth of an encoder level - mlp1 / shortcut / mlp_rpe1, then pool1.mlp / mlp_rpe2 - are wanted
@@ -311,7 +323,7 @@ typedef struct rl_bn_finalize_item {
     const float* folded_bias;
     int32_t nslots, C, training;
     float momentum, eps;
-    int32_t reserved;
+    int32_t pivoted;
 } rl_bn_finalize_item;
 int rl_bn_finalize_batch(const rl_bn_finalize_item* items, int count, void* stream);
 
@@ -548,6 +560,12 @@ typedef struct rl_pool_desc {
      * of rl_rpe_bn_reduce / rl_rpe_wgrad - when the rpe branch is virtual (u_source > 0).  With a real U tensor GU stays
      * fp32 (it continues into the fp32 GEMM chain).  Needs the bf16x3 arithmetic mode.  0: everything fp32.        */
     int32_t rows_bf16;
+    /* SHIFTED BatchNorm statistics (see rl_gemm_desc.stats_pivot_*): the running mean of mlp_rpe1's / mlp_rpe2's BatchNorm
+     * (modules.py:288-291).  With pivot_mean1, rl_rpe_stats (u_source 1) leaves the sums of (y - pivot_mean1) and its square,
+     * y = raw + b1; with pivot_mean2 so do rl_rpe_stats (u_source 2) and rl_pool_fwd's bn_fwd_stats2 for the second stage.
+     * rl_bn_finalize must then be called with `pivoted` (and no folded bias: these sums are those of y).  NULL: plain sums. */
+    const float* pivot_mean1;
+    const float* pivot_mean2;
 } rl_pool_desc;
 
 int rl_pool_supported(int d, int nbr_k);

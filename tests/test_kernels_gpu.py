@@ -436,6 +436,50 @@ def test_bn_forward_backward(ops, C, rows, one_launch, monkeypatch):
     assert float((Y.detach() * s2 + b2 - ref2).abs().max()) < 1e-5 * max(1.0, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("C,K,rows,fold", [(8, 3, 40000, True), (64, 64, 20000, False), (32, 16, 5001, True), (128, 128, 9000, True),
+                                           (256, 64, 4097, False), (256, 512, 300, True), (64, 256, 2000, True)])
+def test_shifted_batch_statistics(ops, C, K, rows, fold):
+    """Round 5: BatchNorm batch statistics as SHIFTED sums (rl_gemm_desc.stats_pivot_*, rl_bn_finalize pivoted) - every GEMM
+    kernel that leaves statistics (streaming, LDS-tiled wide, split-K reducer) on a layer whose channels have a spread of
+    1e-4 of their mean: the reference's ATen BatchNorm is two-pass (modules.py:85-89), E[y^2] - E[y]^2 on fp32 partial sums
+    loses such a variance altogether.  Against the fp64 statistics of the stored fp32 tensor: mean / invstd / running
+    statistics with the pivot within 1e-4 relative; without it the same launch is off by orders of magnitude (printed)."""
+    torch.manual_seed(C + K + rows)
+    # Y = A.W: column k of A is ~1 with 1e-4 spread; W has one large positive entry per output -> channel mean ~100, spread ~1e-2
+    A = (1.0 + 1e-4 * torch.randn(rows, K, device=DEV)).contiguous()
+    W = torch.zeros(C, K, device=DEV)
+    W[torch.arange(C), torch.arange(C) % K] = 100.0 + torch.arange(C, device=DEV, dtype=torch.float32) % 7
+    bias = torch.randn(C, device=DEV) * 3
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+
+    def run(pivot_on):
+        rm = (W.sum(1) + bias + 0.05 * torch.randn(C, device=DEV)).contiguous()       # a running mean near the batch mean
+        rv = torch.ones(C, device=DEV)
+        rm0 = rm.clone()
+        stats = ops.new_stats(DEV, C)
+        Y = ops.gemm(ops.plain(A, 1, rows), W, 1, K, C, None if fold else bias, stats=stats,
+                     pivot=(rm, bias if fold else None) if pivot_on else None)
+        sc, sh, mean, invstd = ops.bn_finalize(stats, rows, 128, C, gamma, beta, rm, rv, None, 0.99, 1e-6, True,
+                                               folded_bias=bias if fold else None, pivoted=pivot_on)
+        return Y, mean, invstd, rm, rv, rm0
+
+    Y, mean, invstd, rm, rv, rm0 = run(True)
+    Yd = Y.double()
+    m64, v64 = Yd.mean(0), Yd.var(0, unbiased=False)
+    i64 = 1.0 / torch.sqrt(v64 + 1e-6)
+    assert float(v64.max()) < 1e-3 and float(m64.abs().min()) > 50        # the regime this test is about
+    e_mean = float(((mean.double() - m64).abs() / m64.abs()).max())
+    e_inv = float(((invstd.double() - i64).abs() / i64).max())
+    rm_ref = 0.01 * rm0.double() + 0.99 * (m64 + (bias.double() if fold else 0.0))
+    rv_ref = 0.01 * 1.0 + 0.99 * v64 * rows / (rows - 1)
+    _, _, inv_plain, _, _, _ = run(False)
+    e_plain = float(((inv_plain.double() - i64).abs() / i64).max())
+    print(f"[shifted statistics] C={C} K={K} rows={rows}: invstd error with the pivot {e_inv:.2e}, without {e_plain:.2e}")
+    assert e_mean < 1e-6 and e_inv < 1e-4, (e_mean, e_inv)
+    np.testing.assert_allclose(rm.cpu().numpy(), rm_ref.cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), rv_ref.cpu().numpy(), rtol=2e-4, atol=1e-9)
+
+
 # ----------------------------------------------------------------------------- rows, pool
 @pytest.mark.parametrize("C,rows,one_launch", [(32, 5000, False), (128, 999, True), (512, 300, True), (512, 300, False), (32, 2048, True),
                                                (32, 2049, False)])
@@ -789,6 +833,22 @@ def test_virtual_rpe_branch_forward(ops, d, B, n_parent, n):
     assert torch.equal(V1b, V1)
     assert float((t2b[2] - t2[2]).abs().max()) < 1e-6 * max(1.0, float(t2[2].abs().max()))
     assert float((t2b[3] - t2[3]).abs().max()) < 1e-5 * max(1.0, float(t2[3].abs().max()))
+    # round 5: the same statistics as SHIFTED sums around a running mean (rl_pool_desc.pivot_mean*): same moments
+    def bn_piv(stats, nslots, gamma, beta, c, rm):
+        return ops.bn_finalize(stats, rows, 128, c, gamma, beta, rm.clone(), torch.ones(c, device=DEV), None, 0.99, 1e-6, True,
+                               nslots=nslots, pivoted=True)
+    vr.piv1 = (t1[2] + 0.05 * torch.randn(h, device=DEV)).contiguous()
+    vr.piv2 = (t2[2] + 0.05 * torch.randn(h, device=DEV)).contiguous()
+    ps1, ns = ops.rpe_stats(vr, 1)
+    p1 = bn_piv(ps1, ns, g1w, g1b, h, vr.piv1)
+    ps2, ns = ops.rpe_stats(vr, 2)
+    p2 = bn_piv(ps2, ns, g2w, g2b, h, vr.piv2)
+    V1c, st2c, nsc = ops.pool_fwd(vr, g, idx, Ws, n, d, stage=1, next_stats=True)
+    p2c = bn_piv(st2c, nsc, g2w, g2b, h, vr.piv2)
+    assert torch.equal(V1c, V1)
+    for a, b_, what in ((p1[2], t1[2], "mean1"), (p1[3], t1[3], "invstd1"), (p2[2], t2[2], "mean2"), (p2[3], t2[3], "invstd2"),
+                        (p2c[2], t2[2], "mean2 (pool_fwd)"), (p2c[3], t2[3], "invstd2 (pool_fwd)")):
+        assert float((a - b_).abs().max()) < 1e-5 * max(1.0, float(b_.abs().max())), what
 
 
 @pytest.mark.parametrize("d,B,n_parent,n", [(16, 2, 900, 500), (32, 1, 300, 300), (64, 2, 400, 257), (16, 4, 2048, 2048)])
