@@ -2069,6 +2069,9 @@ inline int wgemm_staging() {
     }
     return g_wgemm_staging;
 }
+// diagnostics (rl_set_sgemm_grid_div): the streaming GEMM on 1/div of its workgroups - Y is bitwise the same, only the
+// grouping of the per-lane BatchNorm partial sums changes (the regression knob of tests/test_net_gpu.py)
+int g_sgemm_grid_div = 1;
 // compute units of the current device (256 on an MI355X; fewer in a partitioned mode), asked once per device
 inline int cu_count() {
     static int cached[16] = {0};
@@ -2760,6 +2763,11 @@ extern "C" int rl_set_wgemm_staging(const char* how) {
     g_wgemm_staging = !strcmp(how, "dma");
     return RL_OK;
 }
+extern "C" int rl_set_sgemm_grid_div(int div) {
+    RL_REQUIRE(div >= 1 && div <= 64, RL_ERR_ARGS, "rl_set_sgemm_grid_div: 1 .. 64");
+    g_sgemm_grid_div = div;
+    return RL_OK;
+}
 extern "C" const char* rl_get_wide_gemm(void) {
     const int t = wide_gemm_terms();
     return t == 0 ? "fp32" : t == 1 ? "bf16" : "bf16x3";
@@ -2819,6 +2827,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         // wavefront, fewer and longer-lived workgroups (two per CU) beat one 128-row tile per workgroup
         int sg = gx;
         if ((long)d->K * d->N >= 2048) sg = gx > 512 ? 512 : (gx > 256 ? 256 : gx);
+        if (g_sgemm_grid_div > 1) sg = sg / g_sgemm_grid_div > 0 ? sg / g_sgemm_grid_div : 1;
         if (d->K <= 16)      launch_sgemm<1>(d->N, sg, st, p);
         else if (d->K <= 32) launch_sgemm<2>(d->N, sg, st, p);
         else                 launch_sgemm<4>(d->N, sg, st, p);

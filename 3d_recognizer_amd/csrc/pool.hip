@@ -2684,6 +2684,7 @@ extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) 
     RL_REQUIRE(d->xyz_width != 4 || ((uintptr_t)d->xyz & 15) == 0, RL_ERR_ARGS, "rl_rpe_stats: padded xyz must be 16-byte aligned");
     p.W1 = d->W1; p.b1 = d->b1; p.sc1 = d->scale1; p.sh1 = d->shift1;
     p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
+    p.piv1 = d->pivot_mean1; p.piv2 = d->pivot_mean2;       // shifted sums around the stage's running mean (or null)
     const int g = rpe_grid(p.P);
     hipStream_t st = (hipStream_t)stream;
     const int key = (pool_terms(p.d) == 0 ? 0 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + p.src;

@@ -202,6 +202,7 @@ _SIGNATURES = {
     "rl_set_wide_gemm": (_i, [C.c_char_p]),
     "rl_get_wide_gemm": (C.c_char_p, []),
     "rl_set_wgemm_staging": (_i, [C.c_char_p]),
+    "rl_set_sgemm_grid_div": (_i, [_i]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "rl_wgrad_nsplit": (_i, [_l, _i, _i]),
     "rl_wgrad_batchable": (_i, [C.POINTER(WgradDesc)]),

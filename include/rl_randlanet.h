@@ -220,6 +220,10 @@ const char* rl_get_wide_gemm(void);
  * Same products in the same order: Y is bitwise the same (the BatchNorm partial sums are grouped differently).
  * K % 32 != 0 or K > 1024 always takes "registers".  RL_WGEMM_STAGING sets the initial choice.                        */
 int rl_set_wgemm_staging(const char* how);
+/* Diagnostics: the streaming GEMM (K, N <= 64) on 1/div of its workgroups (1 = default).  Y is bitwise the same; the rows a
+ * lane adds into its BatchNorm partial sums change - the regression knob for "a re-grouping of the statistics must not move
+ * a gradient" (tests/test_net_gpu.py; round 4 met 0.5 - 3 % before the sums were shifted).                              */
+int rl_set_sgemm_grid_div(int div);
 int rl_gemm(const rl_gemm_desc* d, void* stream);
 
 /* Weight / bias gradient of the same layer:  dW(k,c) = sum_r A'[r][k] * dY[r][c],

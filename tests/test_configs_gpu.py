@@ -313,3 +313,64 @@ def test_ragged_sizes_features_and_losses_match_oracle_autograd(C, N, K, F, laye
         r = P[name].grad
         e = float((p.grad.cpu() - r).abs().max())
         assert e < 5e-3 * float(r.abs().max()) + 2e-5, (name, e, float(r.abs().max()))
+
+
+def test_statistics_regrouping_does_not_move_gradients(monkeypatch):
+    """Round-4 finding, round-5 regression: a mere RE-GROUPING of the BatchNorm partial sums (then: sgemm's per-lane sums after a
+    transposed product) moved parameter gradients of the 1029-point ragged configuration by 0.5 - 3 % - mean / variance came out
+    of sum and sum of squares by subtraction, and this configuration has nearly degenerate channels.  With the statistics as
+    SHIFTED sums around the running mean (rl_gemm_desc.stats_pivot_*) the grouping must not matter: the same train step with
+    the streaming GEMM on a third / a seventh of its workgroups (rl_set_sgemm_grid_div: Y bitwise equal, other lanes add other
+    rows) and the wide GEMM register-staged (other per-tile grouping), exact-product mode, every gradient within 2e-4 of its
+    tensor's largest entry.  The spread WITHOUT the pivot (RL_NO_BN_PIVOT) is printed next to it."""
+    from oracle import randlanet_oracle as O
+    from oracle.init_formula import formula_state_dict
+    from randlanet import _engine as E
+    from randlanet import _ops as ops
+    from randlanet.utils.losses import get_loss
+    from randlanet.utils.modules import RandLANet, RandLANetSettings
+    C, N, K, F, layers, B = 3, 1029, 8, 1, [16, 32, 64], 1
+    sd = formula_state_dict(O.state_dict_layout(C, F, layers), seed=C + N)
+    # a trained network's running means sit at its batch means: start there (one step with momentum 0.99), so that the pivot
+    # is what it is in a training run rather than the constructor's zeros
+    rs = np.random.RandomState(N)
+    x = torch.from_numpy(rs.uniform(0, 1, (B, N, 3 + F)).astype(np.float32)).to(DEV)
+    y = torch.from_numpy(np.minimum((x[..., 2].cpu().numpy() * C).astype(np.int64), C - 1)).to(DEV)
+    lib = ops.H.lib()
+
+    def grads(div, staging, pivot):
+        monkeypatch.setattr(E, "BN_PIVOT", pivot)
+        net = RandLANet(RandLANetSettings(n_classes=C, n_points=N, n_features=F, n_neighbors=K, layer_sizes=list(layers)), DEV)
+        net.load_state_dict(sd)
+        net.fc_end[2].p = 0.0
+        net.train()
+        out = None
+        for it in range(2):            # the first step moves the running means onto the batch; the second is the one compared
+            net.zero_grad()
+            assert lib.rl_set_sgemm_grid_div(div if it else 1) == 0
+            ops.set_wgemm_staging(staging if it else "dma")
+            np.random.seed(21)
+            logits = net(x)
+            get_loss("cross_entropy")(logits, y).backward()
+            out = {n: p.grad.detach().cpu().clone() for n, p in net.named_parameters()}
+        return out
+
+    default = ops.get_wide_gemm()
+    try:
+        ops.set_wide_gemm("fp32")
+        for pivot in (True, False):
+            base = grads(1, "dma", pivot)
+            worst = (0.0, "")
+            for div, staging in ((3, "dma"), (7, "dma"), (1, "registers"), (5, "registers")):
+                g = grads(div, staging, pivot)
+                for name, r in base.items():
+                    # (+ 1e-7 absolute, as in test_equivalence_gpu: conv biases in front of a BatchNorm have a true gradient of 0)
+                    e = max(0.0, float((g[name] - r).abs().max()) - 1e-7) / (float(r.abs().max()) + 1e-12)
+                    worst = max(worst, (e, name))
+            print(f"[regrouping] shifted sums {'on ' if pivot else 'off'}: worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
+            if pivot:
+                assert worst[0] < 2e-4, worst
+    finally:
+        ops.set_wide_gemm(default)
+        ops.set_wgemm_staging("dma")
+        lib.rl_set_sgemm_grid_div(1)
