@@ -27,22 +27,33 @@ struct V3 {
 // whole cloud reduces in three steps: the workgroup's own sum (fixed butterfly + wavefronts in order), one record per workgroup
 // in `part`, a barrier over the cloud's workgroups, and every workgroup adds the gw records in index order (deterministic, the
 // same value in all of them).  The barrier is an arrival counter per cloud: gw device-scope atomics at ~35 ns each (64 of them
-// on one address cost as much as a launch - tools/micro/grid_barrier_bench.hip - 16 do not); all gw * B <= 256 workgroups of a
-// launch are resident by construction.  The counters return to zero when the cloud's last workgroup leaves.
+// on one address cost as much as a launch - tools/micro/grid_barrier_bench.hip - 16 do not); the gw * B workgroups of a launch
+// fit the device at once (sized from the occupancy calculator, per device), other streams' kernels only delay them, and the spin
+// is bounded (cloud_barrier).  Records and counters live in the caller's scratch, zeroed by a kernel of this call.
 struct CloudSync {
     double* part;                  // [gw][4] records of this cloud, reused stage after stage
     unsigned* arrive;              // this cloud's arrival counter
     unsigned passed;               // barriers this workgroup has been through
     int gw, w;
+    int* gave_up;                  // (LDS) set when a barrier timed out: see below
 };
+// Every wavefront reaches the end of the kernel whatever its peers do: the spin is BOUNDED (~2^22 polls of ~0.25 us: about a
+// second, against ~1 us for a barrier that works).  A workgroup whose peers never arrive - the launch was not co-resident: a CU
+// mask, a partition mode - stops waiting for good and poisons its share of the output with NaN (the loss of the step shows
+// it) instead of hanging the GPU.
+constexpr unsigned ASM_SPIN_LIMIT = 1u << 22;
 __device__ __forceinline__ void cloud_barrier(CloudSync& cs) {
     __syncthreads();
     if (cs.gw > 1) {
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && !*cs.gave_up) {
             __threadfence();
             const unsigned target = (cs.passed + 1u) * (unsigned)cs.gw;
             atomicAdd(cs.arrive, 1u);
-            while (__hip_atomic_load(cs.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+            unsigned spins = 0;
+            while (__hip_atomic_load(cs.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > ASM_SPIN_LIMIT) { *cs.gave_up = 1; break; }
+            }
             __threadfence();
         }
         __syncthreads();
@@ -132,13 +143,16 @@ __global__ __launch_bounds__(1024) void batch_assemble_kernel(const rl_cloud_job
                                                               const double* __restrict__ noise, int n, int F,
                                                               double* __restrict__ scratch, float* __restrict__ out_input,
                                                               int64_t* __restrict__ out_labels, double* __restrict__ sync_part,
-                                                              unsigned* __restrict__ sync_count) {
+                                                              unsigned* __restrict__ sync_count, int sync_stride) {
     __shared__ double red[16];
+    __shared__ int gave_up;
+    if (threadIdx.x == 0) gave_up = 0;
+    __syncthreads();
     const int b = blockIdx.y, gw = gridDim.x;
     CloudSync cs;
-    cs.gw = gw; cs.w = blockIdx.x; cs.passed = 0u;
-    cs.part = sync_part + (long)b * 128;          // two sets of 16 records of 4 doubles
-    cs.arrive = sync_count + 2 * b;
+    cs.gw = gw; cs.w = blockIdx.x; cs.passed = 0u; cs.gave_up = &gave_up;
+    cs.part = sync_part + (long)b * sync_stride;          // two sets of 16 records of 4 doubles (sync_stride doubles per cloud)
+    cs.arrive = sync_count + 2l * b * sync_stride;         // (unsigned units: two per double)
     const rl_cloud_job job = jobs[b];
     const int64_t* idx = indices + (long)b * n;
     double* X = scratch + (long)b * n * 3;
@@ -241,17 +255,12 @@ __global__ __launch_bounds__(1024) void batch_assemble_kernel(const rl_cloud_job
         __syncthreads();
     }
     // torch.from_numpy(xyz).float() (dataset.py:51): round to float32, coordinates first (dataset.py:53)
+    __syncthreads();
+    const bool poisoned = gave_up != 0;          // a cloud-wide sum never completed: nothing of this share is trustworthy
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        out[(long)i * C + 0] = (float)X[3 * i + 0];
-        out[(long)i * C + 1] = (float)X[3 * i + 1];
-        out[(long)i * C + 2] = (float)X[3 * i + 2];
-    }
-    // the cloud's last workgroup to leave puts both counters back to zero for the next launch
-    if (gw > 1 && threadIdx.x == 0) {
-        if (atomicAdd(cs.arrive + 1, 1u) == (unsigned)gw - 1u) {
-            __hip_atomic_store(cs.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cs.arrive + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        out[(long)i * C + 0] = poisoned ? __builtin_nanf("") : (float)X[3 * i + 0];
+        out[(long)i * C + 1] = poisoned ? __builtin_nanf("") : (float)X[3 * i + 1];
+        out[(long)i * C + 2] = poisoned ? __builtin_nanf("") : (float)X[3 * i + 2];
     }
 }
 
@@ -339,25 +348,37 @@ extern "C" int rl_batch_draw(const rl_cloud_job* jobs_dev, int B, int n, uint64_
     return RL_OK;
 }
 
-// scratch for the cloud-wide sums of rl_batch_assemble: per cloud two sets of 16 records of 4 doubles and two counters (zero at first use,
-// zero again after every launch); owned by the library, one per device
-static int assemble_sync(int B, double** part, unsigned** count) {
-    static double* s_part[16] = {nullptr};
-    static unsigned* s_count[16] = {nullptr};
-    static int s_cap[16] = {0};
+// Workgroups per cloud a launch may use: all gw * B of them must be resident at once (cloud_barrier spins).  Per DEVICE and from
+// the occupancy calculator (resident 1024-lane workgroups per CU x CUs), asked once per device under a lock.
+#include <mutex>
+static int assemble_capacity() {
+    static std::mutex mu;
+    static int cached[64] = {0};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return RL_ERR_ARGS;
-    if (s_cap[dev] < B) {
-        // (the old buffers are not freed: a launch that still uses them may be in flight; a few KB, a handful of times)
-        const int cap = B < 64 ? 64 : B;
-        if (hipMalloc((void**)&s_part[dev], (size_t)cap * 128 * sizeof(double)) != hipSuccess) return RL_ERR_LAUNCH;
-        if (hipMalloc((void**)&s_count[dev], (size_t)cap * 2 * sizeof(unsigned)) != hipSuccess) return RL_ERR_LAUNCH;
-        if (hipMemset(s_count[dev], 0, (size_t)cap * 2 * sizeof(unsigned)) != hipSuccess) return RL_ERR_LAUNCH;
-        s_cap[dev] = cap;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (cached[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, batch_assemble_kernel, 1024, 0) != hipSuccess || per_cu <= 0) per_cu = 0;
+        (void)hipGetLastError();
+        cached[dev] = cus > 0 && per_cu > 0 ? cus : -1;        // one workgroup per CU is all this kernel asks for
     }
-    *part = s_part[dev];
-    *count = s_count[dev];
-    return RL_OK;
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+
+// the cloud-wide sums' records and arrival counters live in the CALLER's scratch, behind the coordinates: per cloud two sets of
+// 16 records of 4 doubles, then two counters - zeroed by a kernel of this call (no state in the library: two loaders on two
+// streams do not meet, and a launch that was aborted leaves nothing behind)
+constexpr int ASM_SYNC_DOUBLES = 130;
+__global__ void batch_assemble_reset_kernel(unsigned* __restrict__ count, int stride_u32, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { count[(long)b * stride_u32] = 0u; count[(long)b * stride_u32 + 1] = 0u; }
+}
+
+extern "C" int64_t rl_batch_assemble_scratch_doubles(int B, int n) {
+    if (B <= 0 || n <= 0) return 0;
+    return (int64_t)B * n * 3 + (int64_t)B * ASM_SYNC_DOUBLES;
 }
 
 extern "C" int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int F, const int64_t* indices,
@@ -366,24 +387,24 @@ extern "C" int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int
     RL_REQUIRE(jobs_dev && indices && scratch && out_input && out_labels, RL_ERR_ARGS, "rl_batch_assemble: null pointer");
     RL_REQUIRE(B > 0 && n > 0 && F >= 0, RL_ERR_ARGS, "rl_batch_assemble: bad sizes (B %d, n %d, F %d)", B, n, F);
     // workgroups per cloud: up to 16, all gw * B of a launch resident at once (one of 1024 lanes per CU: 256 on an MI355X)
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        else cus = 64;
-    }
-    int gw = cus / B;
+    const int cap = assemble_capacity();
+    int gw = cap / B;
     gw = gw > 16 ? 16 : (gw < 1 ? 1 : gw);
     while (gw > 1 && (long)(gw - 1) * 1024 >= n) --gw;        // (no workgroup without points)
     if (getenv("RL_ASSEMBLE_ONE_WG")) gw = 1;
-    double* part = nullptr;
-    unsigned* count = nullptr;
+    double* part = scratch + (long)B * n * 3;                 // [B][ASM_SYNC_DOUBLES]: 128 doubles of records, then the counters
+    unsigned* count = reinterpret_cast<unsigned*>(part + 128);
+    hipStream_t st = (hipStream_t)stream;
+    const int sync_stride = ASM_SYNC_DOUBLES;
     if (gw > 1) {
-        const int rc = assemble_sync(B, &part, &count);
-        RL_REQUIRE(rc == RL_OK, rc, "rl_batch_assemble: no scratch for the cloud-wide sums");
+        hipLaunchKernelGGL(batch_assemble_reset_kernel, dim3(rl_cdiv(B, 64)), dim3(64), 0, st, count, 2 * ASM_SYNC_DOUBLES, B);
+        RL_LAUNCH_CHECK("rl_batch_assemble(reset)");
     }
-    hipLaunchKernelGGL(batch_assemble_kernel, dim3(gw, B), dim3(1024), 0, (hipStream_t)stream, jobs_dev, indices, noise, n,
-                       F, scratch, out_input, out_labels, part, count);
+    // (A COOPERATIVE launch - the runtime's own co-residency check - was built and measured in round 5: the loader's launch then
+    // serialises with the training stream's graph replays, Model.train 883 -> 333 clouds/s.  Kept: the capacity from the occupancy
+    // calculator per device, records / counters per call, the bounded spin.)
+    hipLaunchKernelGGL(batch_assemble_kernel, dim3(gw, B), dim3(1024), 0, st, jobs_dev, indices, noise, n,
+                       F, scratch, out_input, out_labels, part, count, sync_stride);
     rl_note_kernel("batch_assemble_kernel");
     RL_LAUNCH_CHECK("rl_batch_assemble");
     return RL_OK;

@@ -2573,6 +2573,7 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
             VFWD(110, 1, 3, 1, false) VFWD(111, 1, 3, 1, true) VFWD(112, 1, 3, 2, false)
             VFWD(120, 2, 3, 1, false) VFWD(121, 2, 3, 1, true) VFWD(122, 2, 3, 2, false)
             VFWD(140, 4, 3, 1, false) VFWD(141, 4, 3, 1, true) VFWD(142, 4, 3, 2, false)
+            default: RL_REQUIRE(false, RL_ERR_UNSUPPORTED, "rl_pool_fwd: no virtual kernel for d %d, source %d (key %d)", p.d, p.src, key);
         }
 #undef VFWD
         rl_note_kernel("vpool_fwd_kernel");
@@ -2630,6 +2631,7 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
             VBWD4(0, 0, false)
             VBWD4(100, 3, false)
             VBWD4(200, 3, true)
+            default: RL_REQUIRE(false, RL_ERR_UNSUPPORTED, "rl_pool_bwd: no virtual kernel for d %d, source %d (key %d)", p.d, p.src, key);
         }
 #undef VBWD4
 #undef VBWD
@@ -2693,6 +2695,7 @@ extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) 
     switch (key) {
         VST(11, 1, 0, 1) VST(12, 1, 0, 2) VST(21, 2, 0, 1) VST(22, 2, 0, 2) VST(41, 4, 0, 1) VST(42, 4, 0, 2)
         VST(111, 1, 3, 1) VST(112, 1, 3, 2) VST(121, 2, 3, 1) VST(122, 2, 3, 2) VST(141, 4, 3, 1) VST(142, 4, 3, 2)
+        default: RL_REQUIRE(false, RL_ERR_UNSUPPORTED, "rl_rpe_stats: no kernel for d %d, source %d (key %d)", p.d, p.src, key);
     }
 #undef VST
     rl_note_kernel("vrpe_stats_kernel");
@@ -2739,6 +2742,7 @@ static int rpe_bwd_fill(RpeBwdParams* q, const rl_pool_desc* d, const float* G, 
             RPE_CASE(KERNEL, 211, 1, 3, 1, true, grid, st, q) RPE_CASE(KERNEL, 212, 1, 3, 2, true, grid, st, q)     \
             RPE_CASE(KERNEL, 221, 2, 3, 1, true, grid, st, q) RPE_CASE(KERNEL, 222, 2, 3, 2, true, grid, st, q)     \
             RPE_CASE(KERNEL, 241, 4, 3, 1, true, grid, st, q) RPE_CASE(KERNEL, 242, 4, 3, 2, true, grid, st, q)     \
+            default: RL_REQUIRE(false, RL_ERR_UNSUPPORTED, "rpe backward: no kernel for d %d, source %d (key %d)", (q).pp.d, (q).pp.src, key_); \
         }                                                                                                          \
     } while (0)
 #define RPE_CASE(KERNEL, K, DT, TERMS, SRC, GB, grid, st, q) \

@@ -79,7 +79,10 @@ class Engine:
         self.P = params      # reference state_dict names -> tensors (parameters)
         self.Bf = buffers    # running_mean / running_var / num_batches_tracked
         self._side: Optional[torch.cuda.Stream] = None   # weight gradients run beside the dgrad chain
-        self._eval_spec = None          # eval mode: the BatchNorm layers of a forward (name -> (C, folded conv bias)), see _fold
+        # eval mode: the BatchNorm layers of a forward (name -> (C, folded conv bias)), see _fold - one table per SIGNATURE of the
+        # forward (which levels run the virtual rpe branch: it folds mlp_rpe1/2's BatchNorm without the conv bias, the stored
+        # branch with it, and which one a level takes depends on the batch's shape)
+        self._eval_specs: Dict[tuple, dict] = {}
         self._eval_spec_build = {}
         # Dropout(fc_end): Philox mask keyed by (seed, pass counter); the counter lives on the device so that captured
         # graphs draw a new mask per replay.  The seed comes from torch's seed WITHOUT consuming its random stream.
@@ -111,8 +114,9 @@ class Engine:
         if not ctx.training:
             pre = getattr(ctx, "eval_folds", None)
             if pre is not None and bn_name in pre:
-                scale, shift = pre[bn_name]
-                return scale, shift, None, None
+                scale, shift, spec_C, spec_fb = pre[bn_name]
+                if spec_C == C and spec_fb is folded_bias:          # (a fold made for another path is not this layer's fold)
+                    return scale, shift, None, None
             self._eval_spec_build[bn_name] = (C, folded_bias)
         nbt = self.Bf.get(f"{bn_name}.num_batches_tracked")
         return ops.bn_finalize(
@@ -121,14 +125,14 @@ class Engine:
             nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, folded_bias=folded_bias,
             nslots=nslots, defer=getattr(ctx, "bn_defer", None), pivoted=ctx.training and BN_PIVOT)
 
-    def _eval_folds(self):
+    def _eval_folds(self, spec: dict):
         """(scale, shift) of every BatchNorm layer from the running statistics, as grouped launches."""
         lst, out = [], {}
-        for bn_name, (C, fb) in self._eval_spec.items():
+        for bn_name, (C, fb) in spec.items():
             scale, shift, _, _ = ops.bn_finalize(
                 None, 1, 128, C, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"], self.Bf[f"{bn_name}.running_mean"],
                 self.Bf[f"{bn_name}.running_var"], None, BN_MOMENTUM, BN_EPS, False, folded_bias=fb, nslots=1, defer=lst)
-            out[bn_name] = (scale, shift)
+            out[bn_name] = (scale, shift, C, fb)
         ops.bn_finalize_flush(lst)
         return out
 
@@ -278,10 +282,12 @@ class Engine:
         ctx.training, ctx.B, ctx.N, ctx.perm = training, B, N, perm
         L, dec = len(self.layers), self.dec
         ctx.eval_folds = None
+        ctx.eval_sig = tuple(ops.virtual_rpe_supported(d, self.K, B * (N // dec ** l), N // dec ** l) for l, d in enumerate(self.layers))
         if not training:
             self._eval_spec_build = {}
-            if self._eval_spec is not None and self.sync is None and not ops.NO_BN_BATCH:
-                ctx.eval_folds = self._eval_folds()
+            spec = self._eval_specs.get(ctx.eval_sig)
+            if spec is not None and self.sync is None and not ops.NO_BN_BATCH:
+                ctx.eval_folds = self._eval_folds(spec)
 
         # wide layers: bf16 head / tail planes of their weights, both orientations, in one launch (the weights change every step)
         ctx.wsplit = ops.split_weights(self._wide_weight_uses(training))
@@ -386,7 +392,7 @@ class Engine:
         lp = self._mlp(ctx, x, "fc_end.3", self.C, bn=False)
         ctx.logits_perm = lp
         if not training and ctx.eval_folds is None and self._eval_spec_build:
-            self._eval_spec = dict(self._eval_spec_build)        # (the next eval forward folds all of them up front)
+            self._eval_specs[ctx.eval_sig] = dict(self._eval_spec_build)        # (the next eval forward of this signature folds all of them up front)
         logits = ops.logits_unpermute(lp.raw, perm, B, N, out=logits_out)
         return logits, ctx
 
@@ -515,7 +521,9 @@ class Engine:
                                             grads[bname] if bname else None, pending=ctx.pending, batch=ctx.wbatch), G)
         halves = getattr(a, "concat", None) if (a_grad and isinstance(a, Lazy)) else None
         if (halves is not None and not ops.NO_SPLIT_SCATTER and (n_out > 64 or a.C > 64) and id(a.raw) not in ctx.grads
-                and halves[1].bstride == halves[1].n and halves[1].raw.shape[0] == a.rows and not self._gbuf(ctx, halves[1])[1]):
+                and halves[1].bstride == halves[1].n and halves[1].raw.shape[0] == a.rows
+                and halves[1].raw.shape[1] == halves[1].C and halves[0].C % 4 == 0      # out2 is addressed as a dense (rows, skip.C) tensor
+                and not ctx.grads.get(id(halves[1].raw), (None, False))[1]):
             # the decoder's concat [interpolated | skip] (modules.py:362): its gradient leaves the dgrad GEMM in two pieces - the
             # interpolated half to a dense tensor (summed per coarse point by the record behind this one), the skip half
             # straight into the skip tensor's gradient, whose FIRST writer this is (the encoder's own contributions follow) -

@@ -107,16 +107,6 @@ class TrainState:
         self.exp_avg_sq = torch.zeros_like(self.flat.param)
         self.lr = torch.tensor([lr], dtype=torch.float32, device=self.dev)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        # TEST-ONLY (RL_ZERO_BN_BIAS_GRADS=1, tests/test_model_gpu.py): the gradients whose true value is exactly 0 - conv biases
-        # in front of a BatchNorm - are set to 0 before every Adam step, as tests/golden/drift_probe.py does to the reference
-        self.grad_mask: Optional[torch.Tensor] = None
-        if int(__import__("os").environ.get("RL_ZERO_BN_BIAS_GRADS", "0")):
-            mask = torch.ones_like(self.flat.grad)
-            for name, g in self.flat.grads.items():
-                if name.endswith("conv.bias") and not name.startswith("fc_end.3"):
-                    off = (g.data_ptr() - self.flat.grad.data_ptr()) // 4
-                    mask[off:off + g.numel()] = 0.0
-            self.grad_mask = mask
 
     def set_lr(self, lr: float) -> None:
         self.lr.fill_(float(lr))
@@ -195,8 +185,6 @@ class TrainStep:
             self.engine.drop_stream = stream
 
     def _adam(self):
-        if self.state.grad_mask is not None:          # test-only, see TrainState
-            self.flat.grad.mul_(self.state.grad_mask)
         # per-rank losses are averaged (grad / world); the equivalence mode's loss is already the global one (grad summed)
         ops.adam_step(self.flat.param, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.step_count,
                       grad_scale=1.0 if self.sync is not None else 1.0 / self.world)

@@ -195,7 +195,7 @@ class DeviceDataLoader:
                 H.check(H.lib().rl_batch_draw(jobs_dev.data_ptr(), B, n, (self._seed << 32) | (self._draws & 0xFFFFFFFF),
                                               indices.data_ptr() if want_idx else None, H.ptr(noise),
                                               torch.cuda.current_stream(dev).cuda_stream), "rl_batch_draw")
-        scratch = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
+        scratch = torch.empty(H.lib().rl_batch_assemble_scratch_doubles(B, n), dtype=torch.float64, device=dev)
         inp = torch.empty((B, n, 3 + F), dtype=torch.float32, device=dev)
         lab = torch.empty((B, n), dtype=torch.int64, device=dev)
         H.check(H.lib().rl_batch_assemble(jobs_dev.data_ptr(), B, n, F, indices.data_ptr(), H.ptr(noise),

@@ -630,7 +630,12 @@ int rl_rpe_build_dist(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_
  * where the reference does (dataset.py:51).  One rl_cloud_job per cloud, array in DEVICE memory.
  *   indices (B,n) int64: rows of the source cloud to take (preprocessing.sample_points, :35-62)
  *   noise   (B,n,3) float64 standard-normal draws for the jitter, or NULL (no jitter)
- *   scratch (B,n,3) float64 work space
+ *   scratch rl_batch_assemble_scratch_doubles(B, n) float64 of work space ((B,n,3) coordinates + the records / arrival
+ *           counters of the cloud-wide sums; any content - the call resets what it needs; one scratch per concurrent call)
+ * Up to 16 workgroups share a cloud and meet at an arrival-counter barrier per cloud-wide sum; their number is sized so that
+ * a launch fits the device at once (occupancy calculator, per device), and the wait is BOUNDED: a workgroup whose peers do not
+ * arrive within ~1 s (a CU mask or partition mode the attribute does not show) gives up and writes NaN coordinates for its
+ * share of the cloud instead of hanging the GPU.  RL_ASSEMBLE_ONE_WG=1 forces one workgroup per cloud (no rendezvous).
  *   out_input (B,n,3+F) float32 = [xyz, features], out_labels (B,n) int64                       */
 typedef struct rl_cloud_job {
     const void* xyz;          /* (n_points,3) float32, or float64 when xyz_f64 != 0 */
@@ -647,6 +652,7 @@ typedef struct rl_cloud_job {
     double shift[3];          /* np.random.uniform(-shift_limit, shift_limit, 3), before the radius factor */
 } rl_cloud_job;
 
+int64_t rl_batch_assemble_scratch_doubles(int B, int n);
 int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int F, const int64_t* indices,
                       const double* noise, double* scratch, float* out_input, int64_t* out_labels,
                       void* stream);

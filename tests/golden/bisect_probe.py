@@ -183,10 +183,19 @@ def main():
     ap.add_argument("--worker", default=None)
     ap.add_argument("--tag", default=None, help="file name under bisect/ (default: the variant)")
     ap.add_argument("--report", action="store_true")
+    ap.add_argument("--export", action="store_true",
+                    help="write tests/golden/train_seeds_denoised_256.npz: the de-noised reference's histories over 256 seeds, "
+                         "two draws (bisect/base.npz: 1 thread per process, bisect/base_t2.npz: 2 threads)")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.report:
         return report()
+    if a.export:
+        d1, d2 = np.load(os.path.join(OUT, "base.npz")), np.load(os.path.join(OUT, "base_t2.npz"))
+        assert np.array_equal(d1["seeds"], d2["seeds"]) and np.array_equal(d1["seeds"], np.arange(len(d1["seeds"])))
+        np.savez_compressed(os.path.join(HERE, "train_seeds_denoised_256.npz"), seeds=d1["seeds"],
+                            histories=np.stack([d1["histories"], d2["histories"]]))
+        return
     first, last = (int(v) for v in a.seeds.split(":"))
     if a.worker is not None:
         h = run_seeds(a.variant, first, last, a.threads)

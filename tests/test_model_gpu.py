@@ -216,43 +216,63 @@ def test_miou_parity_over_seeds(golden_dir):
     np.testing.assert_allclose(hip_h[:, :, 0].mean(0), ref_h[:, :, 0].mean(0), atol=0.01)
 
 
+def _freeze_zero_gradient_biases(monkeypatch):
+    """Test-only: the gradients whose true value is exactly 0 - conv biases in front of a BatchNorm - are set to 0 before every
+    Adam step of every TrainStep, as tests/golden/drift_probe.py does to the reference (a mask multiplied into the flat gradient,
+    inside the captured step like any other launch of it)."""
+    from randlanet import _train as T
+    orig = T.TrainStep._adam
+
+    def adam(self):
+        mask = getattr(self.state, "_test_grad_mask", None)
+        if mask is None:
+            mask = torch.ones_like(self.flat.grad)
+            for name, g in self.flat.grads.items():
+                if name.endswith("conv.bias") and not name.startswith("fc_end.3"):
+                    off = (g.data_ptr() - self.flat.grad.data_ptr()) // 4
+                    mask[off:off + g.numel()] = 0.0
+            self.state._test_grad_mask = mask
+        self.flat.grad.mul_(mask)
+        orig(self)
+    monkeypatch.setattr(T.TrainStep, "_adam", adam)
+
+
 def test_denoised_training_matches_denoised_reference(golden_dir, monkeypatch):
     """The explanation of the +0.02 validation-mIoU offset of test_miou_parity_over_seeds, tested from the HIP side: with
     EXACTLY the gradients zeroed that tests/golden/drift_probe.py zeroes in the reference (conv biases in front of a BatchNorm:
-    true gradient 0; RL_ZERO_BN_BIAS_GRADS=1, a test-only switch of TrainState), the HIP path on seeds 0-63 must agree with the
-    de-noised reference (train_seeds_denoised.npz) - two-sided, paired by seed - for the final / best / last-three validation
-    mIoU, and the training loss must stay where it was.
+    true gradient 0; _freeze_zero_gradient_biases), the HIP path must agree with the de-noised reference - two-sided, paired by
+    seed, within max(0.1 pt, 2 standard errors) - for the final / best / last-three validation mIoU, and the training loss must
+    stay where it was.
 
-    What "agree" can mean here.  A run is chaotic in the last bit of any kernel, so every change of a summation order or of
-    the arithmetic mode re-draws the 64 HIP outcomes against the SAME 64 reference outcomes.  Four such draws of round 4
-    (paired difference of final / best / last-3, in mIoU; one standard error is 0.009 / 0.006 / 0.007):
-        bf16x3, BatchNorm backward of small tensors as three launches   -0.0067 / -0.0114 / -0.0111
-        bf16x3, as one launch (rl_bn_bwd_fused)                         -0.0221 / -0.0209 / -0.0135
-        fp32 products, one launch                                       -0.0065 / -0.0084 / -0.0113
-        fp32 products, three launches                                   -0.0113 / -0.0200 / -0.0107
-    i.e. an offset of -0.012 ... -0.015 (HIP BELOW the de-noised reference by 1.3 +- 0.5 points; the plain runs sit 2 points ABOVE
-    the plain reference), whatever the arithmetic: removing the bias-gradient noise explains the sign of the training-run drift
-    and over-explains its size by about a point, which 64 seeds resolve at 2.5 sigma and no more.  A window of 2 standard errors
-    around zero (the first form of this test) therefore rejects most builds, one of 3 every third: the assertion is the
-    two-sided bound the data support, |difference| <= 3 points, with the draws above on record."""
-    monkeypatch.setenv("RL_ZERO_BN_BIAS_GRADS", "1")
-    den = np.load(f"{golden_dir}/train_seeds_denoised.npz")
-    den_h, seeds = den["histories"], den["seeds"]
+    Round 4 ran this over seeds 0-63 against ONE 64-seed draw of the reference (train_seeds_denoised.npz) and read -1.3 +- 0.5
+    points off four HIP draws.  Round 5 measured the NULL distribution on the CPU (tests/golden/bisect_probe.py): the de-noised
+    REFERENCE against ITSELF - same seeds, another summation order (1 / 2 / 8 threads) - differs by -1.4 ... +2.2 points over a
+    64-seed block (7 blocks; one of them "3.2 sigma"): a run is chaotic in the last bit, 64 seeds resolve nothing below ~1.5
+    points, and the four round-4 draws shared one reference draw.  So: 256 seeds, the reference as the per-seed mean of TWO
+    draws (train_seeds_denoised_256.npz; between themselves -0.0004 / +0.0048 / +0.0037 +- 0.0045), bound 2 SE of the paired
+    difference (~0.8 points).  The two reference draws' own difference is printed beside the HIP one."""
+    _freeze_zero_gradient_biases(monkeypatch)
+    den = np.load(f"{golden_dir}/train_seeds_denoised_256.npz")
+    draws, seeds = den["histories"], den["seeds"]                  # (2, S, 6, 4): loss, mIoU, val_loss, val_mIoU
     hip_h = np.stack([_mock_training_run(golden_dir, int(s))[2] for s in seeds])
 
     def stat(h):
         v = h[:, :, 3]
         return {"final": v[:, -1], "best": v.max(1), "last3": v[:, -3:].mean(1)}
-    r, g = stat(den_h), stat(hip_h)
+    r1, r2, g = stat(draws[0]), stat(draws[1]), stat(hip_h)
     S = len(seeds)
     worst = []
     for key in ("final", "best", "last3"):
-        diff = g[key] - r[key]
+        ref = 0.5 * (r1[key] + r2[key])
+        diff = g[key] - ref
         dse = diff.std(ddof=1) / np.sqrt(S)
-        print(f"val mIoU [{key}] de-noised: reference {r[key].mean():.4f} +- {r[key].std(ddof=1):.4f}, hip {g[key].mean():.4f} +- "
-              f"{g[key].std(ddof=1):.4f}; paired difference {diff.mean():+.4f} (SE {dse:.4f}, {diff.mean() / dse:+.2f} sigma)")
+        null = r1[key] - r2[key]
+        print(f"val mIoU [{key}] de-noised, {S} seeds: reference {ref.mean():.4f} (draws {r1[key].mean():.4f} / {r2[key].mean():.4f}, their "
+              f"difference {null.mean():+.4f} +- {null.std(ddof=1) / np.sqrt(S):.4f}), hip {g[key].mean():.4f} +- {g[key].std(ddof=1):.4f}; "
+              f"paired difference {diff.mean():+.4f} (SE {dse:.4f}, {diff.mean() / dse:+.2f} sigma)")
         worst.append((key, diff.mean(), dse))
     for key, d, dse in worst:
-        assert abs(d) <= 0.03, (key, d, dse)
-    np.testing.assert_allclose(hip_h[:, 0, 0], den_h[:, 0, 0], atol=5e-3)
-    np.testing.assert_allclose(hip_h[:, :, 0].mean(0), den_h[:, :, 0].mean(0), atol=0.01)
+        assert abs(d) <= max(1e-3, 2 * dse), (key, d, dse)
+    ref_loss = 0.5 * (draws[0][:, :, 0] + draws[1][:, :, 0])
+    np.testing.assert_allclose(hip_h[:, 0, 0], ref_loss[:, 0], atol=5e-3)
+    np.testing.assert_allclose(hip_h[:, :, 0].mean(0), ref_loss.mean(0), atol=0.01)

@@ -193,3 +193,54 @@ def test_bad_arguments_fail_loudly():
         DeviceDataLoader(ds, 8, 1, device="cpu")
     with pytest.raises(AssertionError):
         DeviceDataLoader([(np.zeros((10, 2), np.float32), np.zeros((10, 0), np.float32), np.zeros(10, np.int64))], 8, 1, device="cuda")
+
+
+def test_loader_beside_a_replaying_train_step():
+    """rl_batch_assemble shares a cloud between up to 16 workgroups that meet at an arrival-counter barrier (bounded spin);
+    its records / counters live in the call's own scratch.  Here the device-rng loader runs on a stream of
+    its own BESIDE a replaying TrainStep graph (persistent wide-GEMM workgroups with 152 KB of LDS per CU hold the CUs the
+    loader's workgroups want): 48 batches, every one equal to the batch a serial pass of an identically seeded loader gives."""
+    from randlanet import AugmentationSettings
+    from randlanet._train import TrainStep
+    from randlanet.utils.device_dataset import DeviceDataLoader
+    from randlanet.utils.modules import RandLANet, RandLANetSettings
+    rs = np.random.RandomState(3)
+    n_src, n, B = 9000, 8192, 4
+    ds = [(rs.rand(n_src, 3).astype(np.float32), np.zeros((n_src, 0), np.float32), rs.randint(0, 2, n_src).astype(np.int64))
+          for _ in range(16)]
+    aug = AugmentationSettings()
+
+    def loader():
+        np.random.seed(11)
+        torch.manual_seed(11)
+        return DeviceDataLoader(ds, n, B, shuffle=True, consistent_sampling=False, augmentation_settings=aug, device="cuda", rng="device")
+
+    serial = []
+    ld = loader()
+    for _ in range(12):
+        for inp, lab, _ids in ld:
+            serial.append((inp.cpu(), lab.cpu()))
+    torch.manual_seed(0)
+    net = RandLANet(RandLANetSettings(n_classes=2, n_points=n, n_neighbors=16, layer_sizes=[16, 64, 128, 256]), torch.device("cuda"))
+    step = TrainStep(net, B, n)
+    step.capture()
+    from randlanet import _hip as H
+    side = torch.cuda.Stream()
+    ld = loader()
+    got = []
+    for _ in range(12):
+        it = iter(ld)
+        while True:
+            perm = np.random.RandomState(len(got)).permutation(n)      # (not from the global stream: the loader draws from it)
+            step.step(perm)                                # main stream: one replay of the step graph
+            step.step(perm)
+            with torch.cuda.stream(side):                  # the loader's launches beside it
+                try:
+                    inp, lab, _ids = next(it)
+                except StopIteration:
+                    break
+                got.append((inp, lab))
+    torch.cuda.synchronize()
+    assert len(got) == len(serial) == 48
+    for (a, la), (b_, lb) in zip(got, serial):
+        assert torch.equal(a.cpu(), b_) and torch.equal(la.cpu(), lb)
