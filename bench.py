@@ -246,13 +246,22 @@ def roofline_pass(stepper, eager_steps=3):
                  launches_per_step=round(f["launches"], 1))
         e.update(function_roofline(fname, f))
         roof["by_function"].append(e)
+    # PMC traffic (profiles/pmc_traffic.json, rocprofv3 --pmc passes of the committed profile): keyed by "<function>|<op>" per
+    # LAUNCH SHAPE, so that the bytes printed here belong to the shape printed beside them; the ratio to that launch's
+    # algorithmic bytes, and the same ratio over all launches of the function ("<function>|*": sum PMC / sum algorithmic)
     pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            t = json.load(open(pmc)).get(roof["largest_shape"]["op"]) or json.load(open(pmc)).get(name)
-            if t is not None:
-                roof["traffic"] = t
+            table = json.load(open(pmc))
+            key = f"{name}|{roof['largest_shape']['op']}"
+            if key in table:
+                roof["traffic"] = table[key]
                 roof["traffic_shape"] = roof["largest_shape"]["op"]
+                roof["traffic_over_algorithmic"] = round(table[key] / max(big["bytes"], 1), 3)
+            tot = table.get(f"{name}|*")
+            if tot is not None:
+                roof["traffic_function_per_step"] = tot
+                roof["traffic_function_over_algorithmic"] = round(tot / max(top["bytes"], 1), 3)
         except Exception:
             pass
     roof["kernel_launches_per_step"] = round(kernel_launches, 1)
@@ -433,6 +442,35 @@ def trainer_e2e(dev, clouds=400, batch=4):
             os.environ.pop("RL_PIPELINE_RNG", None)
         torch.cuda.empty_cache()
     return out
+
+
+def train_py_setting(dev, steps=100, warmup=10):
+    """The setting the reference's own CLI trains with (reference train.py:50-59: n_points 2500, n_neighbors 32, batch 4,
+    2 classes, 4 layers): K = 32 takes the UN-FUSED path on every level (gather + score GEMM + softmax-pool kernels; the fused /
+    virtual tile kernels are written for 16 neighbours).  One replayed step graph, inputs resident in HBM."""
+    from randlanet._train import TrainStep
+    cfg = dict(n_points=2500, n_classes=2, n_neighbors=32, layer_sizes=[16, 64, 128, 256], per_gpu_batch=4)
+    m = build_model(dev, seed=0, cfg=cfg)
+    m.train()
+    B, N = cfg["per_gpu_batch"], cfg["n_points"]
+    st = TrainStep(m, B, N, loss="dice", lr=1e-2)
+    x, y = synthetic_batch(B, N, cfg["n_classes"], 99)
+    st.set_batch(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev))
+    st.capture()
+    for _ in range(warmup):
+        st.step(np.random.permutation(N))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.step(np.random.permutation(N))
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    m_ = st.last_metrics()
+    if not np.isfinite(m_["loss"]):
+        raise SystemExit("bench.py: the train.py-setting step produced a non-finite loss")
+    return {"workload": "reference train.py:50-59 setting: 2500 pts/cloud, K=32, bs=4, 2 classes, 4 layers (un-fused pooling path)",
+            "value": round(B * steps / dt, 1), "unit": "clouds/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "final_loss": round(m_["loss"], 5)}
 
 
 def predict_latency(reps=20, n_cloud=120000):
@@ -641,10 +679,11 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()             # every collective is done: the other ranks leave, rank 0 times the host path
-    callers_train = callers_predict = None
+    callers_train = callers_predict = train_py = None
     if rank == 0 and not args.no_callers:
         callers_train = trainer_e2e(dev)
         callers_predict = predict_latency()
+        train_py = train_py_setting(dev)
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
@@ -687,8 +726,33 @@ def main():
             "per_gpu_batch_sweep": sweep,
             "trainer_e2e": callers_train,
             "predict_P": callers_predict,
+            "train_py_setting": train_py,
             "inference": infer,
         }
+        # the side objects once more as FLAT scalars / strings (the driver's parser keeps top-level scalars only)
+        flat = {
+            "fp32_exact_value": fp32_exact["value"] if fp32_exact else None,
+            "bf16_operands_value": bf16_ops["value"] if bf16_ops else None,
+            "bf16_storage_value": bf16_storage["value"] if bf16_storage else None,
+            "config_A_value": config_a["value"] if config_a else None,
+            "config_S_value": config_s["value"] if config_s else None,
+            "config_Kt_shard_value": config_kt["value"] if config_kt else None,
+            "trainer_e2e_device_value": callers_train["rng_device"]["value"] if callers_train else None,
+            "trainer_e2e_numpy_value": callers_train["rng_numpy"]["value"] if callers_train else None,
+            "predict_P_ms": callers_predict["value"] if callers_predict else None,
+            "train_py_setting_value": train_py["value"] if train_py else None,
+            "inference_value": infer["value"] if infer else None,
+            "fixed_ms_per_step": sweep.get("fixed_ms_per_step") if sweep else None,
+            "marginal_ms_per_cloud": sweep.get("marginal_ms_per_cloud") if sweep else None,
+            "kernel_launches_per_step": roof.get("kernel_launches_per_step") if roof else None,
+            "whole_step_frac": roof["whole_step"]["frac"] if roof and roof.get("whole_step") else None,
+            "roofline_frac": roof.get("frac") if roof else None,
+            "roofline_kernel": roof.get("kernel") if roof else None,
+            "by_function_top3": "; ".join(f"{e['kernel']} {e['ms_per_step']:.3f} ms ({e['frac']:.2f} of {e['bound']})"
+                                          for e in roof["by_function"][:3]) if roof and roof.get("by_function") else None,
+            "cpu_baseline_value": cpu["value"] if cpu else None,
+        }
+        line.update(flat)
         if breakdown is not None:
             os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
             with open(os.path.join(REPO, "gpurun_out", f"bench_breakdown_n{world}.json"), "w") as f:

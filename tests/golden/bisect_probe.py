@@ -185,16 +185,20 @@ def main():
     ap.add_argument("--report", action="store_true")
     ap.add_argument("--export", action="store_true",
                     help="write tests/golden/train_seeds_denoised_256.npz: the de-noised reference's histories over 256 seeds, "
-                         "two draws (bisect/base.npz: 1 thread per process, bisect/base_t2.npz: 2 threads)")
+                         "two draws each (1 thread per process / 2 threads) of the variants base and fcstart")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.report:
         return report()
     if a.export:
         d1, d2 = np.load(os.path.join(OUT, "base.npz")), np.load(os.path.join(OUT, "base_t2.npz"))
-        assert np.array_equal(d1["seeds"], d2["seeds"]) and np.array_equal(d1["seeds"], np.arange(len(d1["seeds"])))
+        f1, f2 = np.load(os.path.join(OUT, "fcstart.npz")), np.load(os.path.join(OUT, "fcstart_t2.npz"))
+        for z in (d1, d2, f1, f2):
+            assert np.array_equal(z["seeds"], np.arange(len(d1["seeds"])))
+        # histories: conv biases in front of a BatchNorm frozen (drift_probe.py's protocol); histories_fcstart: fc_start.bias too
         np.savez_compressed(os.path.join(HERE, "train_seeds_denoised_256.npz"), seeds=d1["seeds"],
-                            histories=np.stack([d1["histories"], d2["histories"]]))
+                            histories=np.stack([d1["histories"], d2["histories"]]),
+                            histories_fcstart=np.stack([f1["histories"], f2["histories"]]))
         return
     first, last = (int(v) for v in a.seeds.split(":"))
     if a.worker is not None:

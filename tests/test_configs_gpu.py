@@ -222,15 +222,18 @@ def test_train_step_at_benchmark_size_matches_oracle_autograd(tag, C, N, K, laye
 # Gradient bounds per arithmetic mode.  "fp32" (exact fp32 products) is held to the 5e-3 of the parity contract.  The
 # default "bf16x3" carries ~2^-16 relative error per product, and these random-weight test points are ill-conditioned: in
 # the fp32 CPU oracle ITSELF a 1e-5 relative perturbation of the weights moves the logits by 4e-4 and the gradients by up
-# to 3.3 % (1e-6: 4e-5 and 0.13 %; measured at the K = 32 point below).  So bf16x3 gradients are bounded by 3e-2 of each
-# tensor's largest entry - the sensitivity of the function, not an arithmetic defect - while loss and logits keep 1e-5 / 1e-3.
-GRAD_BOUND = {"fp32": 5e-3, "bf16x3": 3e-2}
+# to 3.3 % (1e-6: 4e-5 and 0.13 %; measured at the K = 32 point below).  So bf16x3 gradients are bounded by 2e-2 of each
+# tensor's largest entry - the sensitivity of the function, not an arithmetic defect - while loss and logits keep 1e-5 / 1e-3
+# (round 5, BatchNorm statistics as shifted sums: worst measured 1.3e-2 - config S, B = 1 - down from a 3e-2 bound).
+GRAD_BOUND = {"fp32": 5e-3, "bf16x3": 2e-2}
 # ... and the same statement made properly, against an fp64 evaluation of the oracle (_yardstick): the multiple of the
 # yardstick's own distance from fp64 that a tensor's gradient may sit at.
-# Measured on the MI355X: fp32 mode <= 1.04 everywhere; bf16x3 <= 2.4 at the K = 32 point and <= 2.5 on config A except the
-# two BatchNorm weight gradients of level 2's residual junction (6.6 and 10.7: sums of 20480 x 256 products that cancel to
-# 2e-3 of their terms) - hence 16 there.
-YARD = {"fp32": 4.0, "bf16x3": 16.0}
+# Measured on the MI355X (round 5): bf16x3 <= 2.4 on config A and <= 1.9 at the K = 32 point - the two round-4 outliers
+# (BatchNorm weight gradients of level 2's residual junction at 6.6 / 10.7 x the yardstick, hence a bound of 16 then) are gone
+# with the shifted statistics; fp32 mode <= 3.0 (worst: fc_end.0.conv.weight; round 4: <= 1.04): these test points carry
+# RANDOM running means (oracle/init_formula.py), i.e. an arbitrary pivot up to ten standard deviations off the batch mean - in
+# a training run the pivot is the previous batch's mean.
+YARD = {"fp32": 4.0, "bf16x3": 6.0}
 WIDE_NOISE = 5e-6
 
 
