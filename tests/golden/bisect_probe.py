@@ -20,7 +20,9 @@ against the unmodified de-noised reference over the same seeds says whether that
 
 Usage:  python tests/golden/bisect_probe.py --variant base --seeds 0:256 [--procs 8] [--threads 1]
         python tests/golden/bisect_probe.py --report          (table of every stored variant against `base`)
-Results: tests/golden/bisect/<variant>.npz (seeds, histories (S, 6, 4): loss, mIoU, val_loss, val_mIoU).
+Results: tests/golden/bisect/<variant>.npz (seeds, histories (S, 6, 4): loss, mIoU, val_loss, val_mIoU); the fixtures of
+tests/test_model_gpu.py::test_denoised_training_matches_denoised_reference: --export (256 seeds, two draws of `base`) and
+--variant fcstart --seeds 0:4096 --fixture train_seeds_denoised_fc4096.npz (one draw; ~25 minutes on 8 cores).
 """
 import argparse
 import os
@@ -185,20 +187,20 @@ def main():
     ap.add_argument("--report", action="store_true")
     ap.add_argument("--export", action="store_true",
                     help="write tests/golden/train_seeds_denoised_256.npz: the de-noised reference's histories over 256 seeds, "
-                         "two draws each (1 thread per process / 2 threads) of the variants base and fcstart")
+                         "two draws (bisect/base.npz: 1 thread per process, bisect/base_t2.npz: 2 threads)")
+    ap.add_argument("--fixture", default=None,
+                    help="write the merged histories (float32) as tests/golden/<name> instead of bisect/<tag>.npz; "
+                         "train_seeds_denoised_fc4096.npz = --variant fcstart --seeds 0:4096 --fixture train_seeds_denoised_fc4096.npz")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.report:
         return report()
     if a.export:
         d1, d2 = np.load(os.path.join(OUT, "base.npz")), np.load(os.path.join(OUT, "base_t2.npz"))
-        f1, f2 = np.load(os.path.join(OUT, "fcstart.npz")), np.load(os.path.join(OUT, "fcstart_t2.npz"))
-        for z in (d1, d2, f1, f2):
+        for z in (d1, d2):
             assert np.array_equal(z["seeds"], np.arange(len(d1["seeds"])))
-        # histories: conv biases in front of a BatchNorm frozen (drift_probe.py's protocol); histories_fcstart: fc_start.bias too
         np.savez_compressed(os.path.join(HERE, "train_seeds_denoised_256.npz"), seeds=d1["seeds"],
-                            histories=np.stack([d1["histories"], d2["histories"]]),
-                            histories_fcstart=np.stack([f1["histories"], f2["histories"]]))
+                            histories=np.stack([d1["histories"], d2["histories"]]))
         return
     first, last = (int(v) for v in a.seeds.split(":"))
     if a.worker is not None:
@@ -218,10 +220,13 @@ def main():
     rc = [p.wait() for p in procs]
     assert not any(rc), rc
     zs = [np.load(p) for p in parts]
-    np.savez_compressed(os.path.join(OUT, f"{a.tag or a.variant}.npz"), seeds=np.concatenate([z["seeds"] for z in zs]),
-                        histories=np.concatenate([z["histories"] for z in zs]))
+    seeds, hist = np.concatenate([z["seeds"] for z in zs]), np.concatenate([z["histories"] for z in zs])
     for p in parts:
         os.remove(p)
+    if a.fixture:
+        np.savez_compressed(os.path.join(HERE, a.fixture), seeds=seeds, histories=hist.astype(np.float32))
+        return
+    np.savez_compressed(os.path.join(OUT, f"{a.tag or a.variant}.npz"), seeds=seeds, histories=hist)
     report()
 
 
