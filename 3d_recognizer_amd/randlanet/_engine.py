@@ -68,6 +68,17 @@ class Context:
         self.logits_perm: Optional[Lazy] = None
 
 
+class Prep:
+    """The coordinate-only part of a forward (Engine.prepare)."""
+
+    def __init__(self):
+        self.B = self.N = 0
+        self.training = False
+        self.inp_p = self.xyz = self.xyz4 = None
+        self.searches = self.csrs = None
+        self.csr_ready = None
+
+
 class Engine:
     def __init__(self, layer_sizes, n_neighbors: int, decimation: int, n_classes: int, n_features: int,
                  params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor]):
@@ -269,10 +280,74 @@ class Engine:
         L = len(self.layers)
         return max(self.K * self.dec ** (L - 1), 2 * self.dec ** L)       # modules.py:488-491
 
+    def prepare(self, inp: torch.Tensor, perm: torch.Tensor, training: bool) -> "Prep":
+        """Everything of a forward that depends on the INPUT ROWS AND THE PERMUTATION ALONE - no weight, no activation: the
+        permuted rows (modules.py:571-573), every neighbour search of the pass (the K-NN of the L encoder levels, modules.py:309,
+        and the 1-NN of the L decoder steps, modules.py:358, as one batch), the padded coordinates, and - training - the transpose
+        of every neighbour graph.  A caller may run this ahead of / beside the network (`_train.TrainStep`: as its own graph on a
+        second stream, under the previous step's kernels) and hand the result to forward(prep=...)."""
+        B, N, cin = inp.shape
+        assert cin == 3 + self.F and inp.dtype == torch.float32 and inp.is_cuda and inp.is_contiguous()
+        assert perm.dtype == torch.int64 and perm.numel() == N and perm.is_cuda
+        assert N >= self.min_points()
+        dev = inp.device
+        L, dec = len(self.layers), self.dec
+        prep = Prep()
+        prep.B, prep.N, prep.training = B, N, training
+        # random permutation of the rows (modules.py:571-573), once, on the input
+        inp_p = torch.empty((B * N, cin), dtype=torch.float32, device=dev)
+        ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=perm, index_shared=True)
+        if cin == 3:
+            xyz = inp_p.view(B, N, 3)
+        else:
+            xyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+            ops.copy_rows(inp_p, (0, 3), N, xyz.view(B * N, 3), (0, 3), B * N, N)
+        prep.inp_p, prep.xyz = inp_p, xyz
+
+        # every neighbour search of this forward depends on the coordinates only: the K-NN of the L encoder
+        # levels (modules.py:309) and the 1-NN of the L decoder steps (modules.py:358) go out as one batch
+        tasks, ratio = [], 1
+        for _ in self.layers:
+            tasks.append((N // ratio, N // ratio, self.K))
+            ratio *= dec
+        for _ in self.layers:
+            tasks.append((N // ratio, dec * N // ratio, 1))
+            ratio //= dec
+        searches = ops.knn_multi(xyz, tasks)
+        # coordinates padded to 16 bytes for the kernels that gather them per neighbour (virtual rpe branch)
+        xyz4 = None
+        if any(ops.virtual_rpe_supported(d, self.K, B * (N // dec ** l), N // dec ** l) for l, d in enumerate(self.layers)):
+            xyz4 = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+            ops.copy_rows(xyz.view(B * N, 3), (0, 3), N, xyz4.view(B * N, 4), (0, 3), B * N, N)
+        prep.xyz4, prep.searches = xyz4, searches
+        # training: the transpose of every neighbour graph ("who gathered from me"), so that the gathers' backward sums
+        # each destination row in a fixed order (bitwise reproducible steps; torch's scatter_add_ has no defined order)
+        csrs = [None] * (2 * L)
+        prep.csr_ready = None
+        if training and CSR_SIDE_STREAM:
+            # only the backward needs the transposes, and they depend on the neighbour indices alone: built on a second
+            # stream beside the forward (ONE fork here, ONE join at the top of backward - two graph edges, not two per layer)
+            main = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self._side.wait_event(fork)
+            with torch.cuda.stream(self._side):
+                csrs = ops.csr_build([(searches[i][0], tasks[i][0]) for i in range(2 * L)])
+                prep.csr_ready = torch.cuda.Event()
+                prep.csr_ready.record(self._side)
+        elif training:
+            csrs = ops.csr_build([(searches[i][0], tasks[i][0]) for i in range(2 * L)])
+        prep.csrs = csrs
+        return prep
+
     def forward(self, inp: torch.Tensor, perm: torch.Tensor, training: bool, dropout_p: float = 0.5,
-                keep_mask: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None):
+                keep_mask: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None,
+                prep: Optional["Prep"] = None):
         """inp (B,N,3+F) fp32 on the device, perm (N,) int64 on the device -> logits (B,C,N), ctx.
-        keep_mask (B*N, 32) uint8: an explicit Dropout mask (parity tests); by default the mask is generated in the kernel."""
+        keep_mask (B*N, 32) uint8: an explicit Dropout mask (parity tests); by default the mask is generated in the kernel.
+        prep: the result of prepare(inp, perm, training) when the caller has run it already (same inp / perm contents)."""
         B, N, cin = inp.shape
         assert cin == 3 + self.F and inp.dtype == torch.float32 and inp.is_cuda and inp.is_contiguous()
         assert perm.dtype == torch.int64 and perm.numel() == N and perm.is_cuda
@@ -291,52 +366,16 @@ class Engine:
 
         # wide layers: bf16 head / tail planes of their weights, both orientations, in one launch (the weights change every step)
         ctx.wsplit = ops.split_weights(self._wide_weight_uses(training))
-        # random permutation of the rows (modules.py:571-573), once, on the input
-        inp_p = torch.empty((B * N, cin), dtype=torch.float32, device=dev)
-        ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=perm, index_shared=True)
-        if cin == 3:
-            xyz = inp_p.view(B, N, 3)
-        else:
-            xyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-            ops.copy_rows(inp_p, (0, 3), N, xyz.view(B * N, 3), (0, 3), B * N, N)
+        if prep is None:
+            prep = self.prepare(inp, perm, training)
+        assert prep.B == B and prep.N == N and prep.training >= training
+        inp_p, xyz, searches, csrs = prep.inp_p, prep.xyz, prep.searches, prep.csrs
         ctx.keep += [inp_p, xyz]
-
-        # every neighbour search of this forward depends on the coordinates only: the K-NN of the L encoder
-        # levels (modules.py:309) and the 1-NN of the L decoder steps (modules.py:358) go out as one batch
-        tasks, ratio = [], 1
-        for _ in self.layers:
-            tasks.append((N // ratio, N // ratio, self.K))
-            ratio *= dec
-        for _ in self.layers:
-            tasks.append((N // ratio, dec * N // ratio, 1))
-            ratio //= dec
-        searches = ops.knn_multi(xyz, tasks)
-        # coordinates padded to 16 bytes for the kernels that gather them per neighbour (virtual rpe branch)
-        xyz4 = None
-        if any(ops.virtual_rpe_supported(d, self.K, B * (N // dec ** l), N // dec ** l) for l, d in enumerate(self.layers)):
-            xyz4 = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
-            ops.copy_rows(xyz.view(B * N, 3), (0, 3), N, xyz4.view(B * N, 4), (0, 3), B * N, N)
-            ctx.keep.append(xyz4)
-        ctx.xyz4 = xyz4
-        # training: the transpose of every neighbour graph ("who gathered from me"), so that the gathers' backward sums
-        # each destination row in a fixed order (bitwise reproducible steps; torch's scatter_add_ has no defined order)
-        csrs = [None] * (2 * L)
-        ctx.csr_ready = None
-        if training and CSR_SIDE_STREAM:
-            # only the backward needs the transposes, and they depend on the neighbour indices alone: built on a second
-            # stream beside the forward (ONE fork here, ONE join at the top of backward - two graph edges, not two per layer)
-            main = torch.cuda.current_stream(dev)
-            if self._side is None:
-                self._side = torch.cuda.Stream(dev)
-            fork = torch.cuda.Event()
-            fork.record(main)
-            self._side.wait_event(fork)
-            with torch.cuda.stream(self._side):
-                csrs = ops.csr_build([(searches[i][0], tasks[i][0]) for i in range(2 * L)])
-                ctx.csr_ready = torch.cuda.Event()
-                ctx.csr_ready.record(self._side)
-        elif training:
-            csrs = ops.csr_build([(searches[i][0], tasks[i][0]) for i in range(2 * L)])
+        if prep.xyz4 is not None:
+            ctx.keep.append(prep.xyz4)
+        ctx.xyz4 = prep.xyz4
+        ctx.csr_ready = prep.csr_ready
+        prep.csr_ready = None
 
         # fc_start + bn_start (modules.py:565-566)
         x = self._linear(ctx, ops.plain(inp_p, B, N), "fc_start.weight", "fc_start.bias", 8, bn="bn_start.0",

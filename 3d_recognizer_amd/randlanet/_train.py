@@ -20,6 +20,12 @@ from . import _hip as H
 from . import _ops as ops
 
 _PERM_BY_KERNEL = os.environ.get("RL_PERM_MEMCPY", "0") != "1"      # A/B: hipMemcpyAsync for the step's permutation
+# The coordinate-only part of a step (permutation, neighbour searches, graph transposes: 0.55 of 6.7 ms at bs = 8) as its own graph
+# on a second stream, under the previous step's kernels (round 5).  Built, bit-identical - and measured: 6.73 -> 6.78 ms per step.
+# The kernel trace shows the preparation running on its own hardware queue beside two or three network kernels, and every one of
+# them stretching by what the other takes (grid_query 243 -> 293 - 326 us; 67.3 ms of kernel time in a 59.9 ms window): the
+# network's kernels already fill the chip, so OFF by default; RL_PREP_PIPELINE=1 / TrainStep(pipeline=True) turns it on.
+_PREP_PIPELINE = os.environ.get("RL_PREP_PIPELINE", "0") == "1"
 
 
 def _upload_perm(perm_dev: torch.Tensor, staging: torch.Tensor, N: int) -> None:
@@ -131,12 +137,18 @@ class TrainStep:
 
     def __init__(self, module, B: int, N: int, loss: str = "dice", lr: float = 1e-2, use_graph: bool = True,
                  process_group=None, world_size: int = 1, state: Optional[TrainState] = None,
-                 sync: Optional[ops.SyncGroup] = None, split_schedule: bool = False):
+                 sync: Optional[ops.SyncGroup] = None, split_schedule: bool = False, pipeline: Optional[bool] = None):
         """split_schedule: run the multi-rank schedule (forward + backward graph, gradient all-reduce, Adam graph) with ONE
         rank too - a one-rank RCCL group then exercises the collective path on a single GPU (tests/test_rccl_gpu.py).
         sync: the data-parallel EQUIVALENCE mode - BatchNorm batch statistics and the loss' class
         sums of the GLOBAL batch (all-reduced), gradients summed instead of averaged: N ranks on shards reproduce the
-        single-process step on the whole batch.  Eager launches only (collectives between kernels)."""
+        single-process step on the whole batch.  Eager launches only (collectives between kernels).
+        pipeline (graph mode; default OFF - measured neutral, see _PREP_PIPELINE; RL_PREP_PIPELINE=1): the part of a step that
+        depends on the input rows and the permutation alone (Engine.prepare: permuted rows, all neighbour searches, graph
+        transposes) is captured as its OWN graph and replayed on a second stream, so that step t's preparation runs under
+        step t - 1's network kernels (the host submits ahead of the GPU).  Two sets of its outputs alternate (and two
+        captures of the network graph, one per set): preparation t + 1 never writes what network t still reads.  Same
+        kernels, same order per stream: results are bit-identical to the unpipelined step (tests/test_net_gpu.py)."""
         self.state = state if state is not None else TrainState(module, lr, process_group, world_size)
         self.sync = sync
         if sync is not None:
@@ -168,15 +180,21 @@ class TrainStep:
         self.use_graph = use_graph
         self._g_main: Optional[torch.cuda.CUDAGraph] = None
         self._g_adam: Optional[torch.cuda.CUDAGraph] = None
+        # pipelined preparation: set k = step % 2 (its own permutation buffer, Engine.Prep, preparation graph, network graph)
+        self.pipeline = bool(use_graph and sync is None and (_PREP_PIPELINE if pipeline is None else pipeline))
+        self._sets: list = []
+        self._side: Optional[torch.cuda.Stream] = None
+        self._turn = 0
+        self._batch_ready: Optional[torch.cuda.Event] = None
 
     # -- the schedule ------------------------------------------------------------------------
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, perm: Optional[torch.Tensor] = None, prep=None):
         self.engine.sync = self.sync
         stream = self.engine.drop_stream
         if self.sync is not None:
             self.engine.drop_stream = 0     # one mask for the whole batch, sliced by sync.cloud_offset
         try:
-            logits, ctx = self.engine.forward(self.inp, self.perm, True, self.p_drop)
+            logits, ctx = self.engine.forward(self.inp, self.perm if perm is None else perm, True, self.p_drop, prep=prep)
             _, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True, out=self.out, sync=self.sync)
             dlogits = ops.loss_backward(logits, self.labels, self.kind, self.alpha, self.gamma, True, work, sync=self.sync)
             self.engine.backward(ctx, dlogits, self.flat.grads)
@@ -215,11 +233,14 @@ class TrainStep:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls count
-        self._g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_main, capture_error_mode="thread_local"):
-            self._fwd_bwd()
-            if not self.split:
-                self._adam()
+        if self.pipeline:
+            self._capture_pipeline()
+        else:
+            self._g_main = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_main, capture_error_mode="thread_local"):
+                self._fwd_bwd()
+                if not self.split:
+                    self._adam()
         if self.split:
             self._g_adam = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_adam, capture_error_mode="thread_local"):
@@ -228,15 +249,82 @@ class TrainStep:
         self.state.restore(snap)
         torch.cuda.synchronize(self.dev)
 
+    def _capture_pipeline(self) -> None:
+        """Two sets {permutation, preparation graph -> Engine.Prep, network graph reading that Prep}.  The preparation graphs are
+        captured on the side stream (their outputs live in their own graph pools: static addresses the network graphs bake in)."""
+        main = torch.cuda.current_stream(self.dev)
+        self._side = torch.cuda.Stream(self.dev)
+        self._sets = []
+        for k in range(2):
+            st = dict(perm=self.perm if k == 0 else self.perm.clone(), prep=None, g_prep=torch.cuda.CUDAGraph(),
+                      g_main=torch.cuda.CUDAGraph(), prep_done=None, main_done=None)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self.engine.prepare(self.inp, st["perm"], True)            # (allocator warm-up of this stream)
+                with torch.cuda.graph(st["g_prep"], stream=self._side, capture_error_mode="thread_local"):
+                    st["prep"] = self.engine.prepare(self.inp, st["perm"], True)
+                st["g_prep"].replay()                                       # valid contents for the capture pass below
+            main.wait_stream(self._side)
+            # (the two network graphs never run at the same time and keep nothing between steps: one memory pool for both)
+            pool = self._sets[0]["g_main"].pool() if k else None
+            with torch.cuda.graph(st["g_main"], pool=pool, capture_error_mode="thread_local"):
+                self._fwd_bwd(st["perm"], st["prep"])
+                if not self.split:
+                    self._adam()
+            self._sets.append(st)
+        self._g_main = self._sets[0]["g_main"]      # (what "a captured step exists" is asked of)
+
     def set_batch(self, inp: torch.Tensor, labels: torch.Tensor) -> None:
+        """The batch of the steps submitted from now on (current stream).  Pipelined mode: these copies sit behind every network
+        graph submitted so far - each of which waited for its own preparation - so no preparation still reads the old rows."""
         self.inp.copy_(inp, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
+        if self.pipeline:
+            self._batch_ready = torch.cuda.Event()
+            self._batch_ready.record(torch.cuda.current_stream(self.dev))
 
     def step(self, perm: np.ndarray) -> None:
         with torch.cuda.device(self.dev):
             self._step(perm)
 
+    def _step_pipelined(self, perm: np.ndarray) -> None:
+        """side stream:  [wait: the batch is there, network graph k of two steps ago is done]  permutation -> set k, preparation graph k
+        main stream:  [wait: preparation k]  network graph k  (all-reduce, Adam graph).
+        The host runs ahead of the GPU, so preparation k is submitted while network graph 1 - k of the previous step executes."""
+        main = torch.cuda.current_stream(self.dev)
+        st = self._sets[self._turn]
+        self._turn ^= 1
+        slot = self._perm_slot
+        self._perm_slot = (slot + 1) % len(self._perm_ring)
+        if self._perm_events[slot] is not None:
+            self._perm_events[slot].synchronize()
+        self._perm_ring_np[slot][:] = perm
+        # the side stream waits for exactly two things of the main stream: the batch (set_batch's copies) and the last reader of
+        # this set, network graph k of two steps ago - NOT for the previous step's network graph, which it is to run beside
+        if self._batch_ready is not None:
+            self._side.wait_event(self._batch_ready)
+        if st["main_done"] is not None:
+            self._side.wait_event(st["main_done"])
+        with torch.cuda.stream(self._side):
+            _upload_perm(st["perm"], self._perm_ring[slot], self.N)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._perm_events[slot] = ev
+            st["g_prep"].replay()
+            done = torch.cuda.Event()
+            done.record(self._side)
+        main.wait_event(done)
+        st["g_main"].replay()
+        st["main_done"] = torch.cuda.Event()
+        st["main_done"].record(main)
+        if self.split:
+            self._allreduce()
+            self._g_adam.replay()
+        self.out_host.copy_(self.out, non_blocking=True)
+
     def _step(self, perm: np.ndarray) -> None:
+        if self.pipeline and self._sets and self._g_main is not None:
+            return self._step_pipelined(perm)
         slot = self._perm_slot
         self._perm_slot = (slot + 1) % len(self._perm_ring)
         if self._perm_events[slot] is not None:
