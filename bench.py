@@ -210,10 +210,14 @@ def roofline_pass(stepper, eager_steps=3):
         stepper._g_main, stepper._g_adam = g_main, g_adam
     shapes = {}
     for cat, key, nbytes, flops, e0, e1, kern, lvl in records:
-        a = shapes.setdefault((kern, cat, key, lvl), dict(kernel=kern, category=cat, shape=key, times=[], bytes=nbytes, flops=flops, level=lvl))
+        a = shapes.setdefault((kern, cat, key, lvl), dict(kernel=kern, category=cat, shape=key, times=[], nb=[], fl=[], level=lvl))
         a["times"].append(e0.elapsed_time(e1))
+        a["nb"].append(nbytes)
+        a["fl"].append(flops)
     rows = []
     for a in shapes.values():
+        # (launches that share an op string - the two pooling stages of a level - differ in their algorithmic bytes: the mean)
+        a["bytes"], a["flops"] = float(np.mean(a["nb"])), float(np.mean(a["fl"]))
         per_launch = float(np.median(a["times"]))
         launches = len(a["times"]) / eager_steps
         rows.append(dict(kernel=a["kernel"], category=a["category"], shape=a["shape"], level=a["level"], ms_per_launch=per_launch,

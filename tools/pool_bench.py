@@ -75,5 +75,11 @@ def level(l, B=8, N=40960):
     print(f"level {l} (d = {d}, {B * n} points, storage {ops.get_storage()}): " + "  ".join(f"{k} {v:.0f} us" for k, v in out.items()), flush=True)
 
 
+# RL_BENCH_POINTS=p: p points per launch instead of the benchmark's (e.g. 5120 = one point per resident wavefront: what a launch
+# costs before its first point - the prologue that stages W and loads the per-lane constants)
 for l in ([int(a) for a in sys.argv[1:]] or [0, 1]):
-    level(l)
+    pts = int(os.environ.get("RL_BENCH_POINTS", "0"))
+    if pts:
+        level(l, 8, (pts // 8) * 4 ** l)
+    else:
+        level(l)
