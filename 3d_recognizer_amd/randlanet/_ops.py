@@ -950,7 +950,9 @@ def pool_fwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, sta
     pd.Pout = out.data_ptr()
     P = u.B * n
     virt = isinstance(u, VirtualRpe)
-    with _rec("pool_fwd_virtual" if virt else "pool_fwd", (P, 16, d), 4 * ((0 if virt else P * 16 * (d // 2)) + P * 16 * (d // 2) + P * 16 * (2 if virt else 1) + P * d), 2 * P * 16 * d * d):
+    # (virtual: index, distance, output + gathered coordinates and rows - DESIGN.md section 5)
+    fbytes = P * (4 * (32 + d) + 16 * (16 + 4 * (d // 2))) if virt else 4 * (2 * P * 16 * (d // 2) + P * 16 + P * d)
+    with _rec("pool_fwd_virtual" if virt else "pool_fwd", (P, 16, d), fbytes, 2 * P * 16 * d * d):
         H.check(H.lib().rl_pool_fwd(C.byref(pd), _st()), "rl_pool_fwd")
     if next_stats:
         return out, stats2, ns
@@ -980,10 +982,14 @@ def pool_bwd(u, g: Lazy, idx: torch.Tensor, W: torch.Tensor, n: int, d: int, dP:
         assert bn_bwd_stats.numel() >= H.lib().rl_pool_bwd_slots(P, d) * d
         pd.bn_bwd_stats = bn_bwd_stats.data_ptr()
     pd.dP, pd.GU, pd.gu_accumulate, pd.DG, pd.dW = dP.data_ptr(), GU.data_ptr(), int(gu_accumulate), DG.data_ptr(), dW.data_ptr()
-    # reads: U (a real tensor; virtual: 16 B of coordinates + 8 B of index / distance per row - counted in P*16*... below), the
-    # gathered rows, dP, idx; writes: DG and GU (read first when accumulating)
-    nbytes = (4 * (2 * P * 16 * (d // 2) + P * 16 + 2 * P * d) + es * P * 16 * (d // 2)
-              + (es if virt else 4) * P * 16 * (d // 2) * (1 + int(gu_accumulate)))
+    # algorithmic bytes.  Virtual rpe half: per point the forward's 4*(32 + d) (index, distance, output) +
+    # 16*(16 + 4*d/2) (gathered coordinates and rows), + 4*d (dP) + DG and GU rows (GU read first when accumulating).  A real U
+    # tensor: its rows instead of the coordinates and distances.
+    h = d // 2
+    if virt:
+        nbytes = P * (4 * (32 + d) + 16 * (16 + 4 * h) + 4 * d + es * 16 * h * (2 + int(gu_accumulate)))
+    else:
+        nbytes = (4 * (2 * P * 16 * h + P * 16 + 2 * P * d) + es * P * 16 * h + 4 * P * 16 * h * (1 + int(gu_accumulate)))
     if d == 128:
         X = torch.empty((P * 16, d), dtype=rdt, device=W.device)
         dS = torch.empty((P * 16, d), dtype=rdt, device=W.device)
