@@ -87,21 +87,26 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(double* __restrict__
                                                             int kind, float alpha, float gamma, int neglect,
                                                             double* __restrict__ out, int mode) {
     __shared__ double tot[5 * LS_MAXC + 1];
+    __shared__ double part[4][5 * LS_MAXC + 1];
     const int rs = rec_size(C);
-    // one wavefront per record entry, lanes stride over the slots (fixed order -> deterministic)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = wave; e < rs; e += 4) {
-        double s = 0.0;
-        if (mode & 1) {
-            for (int i = lane; i < nslots; i += 64) s += work[(long)i * rs + e];
+    if (mode & 1) {
+        // every thread owns the slots t, t + 256, ... (all their loads are independent: one memory round trip for the kernel, where
+        // a wavefront per entry walked three entries one after the other); fixed order -> deterministic
+        for (int e = 0; e < rs; ++e) {
+            double s = 0.0;
+            for (int i = threadIdx.x; i < nslots; i += 256) s += work[(long)i * rs + e];
             s = rl_wave_sum(s);
-        } else {
-            s = work[(long)RL_MAX_SLOTS * rs + e];
+            if (lane == 0) part[wave][e] = s;
         }
-        if (lane == 0) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < rs; e += 256) {
+            const double s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
             tot[e] = s;
-            if (mode & 1) work[(long)RL_MAX_SLOTS * rs + e] = s;  // totals record, read by the backward kernel
+            work[(long)RL_MAX_SLOTS * rs + e] = s;      // totals record, read by the backward kernel
         }
+    } else {
+        for (int e = threadIdx.x; e < rs; e += 256) tot[e] = work[(long)RL_MAX_SLOTS * rs + e];
     }
     __syncthreads();
     if (!(mode & 2)) return;
@@ -200,6 +205,451 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
                     dp = -yy * (powf(1.f - pc, gamma) / pc - gamma * logf(pc) * powf(1.f - pc, gamma - 1.f)) * invn;
             }
             dz[(long)c * N] = pc * (dp - dot) * grad_scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The HEAD of the network as one kernel each way (round 5): Dropout -> fc_end.3 (32 -> C, no BatchNorm) -> un-permute -> loss +
+// metric counts  (reference modules.py:525-530, 608-611; losses.py:17-87; metrics.py:8-59), for the fused training step only
+// (`_train.TrainStep`): seven launches over a (rows x 32) tensor and (B, C, N) logits - dropout, GEMM, un-permute, loss partials;
+// loss backward, permute, input-gradient GEMM, dropout backward, the BatchNorm-backward sums of fc_end.1, fc_end.3's share of the
+// narrow weight gradients - become two.  The logits of the step are never stored.
+//   rows are in PERMUTED order (row r of cloud b is point perm[r] of that cloud: its label is labels[b][perm[r]]);
+//   eight lanes share a row (16 bytes each): the 32 -> C product is 4 FMAs per class and lane + a 3-step butterfly over the octet;
+//   the Dropout mask is dropout_kernel's: Philox4x32-10 on (quad index, key | seed) - same bits as the un-fused path;
+//   forward: one (5C + 1)-double record per workgroup in loss_fwd_kernel's layout, finished by loss_finalize_kernel;
+//   backward: dz from the finished totals (loss_bwd_kernel's formulas), G = (dz . W) * mask -> the gradient w.r.t. fc_end.1's
+//   ACTIVATED output, the two BatchNorm-backward sums of fc_end.1 (rl_bn_bwd_reduce's slots) and one partial slab of fc_end.3's
+//   weight / bias gradient per workgroup (rl_wgrad_reduce_batch's layout: dW[C][32], then db[C]).
+constexpr int HD_MAXC = 8;          // classes the fused head carries in registers (the metric: 2); more -> the un-fused path
+constexpr int HD_K = 32;            // input channels of fc_end.3 (modules.py:529)
+struct HeadParams {
+    const float* X;                 // (rows, 32) raw output of fc_end.1
+    RlLazy lazy;                    // its folded BatchNorm + activation
+    const float* mean; const float* invstd;     // backward: saved batch statistics of fc_end.1
+    const float* W; const float* bias;          // fc_end.3: [C][32], [C]
+    const int64_t* perm; const int64_t* labels;
+    int B, N, C;
+    int kind; float alpha, gamma; int neglect;
+    const int64_t* key; unsigned long long seed; unsigned threshold; float dscale; unsigned long long first_quad; int drop;
+    double* work;
+    float* G; double* bstats; float* slab; float grad_scale; double norm_points;
+    unsigned* mask;                 // (rows) the Dropout keep bits of a row as one word: written by the forward, read by the backward (or null)
+};
+
+// this lane's four activated values of row R (lane l of the row's octet holds channels 4l .. 4l+3): x raw, z activated
+__device__ __forceinline__ void head_load(const HeadParams& p, long R, int l, float4& x, float4& z) {
+    x = *reinterpret_cast<const float4*>(p.X + R * HD_K + 4 * l);
+    z.x = rl_lazy(p.lazy, x.x, 4 * l + 0); z.y = rl_lazy(p.lazy, x.y, 4 * l + 1);
+    z.z = rl_lazy(p.lazy, x.z, 4 * l + 2); z.w = rl_lazy(p.lazy, x.w, 4 * l + 3);
+}
+// the keep bits of this lane's quad (bit j: element 4l + j is kept): Philox4x32-10 exactly as rows.hip's dropout_kernel
+__device__ __forceinline__ unsigned head_keep_bits(const HeadParams& p, unsigned long long k, long R, int l) {
+    const unsigned long long gq = p.first_quad + (unsigned long long)(R * (HD_K / 4) + l);
+    uint4 c = make_uint4((unsigned)gq, (unsigned)(gq >> 32), (unsigned)k, (unsigned)(k >> 32));
+    uint2 kk = make_uint2((unsigned)p.seed, (unsigned)(p.seed >> 32));
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+        c = make_uint4((unsigned)(p1 >> 32) ^ c.y ^ kk.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ c.w ^ kk.y, (unsigned)p0);
+        kk.x += 0x9E3779B9u;
+        kk.y += 0xBB67AE85u;
+    }
+    return (c.x >= p.threshold ? 1u : 0u) | (c.y >= p.threshold ? 2u : 0u) | (c.z >= p.threshold ? 4u : 0u) | (c.w >= p.threshold ? 8u : 0u);
+}
+// Dropout of the quad: v * scale or 0 (like dropout_kernel: not v * keep, which would turn an infinite v into NaN where it is dropped)
+__device__ __forceinline__ float4 head_drop(const float4 v, unsigned bits, float scale) {
+    return make_float4((bits & 1u) ? v.x * scale : 0.f, (bits & 2u) ? v.y * scale : 0.f, (bits & 4u) ? v.z * scale : 0.f,
+                       (bits & 8u) ? v.w * scale : 0.f);
+}
+// logit c of the row: every lane of the octet gets it (w: this lane's quad of the class' weight row, b: the class' bias)
+__device__ __forceinline__ float head_logit(const float4 d, const float4 w, float b) {
+    float v = ((d.x * w.x + d.y * w.y) + (d.z * w.z + d.w * w.w));
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v + b;
+}
+// What a trip needs that does not change between trips lives in registers: this lane's quad of the folded BatchNorm, of every
+// class' weight row, the biases, the Dropout key.  Left as loads inside the trip loop the compiler cannot hoist them (the loop stores)
+// and each is a dependent round trip behind an s_waitcnt vmcnt(0) - which also waits for the next trip's prefetch.
+template <int MC>
+struct HeadConst {
+    float4 sc, sh;          // lazy scale / shift of channels 4l .. 4l+3 (1 / 0 when the input is already activated)
+    bool lazy;
+    float4 w[MC];
+    float b[MC];
+    unsigned long long key;
+    __device__ __forceinline__ void load(const HeadParams& p, int l) {
+        lazy = p.lazy.scale != nullptr;
+        sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lazy) {
+            sc = *reinterpret_cast<const float4*>(p.lazy.scale + 4 * l);
+            sh = *reinterpret_cast<const float4*>(p.lazy.shift + 4 * l);
+        }
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            w[c] = c < p.C ? *reinterpret_cast<const float4*>(p.W + c * HD_K + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+            b[c] = c < p.C ? p.bias[c] : 0.f;
+        }
+        key = p.drop ? (unsigned long long)p.key[0] : 0ull;
+    }
+    __device__ __forceinline__ float4 act(const HeadParams& p, const float4 x) const {
+        if (!lazy) return x;
+        return make_float4(rl_act(x.x * sc.x + sh.x, p.lazy.act, p.lazy.slope), rl_act(x.y * sc.y + sh.y, p.lazy.act, p.lazy.slope),
+                           rl_act(x.z * sc.z + sh.z, p.lazy.act, p.lazy.slope), rl_act(x.w * sc.w + sh.w, p.lazy.act, p.lazy.slope));
+    }
+};
+
+// Work split inside a trip of 32 rows: the eight lanes of a row's octet do what is per CHANNEL (load, BatchNorm + activation,
+// the Dropout bits, the 32 -> C product); the logits then cross LDS and ONE lane per row (lanes 0 - 31 of the workgroup) does what
+// is per ROW (softmax, loss terms, counts) - in the octet layout that part cost eight times its work, and the per-trip wavefront
+// reductions of its sums as much again: the sums stay in that lane's registers (a lane sees ~10 rows) until the end.
+// An LDS-only rendezvous: __syncthreads() also waits for every global load in flight (vmcnt(0)) - the loads of the NEXT trip that
+// these kernels issue at the top of a trip would have to land before its first barrier.
+__device__ __forceinline__ void head_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// The label of row Rr (permuted order) is labels[b][perm[r]]: two DEPENDENT loads.  Issued together they put a full memory round
+// trip into the middle of every trip (the row lanes wait for the index before they can ask for the label, the other wavefronts wait
+// for the row lanes at the barrier): the index is fetched TWO trips ahead, the label one trip ahead with the index of the trip before.
+struct HeadLab {
+    unsigned off;       // b * N of the row whose index is in flight / at hand
+    long idx;           // perm[r]
+};
+__device__ __forceinline__ HeadLab head_perm(const HeadParams& p, long Rr, long total) {
+    const unsigned Rc = (unsigned)(Rr < total ? Rr : total - 1);        // rows < 2^27 (host check): 32-bit division (a 64-bit one is ~100 instructions)
+    const unsigned b = Rc / (unsigned)p.N;
+    HeadLab h;
+    h.off = b * (unsigned)p.N;
+    h.idx = p.perm[Rc - h.off];
+    return h;
+}
+__device__ __forceinline__ int head_label(const HeadParams& p, const HeadLab& h) { return (int)p.labels[(long)h.off + h.idx]; }
+
+template <int MC>      // classes carried in registers: 2, 4 or 8 (the smallest that holds C)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
+    __shared__ float lgs[2][32][MC];
+    const int tid = threadIdx.x, l = tid & 7;
+    const int C = p.C;
+    float acc[5 * MC + 1];
+#pragma unroll
+    for (int e = 0; e < 5 * MC + 1; ++e) acc[e] = 0.f;
+    const long total = (long)p.B * p.N;
+    const long niter = (total + 31) / 32;
+    int buf = 0;
+    HeadConst<MC> hc;
+    hc.load(p, l);
+    // one trip ahead: the row's 16 bytes of this lane and (row lanes) the row's label
+    long it = blockIdx.x;
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    int labn = 0;
+    HeadLab hn = {0u, 0};
+    if (it < niter) {
+        const long R0 = it * 32 + (tid >> 3);
+        xn = *reinterpret_cast<const float4*>(p.X + (R0 < total ? R0 : total - 1) * HD_K + 4 * l);
+        if (tid < 32) {
+            labn = head_label(p, head_perm(p, it * 32 + tid, total));
+            hn = head_perm(p, (it + gridDim.x < niter ? it + gridDim.x : it) * 32 + tid, total);
+        }
+    }
+    for (; it < niter; it += gridDim.x, buf ^= 1) {
+        const long R = it * 32 + (tid >> 3);
+        const bool valid = R < total;
+        const long Rc = valid ? R : total - 1;
+        const float4 x = xn;
+        const int lab = labn;
+        {       // the next trip's loads (past the last trip: this one's again, never used - no branch around a load)
+            const long itn = it + gridDim.x < niter ? it + gridDim.x : it;
+            const long Rn = itn * 32 + (tid >> 3);
+            xn = *reinterpret_cast<const float4*>(p.X + (Rn < total ? Rn : total - 1) * HD_K + 4 * l);
+            if (tid < 32) {
+                labn = head_label(p, hn);                      // the next trip's label: its index arrived a trip ago
+                const long it2 = it + 2 * gridDim.x < niter ? it + 2 * gridDim.x : itn;
+                hn = head_perm(p, it2 * 32 + tid, total);      // the index of the trip after next
+            }
+        }
+        const float4 z = hc.act(p, x);
+        float4 d = z;
+        if (p.drop) {
+            unsigned bits = head_keep_bits(p, hc.key, Rc, l);
+            d = head_drop(z, bits, p.dscale);
+            if (p.mask) {       // the row's 32 keep bits as one word for the backward (bit 4l + j)
+                unsigned wbits = bits << (4 * l);
+                wbits |= __shfl_xor(wbits, 1, 64); wbits |= __shfl_xor(wbits, 2, 64); wbits |= __shfl_xor(wbits, 4, 64);
+                if (l == 0 && valid) p.mask[R] = wbits;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            if (c >= C) break;
+            const float v = head_logit(d, hc.w[c], hc.b[c]);
+            if (l == 0) lgs[buf][tid >> 3][c] = v;
+        }
+        head_lds_barrier();        // (one barrier per trip: the next trip writes the other buffer)
+        if (tid < 32) {
+            const long Rr = it * 32 + tid;
+            if (Rr < total) {
+                float lg[MC];
+#pragma unroll
+                for (int c = 0; c < MC; ++c) lg[c] = c < C ? lgs[buf][tid][c] : -INFINITY;
+                float m = -INFINITY;
+                int pred = 0;
+#pragma unroll
+                for (int c = 0; c < MC; ++c)
+                    if (c < C && lg[c] > m) { m = lg[c]; pred = c; }
+                float den = 0.f;
+#pragma unroll
+                for (int c = 0; c < MC; ++c)
+                    if (c < C) den += expf(lg[c] - m);
+                const float inv = 1.f / den;
+#pragma unroll
+                for (int c = 0; c < MC; ++c) {
+                    if (c >= C) break;
+                    const float zc = lg[c];
+                    const float pc = expf(zc - m) * inv;
+                    const float yc = (lab == c) ? 1.f : 0.f;
+                    acc[0 * MC + c] += yc * pc;
+                    acc[1 * MC + c] += pc;
+                    acc[2 * MC + c] += (pred == c && lab == c) ? 1.f : 0.f;
+                    acc[3 * MC + c] += (lab == c) ? 1.f : 0.f;
+                    acc[4 * MC + c] += (pred == c) ? 1.f : 0.f;
+                    if (p.kind == 0) {
+                        if (lab == c) acc[5 * MC] += (logf(den) + m) - zc;
+                    } else if (p.kind == 1) {
+                        const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
+                        const float pp = fminf(fmaxf(pc, LS_EPS), 1.f - LS_EPS);
+                        acc[5 * MC] += -yy * logf(pp) * powf(1.f - pp, p.gamma);
+                    }
+                }
+            }
+        }
+    }
+    // the 32 row lanes (half of wavefront 0) hold the workgroup's sums: doubles, a fixed butterfly over those 32 lanes
+    if (tid < 64) {
+        const int rs = rec_size(C);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int c = 0; c < MC; ++c) {
+                if (c >= C) break;
+                double v = tid < 32 ? (double)acc[k * MC + c] : 0.0;
+                v = rl_wave_sum(v);
+                if (tid == 0) p.work[(long)blockIdx.x * rs + k * C + c] = v;
+            }
+        double v = tid < 32 ? (double)acc[5 * MC] : 0.0;
+        v = rl_wave_sum(v);
+        if (tid == 0) p.work[(long)blockIdx.x * rs + 5 * C] = v;
+    }
+}
+
+template <int MC>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
+    __shared__ float cu[MC], cw[MC];  // dL/dp_c[n] = cu[c]*y_c[n] + cw[c]  (loss_bwd_kernel)
+    __shared__ float lgs[32][MC], dzs[32][MC];
+    __shared__ float red[4][8][MC * 4 + MC + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = tid & 7;
+    const int C = p.C;
+    const int rs = rec_size(C);
+    const double* totals = p.work + (long)RL_MAX_SLOTS * rs;
+    if (tid < MC) {
+        float u = 0.f, w = 0.f;
+        const int c = tid;
+        const int c0 = p.neglect ? 1 : 0;
+        if (p.kind == 2 && c < C && c >= c0) {
+            const double tp = totals[c], sp = totals[C + c], sy = totals[3 * C + c];
+            const double D = tp + (double)p.alpha * (sy - tp) + (1.0 - (double)p.alpha) * (sp - tp) + (double)LS_EPS;
+            const double ti = (tp + (double)LS_EPS) / D;
+            const double base = 1.0 - ti;
+            const double dl = -((double)p.gamma / (double)(C - c0)) *
+                              ((p.gamma == 1.f) ? 1.0 : pow(base > 0.0 ? base : 0.0, (double)p.gamma - 1.0));
+            u = (float)(dl / D);
+            w = (float)(-dl * (tp + (double)LS_EPS) * (1.0 - (double)p.alpha) / (D * D));
+        }
+        cu[c] = u;
+        cw[c] = w;
+    }
+    __syncthreads();
+    const float invn = 1.f / (float)p.norm_points;
+    // per-lane partial sums over the rows this lane's octet position sees: dW[c][4l .. 4l+3], db[c] (lane l == 0 only), and the
+    // BatchNorm-backward sums of fc_end.1's channels 4l .. 4l+3
+    float4 aw[MC];
+    float ab[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) { aw[c] = make_float4(0.f, 0.f, 0.f, 0.f); ab[c] = 0.f; }
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sx = sg;
+    float4 mu = sg, is = sg;
+    if (p.bstats) {
+        mu = *reinterpret_cast<const float4*>(p.mean + 4 * l);
+        is = *reinterpret_cast<const float4*>(p.invstd + 4 * l);
+    }
+    HeadConst<MC> hc;
+    hc.load(p, l);
+    const float4 bsc = hc.sc, bsh = hc.sh;
+    const long total = (long)p.B * p.N;
+    const long niter = (total + 31) / 32;
+    // one trip ahead: this lane's 16 bytes of the row, the row's Dropout bits and (row lanes) its label
+    long it = blockIdx.x;
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned mwn = 0xFFFFFFFFu;
+    int labn = 0;
+    HeadLab hn = {0u, 0};
+    const bool use_mask = p.drop && p.mask;
+    if (it < niter) {
+        const long R0 = it * 32 + (tid >> 3), Rq = R0 < total ? R0 : total - 1;
+        xn = *reinterpret_cast<const float4*>(p.X + Rq * HD_K + 4 * l);
+        if (use_mask) mwn = p.mask[Rq];
+        if (tid < 32) {
+            labn = head_label(p, head_perm(p, it * 32 + tid, total));
+            hn = head_perm(p, (it + gridDim.x < niter ? it + gridDim.x : it) * 32 + tid, total);
+        }
+    }
+    for (; it < niter; it += gridDim.x) {
+        const long R = it * 32 + (tid >> 3);
+        const bool valid = R < total;
+        const long Rc = valid ? R : total - 1;
+        const float4 x = xn;
+        const unsigned mw = mwn;
+        const int lab = labn;
+        {       // the next trip's loads (past the last trip: this one's again, never used)
+            const long itn = it + gridDim.x < niter ? it + gridDim.x : it;
+            const long Rn = itn * 32 + (tid >> 3), Rq = Rn < total ? Rn : total - 1;
+            xn = *reinterpret_cast<const float4*>(p.X + Rq * HD_K + 4 * l);
+            if (use_mask) mwn = p.mask[Rq];
+            if (tid < 32) {
+                labn = head_label(p, hn);
+                const long it2 = it + 2 * gridDim.x < niter ? it + 2 * gridDim.x : itn;
+                hn = head_perm(p, it2 * 32 + tid, total);
+            }
+        }
+        const float4 z = hc.act(p, x);
+        unsigned bits = 15u;
+        if (p.drop) bits = use_mask ? (mw >> (4 * l)) & 15u : head_keep_bits(p, hc.key, Rc, l);
+        const float4 d = p.drop ? head_drop(z, bits, p.dscale) : z;
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            if (c >= C) break;
+            const float v = head_logit(d, hc.w[c], hc.b[c]);
+            if (l == 0) lgs[tid >> 3][c] = v;
+        }
+        head_lds_barrier();
+        if (tid < 32) {         // per ROW: softmax and the loss derivative (loss_bwd_kernel's formulas)
+            const long Rr = it * 32 + tid;
+            float dz[MC];
+#pragma unroll
+            for (int c = 0; c < MC; ++c) dz[c] = 0.f;
+            if (Rr < total) {
+                float lg[MC];
+#pragma unroll
+                for (int c = 0; c < MC; ++c) lg[c] = c < C ? lgs[tid][c] : -INFINITY;
+                float m = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < MC; ++c)
+                    if (c < C) m = fmaxf(m, lg[c]);
+                float den = 0.f;
+#pragma unroll
+                for (int c = 0; c < MC; ++c)
+                    if (c < C) den += expf(lg[c] - m);
+                const float inv = 1.f / den;
+                if (p.kind == 0) {
+#pragma unroll
+                    for (int c = 0; c < MC; ++c)
+                        if (c < C) dz[c] = (expf(lg[c] - m) * inv - (lab == c ? 1.f : 0.f)) * invn * p.grad_scale;
+                } else {
+                    float dot = 0.f;
+                    float dpv[MC], pcv[MC];
+#pragma unroll
+                    for (int c = 0; c < MC; ++c) {
+                        pcv[c] = 0.f; dpv[c] = 0.f;
+                        if (c < C) {
+                            const float pc = expf(lg[c] - m) * inv;
+                            const float yc = (lab == c) ? 1.f : 0.f;
+                            float dp;
+                            if (p.kind == 2) dp = cu[c] * yc + cw[c];
+                            else {
+                                const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
+                                dp = 0.f;
+                                if (pc >= LS_EPS && pc <= 1.f - LS_EPS)
+                                    dp = -yy * (powf(1.f - pc, p.gamma) / pc - p.gamma * logf(pc) * powf(1.f - pc, p.gamma - 1.f)) * invn;
+                            }
+                            pcv[c] = pc; dpv[c] = dp;
+                            dot += pc * dp;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < MC; ++c)
+                        if (c < C) dz[c] = pcv[c] * (dpv[c] - dot) * p.grad_scale;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < MC; ++c) dzs[tid][c] = dz[c];
+        }
+        head_lds_barrier();
+        // per CHANNEL again: fc_end.3's dW[c][k] += dz[c] * d[k], db[c] += dz[c]; dD[k] = sum_c dz[c] * W[c][k]
+        float4 dd = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            if (c >= C) break;
+            const float dzc = dzs[tid >> 3][c];         // (0 for a row past the end)
+            aw[c].x += dzc * d.x; aw[c].y += dzc * d.y; aw[c].z += dzc * d.z; aw[c].w += dzc * d.w;
+            if (l == 0) ab[c] += dzc;
+            dd.x += dzc * hc.w[c].x; dd.y += dzc * hc.w[c].y; dd.z += dzc * hc.w[c].z; dd.w += dzc * hc.w[c].w;
+        }
+        // Dropout backward: the gradient w.r.t. fc_end.1's activated output
+        const float4 g = p.drop ? head_drop(dd, bits, p.dscale) : dd;
+        if (valid) {
+            *reinterpret_cast<float4*>(p.G + R * HD_K + 4 * l) = g;
+            if (p.bstats) {
+                // rl_bn_bwd_reduce's sums for fc_end.1: g' = g * act'(x * scale + shift), xhat = (x - mean) * invstd
+                const float g0 = g.x * rl_act_grad(x.x * bsc.x + bsh.x, p.lazy.act, p.lazy.slope);
+                const float g1 = g.y * rl_act_grad(x.y * bsc.y + bsh.y, p.lazy.act, p.lazy.slope);
+                const float g2 = g.z * rl_act_grad(x.z * bsc.z + bsh.z, p.lazy.act, p.lazy.slope);
+                const float g3 = g.w * rl_act_grad(x.w * bsc.w + bsh.w, p.lazy.act, p.lazy.slope);
+                sg.x += g0; sg.y += g1; sg.z += g2; sg.w += g3;
+                sx.x += g0 * ((x.x - mu.x) * is.x); sx.y += g1 * ((x.y - mu.y) * is.y);
+                sx.z += g2 * ((x.z - mu.z) * is.z); sx.w += g3 * ((x.w - mu.w) * is.w);
+            }
+        }
+    }
+    // combine: over the eight octets of a wavefront (lanes l, l + 8, ...), then over the four wavefronts in a fixed order
+    constexpr int NV = MC * 4 + MC + 8;
+    float v[NV];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+        v[4 * c + 0] = aw[c].x; v[4 * c + 1] = aw[c].y; v[4 * c + 2] = aw[c].z; v[4 * c + 3] = aw[c].w;
+        v[MC * 4 + c] = ab[c];
+    }
+    v[MC * 5 + 0] = sg.x; v[MC * 5 + 1] = sg.y; v[MC * 5 + 2] = sg.z; v[MC * 5 + 3] = sg.w;
+    v[MC * 5 + 4] = sx.x; v[MC * 5 + 5] = sx.y; v[MC * 5 + 6] = sx.z; v[MC * 5 + 7] = sx.w;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        float t = v[j];
+        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+        if (lane < 8) red[wave][lane][j] = t;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        const int ll = tid;
+        float* slab = p.slab + (long)blockIdx.x * (C * HD_K + C);
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                slab[c * HD_K + 4 * ll + j] = (red[0][ll][4 * c + j] + red[1][ll][4 * c + j]) + (red[2][ll][4 * c + j] + red[3][ll][4 * c + j]);
+            if (ll == 0)
+                slab[C * HD_K + c] = (red[0][0][MC * 4 + c] + red[1][0][MC * 4 + c]) + (red[2][0][MC * 4 + c] + red[3][0][MC * 4 + c]);
+        }
+        if (p.bstats) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double a0 = ((double)red[0][ll][MC * 5 + j] + (double)red[1][ll][MC * 5 + j]) +
+                                  ((double)red[2][ll][MC * 5 + j] + (double)red[3][ll][MC * 5 + j]);
+                const double a1 = ((double)red[0][ll][MC * 5 + 4 + j] + (double)red[1][ll][MC * 5 + 4 + j]) +
+                                  ((double)red[2][ll][MC * 5 + 4 + j] + (double)red[3][ll][MC * 5 + 4 + j]);
+                p.bstats[((long)blockIdx.x * 2 + 0) * HD_K + 4 * ll + j] = a0;
+                p.bstats[((long)blockIdx.x * 2 + 1) * HD_K + 4 * ll + j] = a1;
+            }
         }
     }
 }
@@ -326,6 +776,81 @@ extern "C" int rl_loss_backward_global(const float* logits, const int64_t* label
                                        int64_t points_total, float* dlogits, void* stream) {
     return loss_backward_impl(logits, labels, B, C, N, kind, alpha, gamma, neglect_background, work, grad_scale,
                               (double)points_total, dlogits, stream);
+}
+
+// ---- the fused head (Dropout -> fc_end.3 -> un-permute -> loss / counts), see head_fwd_kernel --------------------------------
+static int head_grid(long rows) {
+    long g = (rows + 31) / 32;            // 32 rows per workgroup and trip
+    g = (g + 7) / 8;                      // >= 8 trips per workgroup where there is that much work ...
+    if (g > RL_MAX_SLOTS) g = RL_MAX_SLOTS;      // ... and never more slots than rl_bn_bwd_finalize / the loss finalize read
+    return (int)(g < 1 ? 1 : g);
+}
+extern "C" int rl_head_supported(int C, int K) { return (C >= 1 && C <= HD_MAXC && K == HD_K) ? 1 : 0; }
+extern "C" int rl_head_grid(int64_t rows) { return head_grid(rows); }
+
+static int head_fill(HeadParams* p, const rl_head_desc* d, const char* who, bool backward) {
+    RL_REQUIRE(d && d->X && d->W && d->bias && d->perm && d->labels && d->work, RL_ERR_ARGS, "%s: null pointer", who);
+    RL_REQUIRE(d->B > 0 && d->N > 0 && (int64_t)d->B * d->N * HD_K < (1l << 32), RL_ERR_ARGS, "%s: bad sizes", who);
+    RL_REQUIRE(rl_head_supported(d->C, HD_K), RL_ERR_UNSUPPORTED, "%s: 1 .. %d classes (got %d)", who, HD_MAXC, d->C);
+    RL_REQUIRE(d->loss_kind >= 0 && d->loss_kind <= 2, RL_ERR_ARGS, "%s: unknown loss kind %d", who, d->loss_kind);
+    RL_REQUIRE(!(d->loss_kind == 2 && d->neglect_background && d->C < 2), RL_ERR_ARGS, "%s: needs a foreground class", who);
+    RL_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), RL_ERR_ARGS, "%s: scale / shift must come together", who);
+    RL_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->drop_key), RL_ERR_ARGS, "%s: bad Dropout arguments", who);
+    RL_REQUIRE((((uintptr_t)d->X | (uintptr_t)d->W | (uintptr_t)d->G) & 15) == 0, RL_ERR_ARGS, "%s: X / W / G must be 16-byte aligned", who);
+    p->X = d->X;
+    p->lazy.scale = d->scale; p->lazy.shift = d->shift; p->lazy.act = d->act; p->lazy.slope = d->slope;
+    p->mean = d->mean; p->invstd = d->invstd;
+    p->W = d->W; p->bias = d->bias; p->perm = d->perm; p->labels = d->labels;
+    p->B = d->B; p->N = d->N; p->C = d->C;
+    p->kind = d->loss_kind; p->alpha = d->alpha; p->gamma = d->gamma; p->neglect = d->neglect_background;
+    p->drop = d->drop_p > 0.f;
+    p->key = d->drop_key; p->seed = d->drop_seed;
+    const double t = (double)d->drop_p * 4294967296.0;
+    p->threshold = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    p->dscale = 1.0f / (1.0f - d->drop_p);
+    p->first_quad = (unsigned long long)d->drop_first_row * (HD_K / 4);
+    p->work = d->work;
+    p->G = d->G; p->bstats = d->bn_bwd_stats; p->slab = d->slab;
+    p->grad_scale = d->grad_scale; p->norm_points = (double)d->B * (double)d->N;
+    p->mask = reinterpret_cast<unsigned*>(d->drop_mask);
+    if (backward) {
+        RL_REQUIRE(d->G && d->slab && d->slab_floats >= (int64_t)head_grid((long)d->B * d->N) * (d->C * HD_K + d->C), RL_ERR_ARGS,
+                   "%s: needs G and a slab of rl_head_grid(rows) * (C*32 + C) floats", who);
+        RL_REQUIRE(!d->bn_bwd_stats || (d->scale && d->mean && d->invstd), RL_ERR_ARGS,
+                   "%s: bn_bwd_stats needs the folded BatchNorm and its saved mean / invstd", who);
+    }
+    return RL_OK;
+}
+
+extern "C" int rl_head_fwd(const rl_head_desc* d, double* out, void* stream) {
+    HeadParams p;
+    int rc = head_fill(&p, d, "rl_head_fwd", false);
+    if (rc) return rc;
+    RL_REQUIRE(out, RL_ERR_ARGS, "rl_head_fwd: null out");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = head_grid((long)d->B * d->N);
+    if (d->C <= 2) hipLaunchKernelGGL(head_fwd_kernel<2>, dim3(g), dim3(256), 0, st, p);
+    else if (d->C <= 4) hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(g), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(g), dim3(256), 0, st, p);
+    rl_note_kernel("head_fwd_kernel");
+    RL_LAUNCH_CHECK("rl_head_fwd");
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, d->work, g, (double)d->B * (double)d->N, d->C, d->loss_kind,
+                       d->alpha, d->gamma, d->neglect_background, out, 3);
+    RL_LAUNCH_CHECK("rl_head_fwd(finalize)");
+    return RL_OK;
+}
+
+extern "C" int rl_head_bwd(const rl_head_desc* d, void* stream) {
+    HeadParams p;
+    int rc = head_fill(&p, d, "rl_head_bwd", true);
+    if (rc) return rc;
+    const int g = head_grid((long)d->B * d->N);
+    if (d->C <= 2) hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    else if (d->C <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    rl_note_kernel("head_bwd_kernel");
+    RL_LAUNCH_CHECK("rl_head_bwd");
+    return RL_OK;
 }
 
 extern "C" int rl_softmax_cf(const float* logits, int B, int C, int N, float* out, void* stream) {

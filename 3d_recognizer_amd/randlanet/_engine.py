@@ -344,10 +344,13 @@ class Engine:
 
     def forward(self, inp: torch.Tensor, perm: torch.Tensor, training: bool, dropout_p: float = 0.5,
                 keep_mask: Optional[torch.Tensor] = None, logits_out: Optional[torch.Tensor] = None,
-                prep: Optional["Prep"] = None):
+                prep: Optional["Prep"] = None, head: Optional[ops.Head] = None):
         """inp (B,N,3+F) fp32 on the device, perm (N,) int64 on the device -> logits (B,C,N), ctx.
         keep_mask (B*N, 32) uint8: an explicit Dropout mask (parity tests); by default the mask is generated in the kernel.
-        prep: the result of prepare(inp, perm, training) when the caller has run it already (same inp / perm contents)."""
+        prep: the result of prepare(inp, perm, training) when the caller has run it already (same inp / perm contents).
+        head (training): the labels / loss of the step - Dropout, fc_end.3, the un-permute and the loss then run as ONE kernel
+        (rl_head_fwd) that fills head.out; no logits are stored and (None, ctx) is returned; backward(ctx, None, grads) starts
+        from rl_head_bwd.  Without it (or where rl_head_supported says no) the layers run one by one and the logits come back."""
         B, N, cin = inp.shape
         assert cin == 3 + self.F and inp.dtype == torch.float32 and inp.is_cuda and inp.is_contiguous()
         assert perm.dtype == torch.int64 and perm.numel() == N and perm.is_cuda
@@ -355,6 +358,7 @@ class Engine:
         dev = inp.device
         ctx = Context()
         ctx.training, ctx.B, ctx.N, ctx.perm = training, B, N, perm
+        ctx.pending_ok = not (ops.SIDE_STREAM_WGRAD or ops.NO_DEFERRED_WGRAD)      # (the fused head queues its slabs on ctx.pending)
         L, dec = len(self.layers), self.dec
         ctx.eval_folds = None
         ctx.eval_sig = tuple(ops.virtual_rpe_supported(d, self.K, B * (N // dec ** l), N // dec ** l) for l, d in enumerate(self.layers))
@@ -410,6 +414,21 @@ class Engine:
         # fc_end in permuted order; the logits are un-permuted at the very end (modules.py:608-611)
         x = self._mlp(ctx, x, "fc_end.0", 64, H.ACT_RELU)
         x = self._mlp(ctx, x, "fc_end.1", 32, H.ACT_RELU)
+        if (head is not None and training and self.sync is None and keep_mask is None and ctx.pending_ok
+                and ops.head_supported(x, self.C)):
+            key, seed, first_row = None, 0, 0
+            if dropout_p > 0.0:
+                if self._drop_counter is None or self._drop_counter.device != dev:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise H.HipKernelError("the Dropout counter must exist before a forward is captured")
+                    self._drop_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+                key = ops.dropout_tick(self._drop_counter)
+                seed = (self._drop_seed + 0x9E3779B97F4A7C15 * self.drop_stream) & 0x7FFFFFFFFFFFFFFF
+            drop = (key, seed, dropout_p, first_row)
+            ops.head_fwd(x, self._w2("fc_end.3.conv.weight"), self.P["fc_end.3.conv.bias"], perm, head, drop)
+            ctx.tape.append(("head", x, head, drop))
+            ctx.logits_perm = None
+            return None, ctx
         if training and dropout_p > 0.0:
             if keep_mask is None:
                 if self._drop_counter is None or self._drop_counter.device != dev:
@@ -449,19 +468,23 @@ class Engine:
         if not ctx.training:
             raise H.HipKernelError("backward is implemented for training-mode forwards (batch statistics)")
         B, N = ctx.B, ctx.N
-        assert dlogits.shape == (B, self.C, N) and dlogits.is_cuda
-        dlogits = dlogits.contiguous().float()
-        ctx.grads[id(ctx.logits_perm.raw)] = [ops.logits_permute_grad(dlogits, ctx.perm), True]
+        fused_head = bool(ctx.tape) and ctx.tape[-1][0] == "head"
+        if not fused_head:
+            assert dlogits.shape == (B, self.C, N) and dlogits.is_cuda
+            dlogits = dlogits.contiguous().float()
+            ctx.grads[id(ctx.logits_perm.raw)] = [ops.logits_permute_grad(dlogits, ctx.perm), True]
+        dev = ctx.perm.device
         # Weight gradients are off the critical path (only the optimiser needs them); with RL_SIDE_STREAM=1
         # they run on a side stream beside the dY -> dX chain (everything they read stays referenced until
         # the join below).  Off by default: under hipGraph replay the forks/joins cost more than they hide.
-        self._main = torch.cuda.current_stream(dlogits.device)
+        self._main = torch.cuda.current_stream(dev)
         if self._side is None:
-            self._side = torch.cuda.Stream(dlogits.device)
+            self._side = torch.cuda.Stream(dev)
         if getattr(ctx, "csr_ready", None) is not None:
             self._main.wait_event(ctx.csr_ready)       # the graph transposes built beside the forward
             ctx.csr_ready = None
         ctx.hold = []
+        ctx.bn_pre = {}           # raw tensor -> BatchNorm-backward partials its gradient's producer left (the fused head)
         ctx.bn_done = set()       # raw tensors whose BatchNorm backward already happened (fused at the residual junction)
         # weight-gradient slabs are summed by ONE launch after the last layer (they are only needed by the optimiser)
         ctx.pending = None if (ops.SIDE_STREAM_WGRAD or ops.NO_DEFERRED_WGRAD) else []
@@ -514,6 +537,13 @@ class Engine:
                     gs = self._gbuf(ctx, skip)
                     ops.copy_rows(G, (prev.C, skip.C), catl.n, gs[0], (0, skip.C), catl.rows, catl.n, accumulate=gs[1])
                     gs[1] = True
+            elif kind == "head":
+                _, xh, head, drop = rec
+                G, pre = ops.head_bwd(xh, self._w2("fc_end.3.conv.weight"), self.P["fc_end.3.conv.bias"], ctx.perm, head, drop,
+                                      grads["fc_end.3.conv.weight"], grads["fc_end.3.conv.bias"], ctx.pending)
+                ctx.grads[id(xh.raw)] = [G, True]
+                if pre is not None:
+                    ctx.bn_pre[id(xh.raw)] = pre
             elif kind == "dropout_philox":
                 _, src, dropped, key, p_drop, seed, first_row = rec
                 G, init = self._gbuf(ctx, dropped)
@@ -554,7 +584,8 @@ class Engine:
         G, init = self._gbuf(ctx, out)
         assert init, f"no gradient reached {wname}"
         if out.scale is not None and id(out.raw) not in ctx.bn_done:
-            ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True, sync=self.sync)
+            ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True, sync=self.sync,
+                            stats=ctx.bn_pre.pop(id(out.raw), None))
         n_out = out.C
         self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,
                                             grads[bname] if bname else None, pending=ctx.pending, batch=ctx.wbatch), G)

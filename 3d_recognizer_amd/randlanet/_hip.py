@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 # diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
 _LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
-ABI_VERSION = 107      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
+ABI_VERSION = 108      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -85,6 +85,18 @@ class CloudJob(C.Structure):
         ("xyz_f64", C.c_int32), ("normalization", C.c_int32), ("augment", C.c_int32), ("reserved", C.c_int32),
         ("jitter_variance", C.c_double), ("jitter_limit", C.c_double), ("scale", C.c_double),
         ("R", C.c_double * 9), ("shift", C.c_double * 3),
+    ]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("act", C.c_int32), ("slope", C.c_float),
+        ("mean", C.c_void_p), ("invstd", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("perm", C.c_void_p), ("labels", C.c_void_p), ("B", C.c_int32), ("N", C.c_int32), ("C", C.c_int32),
+        ("loss_kind", C.c_int32), ("alpha", C.c_float), ("gamma", C.c_float), ("neglect_background", C.c_int32),
+        ("drop_p", C.c_float), ("drop_key", C.c_void_p), ("drop_seed", C.c_uint64), ("drop_first_row", C.c_int64),
+        ("work", C.c_void_p), ("G", C.c_void_p), ("bn_bwd_stats", C.c_void_p), ("slab", C.c_void_p),
+        ("slab_floats", C.c_int64), ("grad_scale", C.c_float), ("reserved", C.c_int32), ("drop_mask", C.c_void_p),
     ]
 
 
@@ -210,6 +222,10 @@ _SIGNATURES = {
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
     "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "rl_bn_finalize_batch": (_i, [C.POINTER(BnFinalizeItem), _i, _vp]),
+    "rl_head_supported": (_i, [_i, _i]),
+    "rl_head_grid": (_i, [_l]),
+    "rl_head_fwd": (_i, [C.POINTER(HeadDesc), _vp, _vp]),
+    "rl_head_bwd": (_i, [C.POINTER(HeadDesc), _vp]),
     "rl_bn_bwd_finalize_pair": (_i, [_vp, _vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_bn_reduce_slots": (_i, [_vp, _i, _i, _vp, _vp]),
     "rl_bn_bwd_slots": (_i, [_l]),

@@ -608,9 +608,18 @@ def _bn_bwd_finalize(stats, slots: int, rows: int, Cc: int, dgamma, dbeta, coef,
 
 
 def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
-                training: bool, sync: Optional[SyncGroup] = None) -> None:
-    """In place: G (gradient w.r.t. the activated value of `y`) becomes the gradient w.r.t. y.raw."""
+                training: bool, sync: Optional[SyncGroup] = None, stats: Optional[tuple] = None) -> None:
+    """In place: G (gradient w.r.t. the activated value of `y`) becomes the gradient w.r.t. y.raw.
+    stats: (partials, nslots) already left by the kernel that produced G (head_bwd) - no reduce sweep over G and Y here."""
     d = _bn_bwd_desc(G, y.bstride, y)
+    if stats is not None:
+        assert training and y.mean is not None and sync is None
+        coef = torch.empty(2 * y.C, dtype=F32, device=G.device)
+        _bn_bwd_finalize(stats[0], stats[1], y.rows, y.C, dgamma, dbeta, coef, None)
+        d.coef = coef.data_ptr()
+        with _rec("bn_bwd_apply", (y.rows, y.C), 12 * y.rows * y.C, 0):
+            H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
+        return
     if (training and y.mean is not None and sync is None and not NO_BN_SMALL and G.data_ptr() % 16 == 0 and y.raw.data_ptr() % 16 == 0
             and H.lib().rl_bn_bwd_fused_supported(y.rows, y.C, y.raw.shape[1])):
         # a small tensor: reduce, finalize and apply in one launch (a workgroup owns a channel quad and all its rows)
@@ -1176,6 +1185,78 @@ def loss_backward(logits, labels, kind: int, alpha: float, gamma: float, neglect
                                          int(neglect_background), work.data_ptr(), grad_scale, dlogits.data_ptr(),
                                          _st()), "rl_loss_backward")
     return dlogits
+
+
+class Head:
+    """What the fused training step hands to Engine.forward so that the network's head - Dropout, fc_end.3, un-permute, loss and
+    metric counts - runs as one kernel each way (rl_head_fwd / rl_head_bwd): the labels, the loss, where the step's record goes."""
+
+    def __init__(self, labels: torch.Tensor, kind: int, alpha: float, gamma: float, neglect_background: bool, out: torch.Tensor,
+                 grad_scale: float = 1.0):
+        self.labels, self.kind, self.alpha, self.gamma, self.neglect = labels, kind, alpha, gamma, neglect_background
+        self.out, self.grad_scale = out, grad_scale
+        self.work: Optional[torch.Tensor] = None
+        self.mask: Optional[torch.Tensor] = None          # the rows' Dropout keep bits, forward -> backward
+
+
+NO_FUSED_HEAD = bool(int(__import__("os").environ.get("RL_NO_FUSED_HEAD", "0")))      # A/B: the separate launches
+
+
+def head_supported(x: Lazy, Cc: int) -> bool:
+    return (not NO_FUSED_HEAD and x.C == 32 and x.raw.dtype == F32 and x.raw.shape[1] == 32 and x.bstride == x.n
+            and bool(H.lib().rl_head_supported(Cc, 32)))
+
+
+def _head_desc(x: Lazy, W: torch.Tensor, bias: torch.Tensor, perm: torch.Tensor, head: Head, drop) -> "H.HeadDesc":
+    _dev_check(x.raw, W, bias, perm, head.labels, head.out, x.scale, x.shift, x.mean, x.invstd)
+    B, N, Cc = x.B, x.n, W.shape[0]
+    assert W.dtype == F32 and W.numel() == Cc * 32 and bias.numel() == Cc and perm.dtype == torch.int64 and perm.numel() == N
+    assert head.labels.shape == (B, N) and head.labels.dtype == torch.int64 and head.out.numel() == 1 + 4 * Cc
+    d = H.HeadDesc()
+    d.X, d.scale, d.shift, d.act, d.slope = x.raw.data_ptr(), H.ptr(x.scale), H.ptr(x.shift), x.act, x.slope
+    d.mean, d.invstd = H.ptr(x.mean), H.ptr(x.invstd)
+    d.W, d.bias, d.perm, d.labels = W.data_ptr(), bias.data_ptr(), perm.data_ptr(), head.labels.data_ptr()
+    d.B, d.N, d.C = B, N, Cc
+    d.loss_kind, d.alpha, d.gamma, d.neglect_background = head.kind, head.alpha, head.gamma, int(head.neglect)
+    key, seed, p_drop, first_row = drop
+    d.drop_p, d.drop_key, d.drop_seed, d.drop_first_row = (p_drop if key is not None else 0.0), H.ptr(key), seed, first_row
+    d.grad_scale = head.grad_scale
+    return d
+
+
+def head_fwd(x: Lazy, W: torch.Tensor, bias: torch.Tensor, perm: torch.Tensor, head: Head, drop) -> None:
+    """Dropout -> fc_end.3 -> un-permute -> loss + counts of the rows of `x` (fc_end.1's lazy output, permuted order) in one
+    launch + the loss finalize: fills head.out (rl_loss_forward's record) and head.work.  drop = (key, seed, p, first_row)."""
+    d = _head_desc(x, W, bias, perm, head, drop)
+    head.work = torch.empty(H.lib().rl_loss_work_doubles(x.rows, d.C), dtype=torch.float64, device=W.device)
+    d.work = head.work.data_ptr()
+    if d.drop_p > 0.0:
+        head.mask = torch.empty(x.rows, dtype=torch.int32, device=W.device)
+        d.drop_mask = head.mask.data_ptr()
+    with _rec("head_fwd", (x.rows, 32, d.C), 4 * x.rows * 32 + 16 * x.rows, 2 * x.rows * 32 * d.C):
+        H.check(H.lib().rl_head_fwd(C.byref(d), head.out.data_ptr(), _st()), "rl_head_fwd")
+
+
+def head_bwd(x: Lazy, W: torch.Tensor, bias: torch.Tensor, perm: torch.Tensor, head: Head, drop, dW: torch.Tensor,
+             dbias: torch.Tensor, pending: list):
+    """The whole backward of the head: returns (G, (bn_bwd_partials, nslots)) - G the gradient w.r.t. x's ACTIVATED value, the
+    partials what rl_bn_bwd_reduce would leave for x's BatchNorm; fc_end.3's weight / bias gradient slabs join `pending`."""
+    d = _head_desc(x, W, bias, perm, head, drop)
+    Cc = d.C
+    d.work = head.work.data_ptr()
+    g = H.lib().rl_head_grid(x.rows)
+    G = torch.empty((x.rows, 32), dtype=F32, device=W.device)
+    slab = torch.empty(g * (Cc * 32 + Cc), dtype=F32, device=W.device)
+    bstats = torch.empty((g, 2, 32), dtype=torch.float64, device=W.device) if x.mean is not None else None
+    d.G, d.slab, d.slab_floats, d.bn_bwd_stats = G.data_ptr(), slab.data_ptr(), slab.numel(), H.ptr(bstats)
+    d.drop_mask = H.ptr(head.mask)
+    with _rec("head_bwd", (x.rows, 32, Cc), 8 * x.rows * 32 + 16 * x.rows, 4 * x.rows * 32 * Cc):
+        H.check(H.lib().rl_head_bwd(C.byref(d), _st()), "rl_head_bwd")
+    it = H.WgradReduceItem()
+    it.slab, it.dW, it.dbias, it.w_ks, it.w_ns = slab.data_ptr(), dW.data_ptr(), dbias.data_ptr(), 1, 32
+    it.nsplit, it.N, it.K = g, Cc, 32
+    pending.append((it, slab, dW, dbias))
+    return G, ((bstats, g) if bstats is not None else None)
 
 
 def softmax_cf(logits: torch.Tensor) -> torch.Tensor:

@@ -24,8 +24,12 @@ _PERM_BY_KERNEL = os.environ.get("RL_PERM_MEMCPY", "0") != "1"      # A/B: hipMe
 # on a second stream, under the previous step's kernels (round 5).  Built, bit-identical - and measured: 6.73 -> 6.78 ms per step.
 # The kernel trace shows the preparation running on its own hardware queue beside two or three network kernels, and every one of
 # them stretching by what the other takes (grid_query 243 -> 293 - 326 us; 67.3 ms of kernel time in a 59.9 ms window): the
-# network's kernels already fill the chip, so OFF by default; RL_PREP_PIPELINE=1 / TrainStep(pipeline=True) turns it on.
-_PREP_PIPELINE = os.environ.get("RL_PREP_PIPELINE", "0") == "1"
+# network's kernels already fill the chip, so OFF by default on ONE rank; RL_PREP_PIPELINE=1 / TrainStep(pipeline=True) turns it on.
+# With SEVERAL ranks it is the default (RL_PREP_PIPELINE=0 turns it off): the preparation of step t + 1 is then ordered behind
+# step t's network graph and runs beside step t's gradient all-reduce + Adam - a latency-bound collective on a few CUs under half
+# a millisecond of kernels that need no gradient and no weight - so the collective no longer stands alone between two graphs.
+_PREP_PIPELINE_ENV = os.environ.get("RL_PREP_PIPELINE", "")
+_PREP_PIPELINE = _PREP_PIPELINE_ENV == "1"
 
 
 def _upload_perm(perm_dev: torch.Tensor, staging: torch.Tensor, N: int) -> None:
@@ -143,7 +147,8 @@ class TrainStep:
         sync: the data-parallel EQUIVALENCE mode - BatchNorm batch statistics and the loss' class
         sums of the GLOBAL batch (all-reduced), gradients summed instead of averaged: N ranks on shards reproduce the
         single-process step on the whole batch.  Eager launches only (collectives between kernels).
-        pipeline (graph mode; default OFF - measured neutral, see _PREP_PIPELINE; RL_PREP_PIPELINE=1): the part of a step that
+        pipeline (graph mode; default: on with several ranks, where it hides the gradient all-reduce; off with one - measured
+        neutral there, see _PREP_PIPELINE; RL_PREP_PIPELINE=1 / 0 forces it): the part of a step that
         depends on the input rows and the permutation alone (Engine.prepare: permuted rows, all neighbour searches, graph
         transposes) is captured as its OWN graph and replayed on a second stream, so that step t's preparation runs under
         step t - 1's network kernels (the host submits ahead of the GPU).  Two sets of its outputs alternate (and two
@@ -181,11 +186,14 @@ class TrainStep:
         self._g_main: Optional[torch.cuda.CUDAGraph] = None
         self._g_adam: Optional[torch.cuda.CUDAGraph] = None
         # pipelined preparation: set k = step % 2 (its own permutation buffer, Engine.Prep, preparation graph, network graph)
-        self.pipeline = bool(use_graph and sync is None and (_PREP_PIPELINE if pipeline is None else pipeline))
+        if pipeline is None:
+            pipeline = _PREP_PIPELINE or (self.split and _PREP_PIPELINE_ENV != "0")
+        self.pipeline = bool(use_graph and sync is None and pipeline)
         self._sets: list = []
         self._side: Optional[torch.cuda.Stream] = None
         self._turn = 0
         self._batch_ready: Optional[torch.cuda.Event] = None
+        self._net_done: Optional[torch.cuda.Event] = None
 
     # -- the schedule ------------------------------------------------------------------------
     def _fwd_bwd(self, perm: Optional[torch.Tensor] = None, prep=None):
@@ -194,10 +202,15 @@ class TrainStep:
         if self.sync is not None:
             self.engine.drop_stream = 0     # one mask for the whole batch, sliced by sync.cloud_offset
         try:
-            logits, ctx = self.engine.forward(self.inp, self.perm if perm is None else perm, True, self.p_drop, prep=prep)
-            _, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True, out=self.out, sync=self.sync)
-            dlogits = ops.loss_backward(logits, self.labels, self.kind, self.alpha, self.gamma, True, work, sync=self.sync)
-            self.engine.backward(ctx, dlogits, self.flat.grads)
+            # the head of the network (Dropout, fc_end.3, un-permute, loss + counts) as one kernel each way where it is supported
+            head = ops.Head(self.labels, self.kind, self.alpha, self.gamma, True, self.out) if self.sync is None else None
+            logits, ctx = self.engine.forward(self.inp, self.perm if perm is None else perm, True, self.p_drop, prep=prep, head=head)
+            if logits is None:
+                self.engine.backward(ctx, None, self.flat.grads)
+            else:
+                _, work = ops.loss_forward(logits, self.labels, self.kind, self.alpha, self.gamma, True, out=self.out, sync=self.sync)
+                dlogits = ops.loss_backward(logits, self.labels, self.kind, self.alpha, self.gamma, True, work, sync=self.sync)
+                self.engine.backward(ctx, dlogits, self.flat.grads)
         finally:
             self.engine.sync = None
             self.engine.drop_stream = stream
@@ -305,6 +318,12 @@ class TrainStep:
             self._side.wait_event(self._batch_ready)
         if st["main_done"] is not None:
             self._side.wait_event(st["main_done"])
+        # several ranks: the preparation starts when the PREVIOUS step's network graph has finished, i.e. beside that step's
+        # gradient all-reduce and Adam - the collective (latency-bound, a few CUs) hides under ~0.5 ms of coordinate-only kernels
+        # that need neither gradients nor weights, instead of standing alone between two graphs.  (One rank: started earlier it
+        # only time-slices with the network kernels - measured neutral - so the same order costs nothing there.)
+        if self.split and self._net_done is not None:
+            self._side.wait_event(self._net_done)
         with torch.cuda.stream(self._side):
             _upload_perm(st["perm"], self._perm_ring[slot], self.N)
             ev = torch.cuda.Event()
@@ -317,6 +336,7 @@ class TrainStep:
         st["g_main"].replay()
         st["main_done"] = torch.cuda.Event()
         st["main_done"].record(main)
+        self._net_done = st["main_done"]
         if self.split:
             self._allreduce()
             self._g_adam.replay()

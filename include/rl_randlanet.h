@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 107     /* round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted); round 4: rl_launch_count */
+#define RL_VERSION 108     /* round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted), rl_head_*; round 4: rl_launch_count */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -662,6 +662,58 @@ int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int F, const i
  * [0, n_points), no sort; with replacement past n_points), noise (B,n,3) = standard-normal float64; either may be NULL.  Pure
  * functions of (seed, cloud, position). */
 int rl_batch_draw(const rl_cloud_job* jobs_dev, int B, int n, uint64_t seed, int64_t* indices, double* noise, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The head of the network, fused for the training step (round 5): Dropout(p) -> fc_end.3 (Conv2d 32 -> C without BatchNorm,
+ * modules.py:525-530) -> un-permute (modules.py:608) -> loss + metric counts (losses.py:17-87, metrics.py:8-59) as ONE kernel,
+ * and its whole backward - loss derivative, permute, input gradient of fc_end.3, Dropout backward - as ONE more, which also
+ * leaves the BatchNorm-backward sums of fc_end.1 and fc_end.3's weight / bias gradient slabs.  The step's logits are never stored.
+ *   X (B*N, 32): raw output of fc_end.1 in PERMUTED row order, with its folded BatchNorm (scale, shift, act, slope) applied on
+ *     load; perm (N) int64: row r of cloud b is point perm[r] (its label: labels[b][perm[r]]); W (C, 32), bias (C): fc_end.3.
+ *   Dropout: the mask of rl_dropout_fwd (Philox on (element quad, *drop_key | drop_seed), rows offset by drop_first_row);
+ *     drop_p == 0: none.
+ *   work: rl_loss_work_doubles(B*N, C) doubles; rl_head_fwd fills the slots and the totals record and writes `out`
+ *     (1 + 4*C doubles) exactly as rl_loss_forward does; rl_head_bwd reads the totals record.
+ *   rl_head_bwd: G (B*N, 32) = gradient w.r.t. fc_end.1's ACTIVATED output (input of rl_bn_bwd_apply / rl_bn_backward);
+ *     bn_bwd_stats (optional): [rl_head_grid(rows)][2][32] doubles, the partials rl_bn_bwd_reduce would leave for fc_end.1
+ *     (needs mean / invstd); slab: rl_head_grid(rows) partial records of C*32 + C floats (dW[C][32], then db[C]) for
+ *     rl_wgrad_reduce_batch (nsplit = rl_head_grid(rows), N = C, K = 32).
+ * rl_head_supported(C, K): 1 for K == 32 and 1 <= C <= 8; otherwise the caller runs the separate entry points. */
+typedef struct rl_head_desc {
+    const float* X;
+    const float* scale;
+    const float* shift;
+    int32_t act;
+    float slope;
+    const float* mean;
+    const float* invstd;
+    const float* W;
+    const float* bias;
+    const int64_t* perm;
+    const int64_t* labels;
+    int32_t B, N, C;
+    int32_t loss_kind;
+    float alpha, gamma;
+    int32_t neglect_background;
+    float drop_p;
+    const int64_t* drop_key;
+    uint64_t drop_seed;
+    int64_t drop_first_row;
+    double* work;
+    float* G;
+    double* bn_bwd_stats;
+    float* slab;
+    int64_t slab_floats;
+    float grad_scale;
+    int32_t reserved;
+    /* optional (drop_p > 0): B*N uint32 - the forward stores each row's 32 keep bits, the backward reads them instead of running
+     * the generator a second time (a Philox call is ~40 quarter-rate integer multiplies: the dominant cost of both kernels) */
+    void* drop_mask;
+} rl_head_desc;
+int rl_head_supported(int C, int K);
+int rl_head_grid(int64_t rows);
+int rl_head_fwd(const rl_head_desc* d, double* out, void* stream);
+int rl_head_bwd(const rl_head_desc* d, void* stream);
 
 /* Dropout (fc_end, modules.py:528) with a keep-mask drawn by the caller (uint8, 1 = keep):
  * x[i] = mask[i] ? x[i]*scale : 0, in place; the same call is its own backward.             */

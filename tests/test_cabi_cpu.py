@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
 def test_host_only_entry_points(lib):
     from randlanet import _hip
     L = _hip.lib()
-    assert L.rl_version() == _hip.ABI_VERSION == 107
+    assert L.rl_version() == _hip.ABI_VERSION == 108
     assert L.rl_row_blocks(1, 128) == 1 and L.rl_row_blocks(128 * 5000, 128) == 1024
     assert L.rl_row_blocks(129, 128) == 2
     assert L.rl_wgrad_slab_floats(1000, 16, 16) > 0
@@ -95,7 +95,7 @@ def test_ctypes_structures_have_the_headers_layout(tmp_path):
     pairs = {"rl_gemm_desc": _hip.GemmDesc, "rl_wsplit_item": _hip.WsplitItem, "rl_wgrad_desc": _hip.WgradDesc,
              "rl_wgrad_reduce_item": _hip.WgradReduceItem, "rl_bn_bwd_desc": _hip.BnBwdDesc, "rl_knn_task": _hip.KnnTask,
              "rl_pool_desc": _hip.PoolDesc, "rl_resid_bn_bwd_desc": _hip.ResidBnBwdDesc, "rl_csr_task": _hip.CsrTask,
-             "rl_bn_finalize_item": _hip.BnFinalizeItem,
+             "rl_bn_finalize_item": _hip.BnFinalizeItem, "rl_head_desc": _hip.HeadDesc,
              "rl_segsum_desc": _hip.SegsumDesc, "rl_rows_desc": _hip.RowsDesc, "rl_cloud_job": _hip.CloudJob}
     text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]

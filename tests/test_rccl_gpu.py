@@ -1,5 +1,6 @@
 """RCCL on the one leasable GPU: a ONE-rank `nccl` process group runs the multi-rank schedule of TrainStep - forward + backward
-graph, all-reduce(SUM) of the flat gradient buffer through RCCL on the step's stream, Adam graph - and must leave exactly the
+graph, all-reduce(SUM) of the flat gradient buffer through RCCL on the step's stream, Adam graph, with the NEXT step's
+coordinate-only preparation on a second stream beside the collective (and without it) - and must leave exactly the
 parameters of the single-graph schedule (a one-rank sum is the identity, grad_scale 1 / 1).  What this covers that the gloo
 tests cannot: the RCCL library loads and builds a communicator on this image, graph capture coexists with its watchdog thread
 (capture_error_mode "thread_local"), and the collective is ordered between the two graph replays.  Two ranks cannot share a
@@ -15,10 +16,10 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 CFG = dict(n_classes=3, n_points=2048, n_neighbors=16, layer_sizes=[8, 16, 32, 32])
-N, B, STEPS = 2048, 2, 3
+N, B, STEPS = 2048, 2, 5
 
 
-def _run(split, pg=None):
+def _run(split, pg=None, pipeline=None):
     from randlanet._train import TrainStep, broadcast_flat
     from randlanet.utils.modules import RandLANet, RandLANetSettings
     dev = torch.device("cuda", 0)
@@ -28,7 +29,9 @@ def _run(split, pg=None):
     rs = np.random.RandomState(3)
     xyz = rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
     lab = np.clip(np.floor(xyz[..., 2] * 3), 0, 2).astype(np.int64)
-    st = TrainStep(net, B, N, loss="dice", use_graph=True, process_group=pg, split_schedule=split)
+    st = TrainStep(net, B, N, loss="dice", use_graph=True, process_group=pg, split_schedule=split, pipeline=pipeline)
+    # several ranks (or their schedule): the next step's coordinate-only preparation runs on a second stream beside the all-reduce
+    assert st.pipeline == (split if pipeline is None else pipeline)
     st.set_batch(torch.from_numpy(xyz).to(dev), torch.from_numpy(lab).to(dev))
     if split:
         import torch.distributed as dist
@@ -60,7 +63,9 @@ def _worker(port, q):
             dist.all_reduce(t)                              # communicator is built by the first collective
             torch.cuda.synchronize()
             assert dist.get_backend() == "nccl" and t[7].item() == 7.0
-            param, losses = _run(True)
+            param, losses = _run(True)                      # (pipelined preparation: the multi-rank default)
+            param2, losses2 = _run(True, pipeline=False)    # the plain order: graph, all-reduce, Adam graph
+            assert losses2 == losses and np.array_equal(param, param2)
             q.put(("ok", param, losses))
         finally:
             dist.destroy_process_group()
