@@ -93,11 +93,22 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(double* __restrict__
     if (mode & 1) {
         // every thread owns the slots t, t + 256, ... (all their loads are independent: one memory round trip for the kernel, where
         // a wavefront per entry walked three entries one after the other); fixed order -> deterministic
-        for (int e = 0; e < rs; ++e) {
-            double s = 0.0;
-            for (int i = threadIdx.x; i < nslots; i += 256) s += work[(long)i * rs + e];
-            s = rl_wave_sum(s);
-            if (lane == 0) part[wave][e] = s;
+        // (eight entries at a time: their loads are issued together - entry by entry the wavefront sum of one entry stood between
+        // the loads of the next, eleven dependent round trips for two classes)
+        for (int e0 = 0; e0 < rs; e0 += 8) {
+            double s[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] = 0.0;
+            for (int i = threadIdx.x; i < nslots; i += 256) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < rs) s[u] += work[(long)i * rs + e0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double t = rl_wave_sum(s[u]);
+                if (lane == 0 && e0 + u < rs) part[wave][e0 + u] = t;
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < rs; e += 256) {

@@ -53,3 +53,30 @@ for name, rot in (("cold", NB), ("resident", 1)):
     for k, v in acc.items():
         v = sorted(v)
         print(f"{k:16s} {name:9s} median {v[len(v) // 2]:7.1f} us")
+
+# Do G and Y at the SAME offset from equally aligned bases collide in the memory system (same channel / bank, different DRAM
+# rows)?  Y carved out of one big buffer at base + shift: time of the cold reduce sweep per shift.
+print("stagger test: bn_bwd_reduce cold, Y at a 2 MB-aligned base + shift")
+per = (M * C * 4 + (4 << 20)) // 4          # floats per slot: the tensor + 4 MB of room for the shift
+bigG = torch.randn(NB * per, device=dev)
+bigY = torch.randn(NB * per, device=dev)
+assert bigG.data_ptr() % (2 << 20) == 0 and bigY.data_ptr() % (2 << 20) == 0, (bigG.data_ptr(), bigY.data_ptr())
+for shift in (0, 256, 1024, 4096, 8192, 16384, 65536, 262144, 1 << 20, (1 << 20) + 4096):
+    G2 = [bigG[i * per: i * per + M * C].view(M, C) for i in range(NB)]
+    Y2 = [bigY[i * per + shift // 4: i * per + shift // 4 + M * C].view(M, C) for i in range(NB)]
+    lz = []
+    for i in range(NB):
+        y = ops.plain(Y2[i], 1, M)
+        y.scale, y.shift = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        y.mean, y.invstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        y.act, y.slope = 2, 0.2
+        lz.append(y)
+    ops.TIMER = ops.KernelTimer()
+    for i in range(24):
+        ops.bn_backward(G2[i % NB], lz[i % NB], dg, db, True)
+    torch.cuda.synchronize()
+    acc = {}
+    for cat, key, nbytes, flops, e0, e1, kern, lvl in ops.TIMER.records:
+        acc.setdefault(cat, []).append(e0.elapsed_time(e1) * 1e3)
+    ops.TIMER = None
+    print(f"shift {shift:8d} B: " + "  ".join(f"{k} {sorted(v)[len(v) // 2]:6.1f} us" for k, v in acc.items()))
