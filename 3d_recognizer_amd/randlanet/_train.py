@@ -186,6 +186,7 @@ class TrainStep:
         self._g_main: Optional[torch.cuda.CUDAGraph] = None
         self._g_adam: Optional[torch.cuda.CUDAGraph] = None
         # pipelined preparation: set k = step % 2 (its own permutation buffer, Engine.Prep, preparation graph, network graph)
+        self._pipeline_auto = pipeline is None and not _PREP_PIPELINE     # chosen here, not asked for: may fall back (see _capture)
         if pipeline is None:
             pipeline = _PREP_PIPELINE or (self.split and _PREP_PIPELINE_ENV != "0")
         self.pipeline = bool(use_graph and sync is None and pipeline)
@@ -246,9 +247,19 @@ class TrainStep:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls count
-        if self.pipeline:
+        if self.pipeline and self._pipeline_auto:
+            # the multi-rank default is a pure scheduling choice (same kernels, same results): if its capture fails on some
+            # platform, say so and run the plain order instead of failing the job
+            try:
+                self._capture_pipeline()
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"pipelined preparation could not be captured ({e}); using the plain schedule")
+                torch.cuda.synchronize(self.dev)
+                self.pipeline, self._sets, self._g_main = False, [], None
+        elif self.pipeline:
             self._capture_pipeline()
-        else:
+        if not self.pipeline:
             self._g_main = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_main, capture_error_mode="thread_local"):
                 self._fwd_bwd()
