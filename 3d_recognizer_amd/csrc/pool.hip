@@ -142,6 +142,7 @@ struct PoolParams {
     const float* piv1; const float* piv2;      // shifted statistics: running mean of stage 1 / 2 (forward statistics only), or null
     double* fstats2;       // pool_fwd with virtual stage 1: [grid][2][H] partial (sum, sum of squares) of the RAW stage-2 output
     double* bstats;        // pool_bwd with a virtual stage: [grid][2][H] partial sums of g and g*xhat of that stage's BatchNorm
+    int xcd_chunk;         // > 0: workgroups of XCD x (blockIdx.x % 8) take the points [x * xcd_chunk, (x + 1) * xcd_chunk) - see PointSpan
 };
 
 template <int DT>
@@ -227,6 +228,31 @@ struct Cursor {
         return c;
     }
 };
+
+// Which points a wavefront visits: first, first + step, ... < end.
+// Workgroup ids are dealt round-robin over the chip's 8 XCDs, each with an L2 of its own (4 MB).  With the points dealt
+// round-robin over the workgroups too, every XCD gathers neighbour rows (and coordinates) from EVERY cloud of the batch: at
+// bs = 8 the level-0 tables are 10.5 + 3.9 MB, no L2 holds them and nearly every 32-byte gathered row arrives as a 128-byte
+// line from the Infinity Cache (PMC: 620 MB fetched by a level-0 forward launch whose streamed operands are 60 MB).  XCD-local
+// ranges instead: XCD x owns the points [x * chunk, (x + 1) * chunk) - at bs = 8 one cloud, whose tables (1.3 + 0.5 MB) then
+// stay in that XCD's L2.  Same points per workgroup as before, another assignment; partial sums per workgroup as before.
+struct PointSpan { int first, step, end; };
+template <int NW>
+__device__ __forceinline__ PointSpan point_span(const PoolParams& p, int wave) {
+    PointSpan s;
+    if (p.xcd_chunk > 0) {          // (host: the grid is a multiple of 8)
+        const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        const int lo = x * p.xcd_chunk, hi = lo + p.xcd_chunk;
+        s.end = hi < (int)p.P ? hi : (int)p.P;
+        s.first = lo + slot * NW + wave;
+        s.step = ((int)gridDim.x >> 3) * NW;
+    } else {
+        s.end = (int)p.P;
+        s.first = (int)blockIdx.x * NW + wave;
+        s.step = (int)gridDim.x * NW;
+    }
+    return s;
+}
 
 // The 16 x d tile of X for point pt in A layout, in two steps so that the loads of the NEXT point can be in flight
 // while the current one is computed: fetch_x issues the raw loads (rpe-branch rows + gathered rows),
@@ -430,25 +456,26 @@ __global__ __launch_bounds__(64 * NW) void pool_fwd_kernel(const PoolParams p) {
     __syncthreads();
     float* Xs = Xt[wave];
     // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
-    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    const PointSpan span = point_span<NW>(p, wave);
+    const long pstep = span.step, Pend = span.end;
+    long pt = span.first;
+    int idx_cur = pt < Pend ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < Pend ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
     Cursor cu;
     cu.start(pt, p.n);
-    if (pt < p.P) fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
+    if (pt < Pend) fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
                          // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
-    for (; pt < p.P; pt += pstep) {
+    for (; pt < Pend; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, lf, xa, Xs);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        const int idx_n2 = pt + 2 * pstep < Pend ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
-        const Cursor cf = pt + pstep < p.P ? cn : cu;
-        fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
+        const Cursor cf = pt + pstep < Pend ? cn : cu;
+        fetch_x<DT>(p, cf, li, lj, pt + pstep < Pend ? idx_nxt : idx_cur, raw);
         loads_issued();
         cu = cn;
         idx_cur = idx_nxt; idx_nxt = idx_n2;
@@ -517,10 +544,11 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
         for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // software pipeline over the wavefront's points: neighbour index two points ahead, raw rows one point ahead
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
-    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    const PointSpan span = point_span<NW>(p, wave);
+    const long pstep = span.step, Pend = span.end;
+    long pt = span.first;
+    int idx_cur = pt < Pend ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < Pend ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
     Cursor cu;
     cu.start(pt, p.n);
@@ -531,7 +559,7 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     float gp[DT], gp_nxt[DT];          // dP of the current / next point
 #pragma unroll
     for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb] = 0.f;
-    if (pt < p.P) {
+    if (pt < Pend) {
         fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
@@ -539,15 +567,15 @@ __global__ __launch_bounds__(64 * NW) void pool_bwd_kernel(const PoolParams p) {
     constexpr int NGU = DT == 1 ? 1 : DT / 2;     // column blocks that hold rpe-branch (GU) columns
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
                          // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
-    for (; pt < p.P; pt += pstep) {
+    for (; pt < Pend; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, lf, xa, Xs);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        const int idx_n2 = pt + 2 * pstep < Pend ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
-        const Cursor cf = pt + pstep < p.P ? cn : cu;
-        fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
+        const Cursor cf = pt + pstep < Pend ? cn : cu;
+        fetch_x<DT>(p, cf, li, lj, pt + pstep < Pend ? idx_nxt : idx_cur, raw);
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
         f32x4 gacc[NGU];                 // GU of this point when this launch adds to it
@@ -738,32 +766,33 @@ __global__ __launch_bounds__(512) void pool128_bwd_kernel(const PoolParams p) {
     float* Xs = Tiles[wave];
     float* Ds = Tiles[wave];
 
-    const long pstep = (long)gridDim.x * NW;
-    long pt = (long)blockIdx.x * NW + wave;
-    int idx_cur = pt < p.P ? p.idx[pt * 16 + li] : 0;
-    int idx_nxt = pt + pstep < p.P ? p.idx[(pt + pstep) * 16 + li] : 0;
+    const PointSpan span = point_span<NW>(p, wave);
+    const long pstep = span.step, Pend = span.end;
+    long pt = span.first;
+    int idx_cur = pt < Pend ? p.idx[pt * 16 + li] : 0;
+    int idx_nxt = pt + pstep < Pend ? p.idx[(pt + pstep) * 16 + li] : 0;
     float4 raw[DT];
     Cursor cu;
     cu.start(pt, p.n);
     float gp[DT], gp_nxt[DT];      // dP of the current / next point (one load group per iteration, as in pool_bwd_kernel)
 #pragma unroll
     for (int nb = 0; nb < DT; ++nb) gp[nb] = gp_nxt[nb] = 0.f;
-    if (pt < p.P) {
+    if (pt < Pend) {
         fetch_x<DT>(p, cu, li, lj, idx_cur, raw);
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp[nb] = p.dP[pt * D + nb * 16 + li];
     }
     loads_landed();      // the prologue's loads: the loop is then entered with nothing pending, like its back edge (otherwise the
                          // compiler's own wait at the loop top covers both entries and, on the back edge, also the stores)
-    for (; pt < p.P; pt += pstep) {
+    for (; pt < Pend; pt += pstep) {
         const Cursor cn = cu.next(pstep, p.n);
         float4 xa[DT];
         finish_x<DT>(p, li, lj, raw, lf, xa, Xs);
-        const int idx_n2 = pt + 2 * pstep < p.P ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
+        const int idx_n2 = pt + 2 * pstep < Pend ? p.idx[(pt + 2 * pstep) * 16 + li] : 0;
         // no branch around the prefetch: past the last point the CURRENT point is read again (never used).  With a branch
         // the loaded registers are merged with the old ones behind it - copies, and a wait for loads just issued.
-        const Cursor cf = pt + pstep < p.P ? cn : cu;
-        fetch_x<DT>(p, cf, li, lj, pt + pstep < p.P ? idx_nxt : idx_cur, raw);
+        const Cursor cf = pt + pstep < Pend ? cn : cu;
+        fetch_x<DT>(p, cf, li, lj, pt + pstep < Pend ? idx_nxt : idx_cur, raw);
 #pragma unroll
         for (int nb = 0; nb < DT; ++nb) gp_nxt[nb] = p.dP[cf.pt * D + nb * 16 + li];
         loads_issued();
@@ -1412,8 +1441,9 @@ __global__ __launch_bounds__(256) void vpool_fwd_kernel(const PoolParams p) {
     __syncthreads();
     float* Xs = Xt[wave];
     // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
-    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
-    int pt = (int)blockIdx.x * NW + wave;
+    const PointSpan span = point_span<NW>(p, wave);
+    const int P = span.end, pstep = span.step;
+    int pt = span.first;
     const int npts = (int)wave_points(pt, pstep, P);
     // Software pipeline TWO points deep (round 4: with ~160 instructions per point left, one point of prefetch is shorter than a
     // gather's latency).  Two buffers alternate: while buffer U's point is computed, U is refilled for the point two further on
@@ -1550,8 +1580,9 @@ __global__ __launch_bounds__(256) void vrpe_stats_kernel(const PoolParams p, dou
 #pragma unroll
     for (int nb = 0; nb < NCH; ++nb) ssum[nb] = ssq[nb] = splat(0.f);
     // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
-    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
-    int pt = (int)blockIdx.x * NW + wave;
+    const PointSpan span = point_span<NW>(p, wave);
+    const int P = span.end, pstep = span.step;
+    int pt = span.first;
     const int npts = (int)wave_points(pt, pstep, P);
     // two points deep, two alternating buffers (see vpool_fwd_kernel): coordinates + distance of a point, and the neighbour
     // index of the point that takes the buffer next
@@ -1700,8 +1731,9 @@ __global__ __launch_bounds__(64 * NW) void vpool_bwd_kernel(const PoolParams p) 
         for (int kb = 0; kb < DT; ++kb) accw[nb][kb] = splat(0.f);
 
     // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
-    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
-    int pt = (int)blockIdx.x * NW + wave;
+    const PointSpan span = point_span<NW>(p, wave);
+    const int P = span.end, pstep = span.step;
+    int pt = span.first;
     const int npts = (int)wave_points(pt, pstep, P);
     // Software pipeline two points deep (see vpool_fwd_kernel): a buffer holds a point's gathered rows, coordinates, dP and - when
     // this launch adds to GU - its GU rows, plus the neighbour index of the point that takes the buffer next.
@@ -2043,8 +2075,9 @@ __global__ __launch_bounds__(256) void vrpe_bn_reduce_kernel(const RpeBwdParams 
 #pragma unroll
     for (int nb = 0; nb < NCH; ++nb) sg[nb] = sx[nb] = splat(0.f);
     // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
-    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
-    int pt = (int)blockIdx.x * NW + wave;
+    const PointSpan span = point_span<NW>(p, wave);
+    const int P = span.end, pstep = span.step;
+    int pt = span.first;
     RpeIn2 rin = {0.f, 0.f, 0.f}, rin_nxt;
     Cursor cu;
     cu.start(pt, p.n);
@@ -2147,8 +2180,9 @@ __global__ __launch_bounds__(256) void vrpe_wgrad_kernel(const RpeBwdParams q) {
         for (int kb = 0; kb < KB; ++kb) accw[nb][kb] = splat(0.f);
     }
     // 32-bit point arithmetic (points * 16 < 2^31, checked on the host): a 64-bit ordered compare is a VECTOR instruction
-    const int P = (int)p.P, pstep = (int)gridDim.x * NW;
-    int pt = (int)blockIdx.x * NW + wave;
+    const PointSpan span = point_span<NW>(p, wave);
+    const int P = span.end, pstep = span.step;
+    int pt = span.first;
     // two points deep, two alternating buffers (see vpool_fwd_kernel)
     constexpr int NG = 3 + NCH + 1;
     struct Buf { RpeIn2 rin; float4 gin[NCH]; int idx; } A, B;
@@ -2467,6 +2501,16 @@ int pool_grid(long P, int d, bool backward, bool virt = false) {
     return (int)(g < cap ? g : cap);
 }
 
+// XCD-local point ranges (PointSpan): on when the grid is a multiple of 8; RL_NO_XCD_POINTS turns them off (A/B).  Used by the
+// virtual FORWARD launches and the rpe statistics (level 0: 101.7 -> 81 us per launch, PMC fetch 620 -> ~100 MB); measured on
+// every pooling / rpe kernel of a step (round 5): the backward kernels do not gain (+-2 %: bound by vector instructions, and
+// their gathers already share lines), pool128_bwd loses 3 % - those keep the round-robin assignment.
+static int xcd_chunk_for(long P, int grid) {
+    static const bool off = getenv("RL_NO_XCD_POINTS") != nullptr;
+    if (off || grid < 8 || grid % 8 != 0 || P >= (1l << 30)) return 0;
+    return (int)((P + 7) / 8);
+}
+
 // Arithmetic of the tile kernels for a level of width d: the narrow levels are bound by vector-instruction issue, not by
 // the matrix pipe - the head/tail split of every operand costs more than the exact fp32 MFMA it avoids - so d <=
 // RL_POOL_FP32_MAX_D (default 0: measured no gain at d = 16 / 32) would run v_mfma_f32_16x16x4_f32 (exact fp32 products, whatever the wide-GEMM mode).
@@ -2509,6 +2553,7 @@ int fill(PoolParams* p, const rl_pool_desc* d, const char* who, bool backward) {
     p->Pout = d->Pout; p->dP = d->dP; p->GU = d->GU; p->gu_accumulate = d->gu_accumulate; p->DG = d->DG; p->slab = d->slab;
     p->slab_stride = (long)d->d * d->d + (d->dW ? 0 : d->d);
     p->X_out = nullptr; p->dS_out = nullptr;
+    p->xcd_chunk = 0;
     p->src = d->u_source;
     RL_REQUIRE(d->u_source >= 0 && d->u_source <= 2, RL_ERR_ARGS, "%s: u_source must be 0, 1 or 2", who);
     if (d->u_source > 0) {
@@ -2562,6 +2607,7 @@ extern "C" int rl_pool_fwd(const rl_pool_desc* d, void* stream) {
     const int g = pool_grid(p.P, p.d, false);
     hipStream_t st = (hipStream_t)stream;
     if (p.src > 0) {
+        p.xcd_chunk = xcd_chunk_for(p.P, g);
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_fwd: the virtual rpe branch needs its folded BatchNorm(s)");
         const int key = (pool_terms(p.d) == 0 ? 0 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + (p.src == 2 ? 2 : p.fstats2 ? 1 : 0);
 #define VFWD(K, DT, TERMS, SRC, FST) \
@@ -2688,6 +2734,7 @@ extern "C" int rl_rpe_stats(const rl_pool_desc* d, double* stats, void* stream) 
     p.W2 = d->W2; p.b2 = d->b2; p.sc2 = d->scale2; p.sh2 = d->shift2;
     p.piv1 = d->pivot_mean1; p.piv2 = d->pivot_mean2;       // shifted sums around the stage's running mean (or null)
     const int g = rpe_grid(p.P);
+    p.xcd_chunk = xcd_chunk_for(p.P, g);
     hipStream_t st = (hipStream_t)stream;
     const int key = (pool_terms(p.d) == 0 ? 0 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + p.src;
 #define VST(K, DT, TERMS, SRC) \
