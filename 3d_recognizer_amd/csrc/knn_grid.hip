@@ -67,6 +67,7 @@ struct KTask {
 
 struct KMulti {
     int ntasks, B;
+    int xcd;               // grid_query_kernel: workgroups of an XCD serve the clouds b = XCD mod B (see there)
     KTask t[KNN_MAX_TASKS];
 };
 
@@ -324,9 +325,9 @@ __device__ __forceinline__ float axis_gap(const GridGeom& g, int a, int ci, floa
 }
 
 template <int KMAX>
-__device__ __forceinline__ void query_one_lane(const KTask& T, int b) {
+__device__ __forceinline__ void query_one_lane(const KTask& T, int b, int bx) {
     const int k = T.k, Nq = T.Nq, Ns = T.Ns;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = bx * 256 + threadIdx.x;
     if (t >= Nq) return;
     const int self_mode = T.self_mode;
     const float* Q = T.Q;
@@ -505,13 +506,13 @@ __device__ __forceinline__ void scan_range_n(const float4* __restrict__ pts, int
 }
 
 template <int KMAX, int LANES>
-__device__ __forceinline__ void query_n_lanes(const KTask& T, int b, unsigned long long* lds) {
+__device__ __forceinline__ void query_n_lanes(const KTask& T, int b, int bx, unsigned long long* lds) {
     constexpr int QPB = 256 / LANES;           // queries per workgroup
     unsigned long long (*lists)[LANES][KMAX] = reinterpret_cast<unsigned long long (*)[LANES][KMAX]>(lds);
     const int k = T.k, Nq = T.Nq, Ns = T.Ns;
     const int qslot = threadIdx.x / LANES, sub = threadIdx.x % LANES;
-    const int t = blockIdx.x * QPB + qslot;
-    if (blockIdx.x * QPB >= Nq) return;        // whole workgroup
+    const int t = bx * QPB + qslot;
+    if (bx * QPB >= Nq) return;                // whole workgroup
     const bool active = t < Nq;                // same for the four lanes of a query; every lane reaches the barrier
     unsigned long long best[KMAX];
 #pragma unroll
@@ -632,14 +633,23 @@ template <int KMAX>
 // spill under the cap and keep their registers.
 __global__ __launch_bounds__(256, KMAX <= 16 ? 4 : 1) void grid_query_kernel(const KMulti m) {
     __shared__ unsigned long long lds[KMAX <= 16 ? 256 * KMAX : 1];
-    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const int task = blockIdx.y / m.B;
+    int b = blockIdx.y % m.B, bx = blockIdx.x;
+    if (m.xcd) {
+        // Workgroup ids go round-robin over the 8 XCDs (id = x + gridDim.x * y), each with its own L2.  The (x, cloud) pairs of a
+        // task are re-dealt so that the cloud is the id modulo B: for B | 8 the workgroups of one XCD then search ONE cloud
+        // (B = 8) or two, whose sorted points and cell table stay in that L2, instead of a slice of every cloud.
+        const int lin = (int)blockIdx.x + (int)gridDim.x * b;
+        b = lin % m.B;
+        bx = lin / m.B;
+    }
     const KTask& T = m.t[task];
     if (kmax_of(T.k) != KMAX) return;            // another instantiation of this kernel serves that task
     if constexpr (KMAX <= 16) {
-        if (T.lanes == 4) { query_n_lanes<KMAX, 4>(T, b, lds); return; }
-        if (T.lanes == 2) { query_n_lanes<KMAX, 2>(T, b, lds); return; }
+        if (T.lanes == 4) { query_n_lanes<KMAX, 4>(T, b, bx, lds); return; }
+        if (T.lanes == 2) { query_n_lanes<KMAX, 2>(T, b, bx, lds); return; }
     }
-    query_one_lane<KMAX>(T, b);
+    query_one_lane<KMAX>(T, b, bx);
 }
 
 struct Plan {
@@ -693,6 +703,8 @@ inline int lanes_for(long queries, int k) {
 
 int run_multi(const KMulti& m_in, hipStream_t st) {
     KMulti m = m_in;
+    static const bool no_xcd = getenv("RL_NO_XCD_POINTS") != nullptr;      // A/B switch shared with the pooling kernels
+    m.xcd = (!no_xcd && m.B > 1 && 8 % m.B == 0) ? 1 : 0;
     for (int i = 0; i < m.ntasks; ++i) m.t[i].lanes = lanes_for((long)m.B * m.t[i].Nq, m.t[i].k);
     int maxNs = 1, maxNq = 1, maxc = 1;
     bool need[6] = {false, false, false, false, false, false};
