@@ -49,7 +49,19 @@ struct CsrMulti {
     CsrTask t[CSR_MAX_TASKS];
     int ntasks;
     int B;
+    int xcd;        // the (tile / bucket, cloud) pairs of a task are re-dealt so that the cloud is the workgroup id modulo B (csr_deal)
 };
+
+// Workgroup ids (x + gridDim.x * y) go round-robin over the 8 XCDs, each with its own L2.  With y = task * B + cloud every XCD
+// worked on a slice of EVERY cloud; dealt this way (B | 8) an XCD's workgroups stay with one cloud (B = 8) or two, whose index /
+// bucket arrays (2.6 MB at level 0) then live in that L2: the scattered 4-byte writes of pass 2 combine there.
+__device__ __forceinline__ void csr_deal(const CsrMulti& m, int& b, int& bx) {
+    if (m.xcd) {
+        const int lin = (int)blockIdx.x + (int)gridDim.x * b;
+        b = lin % m.B;
+        bx = lin / m.B;
+    }
+}
 
 __global__ __launch_bounds__(256) void csr_zero_kernel(const CsrMulti m) {
     const CsrTask& T = m.t[blockIdx.y];
@@ -126,14 +138,16 @@ __global__ __launch_bounds__(256) void csr2_zero_kernel(const CsrMulti m) {
 // pass 1: bucket sizes.  grid (max tiles, ntasks * B)
 __global__ __launch_bounds__(256) void csr2_hist_kernel(const CsrMulti m) {
     __shared__ int hist[CSR_MAX_BUCKETS];
-    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const int task = blockIdx.y / m.B;
+    int b = blockIdx.y % m.B, bx = blockIdx.x;
+    csr_deal(m, b, bx);
     const CsrTask& T = m.t[task];
-    if ((int)blockIdx.x >= T.ntiles) return;
+    if (bx >= T.ntiles) return;
     const int per = T.n_src * T.k;
     for (int i = threadIdx.x; i < T.nbuckets; i += 256) hist[i] = 0;
     __syncthreads();
     const int32_t* idx = T.idx + (long)b * per;
-    const int e0 = blockIdx.x * CSR_TILE;
+    const int e0 = bx * CSR_TILE;
 #pragma unroll 4
     for (int i = 0; i < CSR_TILE / 256; ++i) {
         const int e = e0 + i * 256 + threadIdx.x;
@@ -173,14 +187,16 @@ __global__ __launch_bounds__(1024) void csr2_scan_kernel(const CsrMulti m) {
 // pass 2: entries move to their bucket, packed (destination inside the bucket << 24 | local source row)
 __global__ __launch_bounds__(256) void csr2_scatter_kernel(const CsrMulti m) {
     __shared__ int hist[CSR_MAX_BUCKETS];
-    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const int task = blockIdx.y / m.B;
+    int b = blockIdx.y % m.B, bx = blockIdx.x;
+    csr_deal(m, b, bx);
     const CsrTask& T = m.t[task];
-    if ((int)blockIdx.x >= T.ntiles) return;
+    if (bx >= T.ntiles) return;
     const int per = T.n_src * T.k;
     for (int i = threadIdx.x; i < T.nbuckets; i += 256) hist[i] = 0;
     __syncthreads();
     const int32_t* idx = T.idx + (long)b * per;
-    const int e0 = blockIdx.x * CSR_TILE;
+    const int e0 = bx * CSR_TILE;
     int jv[CSR_TILE / 256], rk[CSR_TILE / 256];
 #pragma unroll
     for (int i = 0; i < CSR_TILE / 256; ++i) {
@@ -220,10 +236,12 @@ template <int CAP>
 __global__ __launch_bounds__(256) void csr2_bucket_kernel(const CsrMulti m) {
     __shared__ int cnt[CSR_BUCKET], start[CSR_BUCKET], cur[CSR_BUCKET];
     __shared__ int seg[CSR_BUCKET][CAP + 1];
-    const int task = blockIdx.y / m.B, b = blockIdx.y % m.B;
+    const int task = blockIdx.y / m.B;
+    int b = blockIdx.y % m.B, bx = blockIdx.x;
+    csr_deal(m, b, bx);
     const CsrTask& T = m.t[task];
-    if (T.cap != CAP || (int)blockIdx.x >= T.nbuckets) return;
-    const int per = T.n_src * T.k, h = blockIdx.x, t = threadIdx.x;
+    if (T.cap != CAP || bx >= T.nbuckets) return;
+    const int per = T.n_src * T.k, h = bx, t = threadIdx.x;
     const int* st = T.bstart + (long)b * (T.nbuckets + 1);
     const int s0 = st[h], mcount = st[h + 1] - s0;
     const int32_t* mid = T.tmp + (long)b * per + s0;
@@ -398,6 +416,9 @@ template <int TPR, bool SB = false>     // SB: the source rows are stored as bf1
 __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p) {
     constexpr int RPW = 256 / TPR;      // destination rows in flight per workgroup
     const int q = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
+    // (XCD-local destination ranges - one cloud's destinations on one XCD, as the CSR passes and the pooling forward have them -
+    // measured neutral here, round 5: <2> 97.3 -> 94.5 us, <8> 35.3 -> 36.6.  A cloud's source rows are 21 MB: the four rows of a
+    // line are summed at four unrelated moments of the sweep.)
     for (long d = (long)blockIdx.x * RPW + rsub; d < p.total; d += (long)gridDim.x * RPW) {
         const unsigned b = (unsigned)d / (unsigned)p.n_dst;
         const int j = (int)((unsigned)d - b * (unsigned)p.n_dst);
@@ -524,6 +545,8 @@ extern "C" int rl_csr_build(const rl_csr_task* tasks, int ntasks, int B, void* w
     CsrMulti m;
     m.ntasks = ntasks;
     m.B = B;
+    static const bool no_xcd = getenv("RL_NO_XCD_POINTS") != nullptr;       // A/B switch shared with the pooling / KNN kernels
+    m.xcd = (!no_xcd && B > 1 && 8 % B == 0) ? 1 : 0;
     char* ws = (char*)workspace;
     int64_t used = 0;
     long max_ent = 1, max_dst = 1;
