@@ -241,6 +241,7 @@ struct HeadParams {
     const float* mean; const float* invstd;     // backward: saved batch statistics of fc_end.1
     const float* W; const float* bias;          // fc_end.3: [C][32], [C]
     const int64_t* perm; const int64_t* labels;
+    long perm_bs;                   // 0: one permutation for all clouds; N: cloud b's own (rl_band_sort)
     int B, N, C;
     int kind; float alpha, gamma; int neglect;
     const int64_t* key; unsigned long long seed; unsigned threshold; float dscale; unsigned long long first_quad; int drop;
@@ -335,7 +336,7 @@ __device__ __forceinline__ HeadLab head_perm(const HeadParams& p, long Rr, long 
     const unsigned b = Rc / (unsigned)p.N;
     HeadLab h;
     h.off = b * (unsigned)p.N;
-    h.idx = p.perm[Rc - h.off];
+    h.idx = p.perm[(long)b * p.perm_bs + (Rc - h.off)];
     return h;
 }
 __device__ __forceinline__ int head_label(const HeadParams& p, const HeadLab& h) { return (int)p.labels[(long)h.off + h.idx]; }
@@ -812,6 +813,8 @@ static int head_fill(HeadParams* p, const rl_head_desc* d, const char* who, bool
     p->lazy.scale = d->scale; p->lazy.shift = d->shift; p->lazy.act = d->act; p->lazy.slope = d->slope;
     p->mean = d->mean; p->invstd = d->invstd;
     p->W = d->W; p->bias = d->bias; p->perm = d->perm; p->labels = d->labels;
+    RL_REQUIRE(d->perm_bstride == 0 || d->perm_bstride >= d->N, RL_ERR_ARGS, "%s: perm_bstride must be 0 or >= N", who);
+    p->perm_bs = (long)d->perm_bstride;
     p->B = d->B; p->N = d->N; p->C = d->C;
     p->kind = d->loss_kind; p->alpha = d->alpha; p->gamma = d->gamma; p->neglect = d->neglect_background;
     p->drop = d->drop_p > 0.f;

@@ -416,22 +416,22 @@ __global__ __launch_bounds__(256) void upsample_cf_kernel(const float* __restric
 
 // out[b][c][perm[i]] = in[b][i][c]
 __global__ __launch_bounds__(256) void logits_unpermute_kernel(const float* __restrict__ in, const int64_t* __restrict__ perm,
-                                                               int B, int N, int C, float* __restrict__ out) {
+                                                               long perm_bs, int B, int N, int C, float* __restrict__ out) {
     const long total = (long)B * N;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long b = e / N;
         const long i = e - b * N;
-        const long j = perm[i];
+        const long j = perm[b * perm_bs + i];
         for (int c = 0; c < C; ++c) out[(b * C + c) * N + j] = in[e * C + c];
     }
 }
 __global__ __launch_bounds__(256) void logits_permute_grad_kernel(const float* __restrict__ dout, const int64_t* __restrict__ perm,
-                                                                  int B, int N, int C, float* __restrict__ din) {
+                                                                  long perm_bs, int B, int N, int C, float* __restrict__ din) {
     const long total = (long)B * N;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long b = e / N;
         const long i = e - b * N;
-        const long j = perm[i];
+        const long j = perm[b * perm_bs + i];
         for (int c = 0; c < C; ++c) din[e * C + c] = dout[(b * C + c) * N + j];
     }
 }
@@ -658,19 +658,29 @@ extern "C" int rl_upsample_cf(const float* feat, const int32_t* idx, const float
     return RL_OK;
 }
 
-extern "C" int rl_logits_unpermute(const float* in, const int64_t* perm, int B, int N, int C, float* out, void* stream) {
-    RL_REQUIRE(in && perm && out && B > 0 && N > 0 && C > 0, RL_ERR_ARGS, "rl_logits_unpermute: bad arguments");
+extern "C" int rl_logits_unpermute_b(const float* in, const int64_t* perm, int64_t perm_bstride, int B, int N, int C, float* out,
+                                     void* stream) {
+    RL_REQUIRE(in && perm && out && B > 0 && N > 0 && C > 0 && (perm_bstride == 0 || perm_bstride >= N), RL_ERR_ARGS,
+               "rl_logits_unpermute: bad arguments");
     hipLaunchKernelGGL(logits_unpermute_kernel, dim3(grid_for((long)B * N)), dim3(256), 0, (hipStream_t)stream, in, perm,
-                       B, N, C, out);
+                       (long)perm_bstride, B, N, C, out);
     RL_LAUNCH_CHECK("rl_logits_unpermute");
     return RL_OK;
 }
+extern "C" int rl_logits_unpermute(const float* in, const int64_t* perm, int B, int N, int C, float* out, void* stream) {
+    return rl_logits_unpermute_b(in, perm, 0, B, N, C, out, stream);
+}
 
-extern "C" int rl_logits_permute_grad(const float* dout, const int64_t* perm, int B, int N, int C, float* din,
-                                      void* stream) {
-    RL_REQUIRE(dout && perm && din && B > 0 && N > 0 && C > 0, RL_ERR_ARGS, "rl_logits_permute_grad: bad arguments");
+extern "C" int rl_logits_permute_grad_b(const float* dout, const int64_t* perm, int64_t perm_bstride, int B, int N, int C,
+                                        float* din, void* stream) {
+    RL_REQUIRE(dout && perm && din && B > 0 && N > 0 && C > 0 && (perm_bstride == 0 || perm_bstride >= N), RL_ERR_ARGS,
+               "rl_logits_permute_grad: bad arguments");
     hipLaunchKernelGGL(logits_permute_grad_kernel, dim3(grid_for((long)B * N)), dim3(256), 0, (hipStream_t)stream, dout,
-                       perm, B, N, C, din);
+                       perm, (long)perm_bstride, B, N, C, din);
     RL_LAUNCH_CHECK("rl_logits_permute_grad");
     return RL_OK;
+}
+extern "C" int rl_logits_permute_grad(const float* dout, const int64_t* perm, int B, int N, int C, float* din,
+                                      void* stream) {
+    return rl_logits_permute_grad_b(dout, perm, 0, B, N, C, din, stream);
 }

@@ -36,6 +36,8 @@ FOLD_BIAS = not bool(int(__import__("os").environ.get("RL_NO_FOLD_BIAS", "0"))) 
 # BatchNorm batch statistics as SHIFTED sums around the running mean (round 5): var = E[(y-c)^2] - E[y-c]^2 keeps the variance
 # of a channel whose spread is tiny against its mean, which E[y^2] - E[y]^2 on fp32 partial sums loses.  A/B: RL_NO_BN_PIVOT=1
 BN_PIVOT = not bool(int(__import__("os").environ.get("RL_NO_BN_PIVOT", "0")))
+# clouds below this size keep the permutation as drawn (a level-0 table of < 128 KB sits in L2 / L1 whatever the order)
+BAND_SORT_MIN_POINTS = 4096
 
 
 class _Tape(list):
@@ -294,9 +296,16 @@ class Engine:
         L, dec = len(self.layers), self.dec
         prep = Prep()
         prep.B, prep.N, prep.training = B, N, training
-        # random permutation of the rows (modules.py:571-573), once, on the input
+        # random permutation of the rows (modules.py:571-573), once, on the input.  The reference sub-samples by PREFIXES of the
+        # permuted order (modules.py:587-598), so only the band [N / dec^(l+1), N / dec^l) a point falls in matters; inside a band
+        # the points are put in cell order, cloud by cloud (ops.band_sort: same sampled sets, neighbour gathers that follow space)
+        prep.perm = perm
+        if not ops.NO_BAND_SORT and N >= BAND_SORT_MIN_POINTS:
+            edges = [0] + [N // dec ** l for l in range(L, -1, -1)]
+            prep.perm = ops.band_sort(inp, perm, edges)
         inp_p = torch.empty((B * N, cin), dtype=torch.float32, device=dev)
-        ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=perm, index_shared=True)
+        ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=prep.perm.view(-1),
+                      index_shared=prep.perm.dim() == 1)
         if cin == 3:
             xyz = inp_p.view(B, N, 3)
         else:
@@ -372,6 +381,8 @@ class Engine:
         ctx.wsplit = ops.split_weights(self._wide_weight_uses(training))
         if prep is None:
             prep = self.prepare(inp, perm, training)
+        perm = prep.perm             # (B, N) when the bands were put in cell order: what the un-permute / the head index with
+        ctx.perm = perm
         assert prep.B == B and prep.N == N and prep.training >= training
         inp_p, xyz, searches, csrs = prep.inp_p, prep.xyz, prep.searches, prep.csrs
         ctx.keep += [inp_p, xyz]

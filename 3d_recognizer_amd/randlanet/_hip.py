@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 # diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
 _LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
-ABI_VERSION = 108      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
+ABI_VERSION = 109      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -96,7 +96,7 @@ class HeadDesc(C.Structure):
         ("loss_kind", C.c_int32), ("alpha", C.c_float), ("gamma", C.c_float), ("neglect_background", C.c_int32),
         ("drop_p", C.c_float), ("drop_key", C.c_void_p), ("drop_seed", C.c_uint64), ("drop_first_row", C.c_int64),
         ("work", C.c_void_p), ("G", C.c_void_p), ("bn_bwd_stats", C.c_void_p), ("slab", C.c_void_p),
-        ("slab_floats", C.c_int64), ("grad_scale", C.c_float), ("reserved", C.c_int32), ("drop_mask", C.c_void_p),
+        ("slab_floats", C.c_int64), ("grad_scale", C.c_float), ("reserved", C.c_int32), ("drop_mask", C.c_void_p), ("perm_bstride", C.c_int64),
     ]
 
 
@@ -273,6 +273,10 @@ _SIGNATURES = {
     "rl_upsample_cf": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rl_logits_unpermute": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_logits_permute_grad": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "rl_logits_unpermute_b": (_i, [_vp, _vp, C.c_int64, _i, _i, _i, _vp, _vp]),
+    "rl_logits_permute_grad_b": (_i, [_vp, _vp, C.c_int64, _i, _i, _i, _vp, _vp]),
+    "rl_band_sort_workspace_bytes": (C.c_int64, [_i, _i, _vp, _i]),
+    "rl_band_sort": (_i, [_vp, C.c_int64, _vp, _i, _i, _vp, _i, _vp, _vp, C.c_int64, _vp]),
     "rl_loss_work_doubles": (_l, [_l, _i]),
     "rl_loss_forward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp]),
     "rl_loss_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _vp, _f, _vp, _vp]),

@@ -4,6 +4,7 @@ shapes on the host before launching (a faulting kernel can reset the GPU) and ra
 HipKernelError on failure - there is no fallback implementation.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -1111,15 +1112,21 @@ def upsample_cf(feat: torch.Tensor, idx: torch.Tensor, d2: Optional[torch.Tensor
     return out
 
 
+def _perm_stride(perm: torch.Tensor, B: int, N: int) -> int:
+    """0 for the reference's ONE permutation of a forward, N for one per cloud (band_sort)."""
+    assert perm.dtype == torch.int64 and perm.is_contiguous() and perm.numel() in (N, B * N)
+    return N if (perm.numel() == B * N and perm.dim() == 2) else 0
+
+
 def logits_unpermute(lp: torch.Tensor, perm: torch.Tensor, B: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     Cc = lp.shape[1]
-    assert lp.shape == (B * N, Cc) and perm.dtype == torch.int64 and perm.numel() == N
+    assert lp.shape == (B * N, Cc)
     if out is None:
         out = torch.empty((B, Cc, N), dtype=F32, device=lp.device)
     else:
         _dev_check(out)
         assert out.shape == (B, Cc, N) and out.dtype == F32
-    H.check(H.lib().rl_logits_unpermute(lp.data_ptr(), perm.data_ptr(), B, N, Cc, out.data_ptr(), _st()),
+    H.check(H.lib().rl_logits_unpermute_b(lp.data_ptr(), perm.data_ptr(), _perm_stride(perm, B, N), B, N, Cc, out.data_ptr(), _st()),
             "rl_logits_unpermute")
     return out
 
@@ -1128,9 +1135,34 @@ def logits_permute_grad(dlogits: torch.Tensor, perm: torch.Tensor) -> torch.Tens
     B, Cc, N = dlogits.shape
     _dev_check(dlogits, perm)
     out = torch.empty((B * N, Cc), dtype=F32, device=dlogits.device)
-    H.check(H.lib().rl_logits_permute_grad(dlogits.data_ptr(), perm.data_ptr(), B, N, Cc, out.data_ptr(), _st()),
-            "rl_logits_permute_grad")
+    H.check(H.lib().rl_logits_permute_grad_b(dlogits.data_ptr(), perm.data_ptr(), _perm_stride(perm, B, N), B, N, Cc, out.data_ptr(),
+                                             _st()), "rl_logits_permute_grad")
     return out
+
+
+NO_BAND_SORT = os.environ.get("RL_NO_BAND_SORT") is not None     # A/B: the reference's permutation as drawn
+
+
+def band_sort(inp: torch.Tensor, perm: torch.Tensor, edges) -> torch.Tensor:
+    """perm (N) -> (B, N): per cloud, the entries of every sampling band [edges[k], edges[k+1]) of the permutation ordered by
+    the 4096-cell Morton code of the cloud's points (stable: ties keep the permutation's order).  The sampled SETS are the
+    permutation's; the order inside them follows space (rl_band_sort).  inp: (B, N, 3 + F) fp32, x y z first."""
+    _dev_check(inp, perm)
+    B, N, cin = inp.shape
+    assert inp.dtype == F32 and inp.is_contiguous() and perm.dtype == torch.int64 and perm.numel() == N
+    e = (C.c_int * len(edges))(*[int(v) for v in edges])
+    nb = len(edges) - 1
+    need = H.lib().rl_band_sort_workspace_bytes(B, N, e, nb)
+    if need < 0:
+        H.check(-1, "rl_band_sort_workspace_bytes")
+    ws = torch.empty(need, dtype=torch.uint8, device=inp.device)
+    out = torch.empty((B, N), dtype=torch.int64, device=inp.device)
+    with _rec("band_sort", (B, N), 40 * B * N, 0):
+        H.check(H.lib().rl_band_sort(inp.data_ptr(), cin, perm.data_ptr(), B, N, e, nb, out.data_ptr(), ws.data_ptr(), need, _st()),
+                "rl_band_sort")
+    return out
+
+
 
 
 # ------------------------------------------------------------------------------ loss, adam
@@ -1210,12 +1242,13 @@ def head_supported(x: Lazy, Cc: int) -> bool:
 def _head_desc(x: Lazy, W: torch.Tensor, bias: torch.Tensor, perm: torch.Tensor, head: Head, drop) -> "H.HeadDesc":
     _dev_check(x.raw, W, bias, perm, head.labels, head.out, x.scale, x.shift, x.mean, x.invstd)
     B, N, Cc = x.B, x.n, W.shape[0]
-    assert W.dtype == F32 and W.numel() == Cc * 32 and bias.numel() == Cc and perm.dtype == torch.int64 and perm.numel() == N
+    assert W.dtype == F32 and W.numel() == Cc * 32 and bias.numel() == Cc
     assert head.labels.shape == (B, N) and head.labels.dtype == torch.int64 and head.out.numel() == 1 + 4 * Cc
     d = H.HeadDesc()
     d.X, d.scale, d.shift, d.act, d.slope = x.raw.data_ptr(), H.ptr(x.scale), H.ptr(x.shift), x.act, x.slope
     d.mean, d.invstd = H.ptr(x.mean), H.ptr(x.invstd)
     d.W, d.bias, d.perm, d.labels = W.data_ptr(), bias.data_ptr(), perm.data_ptr(), head.labels.data_ptr()
+    d.perm_bstride = _perm_stride(perm, x.B, N)
     d.B, d.N, d.C = B, N, Cc
     d.loss_kind, d.alpha, d.gamma, d.neglect_background = head.kind, head.alpha, head.gamma, int(head.neglect)
     key, seed, p_drop, first_row = drop

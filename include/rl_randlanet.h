@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 108     /* round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted), rl_head_*; round 4: rl_launch_count */
+#define RL_VERSION 109     /* round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted), rl_head_*; round 4: rl_launch_count */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -709,6 +709,7 @@ typedef struct rl_head_desc {
     /* optional (drop_p > 0): B*N uint32 - the forward stores each row's 32 keep bits, the backward reads them instead of running
      * the generator a second time (a Philox call is ~40 quarter-rate integer multiplies: the dominant cost of both kernels) */
     void* drop_mask;
+    int64_t perm_bstride;           /* 0: one permutation for every cloud; N: cloud b reads perm + b * N (rl_band_sort) */
 } rl_head_desc;
 int rl_head_supported(int C, int K);
 int rl_head_grid(int64_t rows);
@@ -744,6 +745,21 @@ int rl_logits_unpermute(const float* in, const int64_t* perm, int B, int N, int 
                         void* stream);
 int rl_logits_permute_grad(const float* dout, const int64_t* perm, int B, int N, int C,
                            float* din, void* stream);
+/* the same with one permutation PER CLOUD: cloud b reads perm + b * perm_bstride (0: the shared permutation above) */
+int rl_logits_unpermute_b(const float* in, const int64_t* perm, int64_t perm_bstride, int B, int N, int C, float* out,
+                          void* stream);
+int rl_logits_permute_grad_b(const float* dout, const int64_t* perm, int64_t perm_bstride, int B, int N, int C,
+                             float* din, void* stream);
+
+/* A spatial order INSIDE the sampling bands of the forward's permutation (modules.py:571, 587-598).  The reference sub-samples
+ * by prefixes of ONE random permutation, so only the band [edges[k], edges[k+1]) a point falls in matters (edges = 0, N/dec^L,
+ * ..., N/dec, N); inside a band the order is free, and the kernels run faster when it follows space.  perm_out[b] (N) holds, band
+ * by band, the entries of `perm` in that band ordered by (4096-cell Morton code of cloud b's point, position) - a stable counting
+ * sort, deterministic.  rows: (B, N, row_stride) fp32 with x, y, z first.  workspace: rl_band_sort_workspace_bytes(...) bytes,
+ * 256-byte aligned.  Four launches, no memset, no global atomics.                                                              */
+int64_t rl_band_sort_workspace_bytes(int B, int N, const int* edges, int nbands);
+int rl_band_sort(const float* rows, int64_t row_stride, const int64_t* perm, int B, int N, const int* edges, int nbands,
+                 int64_t* perm_out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Loss + metrics on logits (B,C,N) fp32 and labels (B,N) int64, C <= 32.

@@ -1150,3 +1150,40 @@ def test_grouped_wide_weight_gradients_equal_the_single_launches_bitwise(ops):
     grouped, queued = run(True)
     assert queued == 27
     assert all(torch.equal(w0, w1) and torch.equal(b0, b1) for (w0, b0), (w1, b1) in zip(single, grouped))
+
+
+def _morton4(c):
+    code = np.zeros(len(c), dtype=np.int64)
+    for a in range(3):
+        for bit in range(4):
+            code |= ((c[:, a] >> bit) & 1) << (3 * bit + a)
+    return code
+
+
+@pytest.mark.parametrize("B,N,cin,edges", [
+    (3, 5000, 5, [0, 19, 78, 312, 1250, 5000]),
+    (8, 40960, 3, [0, 160, 640, 2560, 10240, 40960]),        # the metric's shape
+    (2, 1031, 4, [0, 257, 1031]),                            # two bands, ragged tiles
+])
+def test_band_sort_is_a_stable_cell_sort_inside_the_bands(ops, B, N, cin, edges):
+    """rl_band_sort against its definition: per cloud, every band of the permutation ordered by the 4096-cell Morton code of
+    the cloud's points, ties in the permutation's own order (a STABLE sort: deterministic), nothing moved across a band edge."""
+    rs = np.random.RandomState(B * 7 + N)
+    x = rs.normal(0, 1, (B, N, cin)).astype(np.float32)
+    x[0, :, 1] = 0.25                                        # a cloud that is flat in y: extent 0 on one axis
+    perm = rs.permutation(N).astype(np.int64)
+    out = ops.band_sort(torch.from_numpy(x).to(DEV), torch.from_numpy(perm).to(DEV), edges).cpu().numpy()
+    out2 = ops.band_sort(torch.from_numpy(x).to(DEV), torch.from_numpy(perm).to(DEV), edges).cpu().numpy()
+    assert np.array_equal(out, out2)                         # (no arrival order in it)
+    for b in range(B):
+        xyz = x[b, :, :3]
+        lo, hi = xyz.min(0), xyz.max(0)
+        ext = (hi - lo).astype(np.float32)
+        sc = np.where(ext > 0, np.float32(16.0) / np.where(ext > 0, ext, 1), 0).astype(np.float32)
+        cells = np.clip(((xyz - lo).astype(np.float32) * sc).astype(np.int64), 0, 15)
+        code = _morton4(cells)
+        want = perm.copy()
+        for a, e in zip(edges[:-1], edges[1:]):
+            seg = perm[a:e]
+            want[a:e] = seg[np.argsort(code[seg], kind="stable")]
+        assert np.array_equal(out[b], want), (b, int((out[b] != want).sum()))
