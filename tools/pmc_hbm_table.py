@@ -2,7 +2,7 @@
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR_F -- python3 bench.py --steps 2 --warmup 1 --no-graph \
       --no-cpu-baseline --no-inference --no-secondary --no-roofline --no-other-configs
   rocprofv3 --pmc WRITE_SIZE ... -d DIR_W -- (same)
-  python tools/pmc_hbm_table.py DIR_F DIR_W STEPS
+  python tools/pmc_hbm_table.py DIR_F DIR_W STEPS        (STEPS = 0: counted per pass from the adam_kernel launches)
 gfx950 corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: bytes = FETCH_SIZE * 1024 * 2 + WRITE_SIZE * 1024
 (the factor 2 is calibrated for wide streaming reads; narrow / gathered reads are uncalibrated - read them as an upper bound).
 Output: markdown table per kernel function, per step."""
@@ -35,10 +35,14 @@ def load(d, counter):
 
 def main(df, dw, steps):
     f, calls, dur = load(df, "FETCH_SIZE")
-    w, _, _ = load(dw, "WRITE_SIZE")
+    w, wcalls, _ = load(dw, "WRITE_SIZE")
+    # the warm-up of bench.py is time-based: the two passes need not hold the same number of steps - adam_kernel runs once per step
+    steps_w = steps
+    if steps <= 0:
+        steps, steps_w = float(calls["adam_kernel"]), float(wcalls["adam_kernel"])
     rows = []
     for k in set(f) | set(w):
-        rd, wr = f.get(k, 0.0) * 1024 * 2 / steps, w.get(k, 0.0) * 1024 / steps
+        rd, wr = f.get(k, 0.0) * 1024 * 2 / steps, w.get(k, 0.0) * 1024 / steps_w
         rows.append((rd + wr, k, calls[k] / steps, rd, wr, dur.get(k, 0.0) / steps))
     tot = sum(r[0] for r in rows)
     print(f"HBM-side bytes per step: {tot / 1e9:.2f} GB (read {sum(r[3] for r in rows) / 1e9:.2f}, write {sum(r[4] for r in rows) / 1e9:.2f})\n")
