@@ -300,8 +300,9 @@ class Engine:
         # permuted order (modules.py:587-598), so only the band [N / dec^(l+1), N / dec^l) a point falls in matters; inside a band
         # the points are put in cell order, cloud by cloud (ops.band_sort: same sampled sets, neighbour gathers that follow space)
         prep.perm = perm
-        if not ops.NO_BAND_SORT and N >= BAND_SORT_MIN_POINTS:
-            edges = [0] + [N // dec ** l for l in range(L, -1, -1)]
+        edges = [0] + [N // dec ** l for l in range(L, -1, -1)]
+        if (not ops.NO_BAND_SORT and N >= BAND_SORT_MIN_POINTS and len(edges) - 1 <= ops.BAND_SORT_MAX_BANDS
+                and all(a < b for a, b in zip(edges[:-1], edges[1:]))):
             prep.perm = ops.band_sort(inp, perm, edges)
         inp_p = torch.empty((B * N, cin), dtype=torch.float32, device=dev)
         ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=prep.perm.view(-1),

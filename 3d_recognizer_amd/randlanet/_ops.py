@@ -1141,6 +1141,7 @@ def logits_permute_grad(dlogits: torch.Tensor, perm: torch.Tensor) -> torch.Tens
 
 
 NO_BAND_SORT = os.environ.get("RL_NO_BAND_SORT") is not None     # A/B: the reference's permutation as drawn
+BAND_SORT_MAX_BANDS = 8                                           # (bandsort.hip BS_MAXB: encoder levels + 1)
 
 
 def band_sort(inp: torch.Tensor, perm: torch.Tensor, edges) -> torch.Tensor:
