@@ -60,5 +60,7 @@ for name, make in variants:
         st.step(perms[i % 8])
     torch.cuda.synchronize()
     print(f"{name:16s}: {(time.perf_counter() - t) * 10:.3f} ms/step", flush=True)
-# measured on one MI355X: random 7.97 ms/step, band-sorted 7.90 ms/step - the neighbour gathers are not what the step waits for
-# (the gathered tables of a level are a few MB: they live in L2 / the Infinity Cache either way)
+# measured on one MI355X: round 3 (the kernels of that time) random 7.97 ms/step, band-sorted 7.90; round 5 (virtual rpe kernels,
+# clouds on XCDs) random 6.60, band-sorted 6.52 / 6.47 / 6.43 / 6.42 / 6.43 at 2 / 3 / 4 / 5 / 10 bits per axis - which is why
+# Engine.prepare now sorts the bands itself (ops.band_sort, 4 bits per axis); run this probe with RL_NO_BAND_SORT=1 to see the
+# host-sorted permutation against the random one
