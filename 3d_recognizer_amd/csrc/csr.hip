@@ -409,6 +409,7 @@ struct SegParams {
     long per;                // entries per cloud
     long total;              // B * n_dst
     int accumulate;
+    long xcd_chunk;          // > 0: the workgroups of XCD x (blockIdx.x % 8) sum the destinations [x * chunk, (x + 1) * chunk)
 };
 
 // tpr = C/4 lanes (a power of two <= 64... or 128/256 for wider rows) share one destination row, 16 bytes each
@@ -416,10 +417,18 @@ template <int TPR, bool SB = false>     // SB: the source rows are stored as bf1
 __global__ __launch_bounds__(256) void segment_sum_vec_kernel(const SegParams p) {
     constexpr int RPW = 256 / TPR;      // destination rows in flight per workgroup
     const int q = threadIdx.x % TPR, rsub = threadIdx.x / TPR;
-    // (XCD-local destination ranges - one cloud's destinations on one XCD, as the CSR passes and the pooling forward have them -
-    // measured neutral here, round 5: <2> 97.3 -> 94.5 us, <8> 35.3 -> 36.6.  A cloud's source rows are 21 MB: the four rows of a
-    // line are summed at four unrelated moments of the sweep.)
-    for (long d = (long)blockIdx.x * RPW + rsub; d < p.total; d += (long)gridDim.x * RPW) {
+    // XCD-local destination ranges (as the pooling forward's PointSpan) where a source row is narrower than a 128-byte line: the
+    // four 32-byte rows of a line belong to ONE source point and go to four of its neighbours - with the points in cell order
+    // (rl_band_sort) those are destinations a few positions apart, and on one XCD the line is fetched into that L2 once
+    // (<2>: 77.1 -> 70.3 us per launch; before the cell order 97.3 -> 94.5; rows of a full line or more: 35.9 -> 37.5, not used).
+    long d = (long)blockIdx.x * RPW + rsub, dstep = (long)gridDim.x * RPW, dend = p.total;
+    if (p.xcd_chunk > 0) {
+        const long lo = (long)(blockIdx.x & 7) * p.xcd_chunk;
+        dend = lo + p.xcd_chunk < p.total ? lo + p.xcd_chunk : p.total;
+        d = lo + (long)(blockIdx.x >> 3) * RPW + rsub;
+        dstep = (long)(gridDim.x >> 3) * RPW;
+    }
+    for (; d < dend; d += dstep) {
         const unsigned b = (unsigned)d / (unsigned)p.n_dst;
         const int j = (int)((unsigned)d - b * (unsigned)p.n_dst);
         const int* off = p.offsets + (long)b * (p.n_dst + 1);
@@ -616,6 +625,7 @@ extern "C" int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream) {
     p.src = d->src; p.lds = d->lds; p.src_bstride = d->src_bstride; p.dst = d->dst; p.ldd = d->ldd;
     p.dst_bstride = d->dst_bstride; p.offsets = d->offsets; p.entries = d->entries; p.n_dst = d->n_dst; p.C = d->C;
     p.per = d->entries_per_cloud; p.total = (long)d->B * d->n_dst; p.accumulate = d->accumulate;
+    p.xcd_chunk = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (d->C % 4 == 0) && (d->lds % 4 == 0) && (d->ldd % 4 == 0) && ((uintptr_t)d->dst & 15) == 0 &&
                      ((uintptr_t)d->src & (d->src_bf16 ? 7 : 15)) == 0;
@@ -628,6 +638,9 @@ extern "C" int rl_segment_sum_rows(const rl_segsum_desc* d, void* stream) {
         long g = (p.total + rpw - 1) / rpw;
         if (g > 8192) g = 8192;
         if (g < 1) g = 1;
+        // XCD-local destination ranges for rows narrower than a line (C <= 16): see segment_sum_vec_kernel
+        static const bool no_xcd = getenv("RL_NO_XCD_POINTS") != nullptr;       // A/B switch shared with the pooling / KNN kernels
+        p.xcd_chunk = (!no_xcd && d->C <= 16 && g >= 8 && g % 8 == 0) ? (p.total + 7) / 8 : 0;
 #define SEG_CASE(T)                                                                                          \
     case T:                                                                                                  \
         if (d->src_bf16) hipLaunchKernelGGL((segment_sum_vec_kernel<T, true>), dim3(g), dim3(256), 0, st, p); \
