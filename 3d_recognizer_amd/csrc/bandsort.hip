@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64) void bs_scatter_kernel(const BandParams p) {
 }
 
 int make_plan(BandPlan* pl, int B, int N, const int* edges, int nbands, const char* who) {
-    RL_REQUIRE(B > 0 && N > 0 && nbands >= 1 && nbands <= BS_MAXB && edges, RL_ERR_ARGS, "%s: bad sizes", who);
+    RL_REQUIRE(B > 0 && B <= 65535 && N > 0 && nbands >= 1 && nbands <= BS_MAXB && edges, RL_ERR_ARGS,
+               "%s: bad sizes (1 .. 65535 clouds, 1 .. %d bands)", who, BS_MAXB);
     RL_REQUIRE(edges[0] == 0 && edges[nbands] == N, RL_ERR_ARGS, "%s: the bands must cover [0, N)", who);
     pl->B = B; pl->N = N; pl->nbands = nbands;
     int tiles = 0;
