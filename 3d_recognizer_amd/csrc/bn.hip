@@ -59,28 +59,36 @@ __device__ __forceinline__ void bn_finalize_body(
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
     const float* __restrict__ folded_bias, const int pivoted, const int c, double (*red)[2]) {
+    // lane 0's per-channel constants are requested BEFORE the slot sums: behind them they were a second, dependent memory round
+    // trip of a kernel that is nothing but latency (only this lane reads the running mean - and rewrites it at the end)
+    float fb = 0.f, g = 1.f, b = 0.f, rm = 0.f, rv = 0.f;
+    if (threadIdx.x == 0) {
+        // folded_bias: the producer left the layer's bias OUT of the tensor (it cancels in y - mean): the statistics are
+        // those of y - bias, and so is the tensor the (scale, shift) pair will be applied to; only the RUNNING mean is that of y
+        if (folded_bias) fb = folded_bias[c];
+        if (gamma) g = gamma[c];
+        if (beta) b = beta[c];
+        if (rmean) rm = rmean[c];
+        if (rvar) rv = rvar[c];
+    }
     double s = 0.0, q = 0.0;
     if (training) slot_sums_wg(stats, nslots, C, c, red, s, q);
-    if (threadIdx.x != 0) return;         // (only this lane reads the running mean below - and rewrites it at the end)
-    // folded_bias: the producer left the layer's bias OUT of the tensor (it cancels in y - mean): the statistics are
-    // those of y - bias, and so is the tensor the (scale, shift) pair will be applied to; only the RUNNING mean is that of y
-    const float fb = folded_bias ? folded_bias[c] : 0.f;
+    if (threadIdx.x != 0) return;
     double mean, var;
     if (training) {
         // pivoted: the sums are those of (t - pivot), (t - pivot)^2 around pivot = running mean - folded bias (the producer
         // subtracted the same fp32 value per element before squaring): a channel whose spread is tiny against its mean keeps
         // its variance, which E[t^2] - E[t]^2 on fp32 partial sums loses (the reference's ATen BatchNorm is two-pass)
-        const double pivot = pivoted ? (double)(rmean[c] - fb) : 0.0;
+        const double pivot = pivoted ? (double)(rm - fb) : 0.0;
         const double ms = s / count;
         mean = pivot + ms;
         var = q / count - ms * ms;
         if (var < 0.0) var = 0.0;
     } else {
-        mean = (double)rmean[c] - (double)fb;
-        var = (double)rvar[c];
+        mean = (double)rm - (double)fb;
+        var = (double)rv;
     }
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = g * invstd;
     scale[c] = sc;
     shift[c] = b - (float)mean * sc;
@@ -88,8 +96,8 @@ __device__ __forceinline__ void bn_finalize_body(
     if (save_invstd) save_invstd[c] = invstd;
     if (training && rmean && rvar) {
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * ((float)mean + fb);
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        rmean[c] = (1.f - momentum) * rm + momentum * ((float)mean + fb);
+        rvar[c] = (1.f - momentum) * rv + momentum * (float)unbiased;
         if (c == 0 && nbt) nbt[0] += 1;
     }
 }
