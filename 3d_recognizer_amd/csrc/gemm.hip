@@ -255,6 +255,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             const double q = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
             p.stats[((long)blockIdx.x * 2 + 0) * N + col0 + tid] = s;
             p.stats[((long)blockIdx.x * 2 + 1) * N + col0 + tid] = q;
+            for (long slot = blockIdx.x + gridDim.x; slot < p.stat_slots; slot += gridDim.x) {
+                p.stats[(slot * 2 + 0) * N + col0 + tid] = 0.0;
+                p.stats[(slot * 2 + 1) * N + col0 + tid] = 0.0;
+            }
         }
     }
 }
@@ -1648,14 +1652,22 @@ __device__ __forceinline__ void glds16x4(const void* g0, const void* g1, const v
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(l0), "s"(l1), "s"(l2), "s"(l3) : "memory");
 }
+__device__ __forceinline__ void glds16x2(const void* g0, const void* g1, unsigned l0, unsigned l1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1), "s"(l0), "s"(l1) : "memory");
+}
 template <int PER>       // s_waitcnt vmcnt(PER * n): PER instructions per chunk, n = 0 .. 4 chunks may stay in flight (wavefront-uniform)
 __device__ __forceinline__ void wait_vm_chunks(int n) {
-    static_assert(PER == 4 || PER == 8, "pieces per loader wavefront and chunk");
+    static_assert(PER == 2 || PER == 4 || PER == 8, "pieces per loader wavefront and chunk");
     if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (n == 1) { if (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else if (n == 2) { if (PER == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else if (n == 3) { if (PER == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-    else { if (PER == 8) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+    else if (n == 1) { if (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (PER == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else if (n == 2) { if (PER == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else if (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else if (n == 3) { if (PER == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else if (PER == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else { if (PER == 8) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else if (PER == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 }
 __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
@@ -1667,13 +1679,23 @@ __device__ __forceinline__ void raw_barrier() {
 #endif
 constexpr int W2_KMAX = 1024;
 constexpr int W2_THREADS = 768;
-template <int TERMS, bool STATS, int AS, int WS>
+// Round 6: the output tile is a template parameter, BM x BN = 128 x 128 (above), 64 x 128 or 64 x 64 - chosen by the host
+// (wide_plan) so that the launches of the deep levels (M = 1280 ... 20480 rows at batch 8: 40 - 160 tiles of 128 x 128 on 256 CUs,
+// most of them behind a K split and its reducer launch) put >= 2x the workgroups on the chip in ONE pass.  The eight compute
+// wavefronts then form BM / 16 row blocks x CG column groups (64-row tiles: 4 x 2), a wavefront owns 16 rows x BN / CG columns;
+// the rings hold BM-row A chunks and BN-column weight chunks (same depth, less LDS), the loaders issue BM / 16 and
+// BN / 16 (x 2 planes) pieces per chunk.  Per accumulator the same products in the same order as the 128 x 128 tile: Y is
+// bitwise the same whatever the tile; only the grouping of the BatchNorm partial sums (slots per 64 rows) differs.
+template <int TERMS, bool STATS, int AS, int WS, int BM = 128, int BN = 128>
 __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) {
     static_assert(AS >= 3 && AS <= 6 && WS >= 2 && WS <= 6, "ring depths vs the wait table");
-    constexpr int BN = 128, NT = 8;
+    static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "tile shapes");
+    constexpr int RB = BM / 16;                 // 16-row blocks of a tile
+    constexpr int CG = 8 / RB;                  // column groups the eight compute wavefronts form
+    constexpr int NT = BN / 16 / CG;            // 16-column blocks per wavefront
     constexpr bool TR = !STATS;                 // transposed accumulator (16-byte epilogue) where no column statistics are wanted
-    constexpr int A_STAGE = 128 * 128;          // bytes: 128 rows x 32 fp32
-    constexpr int W_PLANE = 128 * 64;           // bytes: 128 columns x 32 bf16
+    constexpr int A_STAGE = BM * 128;           // bytes: BM rows x 32 fp32
+    constexpr int W_PLANE = BN * 64;            // bytes: BN columns x 32 bf16
     constexpr int W_STAGE = 2 * W_PLANE;
     constexpr int OFF_W = AS * A_STAGE, OFF_SC = OFF_W + WS * W_STAGE, OFF_RED = OFF_SC + 2 * W2_KMAX * 4;
     constexpr int TOTAL = OFF_RED + (STATS ? 8 * 2 * BN * 8 : 0);
@@ -1689,11 +1711,11 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
     const int col0 = by * BN;
     const int K = p.a.K, N = p.N;
     const long M = p.a.M;
-    const long ntiles = (M + GM_BM - 1) / GM_BM;
+    const long ntiles = (M + BM - 1) / BM;
     const bool lazy = p.a.lazy.scale != nullptr;
     float* lsc = reinterpret_cast<float*>(lds + OFF_SC);
     float* lsh = lsc + W2_KMAX;
-    double* red = reinterpret_cast<double*>(lds + OFF_RED);        // [8 wavefronts][2][128]
+    double* red = reinterpret_cast<double*>(lds + OFF_RED);        // [8 wavefronts][2][BN]
     const unsigned lds0 = lds_address(lds);
     if (lazy) {
         for (int k = tid; k < K; k += W2_THREADS) {
@@ -1718,14 +1740,15 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
 
     if (wave >= 8) __builtin_amdgcn_s_setprio(3);      // the loaders' few instructions go first: 1 - 2 % on the mid-size shapes
     if (wave >= 10) {
-        // ---- W loaders: 16 (8 in the bf16 mode) pieces of 1 KB per chunk, WS - 1 chunks ahead -------------------------------
-        constexpr int WI = TERMS == 3 ? 8 : 4;
+        // ---- W loaders: BN / 16 pieces of 1 KB per plane and chunk (16 at 128 columns in bf16x3), WS - 1 chunks ahead --------
+        constexpr int PPP = BN / 16;                               // pieces per plane
+        constexpr int WI = (TERMS == 3 ? 2 : 1) * PPP / 2;         // per loader wavefront: 8 / 4 / 2
         const int lw = wave - 10;
         const __bf16* wsrc[WI];
         unsigned wdst[WI];
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
-            const int idx = lw * WI + j, plane = idx >> 3, rg = idx & 7;
+            const int idx = lw * WI + j, plane = idx / PPP, rg = idx % PPP;
             int col = col0 + rg * 16 + (lane >> 2);
             col = col < N ? col : N - 1;        // columns past N are never stored
             wsrc[j] = p.wsplit + (long)plane * N * K + (long)col * K + (lane & 3) * 8 + k_begin;
@@ -1734,10 +1757,14 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
         auto issue_w = [&](int q) {
             const int k = (q % nch) * PG_BK;
             const unsigned o = __builtin_amdgcn_readfirstlane((q % WS) * W_STAGE);
+            if constexpr (WI % 4 == 0) {
 #pragma unroll
-            for (int j = 0; j < WI; j += 4)
-                glds16x4(wsrc[j] + k, wsrc[j + 1] + k, wsrc[j + 2] + k, wsrc[j + 3] + k, wdst[j] + o, wdst[j + 1] + o, wdst[j + 2] + o,
-                         wdst[j + 3] + o);
+                for (int j = 0; j < WI; j += 4)
+                    glds16x4(wsrc[j] + k, wsrc[j + 1] + k, wsrc[j + 2] + k, wsrc[j + 3] + k, wdst[j] + o, wdst[j + 1] + o, wdst[j + 2] + o,
+                             wdst[j + 3] + o);
+            } else {
+                glds16x2(wsrc[0] + k, wsrc[1] + k, wdst[0] + o, wdst[1] + o);
+            }
         };
         for (int q = 0; q < WS - 1 && q < T; ++q) issue_w(q);
         for (int q = 0; q < T; ++q) {
@@ -1746,14 +1773,15 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
             if (q + WS - 1 < T) issue_w(q + WS - 1);
         }
     } else if (wave >= 8) {
-        // ---- A loaders: 16 pieces of 1 KB (8 rows x 128 B) per chunk, AS - 1 chunks ahead, across the tiles -----------------
+        // ---- A loaders: BM / 8 pieces of 1 KB (8 rows x 128 B) per chunk, AS - 1 chunks ahead, across the tiles --------------
+        constexpr int AI = BM / 16;             // pieces per loader wavefront and chunk
         const int lw = wave - 8;
-        const float* asrc[8];
+        const float* asrc[AI];
         auto tile_sources = [&](int j) {        // j-th tile of this workgroup
-            const long row0 = ((long)bx + (long)j * p.gx) * GM_BM;
+            const long row0 = ((long)bx + (long)j * p.gx) * BM;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = (lw * 8 + i) * 8 + (lane >> 3);
+            for (int i = 0; i < AI; ++i) {
+                const int r = (lw * AI + i) * 8 + (lane >> 3);
                 long R = row0 + r;
                 R = R < M ? R : M - 1;          // rows past M are never stored
                 asrc[i] = p.a.A + a_row_offset(p.a, R) + (((lane & 7) ^ ((r >> 1) & 7)) << 2) + k_begin;
@@ -1763,15 +1791,15 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
         auto issue_a = [&]() {
             if (ic == 0) tile_sources(iq / nch);
             const int k = ic * PG_BK;
-            const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (iq % AS) * A_STAGE + lw * 8192);
+            const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + (iq % AS) * A_STAGE + lw * AI * 1024);
             glds16x4(asrc[0] + k, asrc[1] + k, asrc[2] + k, asrc[3] + k, l, l + 1024, l + 2048, l + 3072);
-            glds16x4(asrc[4] + k, asrc[5] + k, asrc[6] + k, asrc[7] + k, l + 4096, l + 5120, l + 6144, l + 7168);
+            if constexpr (AI == 8) glds16x4(asrc[4] + k, asrc[5] + k, asrc[6] + k, asrc[7] + k, l + 4096, l + 5120, l + 6144, l + 7168);
             ++iq;
             ic = ic + 1 == nch ? 0 : ic + 1;
         };
         while (iq < AS - 1 && iq < T) issue_a();
         for (int q = 0; q < T; ++q) {
-            wait_vm_chunks<8>(min(AS - 2, T - 1 - q));
+            wait_vm_chunks<AI>(min(AS - 2, T - 1 - q));
             raw_barrier();
             if (iq < T) issue_a();
         }
@@ -1780,10 +1808,12 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
         const int lr = lane & 15, lq = lane >> 4;
         const bool relu = p.a.lazy.act == RL_ACT_RELU;
         const float nslope = p.a.lazy.act == RL_ACT_NONE ? 1.f : p.a.lazy.slope;
-        const int frow = wave * 16 + lr;                             // this lane's fragment row in the tile
+        const int rb = wave % RB, cg = wave / RB;                    // this wavefront's row block and column group of the tile
+        const int cg0 = cg * NT * 16;                                // its first column inside the tile
+        const int frow = rb * 16 + lr;                               // this lane's fragment row in the tile
         const int fsw = (frow >> 1) & 7;
         const int a_frag0 = frow * 128 + (((2 * lq) ^ fsw) << 4), a_frag1 = frow * 128 + (((2 * lq + 1) ^ fsw) << 4);
-        const int w_frag = lr * 64 + lq * 16;
+        const int w_frag = lr * 64 + lq * 16 + cg0 * 64;
         auto actf = [&](float z) {
             const float neg = relu ? 0.f : z * nslope;
             return z > 0.f ? z : neg;
@@ -1845,7 +1875,7 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
             if (++c < nch) continue;
             // ---- the tile is complete: epilogue (the loaders are already AS - 1 chunks into the next tile) -------------------
             c = 0;
-            const long row0 = tile * GM_BM;
+            const long row0 = tile * BM;
             tile += p.gx;
 #if W2_ABLATE == 4
 #pragma unroll
@@ -1856,11 +1886,11 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
 #endif
                 float* slab = p.kslab + (long)blockIdx.z * M * N;
                 if constexpr (TR) {
-                    const long R = row0 + wave * 16 + lr;
+                    const long R = row0 + rb * 16 + lr;
                     if (R < M) {
 #pragma unroll
                         for (int nb = 0; nb < NT; ++nb) {
-                            const int cc = col0 + nb * 16 + lq * 4;
+                            const int cc = col0 + cg0 + nb * 16 + lq * 4;
                             if (vec_t) {
                                 if (cc < N) *reinterpret_cast<f32x4*>(slab + R * N + cc) = acc[nb];
                             } else {
@@ -1873,11 +1903,11 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
                 } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const long R = row0 + wave * 16 + lq * 4 + r;
+                    const long R = row0 + rb * 16 + lq * 4 + r;
                     if (R < M) {
 #pragma unroll
                         for (int nb = 0; nb < NT; ++nb) {
-                            const int cc = col0 + nb * 16 + lr;
+                            const int cc = col0 + cg0 + nb * 16 + lr;
                             if (cc < N) slab[R * N + cc] = acc[nb][r];
                         }
                     }
@@ -1891,8 +1921,8 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
                 float ssum[NT], ssq[NT];
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb) ssum[nb] = ssq[nb] = 0.f;
-                if constexpr (TR) tile_rows_epilogue_t<NT>(p, acc, row0 + wave * 16, col0, lr, lq, vec_t);
-                else tile_rows_epilogue<NT, STATS>(p, acc, row0 + wave * 16, col0, lr, lq, ssum, ssq);
+                if constexpr (TR) tile_rows_epilogue_t<NT>(p, acc, row0 + rb * 16, col0 + cg0, lr, lq, vec_t);
+                else tile_rows_epilogue<NT, STATS>(p, acc, row0 + rb * 16, col0 + cg0, lr, lq, ssum, ssq);
                 if constexpr (STATS) if (p.stats) {
                     // this wavefront's own slice of the scratch: no other wavefront touches it before the final barrier
 #pragma unroll
@@ -1901,8 +1931,8 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
                         sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
                         qv += __shfl_xor(qv, 16, 64); qv += __shfl_xor(qv, 32, 64);
                         if (lane < 16) {
-                            red[(wave * 2 + 0) * BN + nb * 16 + lane] += (double)sv;
-                            red[(wave * 2 + 1) * BN + nb * 16 + lane] += (double)qv;
+                            red[(wave * 2 + 0) * BN + cg0 + nb * 16 + lane] += (double)sv;
+                            red[(wave * 2 + 1) * BN + cg0 + nb * 16 + lane] += (double)qv;
                         }
                     }
                 }
@@ -2014,20 +2044,71 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
         for (int j = 0; j < 4; ++j) {
             p.stats[((long)blockIdx.x * 2 + 0) * N + c + j] = sm[j];
             p.stats[((long)blockIdx.x * 2 + 1) * N + c + j] = sm[4 + j];
+            for (long slot = blockIdx.x + gridDim.x; slot < p.stat_slots; slot += gridDim.x) {
+                p.stats[(slot * 2 + 0) * N + c + j] = 0.0;
+                p.stats[(slot * 2 + 1) * N + c + j] = 0.0;
+            }
         }
     }
 }
 
-// how many K splits a wide GEMM with few output tiles should use (1 = none)
-inline int gemm_ksplit(long M, int N, int K) {
-    if (N % 4) return 1;
-    const long tiles = ((M + GM_BM - 1) / GM_BM) * ((N + 127) / 128);
-    if (tiles >= 128 || K < 256) return 1;
+// compute units of the current device (256 on an MI355X; fewer in a partitioned mode), asked once per device
+inline int cu_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n : 256;
+    }
+    return cached[dev];
+}
+
+// Output tile of the LDS-DMA wide GEMM (round 6): 128 x 128, or - when that leaves at most half / a quarter of the CUs with a tile -
+// 64 x 128 / 64 x 64, so that the deep levels' launches put twice / four times the workgroups on the chip in one pass (most of
+// them lose their K split and its reducer launch that way).  RL_WGEMM_TILE=128 keeps the one tile (A/B switch, bitwise the same Y).
+int g_wgemm_small = -1;
+inline bool wgemm_small_tiles() {
+    if (g_wgemm_small < 0) {
+        const char* e = getenv("RL_WGEMM_TILE");
+        g_wgemm_small = (e && !strcmp(e, "128")) ? 0 : 1;
+    }
+    return g_wgemm_small == 1;
+}
+int g_wgemm_force = 0;          // rl_set_wgemm_tile("64x128" / "64x64"): that tile for every launch of the LDS-DMA kernel (measurements)
+int g_gemm_no_ksplit = 0;       // rl_set_gemm_ksplit(0): tests compare kernels / tiles bit for bit on ONE summation order
+struct WidePlan { int bm, bn, ksplit; };
+// dma: the launch will run wgemm2_kernel (the only kernel with the small tiles)
+inline WidePlan wide_plan(long M, int N, int K, bool dma) {
+    WidePlan w{128, 128, 1};
+    long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int cus = cu_count();
+    if (dma && g_wgemm_force && N > 64) {           // diagnostics: one small tile everywhere (tools/wgemm_tile_bench.py)
+        w.bm = 64;
+        w.bn = g_wgemm_force == 2 ? 64 : 128;
+        tiles = ((M + 63) / 64) * ((N + w.bn - 1) / w.bn);
+    } else if (dma && wgemm_small_tiles() && N > 64) {
+        if (2 * tiles <= cus) {
+            w.bm = 64;
+            tiles = ((M + 63) / 64) * ((N + 127) / 128);
+            if (2 * tiles <= cus) {
+                w.bn = 64;
+                tiles = ((M + 63) / 64) * ((N + 63) / 64);
+            }
+        }
+    }
+    // K splits of a launch with few output tiles (1 = none).  Never for the LDS-DMA kernel (round 6): its rings keep a workgroup
+    // fed through a long K loop, and a split costs a second launch (the reducer) plus the slab round trip - measured on every
+    // wide shape of config A at 1 / 2 / 4 / 8 clouds (tools/wgemm_tile_bench.py): the single pass wins or ties everywhere, by
+    // up to 2x on the deep levels (e.g. 2560 x 256 x 128: 14.8 -> 9.5 us forward, 13.7 -> 7.1 us input gradient)
+    if (dma || g_gemm_no_ksplit || N % 4 || tiles >= 128 || K < 256) return w;
     long s = 256 / tiles;
     if (s > K / 64) s = K / 64;      // at least two 32-deep chunks per split
     if (s > 16) s = 16;
-    return s < 2 ? 1 : (int)s;
+    w.ksplit = s < 2 ? 1 : (int)s;
+    return w;
 }
+inline int gemm_ksplit(long M, int N, int K) { return wide_plan(M, N, K, false).ksplit; }      // (the upper bound over both plans)
 
 // wide-GEMM arithmetic (see pgemm_kernel): 0 = fp32 MFMA, 3 = bf16x3 (default), 1 = bf16.  Initial value from
 // RL_WIDE_GEMM = fp32 | bf16x3 | bf16; rl_set_wide_gemm() changes it at run time.
@@ -2072,35 +2153,35 @@ inline int wgemm_staging() {
 // diagnostics (rl_set_sgemm_grid_div): the streaming GEMM on 1/div of its workgroups - Y is bitwise the same, only the
 // grouping of the per-lane BatchNorm partial sums changes (the regression knob of tests/test_net_gpu.py)
 int g_sgemm_grid_div = 1;
-// compute units of the current device (256 on an MI355X; fewer in a partitioned mode), asked once per device
-inline int cu_count() {
-    static int cached[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    if (cached[dev] == 0) {
-        int n = 0;
-        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n : 256;
-    }
-    return cached[dev];
+// the LDS-DMA kernel takes this launch (else the register-staged wgemm_kernel)
+inline bool wgemm2_usable(const GemmParams& p) {
+    return wgemm_staging() == 1 && p.a.K % PG_BK == 0 && p.a.K <= W2_KMAX && (((uintptr_t)p.a.A | (uintptr_t)(p.a.lda * 4)) & 15) == 0;
 }
-
-// returns the kernel function it dispatched to
-const char* launch_wgemm(dim3 logical, hipStream_t st, GemmParams p, bool splitk = false) {
+template <int TERMS, bool STATS>
+void launch_wgemm2_tile(const WidePlan& w, dim3 g2, hipStream_t st, const GemmParams& p) {
+    if (w.bm == 128)     hipLaunchKernelGGL((wgemm2_kernel<TERMS, STATS, W2_AS, W2_WS, 128, 128>), g2, dim3(W2_THREADS), 0, st, p);
+    else if (w.bn == 128) hipLaunchKernelGGL((wgemm2_kernel<TERMS, STATS, W2_AS, W2_WS, 64, 128>), g2, dim3(W2_THREADS), 0, st, p);
+    else                 hipLaunchKernelGGL((wgemm2_kernel<TERMS, STATS, W2_AS, W2_WS, 64, 64>), g2, dim3(W2_THREADS), 0, st, p);
+}
+// returns the kernel function it dispatched to.  `w`: the output tile (wide_plan) when the LDS-DMA kernel runs the launch
+const char* launch_wgemm(dim3 logical, hipStream_t st, GemmParams p, bool splitk = false, WidePlan w = WidePlan{128, 128, 1}) {
     p.gx = (int)logical.x; p.ny = (int)logical.y;
     const dim3 grid(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : logical.x, 1, logical.z);
     const bool stats = p.stats != nullptr && p.ksplit <= 1;
-    if (wgemm_staging() == 1 && p.a.K % PG_BK == 0 && p.a.K <= W2_KMAX && (((uintptr_t)p.a.A | (uintptr_t)(p.a.lda * 4)) & 15) == 0) {
+    if (wgemm2_usable(p)) {
         // one persistent workgroup per CU: the row tiles are dealt round-robin to gx = CUs / ny workgroup rows
+        p.gx = rl_cdiv(p.a.M, w.bm);
+        p.ny = rl_cdiv(p.N, w.bn);
         int cap = cu_count() / (p.ny > 0 ? p.ny : 1) / 8 * 8;
         if (cap < 8) cap = 8;
         if (p.gx > cap) p.gx = cap;
         const dim3 g2(p.ny > 1 ? (unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny) : (unsigned)p.gx, 1, logical.z);
         if (wide_gemm_terms() == 1) {
-            if (stats) hipLaunchKernelGGL((wgemm2_kernel<1, true, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
-            else       hipLaunchKernelGGL((wgemm2_kernel<1, false, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
+            if (stats) launch_wgemm2_tile<1, true>(w, g2, st, p);
+            else       launch_wgemm2_tile<1, false>(w, g2, st, p);
         } else {
-            if (stats) hipLaunchKernelGGL((wgemm2_kernel<3, true, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
-            else       hipLaunchKernelGGL((wgemm2_kernel<3, false, W2_AS, W2_WS>), g2, dim3(W2_THREADS), 0, st, p);
+            if (stats) launch_wgemm2_tile<3, true>(w, g2, st, p);
+            else       launch_wgemm2_tile<3, false>(w, g2, st, p);
         }
         return splitk ? "wgemm2_kernel+splitk" : "wgemm2_kernel";
     }
@@ -2763,6 +2844,17 @@ extern "C" int rl_set_wgemm_staging(const char* how) {
     g_wgemm_staging = !strcmp(how, "dma");
     return RL_OK;
 }
+extern "C" int rl_set_wgemm_tile(const char* how) {
+    RL_REQUIRE(how && (!strcmp(how, "auto") || !strcmp(how, "128") || !strcmp(how, "64x128") || !strcmp(how, "64x64")), RL_ERR_ARGS,
+               "rl_set_wgemm_tile: expected auto | 128 | 64x128 | 64x64");
+    g_wgemm_force = !strcmp(how, "64x128") ? 1 : !strcmp(how, "64x64") ? 2 : 0;
+    g_wgemm_small = strcmp(how, "128") ? 1 : 0;
+    return RL_OK;
+}
+extern "C" int rl_set_gemm_ksplit(int enable) {
+    g_gemm_no_ksplit = enable ? 0 : 1;
+    return RL_OK;
+}
 extern "C" int rl_set_sgemm_grid_div(int div) {
     RL_REQUIRE(div >= 1 && div <= 64, RL_ERR_ARGS, "rl_set_sgemm_grid_div: 1 .. 64");
     g_sgemm_grid_div = div;
@@ -2805,7 +2897,8 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     }
     const int gx = rl_row_blocks_host(p.a.M, GM_BM);
     hipStream_t st = (hipStream_t)stream;
-    p.stat_slots = gx;
+    // the slots the caller's finalize reads (rl_gemm_stat_slots): every kernel below zero-fills those beyond its own grid
+    p.stat_slots = (int)rl_gemm_stat_slots(p.a.M, d->N, d->K);
     if (split) {
         RL_REQUIRE((d->K > 64 || d->N > 64), RL_ERR_UNSUPPORTED, "rl_gemm: split-scatter epilogue needs K or N > 64");
         p.ksplit = 1; p.kchunk = 0; p.kslab = nullptr;
@@ -2816,7 +2909,11 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
         const char* wide = nullptr;
         if (d->N <= 64) {}
-        else if (wgemm_ok(p)) wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
+        else if (wgemm_ok(p)) {
+            WidePlan w = wide_plan(p.a.M, d->N, d->K, wgemm2_usable(p));
+            w.ksplit = 1;
+            wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p, false, w);
+        }
         else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
         rl_note_kernel(wide ? wide : d->N <= 64 ? "pgemm_kernel" : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(split-scatter)");
@@ -2836,15 +2933,16 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         return RL_OK;
     }
     p.ksplit = 1; p.kchunk = 0; p.kslab = nullptr;
+    WidePlan plan = wide_plan(p.a.M, d->N, d->K, pgemm_ok(p) && d->N > 64 && wgemm_ok(p) && wgemm2_usable(p));
     if (pgemm_ok(p) && d->N > 64 && d->kslab != nullptr) {
-        const int ks = gemm_ksplit(p.a.M, d->N, d->K);
+        const int ks = plan.ksplit;
         if (ks > 1 && d->kslab_floats >= (int64_t)ks * p.a.M * d->N) {
             p.ksplit = ks;
             p.kchunk = ((d->K + ks - 1) / ks + 31) / 32 * 32;
             p.ksplit = (d->K + p.kchunk - 1) / p.kchunk;
             p.kslab = d->kslab;
             const char* wide = nullptr;
-            if (wgemm_ok(p)) wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p, true);
+            if (wgemm_ok(p)) wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p, true, plan);
             else launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128), p.ksplit), st, p);
             rl_note_kernel(wide ? wide : "pgemm_kernel<8>+splitk");
             RL_LAUNCH_CHECK("rl_gemm(split-K)");
@@ -2862,7 +2960,7 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         else if (d->N <= 64) launch_pgemm<4>(dim3(gx, 1), st, p);
         const char* wide = nullptr;
         if (d->N <= 64) {}
-        else if (wgemm_ok(p)) wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p);
+        else if (wgemm_ok(p)) { plan.ksplit = 1; wide = launch_wgemm(dim3(gx, rl_cdiv(d->N, 128)), st, p, false, plan); }
         else                 launch_pgemm<8>(dim3(gx, rl_cdiv(d->N, 128)), st, p);
         rl_note_kernel(d->N <= 16 ? "pgemm_kernel<1>" : d->N <= 32 ? "pgemm_kernel<2>" : d->N <= 64 ? "pgemm_kernel<4>" : wide ? wide : "pgemm_kernel<8>");
         RL_LAUNCH_CHECK("rl_gemm(pipelined)");
@@ -2898,6 +2996,16 @@ extern "C" int rl_split_weights(const rl_wsplit_item* items, int count, void* st
     }
     rl_note_kernel("split_weights_kernel");
     return RL_OK;
+}
+
+// BatchNorm partial-statistics slots rl_gemm fills for an (M, N, K) product: one per 128-row block, or per 64-row block where
+// the wide GEMM may run on 64-row tiles (wide_plan) - whichever kernel takes the launch zero-fills the slots it does not use.
+extern "C" int64_t rl_gemm_stat_slots(int64_t M, int N, int K) {
+    if (N > 64 && K % PG_BK == 0 && K <= W2_KMAX && wide_gemm_terms() != 0 && wgemm_staging() == 1) {
+        const WidePlan w = wide_plan(M, N, K, true);
+        if (w.bm == 64 && w.ksplit == 1) return rl_row_blocks_host(M, 64);
+    }
+    return rl_row_blocks_host(M, GM_BM);
 }
 
 extern "C" int64_t rl_gemm_kslab_floats(int64_t M, int N, int K) {

@@ -149,8 +149,8 @@ class Engine:
         ops.bn_finalize_flush(lst)
         return out
 
-    def _bn(self, ctx: Context, out: Lazy, stats, bn_name: str, act: int, slope: float, folded_bias=None):
-        scale, shift, mean, invstd = self._fold(ctx, bn_name, stats, out.rows, out.C, folded_bias)
+    def _bn(self, ctx: Context, out: Lazy, stats, bn_name: str, act: int, slope: float, folded_bias=None, nslots=None):
+        scale, shift, mean, invstd = self._fold(ctx, bn_name, stats, out.rows, out.C, folded_bias, nslots)
         out.scale, out.shift, out.mean, out.invstd = scale, shift, mean, invstd
         out.act, out.slope, out.bn = act, slope, bn_name
 
@@ -170,7 +170,8 @@ class Engine:
         rpb = a.n * a.K if isinstance(a, Rpe) else a.n
         out = Lazy(Y, a.B, rpb, rpb, n_out)
         if bn:
-            self._bn(ctx, out, stats, bn, act, slope, folded_bias=self.P[bname] if fold else None)
+            self._bn(ctx, out, stats, bn, act, slope, folded_bias=self.P[bname] if fold else None,
+                     nslots=ops.gemm_stat_slots(out.rows, n_out, K) if stats is not None else None)
         else:
             assert act == H.ACT_NONE
         ctx.tape.append(("linear", a, out, wname, bname, ks, ns, a_grad))

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 # diagnostics only: an experimental build of the same library (kernel variants measured side by side, tools/pool_bench.py)
 _LIB_PATH = os.environ.get("RL_HIP_LIB", _LIB_PATH)
 
-ABI_VERSION = 109      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
+ABI_VERSION = 110      # RL_VERSION the signatures below were written for (include/rl_randlanet.h)
 MAX_SLOTS = 1024
 KNN_MAX_K = 64
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -208,12 +208,15 @@ _SIGNATURES = {
     "rl_knn_multi_workspace_bytes": (_l, [C.POINTER(KnnTask), _i, _i]),
     "rl_knn_multi": (_i, [C.POINTER(KnnTask), _i, _i, _vp, _l, _vp]),
     "rl_gemm_kslab_floats": (_l, [_l, _i, _i]),
+    "rl_gemm_stat_slots": (_l, [_l, _i, _i]),
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "rl_split_weights": (_i, [C.POINTER(WsplitItem), _i, _vp]),
     "rl_wgrad_slab_floats": (_l, [_l, _i, _i]),
     "rl_set_wide_gemm": (_i, [C.c_char_p]),
     "rl_get_wide_gemm": (C.c_char_p, []),
     "rl_set_wgemm_staging": (_i, [C.c_char_p]),
+    "rl_set_wgemm_tile": (_i, [C.c_char_p]),
+    "rl_set_gemm_ksplit": (_i, [_i]),
     "rl_set_sgemm_grid_div": (_i, [_i]),
     "rl_wgrad": (_i, [C.POINTER(WgradDesc), _vp]),
     "rl_wgrad_nsplit": (_i, [_l, _i, _i]),

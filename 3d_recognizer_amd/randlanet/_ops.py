@@ -258,6 +258,16 @@ def set_wgemm_staging(how: str) -> None:
     H.check(H.lib().rl_set_wgemm_staging(how.encode()), "rl_set_wgemm_staging")
 
 
+def set_wgemm_tile(how: str) -> None:
+    """Output tile of the LDS-DMA wide GEMM: "auto" (64-row / 64-column tiles for launches with few rows) or "128"; same Y."""
+    H.check(H.lib().rl_set_wgemm_tile(how.encode()), "rl_set_wgemm_tile")
+
+
+def set_gemm_ksplit(enable: bool) -> None:
+    """Diagnostics: the K split of wide products with few output tiles on / off (rl_set_gemm_ksplit)."""
+    H.check(H.lib().rl_set_gemm_ksplit(int(bool(enable))), "rl_set_gemm_ksplit")
+
+
 def rpe_build(a: "Rpe", distances: bool = False) -> Lazy:
     """The relative position encoding of every neighbourhood row, written out once (rows x 12 floats: 10 channels +
     2 of padding) so that mlp_rpe1's forward and weight gradient read a plain tensor (modules.py:173-186)."""
@@ -333,6 +343,11 @@ def split_weights(entries) -> dict:
     return out_map
 
 
+def gemm_stat_slots(M: int, N: int, K: int) -> int:
+    """Slots of `stats` that gemm(..., stats=...) fills for an (M, K) x (K, N) product - the count bn_finalize must be given."""
+    return int(H.lib().rl_gemm_stat_slots(M, N, K))
+
+
 def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.Tensor] = None, *,
          out: Optional[torch.Tensor] = None, out_bstride: Optional[int] = None,
          accumulate: bool = False, stats: Optional[torch.Tensor] = None,
@@ -360,7 +375,7 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     if bias is not None:
         assert bias.numel() == N
     if stats is not None:
-        assert stats.dtype == torch.float64 and stats.numel() >= H.row_blocks(M, 128) * 2 * N
+        assert stats.dtype == torch.float64 and stats.numel() >= gemm_stat_slots(M, N, K) * 2 * N
     d.N, d.W, d.w_ks, d.w_ns, d.bias = N, W.data_ptr(), w_ks, w_ns, H.ptr(bias)
     planes = wsplit.get((W.data_ptr(), w_ks, w_ns, K, N)) if wsplit else None
     if planes is not None:

@@ -108,7 +108,8 @@ class _SharedMLPRows(torch.autograd.Function):
         if bn is not None:
             y.scale, y.shift, y.mean, y.invstd = ops.bn_finalize(
                 stats, M, 128, n_out, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
-                bn.num_batches_tracked if train_stats else None, 0.99, 1e-6, train_stats, pivoted=train_stats)
+                bn.num_batches_tracked if train_stats else None, 0.99, 1e-6, train_stats, pivoted=train_stats,
+                nslots=ops.gemm_stat_slots(M, n_out, n_in) if train_stats else None)
             if not train_stats:      # eval mode: the "batch" statistics of the backward formulas are the running ones
                 y.mean, y.invstd = bn.running_mean.clone(), torch.rsqrt(bn.running_var + 1e-6)
         elif act != H.ACT_NONE:
@@ -173,7 +174,8 @@ class SharedMLP(nn.Module):
         if bn is not None:
             scale, shift, _, _ = ops.bn_finalize(stats, M, 128, n_out, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                  bn.running_var, bn.num_batches_tracked if train_stats else None,
-                                                 0.99, 1e-6, train_stats, pivoted=train_stats)
+                                                 0.99, 1e-6, train_stats, pivoted=train_stats,
+                                                 nslots=ops.gemm_stat_slots(M, n_out, n_in) if train_stats else None)
         elif act != H.ACT_NONE:
             scale, shift = torch.ones(n_out, device=rows.device), torch.zeros(n_out, device=rows.device)
         else:

@@ -159,8 +159,9 @@ TILE_KERNELS = ("vpool_fwd_kernel", "vpool_bwd_kernel", "vrpe_wgrad_kernel", "vr
 
 def function_name(kernel: str) -> str:
     """Kernel FUNCTION of a launch: the name without its template arguments - every instantiation of a function is summed,
-    the way `rocprofv3 --stats` rows are summed per function when the dominant one is picked."""
-    return kernel.split("<")[0].strip()
+    the way `rocprofv3 --stats` rows are summed per function when the dominant one is picked.  A split-K launch is reported
+    by the library as "<function>+splitk" (its event window also holds the few-microsecond reducer): it counts under the function."""
+    return kernel.split("<")[0].split("+")[0].strip()
 
 
 def function_roofline(name, f):

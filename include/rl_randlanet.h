@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 109     /* round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted), rl_head_*; round 4: rl_launch_count */
+#define RL_VERSION 110     /* round 6: rl_gemm_stat_slots (64-row tiles of the wide GEMM); round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted), rl_head_*; round 4: rl_launch_count */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -132,8 +132,8 @@ int rl_knn_multi(const rl_knn_task* tasks, int ntasks, int B, void* workspace, i
  *                                           ConvTranspose2d weight (K,N): w_ks=N, w_ns=1)
  *   Y row (b,i) = Y + (b*y_bstride + i)*ldy ; accumulate != 0 adds into Y.
  *   stats != NULL: per-block column sums of Y and Y*Y are written as doubles to
- *       stats[slot][0][c], stats[slot][1][c] for slot < rl_row_blocks(M,128) (BatchNorm batch
- *       statistics, finished by rl_bn_finalize).                                            */
+ *       stats[slot][0][c], stats[slot][1][c] for slot < rl_gemm_stat_slots(M,N,K) (BatchNorm batch
+ *       statistics, finished by rl_bn_finalize with that slot count).                        */
 typedef struct rl_gemm_desc {
     const float* A;
     int64_t lda, a_bstride;
@@ -201,6 +201,10 @@ typedef struct rl_wsplit_item {
 int rl_split_weights(const rl_wsplit_item* items, int count, void* stream);
 
 int64_t rl_gemm_kslab_floats(int64_t M, int N, int K);
+/* slots of `stats` an (M, N, K) product fills (<= RL_MAX_SLOTS): one per 128-row block, or one per 64-row block where the
+ * wide GEMM may run on 64-row output tiles (few rows, N > 64) - every kernel zero-fills the slots it does not use, so this
+ * is the count to hand to rl_bn_finalize whichever kernel took the launch. */
+int64_t rl_gemm_stat_slots(int64_t M, int N, int K);
 
 /* Arithmetic of the wide kernels (K or N > 64: rl_gemm's LDS-tiled kernel, rl_wgrad's 128x128 kernel):
  *   "bf16x3" (default)  every fp32 operand is split into a bf16 head and tail on its way into LDS and a product is
@@ -220,6 +224,14 @@ const char* rl_get_wide_gemm(void);
  * Same products in the same order: Y is bitwise the same (the BatchNorm partial sums are grouped differently).
  * K % 32 != 0 or K > 1024 always takes "registers".  RL_WGEMM_STAGING sets the initial choice.                        */
 int rl_set_wgemm_staging(const char* how);
+/* Output tile of the "dma" kernel: "auto" (default) = 128 x 128, or 64 x 128 / 64 x 64 where 128 x 128 tiles would leave
+ * at most half / a quarter of the CUs with a tile (the deep levels: few rows) - more workgroups in one pass, mostly no K split;
+ * "128" = always 128 x 128 (round 5).  Y is bitwise the same; the BatchNorm partial sums are grouped per 64 rows
+ * (rl_gemm_stat_slots).  RL_WGEMM_TILE sets the initial choice.                                                         */
+int rl_set_wgemm_tile(const char* how);
+/* Diagnostics: enable = 0 switches the K split of wide products with few output tiles off (one summation order whatever the
+ * kernel and its tile: what the bitwise kernel-against-kernel tests compare on); 1 (default) restores it.               */
+int rl_set_gemm_ksplit(int enable);
 /* Diagnostics: the streaming GEMM (K, N <= 64) on 1/div of its workgroups (1 = default).  Y is bitwise the same; the rows a
  * lane adds into its BatchNorm partial sums change - the regression knob for "a re-grouping of the statistics must not move
  * a gradient" (tests/test_net_gpu.py; round 4 met 0.5 - 3 % before the sums were shifted).                              */

@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
 def test_host_only_entry_points(lib):
     from randlanet import _hip
     L = _hip.lib()
-    assert L.rl_version() == _hip.ABI_VERSION == 109
+    assert L.rl_version() == _hip.ABI_VERSION == 110
     assert L.rl_row_blocks(1, 128) == 1 and L.rl_row_blocks(128 * 5000, 128) == 1024
     assert L.rl_row_blocks(129, 128) == 2
     assert L.rl_wgrad_slab_floats(1000, 16, 16) > 0

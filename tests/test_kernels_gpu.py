@@ -185,7 +185,7 @@ def test_gemm_forward(ops, B, n, K, N, transposed, lazy, bias):
     ref = ref_in.double() @ Wm.double() + (b.double() if bias else 0)
     tol = 2e-6 * K ** 0.5 * float(ref.abs().max()) + 1e-6   # exact-fp32 FMA chain vs fp64
     assert float((Y.double() - ref).abs().max()) <= tol
-    nslots = min(-(-B * n // 128), 1024)
+    nslots = ops.gemm_stat_slots(B * n, N, K)
     s = stats[:nslots]
     np.testing.assert_allclose(s[:, 0].sum(0).cpu().numpy(), Y.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(s[:, 1].sum(0).cpu().numpy(), (Y.double() ** 2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
@@ -978,7 +978,7 @@ def test_knn_multi_and_csr_replay_from_a_captured_graph(ops):
 
 
 @pytest.mark.parametrize("M,K,N,orient", [(5000, 256, 256, "fwd"), (3000, 128, 512, "bwd"), (700, 512, 128, "fwd"), (4096, 64, 256, "bwd")])
-def test_wide_gemm_with_presplit_weights(ops, M, K, N, orient):
+def test_wide_gemm_with_presplit_weights(ops, request, M, K, N, orient):
     """rl_gemm with W_split (rl_split_weights: bf16 head / tail planes in the product's orientation) runs the 8-wavefront
     kernel; same operands, same MFMA sequence per accumulator -> the SAME BITS as the 4-wavefront kernel, with the lazy
     BatchNorm operand, bias, accumulate, the split epilogue and split-K; statistics agree to rounding."""
@@ -998,13 +998,14 @@ def test_wide_gemm_with_presplit_weights(ops, M, K, N, orient):
     ws = ops.split_weights([(W, ks, ns, K, N)])
     assert len(ws) == 1
     st0, st1 = ops.new_stats(DEV, N), ops.new_stats(DEV, N)
+    ops.set_gemm_ksplit(False)          # one summation order for both kernels (the LDS-DMA kernel's small tiles split K less often)
+    request.addfinalizer(lambda: ops.set_gemm_ksplit(True))
     Y0 = ops.gemm(a, W, ks, ns, N, bias, stats=st0)
     Y1 = ops.gemm(a, W, ks, ns, N, bias, stats=st1, wsplit=ws)
     assert torch.equal(Y0, Y1)
     ref = torch.nn.functional.leaky_relu(A * a.scale + a.shift, 0.2).double() @ (W.double().t() if orient == "fwd" else W.double()) + bias.double()
     assert float((Y1.double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
-    from randlanet import _hip as H
-    nsl = H.row_blocks(M, 128)
+    nsl = ops.gemm_stat_slots(M, N, K)
     assert torch.allclose(st0[:nsl].sum(0), st1[:nsl].sum(0), rtol=2e-6, atol=1e-4)      # per-lane fp32 partial sums, other row grouping
     # accumulate + split epilogue (addend, two destinations)
     acc0 = torch.randn(M, N, device=DEV)
@@ -1037,14 +1038,13 @@ def test_wide_gemm_stagings_agree_bitwise(ops, M, K, N):
     W = torch.randn(N, K, device=DEV) / K ** 0.5
     ws = ops.split_weights([(W, 1, K, K, N)])
     bias, addend, old = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV), torch.randn(M, N, device=DEV)
-    nsl = H.row_blocks(M, 128)
     h = N // 2 if N % 256 == 0 else 96              # 96: the first 128-column tile straddles the split
 
     def run():
         res = []
         st = ops.new_stats(DEV, N)
         res.append(ops.gemm(a, W, 1, K, N, bias, stats=st, wsplit=ws))
-        res.append(st[:nsl].sum(0))
+        res.append(st[:ops.gemm_stat_slots(M, N, K)].sum(0))
         acc = old.clone()
         ops.gemm(a, W, 1, K, N, None, out=acc, out_bstride=M, accumulate=True, wsplit=ws)
         res.append(acc)
@@ -1060,17 +1060,88 @@ def test_wide_gemm_stagings_agree_bitwise(ops, M, K, N):
         torch.cuda.synchronize()
         return res
     try:
+        ops.set_gemm_ksplit(False)                   # one summation order on both sides (the LDS-DMA kernel never splits K)
         ops.set_wgemm_staging("registers")
         r0 = run()
         ops.set_wgemm_staging("dma")
         r1 = run()
+        ops.set_gemm_ksplit(True)                    # the register-staged kernel as shipped: K split where tiles are few
+        ops.set_wgemm_staging("registers")
+        r0s = run()
     finally:
         ops.set_wgemm_staging("dma")
+        ops.set_gemm_ksplit(True)
     ref = torch.relu(A * a.scale + a.shift).double() @ W.double().t() + bias.double()
+    for x, y in zip(r0, r0s):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-4 * max(1.0, float(ref.abs().max())))
     assert float((r1[0].double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
     for i, (x, y) in enumerate(zip(r0, r1)):
         if x.dtype == torch.float64:
             assert torch.allclose(x, y, rtol=1e-12, atol=0.0), i
+        else:
+            assert torch.equal(x, y), i
+
+
+@pytest.mark.parametrize("M,K,N", [(5120, 256, 128), (5120, 512, 256), (1280, 512, 512), (5120, 128, 256), (2600, 1024, 192),
+                                   (300, 512, 256), (130, 32, 128), (5000, 64, 160), (4099, 256, 100)])
+def test_wide_gemm_tiles_agree_bitwise(ops, M, K, N):
+    """The output tile of the LDS-DMA wide GEMM (rl_set_wgemm_tile: "auto" = 64 x 128 / 64 x 64 where 128 x 128 tiles leave most
+    CUs without one - the deep levels' launches, round 6; "128" = one tile shape) does not change a product: Y is bitwise the
+    same with every epilogue option (bias + statistics, accumulate, addend + two destinations incl. a tile that straddles
+    split_col, a batch stride, what is left of split-K), the partial statistics agree after summation (slots per 64 rows)."""
+    if ops.get_wide_gemm() == "fp32":
+        pytest.skip("the pre-split path exists in the bf16 arithmetic modes")
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV)
+    a = ops.plain(A, 1, M)
+    a.scale, a.shift, a.act, a.slope = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.3, 2, 0.2
+    W = torch.randn(N, K, device=DEV) / K ** 0.5
+    Wt = W.t().contiguous()
+    ws = ops.split_weights([(W, 1, K, K, N), (Wt, N, 1, K, N)])
+    bias, addend, old = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV), torch.randn(M, N, device=DEV)
+    piv = torch.randn(N, device=DEV) * 0.1
+    h = N // 2 if N % 256 == 0 else (96 if N > 128 else 48)
+
+    def run():
+        res = []
+        st = ops.new_stats(DEV, N)
+        res.append(ops.gemm(a, W, 1, K, N, bias, stats=st, wsplit=ws, pivot=(piv, None)))
+        res.append(st[:ops.gemm_stat_slots(M, N, K)].sum(0))
+        res.append(ops.gemm(a, Wt, N, 1, N, None, wsplit=ws))             # the dgrad orientation, no statistics: transposed accumulator
+        acc = old.clone()
+        ops.gemm(a, W, 1, K, N, None, out=acc, out_bstride=M, accumulate=True, wsplit=ws)
+        res.append(acc)
+        if N % 4 == 0:
+            o, d = torch.zeros(M, h, device=DEV), torch.zeros(M, N - h, device=DEV)
+            ops.gemm(a, W, 1, K, N, None, out=o, out_bstride=M, addend=addend, out2=d, split_col=h, wsplit=ws)
+            res += [o, d]
+        if M % 4 == 0:
+            ab = ops.plain(A, 4, M // 4)
+            ab.scale, ab.shift, ab.act, ab.slope = a.scale, a.shift, a.act, a.slope
+            Yb = torch.zeros(4 * (M // 4 + 5), N, device=DEV)
+            ops.gemm(ab, W, 1, K, N, bias, out=Yb, out_bstride=M // 4 + 5, wsplit=ws)
+            res.append(Yb)
+        torch.cuda.synchronize()
+        return res
+    try:
+        ops.set_gemm_ksplit(False)
+        ops.set_wgemm_tile("128")
+        r0 = run()
+        ops.set_wgemm_tile("auto")
+        r1 = run()
+        ops.set_gemm_ksplit(True)                    # as shipped (the switch does not reach the LDS-DMA kernel: it never splits K)
+        r2 = run()
+    finally:
+        ops.set_wgemm_tile("auto")
+        ops.set_gemm_ksplit(True)
+    ref = torch.nn.functional.leaky_relu(A * a.scale + a.shift, 0.2).double() @ W.double().t() + bias.double()
+    assert float((r1[0].double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    assert float((r2[0].double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    for x, y in zip(r1, r2):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-4 * max(1.0, float(ref.abs().max())))
+    for i, (x, y) in enumerate(zip(r0, r1)):
+        if x.dtype == torch.float64:
+            assert torch.allclose(x, y, rtol=1e-6, atol=1e-3), i       # (fp32 per-lane partial sums over another set of rows)
         else:
             assert torch.equal(x, y), i
 
@@ -1085,7 +1156,9 @@ def test_wide_gemm_dispatch_names_the_kernel_it_ran(ops):
     last = lambda: H.lib().rl_last_kernel().decode()
     for M, K, N, planes, staging, want in [(20000, 256, 128, True, "dma", "wgemm2_kernel"), (20000, 256, 128, True, "registers", "wgemm_kernel"),
                                            (20000, 40, 128, True, "dma", "wgemm_kernel"), (20000, 256, 128, False, "dma", "pgemm_kernel<8>"),
-                                           (3000, 512, 256, True, "dma", "wgemm2_kernel+splitk"), (3000, 64, 64, False, "dma", "sgemm_kernel")]:
+                                           (3000, 512, 256, True, "dma", "wgemm2_kernel"),        # (64 x 64 tiles: 188 of them, no K split)
+                                           (300, 512, 256, True, "dma", "wgemm2_kernel"),         # (the LDS-DMA kernel never splits K)
+                                           (300, 512, 256, True, "registers", "wgemm_kernel+splitk"), (3000, 64, 64, False, "dma", "sgemm_kernel")]:
         A = torch.randn(M, K, device=DEV)
         W = torch.randn(N, K, device=DEV)
         ws = ops.split_weights([(W, 1, K, K, N)]) if planes else None
