@@ -39,8 +39,11 @@ struct CloudSync {
 };
 // Every wavefront reaches the end of the kernel whatever its peers do: the spin is BOUNDED (~2^22 polls of ~0.25 us: about a
 // second, against ~1 us for a barrier that works).  A workgroup whose peers never arrive - the launch was not co-resident: a CU
-// mask, a partition mode - stops waiting for good and poisons its share of the output with NaN (the loss of the step shows
-// it) instead of hanging the GPU.
+// mask, a partition mode - stops waiting for good, raises the cloud's ERROR WORD in the call's scratch
+// (rl_batch_assemble_flag_u32: the loader reads the words back asynchronously and raises on the host) and writes the
+// sampled coordinates as they were read - finite, so that the neighbour search behind the loader, whose key network assumes
+// finite inputs, never sees a NaN (round 5 wrote NaN: a rare hang had become a rare out-of-range index) - instead of
+// hanging the GPU.
 constexpr unsigned ASM_SPIN_LIMIT = 1u << 22;
 __device__ __forceinline__ void cloud_barrier(CloudSync& cs) {
     __syncthreads();
@@ -256,11 +259,13 @@ __global__ __launch_bounds__(1024) void batch_assemble_kernel(const rl_cloud_job
     }
     // torch.from_numpy(xyz).float() (dataset.py:51): round to float32, coordinates first (dataset.py:53)
     __syncthreads();
-    const bool poisoned = gave_up != 0;          // a cloud-wide sum never completed: nothing of this share is trustworthy
+    // a cloud-wide sum never completed: nothing of this share is trustworthy - say so in the cloud's error word (the values
+    // written are the finite ones at hand: whatever stage the share reached)
+    if (gave_up != 0 && threadIdx.x == 0) atomicOr(cs.arrive + 2, 1u);
     for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        out[(long)i * C + 0] = poisoned ? __builtin_nanf("") : (float)X[3 * i + 0];
-        out[(long)i * C + 1] = poisoned ? __builtin_nanf("") : (float)X[3 * i + 1];
-        out[(long)i * C + 2] = poisoned ? __builtin_nanf("") : (float)X[3 * i + 2];
+        out[(long)i * C + 0] = (float)X[3 * i + 0];
+        out[(long)i * C + 1] = (float)X[3 * i + 1];
+        out[(long)i * C + 2] = (float)X[3 * i + 2];
     }
 }
 
@@ -373,7 +378,14 @@ static int assemble_capacity() {
 constexpr int ASM_SYNC_DOUBLES = 130;
 __global__ void batch_assemble_reset_kernel(unsigned* __restrict__ count, int stride_u32, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) { count[(long)b * stride_u32] = 0u; count[(long)b * stride_u32 + 1] = 0u; }
+    if (b < B) { count[(long)b * stride_u32] = 0u; count[(long)b * stride_u32 + 1] = 0u; count[(long)b * stride_u32 + 2] = 0u; }
+}
+
+// where cloud b's error word sits, counted in 32-bit words from the start of `scratch` (0 = fine; 1 = a cloud-wide rendezvous
+// timed out and that cloud's output is not what the reference would produce)
+extern "C" int64_t rl_batch_assemble_flag_u32(int B, int n, int b) {
+    if (B <= 0 || n <= 0 || b < 0 || b >= B) return -1;
+    return 2 * ((int64_t)B * n * 3 + (int64_t)b * ASM_SYNC_DOUBLES + 128) + 2;
 }
 
 extern "C" int64_t rl_batch_assemble_scratch_doubles(int B, int n) {
@@ -396,10 +408,9 @@ extern "C" int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int
     unsigned* count = reinterpret_cast<unsigned*>(part + 128);
     hipStream_t st = (hipStream_t)stream;
     const int sync_stride = ASM_SYNC_DOUBLES;
-    if (gw > 1) {
-        hipLaunchKernelGGL(batch_assemble_reset_kernel, dim3(rl_cdiv(B, 64)), dim3(64), 0, st, count, 2 * ASM_SYNC_DOUBLES, B);
-        RL_LAUNCH_CHECK("rl_batch_assemble(reset)");
-    }
+    // (always: the error words are read back by the caller whatever gw was)
+    hipLaunchKernelGGL(batch_assemble_reset_kernel, dim3(rl_cdiv(B, 64)), dim3(64), 0, st, count, 2 * ASM_SYNC_DOUBLES, B);
+    RL_LAUNCH_CHECK("rl_batch_assemble(reset)");
     // (A COOPERATIVE launch - the runtime's own co-residency check - was built and measured in round 5: the loader's launch then
     // serialises with the training stream's graph replays, Model.train 883 -> 333 clouds/s.  Kept: the capacity from the occupancy
     // calculator per device, records / counters per call, the bounded spin.)

@@ -268,6 +268,7 @@ _SIGNATURES = {
     "rl_rpe_build_dist": (_i, [_vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "rl_batch_assemble": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl_batch_assemble_scratch_doubles": (_l, [_i, _i]),
+    "rl_batch_assemble_flag_u32": (_l, [_i, _i, _i]),
     "rl_batch_draw": (_i, [_vp, _i, _i, C.c_uint64, _vp, _vp, _vp]),
     "rl_scale_mask": (_i, [_vp, _vp, _f, _l, _vp]),
     "rl_dropout_tick": (_i, [_vp, _vp, _vp]),

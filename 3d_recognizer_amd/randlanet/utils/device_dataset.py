@@ -55,6 +55,7 @@ class DeviceDataLoader:
         self._draws = 0
         self._consistent_idx = {}
         self._ring = None            # pinned host staging (see _staging)
+        self._checks = []            # (pinned error words of a launched batch, event): see _check_launches
         # the whole dataset moves to HBM once
         self._xyz: List[torch.Tensor] = []
         self._feat: List[torch.Tensor] = []
@@ -201,7 +202,31 @@ class DeviceDataLoader:
         H.check(H.lib().rl_batch_assemble(jobs_dev.data_ptr(), B, n, F, indices.data_ptr(), H.ptr(noise),
                                           scratch.data_ptr(), inp.data_ptr(), lab.data_ptr(),
                                           torch.cuda.current_stream(dev).cuda_stream), "rl_batch_assemble")
+        # the launch's error words (a cloud-wide rendezvous that timed out, rl_randlanet.h) come back asynchronously and are
+        # looked at when they have arrived - no host synchronisation on the way (the host runs ahead of the GPU)
+        f0 = int(H.lib().rl_batch_assemble_flag_u32(B, n, 0))
+        stride = int(H.lib().rl_batch_assemble_flag_u32(B, n, 1)) - f0 if B > 1 else 1
+        words = torch.empty(B, dtype=torch.int32).pin_memory()
+        words.copy_(scratch.view(torch.int32)[f0::stride][:B], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._checks.append((words, ev))
+        self._check_launches(wait=False)
         return inp, lab, torch.tensor(ids, dtype=torch.int64)
+
+    def _check_launches(self, wait: bool) -> None:
+        """Raise if a finished rl_batch_assemble launch reported a timed-out rendezvous (its batch is not what the reference
+        would have produced).  wait=False: only launches whose words have already arrived."""
+        while self._checks:
+            words, ev = self._checks[0]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            self._checks.pop(0)
+            if bool((words != 0).any()):
+                raise H.HipKernelError("rl_batch_assemble: a cloud-wide rendezvous timed out (the launch was not co-resident: "
+                                       "a CU mask or partition mode?); set RL_ASSEMBLE_ONE_WG=1")
 
     def __iter__(self):
         # (Assembling batches one ahead on a stream of the loader's own, beside the training step, was built and measured in
@@ -210,6 +235,7 @@ class DeviceDataLoader:
         order = self._order()
         for start in range(0, len(order), self.batch_size):
             yield self._assemble(order[start:start + self.batch_size])
+        self._check_launches(wait=True)        # (end of an epoch: the trainer synchronises here anyway)
 
 
 def get_device_data_loader(dataset: Sequence[Sample], n_sample_points: int, batch_size: int, shuffle: bool = False,

@@ -646,8 +646,10 @@ int rl_rpe_build_dist(const float* xyz, int64_t xyz_bstride, const int32_t* nbr_
  *           counters of the cloud-wide sums; any content - the call resets what it needs; one scratch per concurrent call)
  * Up to 16 workgroups share a cloud and meet at an arrival-counter barrier per cloud-wide sum; their number is sized so that
  * a launch fits the device at once (occupancy calculator, per device), and the wait is BOUNDED: a workgroup whose peers do not
- * arrive within ~1 s (a CU mask or partition mode the attribute does not show) gives up and writes NaN coordinates for its
- * share of the cloud instead of hanging the GPU.  RL_ASSEMBLE_ONE_WG=1 forces one workgroup per cloud (no rendezvous).
+ * arrive within ~1 s (a CU mask or partition mode the attribute does not show) gives up, sets the cloud's error word in
+ * `scratch` (32-bit word rl_batch_assemble_flag_u32(B, n, b): 0 = fine) and writes the finite coordinates it has - never NaN -
+ * instead of hanging the GPU; the caller reads the B words back (asynchronously) and treats a non-zero one as a failed
+ * launch.  RL_ASSEMBLE_ONE_WG=1 forces one workgroup per cloud (no rendezvous).
  *   out_input (B,n,3+F) float32 = [xyz, features], out_labels (B,n) int64                       */
 typedef struct rl_cloud_job {
     const void* xyz;          /* (n_points,3) float32, or float64 when xyz_f64 != 0 */
@@ -665,6 +667,7 @@ typedef struct rl_cloud_job {
 } rl_cloud_job;
 
 int64_t rl_batch_assemble_scratch_doubles(int B, int n);
+int64_t rl_batch_assemble_flag_u32(int B, int n, int b);
 int rl_batch_assemble(const rl_cloud_job* jobs_dev, int B, int n, int F, const int64_t* indices,
                       const double* noise, double* scratch, float* out_input, int64_t* out_labels,
                       void* stream);

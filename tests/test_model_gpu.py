@@ -253,14 +253,15 @@ def test_denoised_training_matches_denoised_reference(golden_dir, monkeypatch, f
       -1.3 +- 0.5 points off four 64-seed HIP draws that shared ONE 64-seed reference draw; it was the scatter above.
     conv_biases+fc_start_bias: fc_start.bias (the Linear in front of bn_start) frozen too - the reference gains +1.8 ... +2.2
       points from that alone (5 - 7 sigma: the largest single noise source left), the comparison is the tightest available.
-      2048 seeds here (RL_DENOISED_SEEDS: up to the fixture's 4096) against train_seeds_denoised_fc4096.npz.
+      1024 seeds here (RL_DENOISED_SEEDS: up to the fixture's 4096; 2048 until round 5 - the suite then took 604 s of its 900 s
+      limit; the bound max(0.1 pt, 2 SE) is unchanged) against train_seeds_denoised_fc4096.npz.
       Round 5, all 4096 seeds (profiles/r05_denoised_hip_4096.npz): default bf16x3 arithmetic -0.09 +- 0.09 / -0.03 +- 0.06 /
       -0.04 +- 0.06 points; exact fp32 products -0.01 +- 0.08 / +0.03 +- 0.06 / +0.06 +- 0.06."""
     fc = frozen.endswith("fc_start_bias")
     _freeze_zero_gradient_biases(monkeypatch, fc_start=fc)
     if fc:
         den = np.load(f"{golden_dir}/train_seeds_denoised_fc4096.npz")
-        S = min(int(os.environ.get("RL_DENOISED_SEEDS", "2048")), len(den["seeds"]))
+        S = min(int(os.environ.get("RL_DENOISED_SEEDS", "1024")), len(den["seeds"]))
         seeds, draws = den["seeds"][:S], den["histories"][None, :S].astype(np.float64)
     else:
         den = np.load(f"{golden_dir}/train_seeds_denoised_256.npz")
