@@ -58,11 +58,12 @@ __device__ __forceinline__ void bn_finalize_body(
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-    const float* __restrict__ folded_bias, const int pivoted, const int c, double (*red)[2]) {
+    const float* __restrict__ folded_bias, const int pivoted, float* __restrict__ pivot_io, const int c, double (*red)[2]) {
     // lane 0's per-channel constants are requested BEFORE the slot sums: behind them they were a second, dependent memory round
     // trip of a kernel that is nothing but latency (only this lane reads the running mean - and rewrites it at the end)
-    float fb = 0.f, g = 1.f, b = 0.f, rm = 0.f, rv = 0.f;
+    float fb = 0.f, g = 1.f, b = 0.f, rm = 0.f, rv = 0.f, pv = 0.f;
     if (threadIdx.x == 0) {
+        if (pivot_io) pv = pivot_io[c];
         // folded_bias: the producer left the layer's bias OUT of the tensor (it cancels in y - mean): the statistics are
         // those of y - bias, and so is the tensor the (scale, shift) pair will be applied to; only the RUNNING mean is that of y
         if (folded_bias) fb = folded_bias[c];
@@ -79,7 +80,10 @@ __device__ __forceinline__ void bn_finalize_body(
         // pivoted: the sums are those of (t - pivot), (t - pivot)^2 around pivot = running mean - folded bias (the producer
         // subtracted the same fp32 value per element before squaring): a channel whose spread is tiny against its mean keeps
         // its variance, which E[t^2] - E[t]^2 on fp32 partial sums loses (the reference's ATen BatchNorm is two-pass)
-        const double pivot = pivoted ? (double)(rm - fb) : 0.0;
+        // (round 6) pivot_io: the caller's own pivot vector - the PREVIOUS batch's mean of y, left there by this kernel a step ago
+        // (zero for a fresh or freshly loaded model) - instead of the running mean, which may sit anywhere after a
+        // load_state_dict: a pivot ten standard deviations off the batch mean costs var = Q/n - (S/n)^2 two digits
+        const double pivot = pivoted ? (double)((pivot_io ? pv : rm) - fb) : 0.0;
         const double ms = s / count;
         mean = pivot + ms;
         var = q / count - ms * ms;
@@ -100,16 +104,17 @@ __device__ __forceinline__ void bn_finalize_body(
         rvar[c] = (1.f - momentum) * rv + momentum * (float)unbiased;
         if (c == 0 && nbt) nbt[0] += 1;
     }
+    if (training && pivot_io) pivot_io[c] = (float)mean + fb;        // the next step's pivot: this batch's mean of y
 }
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const double* __restrict__ stats, int nslots, double count, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
     int64_t* nbt, float momentum, float eps, int training, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-    const float* __restrict__ folded_bias, int pivoted) {
+    const float* __restrict__ folded_bias, int pivoted, float* __restrict__ pivot_io) {
     __shared__ double red[4][2];
     bn_finalize_body(stats, nslots, count, C, gamma, beta, rmean, rvar, nbt, momentum, eps, training, scale, shift, save_mean,
-                     save_invstd, folded_bias, pivoted, (int)blockIdx.x, red);
+                     save_invstd, folded_bias, pivoted, pivot_io, (int)blockIdx.x, red);
 }
 // Several independent layers' folds in ONE launch (blockIdx.y = layer, blockIdx.x = channel): a fold is a 5 us launch that
 // does 0.5 us of work, and the folds of layers at one dependency depth (mlp1 / shortcut / mlp_rpe1 of an encoder level,
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(256) void bn_finalize_batch_kernel(const BnFoldBatc
     const rl_bn_finalize_item& t = b.it[blockIdx.y];
     if ((int)blockIdx.x >= t.C) return;
     bn_finalize_body(t.stats, t.nslots, (double)t.count, t.C, t.gamma, t.beta, t.running_mean, t.running_var, t.num_batches_tracked,
-                     t.momentum, t.eps, t.training, t.scale, t.shift, t.save_mean, t.save_invstd, t.folded_bias, t.pivoted, (int)blockIdx.x, red);
+                     t.momentum, t.eps, t.training, t.scale, t.shift, t.save_mean, t.save_invstd, t.folded_bias, t.pivoted, t.pivot,
+                     (int)blockIdx.x, red);
 }
 
 // (nslots, 2, C) partials -> (2, C) totals, one wavefront per channel, fixed order: the piece a data-parallel caller
@@ -690,14 +696,16 @@ int fill(BwdParams* p, const rl_bn_bwd_desc* d, const char* who) {
 extern "C" int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                               float momentum, float eps, int training, float* scale, float* shift,
-                              float* save_mean, float* save_invstd, const float* folded_bias, int pivoted, void* stream) {
+                              float* save_mean, float* save_invstd, const float* folded_bias, int pivoted, float* pivot,
+                              void* stream) {
     RL_REQUIRE(C > 0 && scale && shift, RL_ERR_ARGS, "rl_bn_finalize: bad arguments");
-    RL_REQUIRE(!pivoted || (training && running_mean), RL_ERR_ARGS, "rl_bn_finalize: pivoted statistics need training mode and the running mean");
+    RL_REQUIRE(!pivoted || (training && (running_mean || pivot)), RL_ERR_ARGS,
+               "rl_bn_finalize: pivoted statistics need training mode and the pivot (or the running mean)");
     if (training) RL_REQUIRE(stats && nslots > 0 && count > 0, RL_ERR_ARGS, "rl_bn_finalize: training needs partial statistics");
     else RL_REQUIRE(running_mean && running_var, RL_ERR_ARGS, "rl_bn_finalize: eval needs running statistics");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, nslots,
                        (double)count, C, gamma, beta, running_mean, running_var, nbt, momentum, eps, training,
-                       scale, shift, save_mean, save_invstd, folded_bias, pivoted);
+                       scale, shift, save_mean, save_invstd, folded_bias, pivoted, pivot);
     RL_LAUNCH_CHECK("rl_bn_finalize");
     return RL_OK;
 }
@@ -713,7 +721,8 @@ extern "C" int rl_bn_finalize_batch(const rl_bn_finalize_item* items, int count,
             RL_REQUIRE(t.C > 0 && t.scale && t.shift, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: bad arguments", base + i);
             if (t.training) RL_REQUIRE(t.stats && t.nslots > 0 && t.count > 0, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: training needs partial statistics", base + i);
             else RL_REQUIRE(t.running_mean && t.running_var, RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: eval needs running statistics", base + i);
-            RL_REQUIRE(!t.pivoted || (t.training && t.running_mean), RL_ERR_ARGS, "rl_bn_finalize_batch: item %d: pivoted statistics need training mode and the running mean", base + i);
+            RL_REQUIRE(!t.pivoted || (t.training && (t.running_mean || t.pivot)), RL_ERR_ARGS,
+                       "rl_bn_finalize_batch: item %d: pivoted statistics need training mode and the pivot (or the running mean)", base + i);
             b.it[i] = t;
             maxc = t.C > maxc ? t.C : maxc;
         }

@@ -344,11 +344,21 @@ __device__ __forceinline__ int head_label(const HeadParams& p, const HeadLab& h)
 template <int MC>      // classes carried in registers: 2, 4 or 8 (the smallest that holds C)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
     __shared__ float lgs[2][32][MC];
+    // a row lane's fp32 sums are moved into doubles every HD_FLUSH trips (the grid is capped at RL_MAX_SLOTS workgroups, so a
+    // lane's share grows with the batch: rows / 32768 - thousands at tens of millions of rows; the unfused loss_fwd_kernel
+    // promotes per 256-row tile).  Counts stay exact, probability / loss sums keep fp32 rounding over at most 64 terms.
+    constexpr int HD_FLUSH = 64;
+    __shared__ double accd[32][5 * MC + 1];
     const int tid = threadIdx.x, l = tid & 7;
     const int C = p.C;
     float acc[5 * MC + 1];
 #pragma unroll
     for (int e = 0; e < 5 * MC + 1; ++e) acc[e] = 0.f;
+    if (tid < 32) {
+#pragma unroll
+        for (int e = 0; e < 5 * MC + 1; ++e) accd[tid][e] = 0.0;
+    }
+    int trips = 0;
     const long total = (long)p.B * p.N;
     const long niter = (total + 31) / 32;
     int buf = 0;
@@ -437,6 +447,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
                     }
                 }
             }
+            if (++trips == HD_FLUSH) {        // (the row lanes' own LDS row: no other lane touches it)
+                trips = 0;
+#pragma unroll
+                for (int e = 0; e < 5 * MC + 1; ++e) { accd[tid][e] += (double)acc[e]; acc[e] = 0.f; }
+            }
         }
     }
     // the 32 row lanes (half of wavefront 0) hold the workgroup's sums: doubles, a fixed butterfly over those 32 lanes
@@ -447,11 +462,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
 #pragma unroll
             for (int c = 0; c < MC; ++c) {
                 if (c >= C) break;
-                double v = tid < 32 ? (double)acc[k * MC + c] : 0.0;
+                double v = tid < 32 ? accd[tid][k * MC + c] + (double)acc[k * MC + c] : 0.0;
                 v = rl_wave_sum(v);
                 if (tid == 0) p.work[(long)blockIdx.x * rs + k * C + c] = v;
             }
-        double v = tid < 32 ? (double)acc[5 * MC] : 0.0;
+        double v = tid < 32 ? accd[tid][5 * MC] + (double)acc[5 * MC] : 0.0;
         v = rl_wave_sum(v);
         if (tid == 0) p.work[(long)blockIdx.x * rs + 5 * C] = v;
     }

@@ -91,6 +91,13 @@ class Engine:
         self.F = int(n_features)
         self.P = params      # reference state_dict names -> tensors (parameters)
         self.Bf = buffers    # running_mean / running_var / num_batches_tracked
+        # pivots of the shifted batch statistics, one vector per BatchNorm layer: the PREVIOUS training batch's mean of the
+        # layer's output, left there by rl_bn_finalize (round 6; round 5 pivoted on the running mean, which after a
+        # load_state_dict can sit ten standard deviations off the data: var = Q/n - (S/n)^2 then loses two digits).  Zero for
+        # a fresh or freshly loaded model (reset_pivots): the first step runs on plain sums.  Engine state, not module state:
+        # the state_dict keeps the reference's 262 / 320 entries.  Allocated HERE (a captured forward must not allocate them)
+        self.Pv: Dict[str, torch.Tensor] = {k[:-len(".running_mean")]: torch.zeros_like(v) for k, v in buffers.items()
+                                             if k.endswith(".running_mean")}
         self._side: Optional[torch.cuda.Stream] = None   # weight gradients run beside the dgrad chain
         # eval mode: the BatchNorm layers of a forward (name -> (C, folded conv bias)), see _fold - one table per SIGNATURE of the
         # forward (which levels run the virtual rpe branch: it folds mlp_rpe1/2's BatchNorm without the conv bias, the stored
@@ -116,8 +123,13 @@ class Engine:
         return w.view(w.shape[0], w.shape[1])
 
     def _pivot(self, ctx: Context, bn_name: str):
-        """The pivot of a layer's shifted batch statistics: its running mean (training only)."""
-        return self.Bf[f"{bn_name}.running_mean"] if (ctx.training and BN_PIVOT) else None
+        """The pivot of a layer's shifted batch statistics: the previous batch's mean (training only), see self.Pv."""
+        return self.Pv[bn_name] if (ctx.training and BN_PIVOT) else None
+
+    def reset_pivots(self) -> None:
+        """After the weights were replaced (load_state_dict): the pivots of the old weights' activations mean nothing."""
+        for t in self.Pv.values():
+            t.zero_()
 
     def _fold(self, ctx: Context, bn_name: str, stats, rows: int, C: int, folded_bias=None, nslots=None):
         """The BatchNorm fold of one layer (rl_bn_finalize).  Eval mode: the fold depends on nothing the forward computes (running
@@ -136,7 +148,8 @@ class Engine:
             stats, rows, 128, C, self.P[f"{bn_name}.weight"], self.P[f"{bn_name}.bias"],
             self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
             nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, folded_bias=folded_bias,
-            nslots=nslots, defer=getattr(ctx, "bn_defer", None), pivoted=ctx.training and BN_PIVOT)
+            nslots=nslots, defer=getattr(ctx, "bn_defer", None), pivoted=ctx.training and BN_PIVOT,
+            pivot=self._pivot(ctx, bn_name))
 
     def _eval_folds(self, spec: dict):
         """(scale, shift) of every BatchNorm layer from the running statistics, as grouped launches."""

@@ -167,7 +167,7 @@ class BnFinalizeItem(C.Structure):
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p),
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
         ("folded_bias", C.c_void_p), ("nslots", C.c_int32), ("C", C.c_int32), ("training", C.c_int32),
-        ("momentum", C.c_float), ("eps", C.c_float), ("pivoted", C.c_int32),
+        ("momentum", C.c_float), ("eps", C.c_float), ("pivoted", C.c_int32), ("pivot", C.c_void_p),
     ]
 
 
@@ -199,6 +199,7 @@ _SIGNATURES = {
     "rl_last_error": (C.c_char_p, []),
     "rl_last_kernel": (C.c_char_p, []),
     "rl_version": (_i, []),
+    "rl_spin_us": (_i, [_i, _vp]),
     "rl_launch_count": (_l, []),
     "rl_row_blocks": (_i, [_l, _i]),
     "rl_knn_workspace_bytes": (_l, [_i, _i, _i, _i]),
@@ -223,7 +224,7 @@ _SIGNATURES = {
     "rl_wgrad_batchable": (_i, [C.POINTER(WgradDesc)]),
     "rl_wgrad_batch": (_i, [C.POINTER(WgradDesc), _i, _vp]),
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
-    "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "rl_bn_finalize_batch": (_i, [C.POINTER(BnFinalizeItem), _i, _vp]),
     "rl_head_supported": (_i, [_i, _i]),
     "rl_head_grid": (_i, [_l]),

@@ -557,22 +557,38 @@ NO_BN_BATCH = bool(int(__import__("os").environ.get("RL_NO_BN_BATCH", "0")))    
 
 def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, nbt, momentum: float,
                 eps: float, training: bool, sync: Optional[SyncGroup] = None, nslots: Optional[int] = None,
-                folded_bias: Optional[torch.Tensor] = None, defer: Optional[list] = None, pivoted: bool = False):
+                folded_bias: Optional[torch.Tensor] = None, defer: Optional[list] = None, pivoted: bool = False,
+                pivot: Optional[torch.Tensor] = None):
     """folded_bias: the layer's conv bias when the producing GEMM did NOT add it (rl_bn_finalize in rl_randlanet.h).
-    pivoted: the partial sums are shifted around (running_mean - folded_bias), see gemm(pivot=...).
+    pivoted: the partial sums are shifted around (m - folded_bias), m = `pivot` when given, else the running mean - the vector
+    the producer was given, see gemm(pivot=...).
+    pivot (training): the layer's pivot vector (Engine.Pv); the fold leaves this batch's mean of y there for the next step.
     defer (a list): the fold is only queued - the returned tensors are filled by `bn_finalize_flush(defer)`, which runs all
     queued folds as ONE launch; the caller flushes before anything reads them."""
     dev = gamma.device
     nslots = H.row_blocks(rows, tile) if nslots is None else nslots
     if training and sync is not None:            # batch statistics of the GLOBAL batch
         stats = _stats_totals(stats, nslots, C)
+        if pivoted:
+            # the ranks' sums are shifted around EACH RANK's pivot (its running mean - nothing forces the replicas' buffers to
+            # be bit-equal): bring them to pivot 0 in double before they are added - S0 = S + n c, Q0 = Q + 2 c S + n c^2 with
+            # the fp32 pivot c = running_mean - folded_bias the producer subtracted (exact in double up to 2^-53: the variance
+            # keeps what the shift bought) - and finalize the totals as plain sums
+            m = pivot if pivot is not None else rmean
+            c = (m - folded_bias if folded_bias is not None else m).to(torch.float64)
+            S, Q = stats[0, 0].clone(), stats[0, 1].clone()
+            stats[0, 0] = S + rows * c
+            stats[0, 1] = Q + 2.0 * c * S + rows * c * c
+            pivoted = False
         sync.allreduce(stats)
         nslots, rows = 1, sync.global_rows(rows)
     scale = torch.empty(C, dtype=F32, device=dev)
     shift = torch.empty(C, dtype=F32, device=dev)
     mean = torch.empty(C, dtype=F32, device=dev) if training else None
     invstd = torch.empty(C, dtype=F32, device=dev) if training else None
-    _dev_check(stats, gamma, beta, rmean, rvar, nbt, folded_bias)
+    _dev_check(stats, gamma, beta, rmean, rvar, nbt, folded_bias, pivot)
+    if not training:
+        pivot = None
     assert folded_bias is None or folded_bias.numel() == C
     if defer is not None and not NO_BN_BATCH:
         it = H.BnFinalizeItem()
@@ -581,12 +597,13 @@ def bn_finalize(stats, rows: int, tile: int, C: int, gamma, beta, rmean, rvar, n
         it.scale, it.shift, it.save_mean, it.save_invstd = scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd)
         it.folded_bias, it.nslots, it.C, it.training, it.momentum, it.eps = H.ptr(folded_bias), nslots, C, int(training), momentum, eps
         it.pivoted = int(bool(pivoted and training))
+        it.pivot = H.ptr(pivot)
         defer.append((it, stats, scale, shift, mean, invstd))       # (the tensors stay referenced until the launch is issued)
         return scale, shift, mean, invstd
     H.check(H.lib().rl_bn_finalize(H.ptr(stats), nslots, rows, C, H.ptr(gamma), H.ptr(beta),
                                    H.ptr(rmean), H.ptr(rvar), H.ptr(nbt), momentum, eps, int(training),
                                    scale.data_ptr(), shift.data_ptr(), H.ptr(mean), H.ptr(invstd), H.ptr(folded_bias),
-                                   int(bool(pivoted and training)), _st()),
+                                   int(bool(pivoted and training)), H.ptr(pivot), _st()),
             "rl_bn_finalize")
     return scale, shift, mean, invstd
 

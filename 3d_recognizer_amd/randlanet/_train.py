@@ -24,10 +24,13 @@ _PERM_BY_KERNEL = os.environ.get("RL_PERM_MEMCPY", "0") != "1"      # A/B: hipMe
 # on a second stream, under the previous step's kernels (round 5).  Built, bit-identical - and measured: 6.73 -> 6.78 ms per step.
 # The kernel trace shows the preparation running on its own hardware queue beside two or three network kernels, and every one of
 # them stretching by what the other takes (grid_query 243 -> 293 - 326 us; 67.3 ms of kernel time in a 59.9 ms window): the
-# network's kernels already fill the chip, so OFF by default on ONE rank; RL_PREP_PIPELINE=1 / TrainStep(pipeline=True) turns it on.
-# With SEVERAL ranks it is the default (RL_PREP_PIPELINE=0 turns it off): the preparation of step t + 1 is then ordered behind
-# step t's network graph and runs beside step t's gradient all-reduce + Adam - a latency-bound collective on a few CUs under half
-# a millisecond of kernels that need no gradient and no weight - so the collective no longer stands alone between two graphs.
+# network's kernels already fill the chip, so OFF by default; RL_PREP_PIPELINE=1 / TrainStep(pipeline=True) turns it on.
+# With SEVERAL ranks the preparation of step t + 1 is then ordered behind step t's network graph and runs beside step t's gradient
+# all-reduce + Adam - a latency-bound collective on a few CUs under half a millisecond of kernels that need no gradient and no
+# weight.  Round 5 made that the multi-rank default on the strength of the argument alone; round 6 measured it with a spin kernel
+# of the collective's length standing in for the all-reduce on the one leasable GPU (tools/allreduce_standin.py, DESIGN.md
+# section 7) and it is opt-in again for every world size: one schedule for all ranks unless the USER asks for the other, and a
+# capture that fails raises on that rank instead of quietly running another schedule than its peers.
 _PREP_PIPELINE_ENV = os.environ.get("RL_PREP_PIPELINE", "")
 _PREP_PIPELINE = _PREP_PIPELINE_ENV == "1"
 
@@ -123,13 +126,15 @@ class TrainState:
 
     def snapshot(self):
         return (self.flat.param.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.step_count.clone(),
-                {k: v.clone() for k, v in self.module.named_buffers()})
+                {k: v.clone() for k, v in self.module.named_buffers()}, {k: v.clone() for k, v in self.engine.Pv.items()})
 
     def restore(self, snap) -> None:
         self.flat.param.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
         self.step_count.copy_(snap[3])
         for k, v in self.module.named_buffers():
             v.copy_(snap[4][k])
+        for k, v in self.engine.Pv.items():
+            v.copy_(snap[5][k])
 
 
 class TrainStep:
@@ -147,8 +152,7 @@ class TrainStep:
         sync: the data-parallel EQUIVALENCE mode - BatchNorm batch statistics and the loss' class
         sums of the GLOBAL batch (all-reduced), gradients summed instead of averaged: N ranks on shards reproduce the
         single-process step on the whole batch.  Eager launches only (collectives between kernels).
-        pipeline (graph mode; default: on with several ranks, where it hides the gradient all-reduce; off with one - measured
-        neutral there, see _PREP_PIPELINE; RL_PREP_PIPELINE=1 / 0 forces it): the part of a step that
+        pipeline (graph mode; default off for every world size, see _PREP_PIPELINE; RL_PREP_PIPELINE=1 turns it on): the part of a step that
         depends on the input rows and the permutation alone (Engine.prepare: permuted rows, all neighbour searches, graph
         transposes) is captured as its OWN graph and replayed on a second stream, so that step t's preparation runs under
         step t - 1's network kernels (the host submits ahead of the GPU).  Two sets of its outputs alternate (and two
@@ -186,9 +190,8 @@ class TrainStep:
         self._g_main: Optional[torch.cuda.CUDAGraph] = None
         self._g_adam: Optional[torch.cuda.CUDAGraph] = None
         # pipelined preparation: set k = step % 2 (its own permutation buffer, Engine.Prep, preparation graph, network graph)
-        self._pipeline_auto = pipeline is None and not _PREP_PIPELINE     # chosen here, not asked for: may fall back (see _capture)
         if pipeline is None:
-            pipeline = _PREP_PIPELINE or (self.split and _PREP_PIPELINE_ENV != "0")
+            pipeline = _PREP_PIPELINE
         self.pipeline = bool(use_graph and sync is None and pipeline)
         self._sets: list = []
         self._side: Optional[torch.cuda.Stream] = None
@@ -247,18 +250,8 @@ class TrainStep:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         # thread_local: RCCL's watchdog thread polls events while we capture; only this thread's calls count
-        if self.pipeline and self._pipeline_auto:
-            # the multi-rank default is a pure scheduling choice (same kernels, same results): if its capture fails on some
-            # platform, say so and run the plain order instead of failing the job
-            try:
-                self._capture_pipeline()
-            except RuntimeError as e:
-                import warnings
-                warnings.warn(f"pipelined preparation could not be captured ({e}); using the plain schedule")
-                torch.cuda.synchronize(self.dev)
-                self.pipeline, self._sets, self._g_main = False, [], None
-        elif self.pipeline:
-            self._capture_pipeline()
+        if self.pipeline:
+            self._capture_pipeline()             # (asked for explicitly: a failure raises here, on this rank)
         if not self.pipeline:
             self._g_main = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_main, capture_error_mode="thread_local"):

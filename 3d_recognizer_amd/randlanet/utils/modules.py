@@ -358,6 +358,13 @@ class RandLANet(nn.Module):
         self._engine: Optional[Engine] = None
         self._engine_key = None
         self._infer_steps = {}
+        # new weights: the engine's statistic pivots (the previous batch's means under the OLD weights) start over
+        self.register_load_state_dict_post_hook(RandLANet._weights_replaced)
+
+    @staticmethod
+    def _weights_replaced(module, incompatible_keys) -> None:
+        if getattr(module, "_engine", None) is not None:
+            module._engine.reset_pivots()
 
     # -- reference properties (modules.py:534-540)
     @property

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define RL_VERSION 110     /* round 6: rl_gemm_stat_slots (64-row tiles of the wide GEMM); round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted), rl_head_*; round 4: rl_launch_count */
+#define RL_VERSION 110     /* round 6: rl_gemm_stat_slots (64-row tiles of the wide GEMM), rl_bn_finalize pivot vector; round 5: shifted BatchNorm statistics (stats_pivot_* fields, rl_bn_finalize pivoted), rl_head_*; round 4: rl_launch_count */
 
 #define RL_OK 0
 #define RL_ERR_ARGS (-1)         /* bad shape / null pointer / unsupported size            */
@@ -72,6 +72,9 @@ int rl_version(void);
 /* kernel launches issued by this library in the calling process so far (every entry point counts the kernels it launches;
  * a measurement aid: the difference around an eager step = the kernels a rocprofv3 trace shows for it) */
 int64_t rl_launch_count(void);
+/* measurement aid: one idle wavefront that occupies `stream` for `us` microseconds (<= 20000) - stands in for a collective of
+ * known length when a schedule around it is timed on a single GPU (tools/allreduce_standin.py); touches no memory */
+int rl_spin_us(int us, void* stream);
 
 /* Number of partial-statistics slots a row-streaming kernel writes for `rows` rows:
  * rl_gemm uses rows_per_tile = 128, rl_loss 256; rl_bn_bwd_reduce has its own rl_bn_bwd_slots. */
@@ -312,14 +315,18 @@ int rl_wgrad_reduce_batch(const rl_wgrad_reduce_item* items, int count, void* st
  *   producer left it OUT of the tensor - it cancels in (y - mean), so the GEMM epilogue need not add it.  The statistics
  *   and the saved mean are then those of (y - bias), (scale, shift) apply to that tensor, and the running mean is kept
  *   as the reference keeps it: that of y (mean + bias); in eval mode the running mean is read as (running_mean - bias).
- * pivoted != 0 (training): the partial sums are SHIFTED - those of (t - pivot) and (t - pivot)^2 of the stored tensor t,
- *   pivot[c] = running_mean[c] (as it stands BEFORE this call's update) - folded_bias[c]: mean = pivot + S/n,
- *   var = Q/n - (S/n)^2.  The producer must have been given the same two vectors (rl_gemm_desc.stats_pivot_*,
- *   rl_pool_desc.pivot_mean*). */
+ * pivoted != 0 (training): the partial sums are SHIFTED - those of (t - p) and (t - p)^2 of the stored tensor t,
+ *   p[c] = m[c] - folded_bias[c] with m = `pivot` when given, else running_mean (either as it stands BEFORE this call's
+ *   update): mean = p + S/n, var = Q/n - (S/n)^2.  The producer must have been given the same two vectors
+ *   (rl_gemm_desc.stats_pivot_*, rl_pool_desc.pivot_mean*).
+ * pivot (C floats or NULL; training): the caller's pivot vector of this layer (round 6).  After the fold it holds THIS
+ *   batch's mean of y (mean + folded bias) - the next step's pivot: always within the batch-to-batch drift of the mean,
+ *   wherever a loaded checkpoint's running mean sits (a pivot ten standard deviations off costs the variance two digits);
+ *   zero it for a fresh / freshly loaded model (pivot 0 = plain sums for one step). */
 int rl_bn_finalize(const double* stats, int nslots, int64_t count, int C, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, int64_t* nbt,
                    float momentum, float eps, int training, float* scale, float* shift,
-                   float* save_mean, float* save_invstd, const float* folded_bias, int pivoted, void* stream);
+                   float* save_mean, float* save_invstd, const float* folded_bias, int pivoted, float* pivot, void* stream);
 
 /* Several independent layers' folds in one launch (same arithmetic per layer as rl_bn_finalize: same results).  The folds of
  * the layers at one dependency depth of an encoder level - mlp1 / shortcut / mlp_rpe1, then pool1.mlp / mlp_rpe2 - are wanted
@@ -340,6 +347,7 @@ typedef struct rl_bn_finalize_item {
     int32_t nslots, C, training;
     float momentum, eps;
     int32_t pivoted;
+    float* pivot;
 } rl_bn_finalize_item;
 int rl_bn_finalize_batch(const rl_bn_finalize_item* items, int count, void* stream);
 

@@ -33,8 +33,8 @@ def _run(split, pg=None, pipeline=None):
     xyz = rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
     lab = np.clip(np.floor(xyz[..., 2] * 3), 0, 2).astype(np.int64)
     st = TrainStep(net, B, N, loss="dice", use_graph=True, process_group=pg, split_schedule=split, pipeline=pipeline)
-    # several ranks (or their schedule): the next step's coordinate-only preparation runs on a second stream beside the all-reduce
-    assert st.pipeline == (split if pipeline is None else pipeline)
+    # the pipelined preparation (next step's coordinate-only part on a second stream beside the all-reduce) is opt-in (round 6)
+    assert st.pipeline == bool(pipeline)
     st.set_batch(torch.from_numpy(xyz).to(dev), torch.from_numpy(lab).to(dev))
     if split:
         import torch.distributed as dist
@@ -66,8 +66,8 @@ def _worker(port, q):
             dist.all_reduce(t)                              # communicator is built by the first collective
             torch.cuda.synchronize()
             assert dist.get_backend() == "nccl" and t[7].item() == 7.0
-            param, losses = _run(True)                      # (pipelined preparation: the multi-rank default)
-            param2, losses2 = _run(True, pipeline=False)    # the plain order: graph, all-reduce, Adam graph
+            param, losses = _run(True, pipeline=True)       # pipelined preparation beside the collective (opt-in)
+            param2, losses2 = _run(True)                    # the default order: graph, all-reduce, Adam graph
             assert losses2 == losses and np.array_equal(param, param2)
             q.put(("ok", param, losses))
         finally:
@@ -97,7 +97,7 @@ def test_one_rank_rccl_group_runs_the_multi_rank_schedule():
 
 
 # ---- two ranks for real: gloo instead of RCCL (two RCCL ranks cannot share a device), everything else as on an 8-GPU node --------
-def _run2(rank, world, same_data):
+def _run2(rank, world, same_data, pipeline=None):
     """The replayed data-parallel schedule with TWO ranks: forward + backward graph, all-reduce of the flat gradient buffer over
     the default process group, Adam graph (gradient / world), the next step's preparation on the second stream beside it."""
     from randlanet._train import TrainStep, broadcast_flat
@@ -111,8 +111,8 @@ def _run2(rank, world, same_data):
     rs = np.random.RandomState(3 if same_data else 3 + rank)
     xyz = rs.uniform(0, 1, (B, N, 3)).astype(np.float32)
     lab = np.clip(np.floor(xyz[..., 2] * 3), 0, 2).astype(np.int64)
-    st = TrainStep(net, B, N, loss="dice", use_graph=True, world_size=world)
-    assert st.split == (world > 1) and st.pipeline == (world > 1)
+    st = TrainStep(net, B, N, loss="dice", use_graph=True, world_size=world, pipeline=pipeline)
+    assert st.split == (world > 1) and st.pipeline == bool(pipeline)
     st.set_batch(torch.from_numpy(xyz).to(dev), torch.from_numpy(lab).to(dev))
     if world > 1:
         if rank:
@@ -128,7 +128,7 @@ def _run2(rank, world, same_data):
     return st.flat.param.detach().cpu().numpy().copy(), losses
 
 
-def _worker2(rank, world, port, q, same_data):
+def _worker2(rank, world, port, q, same_data, pipeline=None):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (repo, os.path.join(repo, "3d_recognizer_amd")):
@@ -140,7 +140,7 @@ def _worker2(rank, world, port, q, same_data):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         try:
-            param, losses = _run2(rank, world, same_data)
+            param, losses = _run2(rank, world, same_data, pipeline)
             q.put((rank, "ok", param, losses))
         finally:
             dist.destroy_process_group()
@@ -150,18 +150,19 @@ def _worker2(rank, world, port, q, same_data):
 
 
 @pytest.mark.timeout(420)
-@pytest.mark.parametrize("same_data,world", [(True, 2), (False, 2), (False, 4)])
-def test_ranks_sharing_one_gpu_run_the_replayed_data_parallel_schedule(same_data, world):
+@pytest.mark.parametrize("same_data,world,pipeline", [(True, 2, None), (True, 2, True), (False, 2, None), (False, 4, True)])
+def test_ranks_sharing_one_gpu_run_the_replayed_data_parallel_schedule(same_data, world, pipeline):
     """same_data: both ranks hold the SAME batch - the averaged gradient (g + g) / 2 is g exactly, so the two-rank run must
     leave the parameters of the one-rank run bit for bit.  Otherwise: different batches - the replicas must still agree bit
-    for bit after every all-reduce (and not with the one-rank run)."""
+    for bit after every all-reduce (and not with the one-rank run).  pipeline: the default schedule (graph, all-reduce, Adam
+    graph) or, opt-in, the next step's preparation on a second stream beside the collective."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker2, args=(r, world, port, q, same_data)) for r in range(world)]
+    procs = [ctx.Process(target=_worker2, args=(r, world, port, q, same_data, pipeline)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
