@@ -36,6 +36,8 @@ FOLD_BIAS = not bool(int(__import__("os").environ.get("RL_NO_FOLD_BIAS", "0"))) 
 # BatchNorm batch statistics as SHIFTED sums around the running mean (round 5): var = E[(y-c)^2] - E[y-c]^2 keeps the variance
 # of a channel whose spread is tiny against its mean, which E[y^2] - E[y]^2 on fp32 partial sums loses.  A/B: RL_NO_BN_PIVOT=1
 BN_PIVOT = not bool(int(__import__("os").environ.get("RL_NO_BN_PIVOT", "0")))
+# A/B: pivot on the running mean (round 5) instead of the engine's own pivot vectors (the previous batch's mean, round 6)
+BN_PIVOT_RUNNING = bool(int(__import__("os").environ.get("RL_BN_PIVOT_RUNNING", "0")))
 # clouds below this size keep the permutation as drawn (a level-0 table of < 128 KB sits in L2 / L1 whatever the order)
 BAND_SORT_MIN_POINTS = 4096
 
@@ -124,7 +126,9 @@ class Engine:
 
     def _pivot(self, ctx: Context, bn_name: str):
         """The pivot of a layer's shifted batch statistics: the previous batch's mean (training only), see self.Pv."""
-        return self.Pv[bn_name] if (ctx.training and BN_PIVOT) else None
+        if not (ctx.training and BN_PIVOT):
+            return None
+        return self.Bf[f"{bn_name}.running_mean"] if BN_PIVOT_RUNNING else self.Pv[bn_name]
 
     def reset_pivots(self) -> None:
         """After the weights were replaced (load_state_dict): the pivots of the old weights' activations mean nothing."""
@@ -149,7 +153,7 @@ class Engine:
             self.Bf[f"{bn_name}.running_mean"], self.Bf[f"{bn_name}.running_var"],
             nbt if ctx.training else None, BN_MOMENTUM, BN_EPS, ctx.training, sync=self.sync, folded_bias=folded_bias,
             nslots=nslots, defer=getattr(ctx, "bn_defer", None), pivoted=ctx.training and BN_PIVOT,
-            pivot=self._pivot(ctx, bn_name))
+            pivot=None if BN_PIVOT_RUNNING else self._pivot(ctx, bn_name))
 
     def _eval_folds(self, spec: dict):
         """(scale, shift) of every BatchNorm layer from the running statistics, as grouped launches."""

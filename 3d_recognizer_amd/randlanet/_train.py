@@ -126,7 +126,8 @@ class TrainState:
 
     def snapshot(self):
         return (self.flat.param.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.step_count.clone(),
-                {k: v.clone() for k, v in self.module.named_buffers()}, {k: v.clone() for k, v in self.engine.Pv.items()})
+                {k: v.clone() for k, v in self.module.named_buffers()}, {k: v.clone() for k, v in self.engine.Pv.items()},
+                None if self.engine._drop_counter is None else self.engine._drop_counter.clone())
 
     def restore(self, snap) -> None:
         self.flat.param.copy_(snap[0]); self.exp_avg.copy_(snap[1]); self.exp_avg_sq.copy_(snap[2])
@@ -135,6 +136,8 @@ class TrainState:
             v.copy_(snap[4][k])
         for k, v in self.engine.Pv.items():
             v.copy_(snap[5][k])
+        if snap[6] is not None and self.engine._drop_counter is not None:
+            self.engine._drop_counter.copy_(snap[6])       # (the capture's warm-up passes draw no Dropout masks of the run)
 
 
 class TrainStep:

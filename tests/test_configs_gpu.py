@@ -369,8 +369,14 @@ def test_statistics_regrouping_does_not_move_gradients(monkeypatch):
             for div, staging in ((3, "dma"), (7, "dma"), (1, "registers"), (5, "registers")):
                 g = grads(div, staging, pivot)
                 for name, r in base.items():
-                    # (+ 1e-7 absolute, as in test_equivalence_gpu: conv biases in front of a BatchNorm have a true gradient of 0)
-                    e = max(0.0, float((g[name] - r).abs().max()) - 1e-7) / (float(r.abs().max()) + 1e-12)
+                    d = float((g[name] - r).abs().max())
+                    if name == "fc_start.bias" or (name.endswith("conv.bias") and name != "fc_end.3.conv.bias"):
+                        # a bias in front of a BatchNorm: its TRUE gradient is 0 and what is computed is the rounding residue of
+                        # a cancelling sum (1e-9 ... 1e-7 here, another value for every grouping) - held absolutely, not relative
+                        # to itself (round 6: the pivots moved onto the batch mean and one residue went from 4e-8 to 1.04e-7)
+                        assert d < 1e-6, (name, d)
+                        continue
+                    e = max(0.0, d - 1e-7) / (float(r.abs().max()) + 1e-12)
                     worst = max(worst, (e, name))
             print(f"[regrouping] shifted sums {'on ' if pivot else 'off'}: worst relative gradient difference {worst[0]:.2e} ({worst[1]})")
             if pivot:
