@@ -142,6 +142,15 @@ struct GemmParams {
     long out2_bstride;
     int split_col;
     const __bf16* wsplit;      // wgemm: head plane [N][K] (k contiguous), tail plane follows at + N*K
+    // rl_gemm_pair (wgemm2_kernel only): a SECOND product over the same A' in the same launch - the column blocks from pair_ny1
+    // on belong to it: its own weight planes, columns, dense output, statistics and pivot
+    int pair_ny1;              // 0: no second product
+    int N2;
+    float* Y2;
+    double* stats2;
+    const float* piv_mean2;
+    const float* piv_bias2;
+    const __bf16* wsplit2;
 };
 
 __device__ __forceinline__ float stat_pivot(const GemmParams& p, int c) {
@@ -1687,7 +1696,7 @@ constexpr int W2_THREADS = 768;
 // BN / 16 (x 2 planes) pieces per chunk.  Per accumulator the same products in the same order as the 128 x 128 tile: Y is
 // bitwise the same whatever the tile; only the grouping of the BatchNorm partial sums (slots per 64 rows) differs.
 template <int TERMS, bool STATS, int AS, int WS, int BM = 128, int BN = 128>
-__global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) {
+__global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams pk) {
     static_assert(AS >= 3 && AS <= 6 && WS >= 2 && WS <= 6, "ring depths vs the wait table");
     static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "tile shapes");
     constexpr int RB = BM / 16;                 // 16-row blocks of a tile
@@ -1702,11 +1711,20 @@ __global__ __launch_bounds__(W2_THREADS) void wgemm2_kernel(const GemmParams p) 
     __shared__ __attribute__((aligned(1024))) unsigned char lds[TOTAL];       // ONE object
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx = blockIdx.x, by = 0;
-    if (p.ny > 1) {
+    if (pk.ny > 1) {
         const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-        by = s % p.ny;
-        bx = (s / p.ny) * 8 + xcd;
-        if (bx >= p.gx) return;
+        by = s % pk.ny;
+        bx = (s / pk.ny) * 8 + xcd;
+        if (bx >= pk.gx) return;
+    }
+    // a pair launch (rl_gemm_pair: mlp1 + shortcut of an encoder level behind ONE read of their common input): the column blocks
+    // from pair_ny1 on compute the second product - wavefront-uniform, decided once: everything below reads `p`
+    GemmParams p = pk;
+    if (pk.pair_ny1 > 0 && by >= pk.pair_ny1) {
+        by -= pk.pair_ny1;
+        p.N = pk.N2; p.Y = pk.Y2; p.ldy = pk.N2; p.stats = pk.stats2;
+        p.piv_mean = pk.piv_mean2; p.piv_bias = pk.piv_bias2; p.wsplit = pk.wsplit2;
+        p.split_col = pk.N2;
     }
     const int col0 = by * BN;
     const int K = p.a.K, N = p.N;
@@ -2867,7 +2885,7 @@ extern "C" const char* rl_get_wide_gemm(void) {
 
 extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     RL_REQUIRE(d != nullptr, RL_ERR_ARGS, "rl_gemm: null descriptor");
-    GemmParams p;
+    GemmParams p{};
     int rc = fill_a(&p.a, "rl_gemm", d->A, d->lda, d->a_bstride, d->a_mode, d->in_act, d->in_slope,
                     d->in_scale, d->in_shift, d->xyz, d->xyz_bstride, d->nbr_idx, d->nbr_d2, d->nbr_k,
                     d->B, d->n, d->K);
@@ -2972,6 +2990,71 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     else                 hipLaunchKernelGGL((gemm_kernel<8>), dim3(gx, rl_cdiv(d->N, 128)), dim3(256), 0, st, p);
     rl_note_kernel("gemm_kernel");
     RL_LAUNCH_CHECK("rl_gemm");
+    return RL_OK;
+}
+
+// ---- two products over ONE A' in one launch -------------------------------------------------------------------------------------
+// mlp1 and shortcut of an encoder level (modules.py:314, 325) both read the level's input: as two launches the rows are fetched
+// twice and the narrow one (d/2 columns) leaves most of the chip idle.  Here the column blocks of both weights are dealt to the
+// persistent workgroups of ONE wgemm2 launch (128 x 128 tiles; per accumulator the products of a single launch in the same
+// order: Y1 / Y2 are bitwise what rl_gemm gives with the same planes).
+static bool gemm_pair_fits(const rl_gemm_desc* a, const rl_gemm_desc* b) {
+    if (!a || !b) return false;
+    if (a->A != b->A || a->lda != b->lda || a->a_bstride != b->a_bstride || a->a_mode != 0 || b->a_mode != 0) return false;
+    if (a->B != b->B || a->n != b->n || a->K != b->K) return false;
+    if (a->in_scale != b->in_scale || a->in_shift != b->in_shift || a->in_act != b->in_act || a->in_slope != b->in_slope) return false;
+    if (!a->W_split || !b->W_split || wide_gemm_terms() == 0 || wgemm_staging() != 1) return false;
+    if (a->K % PG_BK || a->K > W2_KMAX || a->N <= 0 || b->N <= 0) return false;
+    // a product with K <= 64 and N <= 64 runs on the streaming kernel in EXACT fp32 products (rl_gemm): pairing it would change its
+    // arithmetic to bf16x3 - not done (measured: the 1029-point ragged configuration's gradients moved 4 % over their bound)
+    if ((a->K <= 64 && a->N <= 64) || (b->K <= 64 && b->N <= 64)) return false;
+    if (a->bias || b->bias || a->accumulate || b->accumulate || a->addend || b->addend || a->out2 || b->out2) return false;
+    if ((a->stats == nullptr) != (b->stats == nullptr)) return false;
+    if (a->ldy != a->N || b->ldy != b->N || a->y_bstride != a->n || b->y_bstride != b->n || !a->Y || !b->Y) return false;
+    if ((((uintptr_t)a->A | (uintptr_t)(a->lda * 4) | (uintptr_t)a->W_split | (uintptr_t)b->W_split | (uintptr_t)a->Y | (uintptr_t)b->Y) & 15) != 0)
+        return false;
+    if (a->N % 4 || b->N % 4) return false;
+    return true;
+}
+extern "C" int rl_gemm_pair_supported(const rl_gemm_desc* a, const rl_gemm_desc* b) { return gemm_pair_fits(a, b) ? 1 : 0; }
+extern "C" int rl_gemm_pair(const rl_gemm_desc* a, const rl_gemm_desc* b, void* stream) {
+    RL_REQUIRE(gemm_pair_fits(a, b), RL_ERR_UNSUPPORTED,
+               "rl_gemm_pair: needs one plain A' (K %% 32 == 0, K <= 1024) for both, pre-split weights in a bf16 arithmetic mode, the "
+               "dense outputs, statistics for both or none, no bias / accumulate / split epilogue");
+    GemmParams p{};
+    int rc = fill_a(&p.a, "rl_gemm_pair", a->A, a->lda, a->a_bstride, 0, a->in_act, a->in_slope, a->in_scale, a->in_shift,
+                    nullptr, 0, nullptr, nullptr, 0, a->B, a->n, a->K);
+    if (rc) return rc;
+    p.N = a->N; p.W = a->W; p.w_ks = a->w_ks; p.w_ns = a->w_ns; p.bias = nullptr;
+    p.Y = a->Y; p.ldy = a->ldy; p.y_bstride = a->y_bstride; p.rows_per_batch = a->n; p.y_contig = 1;
+    p.accumulate = 0; p.stats = a->stats;
+    p.piv_mean = a->stats ? a->stats_pivot_mean : nullptr; p.piv_bias = a->stats ? a->stats_pivot_bias : nullptr;
+    p.split_col = a->N; p.wsplit = reinterpret_cast<const __bf16*>(a->W_split);
+    p.ksplit = 1; p.kchunk = 0; p.kslab = nullptr;
+    p.stat_slots = rl_row_blocks_host(p.a.M, GM_BM);          // (128-row tiles: the slot count of both products)
+    p.N2 = b->N; p.Y2 = b->Y; p.stats2 = b->stats; p.wsplit2 = reinterpret_cast<const __bf16*>(b->W_split);
+    p.piv_mean2 = b->stats ? b->stats_pivot_mean : nullptr; p.piv_bias2 = b->stats ? b->stats_pivot_bias : nullptr;
+    p.pair_ny1 = rl_cdiv(a->N, 128);
+    RL_REQUIRE(wgemm2_usable(p), RL_ERR_UNSUPPORTED, "rl_gemm_pair: the LDS-DMA kernel does not take this operand");
+    // the grid of launch_wgemm for ny = the column blocks of both products
+    p.ny = p.pair_ny1 + rl_cdiv(b->N, 128);
+    p.gx = rl_cdiv(p.a.M, 128);
+    int cap = cu_count() / p.ny / 8 * 8;
+    if (cap < 8) cap = 8;
+    if (p.gx > cap) p.gx = cap;
+    const dim3 g2((unsigned)(8 * rl_cdiv(p.gx, 8) * p.ny), 1, 1);
+    const bool stats = p.stats != nullptr;
+    const WidePlan w{128, 128, 1};
+    hipStream_t st = (hipStream_t)stream;
+    if (wide_gemm_terms() == 1) {
+        if (stats) launch_wgemm2_tile<1, true>(w, g2, st, p);
+        else       launch_wgemm2_tile<1, false>(w, g2, st, p);
+    } else {
+        if (stats) launch_wgemm2_tile<3, true>(w, g2, st, p);
+        else       launch_wgemm2_tile<3, false>(w, g2, st, p);
+    }
+    rl_note_kernel("wgemm2_kernel");
+    RL_LAUNCH_CHECK("rl_gemm_pair");
     return RL_OK;
 }
 

@@ -194,6 +194,33 @@ class Engine:
         ctx.tape.append(("linear", a, out, wname, bname, ks, ns, a_grad))
         return out
 
+    def _mlp_pair(self, ctx, a: Lazy, first: tuple, second: tuple):
+        """Two SharedMLPs over the same input (mlp1 and shortcut of an encoder level, modules.py:314, 325) as ONE wide-GEMM launch
+        where rl_gemm_pair takes them; first / second: (name, n_out, act, slope).  The tape gets the two "linear" records it would
+        get from two _mlp calls (the backward is theirs)."""
+        specs, metas = [], []
+        for name, n_out, act, slope in (first, second):
+            wname, bname, bn = f"{name}.conv.weight", f"{name}.conv.bias", f"{name}.batch_norm"
+            W = self._w2(wname)
+            ks, ns = ops.weight_strides(W, False, a.C, n_out)
+            stats = ops.new_stats(W.device, n_out) if ctx.training else None
+            piv = self._pivot(ctx, bn) if stats is not None else None
+            if not FOLD_BIAS:
+                return self._mlp(ctx, a, first[0], first[1], first[2], first[3]), self._mlp(ctx, a, second[0], second[1], second[2], second[3])
+            specs.append((W, ks, ns, n_out, stats, (piv, self.P[bname]) if piv is not None else None))
+            metas.append((wname, bname, bn, n_out, act, slope, ks, ns, stats))
+        res = ops.gemm_pair(a, specs[0], specs[1], getattr(ctx, "wsplit", None))
+        if res is None:
+            return self._mlp(ctx, a, first[0], first[1], first[2], first[3]), self._mlp(ctx, a, second[0], second[1], second[2], second[3])
+        outs = []
+        for Y, (wname, bname, bn, n_out, act, slope, ks, ns, stats) in zip(res, metas):
+            out = Lazy(Y, a.B, a.n, a.n, n_out)
+            self._bn(ctx, out, stats, bn, act, slope, folded_bias=self.P[bname],
+                     nslots=H.row_blocks(out.rows, 128) if stats is not None else None)
+            ctx.tape.append(("linear", a, out, wname, bname, ks, ns, True))
+            outs.append(out)
+        return outs[0], outs[1]
+
     def _mlp(self, ctx, a, name: str, n_out: int, act: int = H.ACT_NONE, slope: float = 0.0, *, transposed=False,
              bn=True, a_grad=True) -> Lazy:
         """SharedMLP (modules.py:60-104)."""
@@ -242,8 +269,7 @@ class Engine:
         # BatchNorm folds wanted at the same moment go out as ONE launch: (mlp1, shortcut, mlp_rpe1), then (pool1.mlp, mlp_rpe2).
         # ctx.bn_defer collects them; every flush sits in front of the first kernel that reads one of the (scale, shift) pairs
         ctx.bn_defer = [] if self.sync is None else None
-        f0 = self._mlp(ctx, xin, f"{e}.mlp1", h, H.ACT_LRELU, 0.2)
-        sc = self._mlp(ctx, xin, f"{e}.shortcut", 2 * d)
+        f0, sc = self._mlp_pair(ctx, xin, (f"{e}.mlp1", h, H.ACT_LRELU, 0.2), (f"{e}.shortcut", 2 * d, H.ACT_NONE, 0.0))
         if ops.virtual_rpe_supported(d, K, B * n, n):
             # the outputs of mlp_rpe1 / mlp_rpe2 are never stored: their consumers recompute them from the coordinates
             vr = ops.VirtualRpe(ctx.xyz4 if getattr(ctx, "xyz4", None) is not None else xyz, idx, d2, B, n, h, self.P[f"{e}.mlp_rpe1.conv.weight"], self.P[f"{e}.mlp_rpe1.conv.bias"],
@@ -285,6 +311,11 @@ class Engine:
                 continue
             a, b = int(W.shape[0]), int(W.shape[1])
             if max(a, b) <= 64:
+                # mlp1 of a level whose shortcut is wide rides along with it (ops.gemm_pair): forward planes of the narrow weight too
+                if name.endswith(".mlp1.conv.weight") and b % 32 == 0 and b > 64 and not ops.NO_GEMM_PAIR:
+                    sc = self.P.get(name.replace(".mlp1.", ".shortcut."))
+                    if sc is not None and int(sc.shape[0]) > 64:
+                        uses.append((W.view(a, b), 1, b, b, a, True))
                 continue
             transposed = name.startswith("decoder.")                 # ConvTranspose2d weights are (in, out)
             K, N = (a, b) if transposed else (b, a)

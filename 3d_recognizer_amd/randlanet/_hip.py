@@ -208,6 +208,8 @@ _SIGNATURES = {
     "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "rl_knn_multi_workspace_bytes": (_l, [C.POINTER(KnnTask), _i, _i]),
     "rl_knn_multi": (_i, [C.POINTER(KnnTask), _i, _i, _vp, _l, _vp]),
+    "rl_gemm_pair_supported": (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc)]),
+    "rl_gemm_pair": (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _vp]),
     "rl_gemm_kslab_floats": (_l, [_l, _i, _i]),
     "rl_gemm_stat_slots": (_l, [_l, _i, _i]),
     "rl_gemm": (_i, [C.POINTER(GemmDesc), _vp]),

@@ -320,11 +320,13 @@ NO_WSPLIT = bool(int(__import__("os").environ.get("RL_NO_WSPLIT", "0")))     # d
 
 
 def split_weights(entries) -> dict:
-    """entries: list of (W, w_ks, w_ns, K, N).  One launch; returns {(data_ptr, w_ks, w_ns, K, N): planes}."""
+    """entries: list of (W, w_ks, w_ns, K, N[, True]).  One launch; returns {(data_ptr, w_ks, w_ns, K, N): planes}.  Products with
+    N <= 64 run on the streaming kernels and get no planes - unless the entry carries a sixth element (the narrow half of a
+    gemm_pair)."""
     out_map = {}
     if NO_WSPLIT or get_wide_gemm() == "fp32" or not entries:
         return out_map
-    entries = [e for e in entries if e[3] % 8 == 0 and e[4] > 64]
+    entries = [e[:5] for e in entries if e[3] % 8 == 0 and (e[4] > 64 or len(e) > 5)]
     if not entries:
         return out_map
     total = sum(2 * K * N + 8 for _, _, _, K, N in entries)
@@ -405,6 +407,43 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
     with _rec("gemm_rpe" if isinstance(a, Rpe) else "gemm", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N * (2 if accumulate else 1) + K * N), 2 * M * K * N):
         H.check(H.lib().rl_gemm(C.byref(d), _st()), "rl_gemm")
     return out
+
+
+NO_GEMM_PAIR = bool(int(__import__("os").environ.get("RL_NO_GEMM_PAIR", "0")))      # A/B: mlp1 / shortcut as two launches
+
+
+def gemm_pair(a, first: tuple, second: tuple, wsplit: Optional[dict]):
+    """Y1 = A'.W1 and Y2 = A'.W2 in ONE launch (rl_gemm_pair: mlp1 + shortcut of an encoder level, which share their input).
+    first / second: (W, w_ks, w_ns, N, stats or None, pivot tuple or None).  Returns (Y1, Y2), or None when the pair cannot go out
+    as one launch (the caller then issues two gemm() calls).  Statistics: H.row_blocks(M, 128) slots each."""
+    if NO_GEMM_PAIR or not wsplit or isinstance(a, Rpe) or a.raw.dtype != F32:
+        return None
+    descs, outs = [], []
+    M = K = None
+    for (W, w_ks, w_ns, N, stats, pivot) in (first, second):
+        d = H.GemmDesc()
+        M, K = _fill_a(d, a)
+        planes = wsplit.get((W.data_ptr(), w_ks, w_ns, K, N))
+        if planes is None:
+            return None
+        _dev_check(W, stats)
+        out = torch.empty((M, N), dtype=F32, device=W.device)
+        d.N, d.W, d.w_ks, d.w_ns, d.W_split = N, W.data_ptr(), w_ks, w_ns, planes.data_ptr()
+        d.Y, d.ldy, d.y_bstride = out.data_ptr(), N, a.n
+        if stats is not None:
+            assert stats.dtype == torch.float64 and stats.numel() >= H.row_blocks(M, 128) * 2 * N
+            d.stats = stats.data_ptr()
+            if pivot is not None:
+                _dev_check(*pivot)
+                d.stats_pivot_mean, d.stats_pivot_bias = pivot[0].data_ptr(), H.ptr(pivot[1])
+        descs.append(d)
+        outs.append(out)
+    if not H.lib().rl_gemm_pair_supported(C.byref(descs[0]), C.byref(descs[1])):
+        return None
+    N1, N2 = first[3], second[3]
+    with _rec("gemm", (M, K, N1 + N2), 4 * (M * K + M * (N1 + N2) + K * (N1 + N2)), 2 * M * K * (N1 + N2)):
+        H.check(H.lib().rl_gemm_pair(C.byref(descs[0]), C.byref(descs[1]), _st()), "rl_gemm_pair")
+    return outs[0], outs[1]
 
 
 _SLAB = {}

@@ -192,6 +192,17 @@ typedef struct rl_gemm_desc {
     const float* stats_pivot_bias;
 } rl_gemm_desc;
 
+/* TWO products over one A' in ONE launch of the LDS-DMA wide GEMM (round 6): Y1 = A'.W1, Y2 = A'.W2 - mlp1 and shortcut of an
+ * encoder level (modules.py:314, 325), which both read the level's input: the rows are fetched once and the narrow product's
+ * few tiles ride along with the wide one's.  Both descriptors must name the same A' (pointer, strides, lazy transform; a_mode 0,
+ * K % 32 == 0, K <= 1024) and carry W_split (bf16 arithmetic modes); neither product narrow enough for the exact-fp32 streaming
+ * kernel (K <= 64 and N <= 64: its arithmetic would change); dense outputs (ldy == N, y_bstride == n);
+ * statistics (with their pivots) for both or for none - each into its own buffer, rl_row_blocks(M, 128) slots; no bias, no
+ * accumulate, no split epilogue.  Bitwise the results of two rl_gemm calls on 128 x 128 tiles.
+ * rl_gemm_pair_supported: 1 if the pair can go out as one launch, else the caller issues two rl_gemm calls. */
+int rl_gemm_pair_supported(const rl_gemm_desc* a, const rl_gemm_desc* b);
+int rl_gemm_pair(const rl_gemm_desc* a, const rl_gemm_desc* b, void* stream);
+
 /* Splits weights for rl_gemm_desc.W_split: out (2*N*K bf16) <- heads, then tails, of W(k, n) = W[k*w_ks + n*w_ns].
  * One launch for all items (every wide layer of a step, in both orientations: forward and dgrad). */
 typedef struct rl_wsplit_item {

@@ -1146,6 +1146,67 @@ def test_wide_gemm_tiles_agree_bitwise(ops, M, K, N):
             assert torch.equal(x, y), i
 
 
+@pytest.mark.parametrize("M,K,N1,N2,stats", [(10240, 128, 32, 128, True), (2560, 128, 64, 256, True), (1300, 256, 128, 512, True),
+                                             (4099, 96, 32, 100, False), (640, 256, 128, 512, False)])
+def test_gemm_pair_equals_two_launches(ops, M, K, N1, N2, stats):
+    """rl_gemm_pair (mlp1 + shortcut of an encoder level in one launch of the LDS-DMA wide GEMM, round 6): both outputs bitwise
+    what two rl_gemm calls give on the same 128 x 128 tiles, the partial statistics of each product in its own buffer (equal
+    after summation), lazy operand, pivots, rows / columns that do not fill a tile."""
+    if ops.get_wide_gemm() == "fp32":
+        pytest.skip("the pre-split path exists in the bf16 arithmetic modes")
+    from randlanet import _hip as H
+    torch.manual_seed(M + N1)
+    A = torch.randn(2 * M + 7, K, device=DEV)[:2 * M]
+    a = ops.plain(A, 2, M)
+    a.scale, a.shift, a.act, a.slope = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.3, 2, 0.2
+    W1, W2 = torch.randn(N1, K, device=DEV) / K ** 0.5, torch.randn(N2, K, device=DEV) / K ** 0.5
+    p1, p2 = torch.randn(N1, device=DEV) * 0.1, torch.randn(N2, device=DEV) * 0.1
+    b2 = torch.randn(N2, device=DEV) * 0.1
+    ws = ops.split_weights([(W1, 1, K, K, N1, True), (W2, 1, K, K, N2)])
+    assert len(ws) == 2
+    nsl = H.row_blocks(2 * M, 128)
+    try:
+        ops.set_wgemm_tile("128")                       # the pair runs on 128 x 128 tiles: the same slots and sums
+        ref, st = [], []
+        for W, N, piv in ((W1, N1, (p1, None)), (W2, N2, (p2, b2))):
+            s = ops.new_stats(DEV, N) if stats else None
+            ref.append(ops.gemm(a, W, 1, K, N, None, stats=s, wsplit=ws, pivot=piv if stats else None))
+            st.append(s)
+    finally:
+        ops.set_wgemm_tile("auto")
+    s1, s2 = (ops.new_stats(DEV, N1), ops.new_stats(DEV, N2)) if stats else (None, None)
+    res = ops.gemm_pair(a, (W1, 1, K, N1, s1, (p1, None) if stats else None), (W2, 1, K, N2, s2, (p2, b2) if stats else None), ws)
+    assert res is not None, "rl_gemm_pair refused a pair it should take"
+    assert H.lib().rl_last_kernel().decode() == "wgemm2_kernel"
+    torch.cuda.synchronize()
+    assert torch.equal(res[1], ref[1])
+    assert torch.equal(res[0], ref[0])      # (K > 64: the narrow product alone runs on the LDS-tiled kernel, the same arithmetic)
+    if stats:
+        if N1 > 64:
+            assert torch.allclose(s1[:nsl].sum(0), st[0][:nsl].sum(0), rtol=1e-12, atol=0.0)
+        assert torch.allclose(s2[:nsl].sum(0), st[1][:nsl].sum(0), rtol=1e-12, atol=0.0)
+    fp64 = torch.nn.functional.leaky_relu(A * a.scale + a.shift, 0.2).double()
+    for Y, W in zip(res, (W1, W2)):
+        r = fp64 @ W.double().t()
+        assert float((Y.double() - r).abs().max()) < 2e-4 * max(1.0, float(r.abs().max()))
+    if stats:       # the narrow product's statistics against the result itself (shifted sums around its pivot)
+        d = res[0].double() - p1.double()
+        assert torch.allclose(s1[:nsl, 0].sum(0), d.sum(0), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(s1[:nsl, 1].sum(0), (d * d).sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_gemm_pair_leaves_exact_fp32_products_alone(ops):
+    """A product with K <= 64 and N <= 64 runs on the streaming kernel in exact fp32 products: rl_gemm_pair does not take it (its
+    arithmetic would become bf16x3) - the caller issues two launches."""
+    if ops.get_wide_gemm() == "fp32":
+        pytest.skip("the pre-split path exists in the bf16 arithmetic modes")
+    M, K, N1, N2 = 2048, 32, 32, 128
+    A = torch.randn(M, K, device=DEV)
+    W1, W2 = torch.randn(N1, K, device=DEV), torch.randn(N2, K, device=DEV)
+    ws = ops.split_weights([(W1, 1, K, K, N1, True), (W2, 1, K, K, N2)])
+    assert ops.gemm_pair(ops.plain(A, 1, M), (W1, 1, K, N1, None, None), (W2, 1, K, N2, None, None), ws) is None
+
+
 def test_wide_gemm_dispatch_names_the_kernel_it_ran(ops):
     """rl_last_kernel after rl_gemm: the LDS-DMA kernel by default where it applies (K % 32 == 0, K <= 1024, pre-split weights),
     the register-staged one on request and for K % 32 != 0, the 4-wavefront kernel without planes, the streaming kernel for
