@@ -2119,7 +2119,8 @@ inline WidePlan wide_plan(long M, int N, int K, bool dma) {
     // fed through a long K loop, and a split costs a second launch (the reducer) plus the slab round trip - measured on every
     // wide shape of config A at 1 / 2 / 4 / 8 clouds (tools/wgemm_tile_bench.py): the single pass wins or ties everywhere, by
     // up to 2x on the deep levels (e.g. 2560 x 256 x 128: 14.8 -> 9.5 us forward, 13.7 -> 7.1 us input gradient)
-    if (dma || g_gemm_no_ksplit || N % 4 || tiles >= 128 || K < 256) return w;
+    // (RL_WGEMM_TILE=128 restores round 5 as a whole - one tile shape AND its K splits - for A/B runs)
+    if ((dma && wgemm_small_tiles()) || g_gemm_no_ksplit || N % 4 || tiles >= 128 || K < 256) return w;
     long s = 256 / tiles;
     if (s > K / 64) s = K / 64;      // at least two 32-deep chunks per split
     if (s > 16) s = 16;
