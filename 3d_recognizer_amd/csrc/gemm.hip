@@ -2096,6 +2096,14 @@ inline bool wgemm_small_tiles() {
 int g_wgemm_force = 0;          // rl_set_wgemm_tile("64x128" / "64x64"): that tile for every launch of the LDS-DMA kernel (measurements)
 int g_gemm_no_ksplit = 0;       // rl_set_gemm_ksplit(0): tests compare kernels / tiles bit for bit on ONE summation order
 struct WidePlan { int bm, bn, ksplit; };
+int g_wgemm_narrow = -1;
+inline bool wgemm_narrow_dma() {
+    if (g_wgemm_narrow < 0) {
+        const char* e = getenv("RL_WGEMM_NARROW");
+        g_wgemm_narrow = (e && !strcmp(e, "0")) ? 0 : 1;
+    }
+    return g_wgemm_narrow == 1 && wgemm_small_tiles();
+}
 // dma: the launch will run wgemm2_kernel (the only kernel with the small tiles)
 inline WidePlan wide_plan(long M, int N, int K, bool dma) {
     WidePlan w{128, 128, 1};
@@ -2973,6 +2981,15 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
             return RL_OK;
         }
     }
+    // (round 6) K > 64 with 16 < N <= 64 (mlp1 of the deep levels, input gradients into narrow tensors): the LDS-DMA kernel on
+    // 64 x 64 tiles instead of the 4-wavefront register-staged one (RL_WGEMM_NARROW=0 keeps that); bitwise the same Y
+    if (pgemm_ok(p) && d->N > 16 && d->N <= 64 && wgemm_narrow_dma() && wgemm_ok(p) && wgemm2_usable(p)) {
+        const WidePlan w{64, 64, 1};
+        const char* wide = launch_wgemm(dim3(gx, 1), st, p, false, w);
+        rl_note_kernel(wide);
+        RL_LAUNCH_CHECK("rl_gemm(dma, narrow)");
+        return RL_OK;
+    }
     if (pgemm_ok(p)) {
         if (d->N <= 16)      launch_pgemm<1>(dim3(gx, 1), st, p);
         else if (d->N <= 32) launch_pgemm<2>(dim3(gx, 1), st, p);
@@ -3089,6 +3106,9 @@ extern "C" int64_t rl_gemm_stat_slots(int64_t M, int N, int K) {
         const WidePlan w = wide_plan(M, N, K, true);
         if (w.bm == 64 && w.ksplit == 1) return rl_row_blocks_host(M, 64);
     }
+    // (the narrow products the LDS-DMA kernel takes on 64 x 64 tiles, see rl_gemm)
+    if (N > 16 && N <= 64 && K > 64 && K % PG_BK == 0 && K <= W2_KMAX && wide_gemm_terms() != 0 && wgemm_staging() == 1 && wgemm_narrow_dma())
+        return rl_row_blocks_host(M, 64);
     return rl_row_blocks_host(M, GM_BM);
 }
 

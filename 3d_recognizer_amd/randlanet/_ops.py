@@ -321,12 +321,12 @@ NO_WSPLIT = bool(int(__import__("os").environ.get("RL_NO_WSPLIT", "0")))     # d
 
 def split_weights(entries) -> dict:
     """entries: list of (W, w_ks, w_ns, K, N[, True]).  One launch; returns {(data_ptr, w_ks, w_ns, K, N): planes}.  Products with
-    N <= 64 run on the streaming kernels and get no planes - unless the entry carries a sixth element (the narrow half of a
+    N <= 64 and K <= 64 run on the streaming kernels and get no planes - unless the entry carries a sixth element (the narrow half of a
     gemm_pair)."""
     out_map = {}
     if NO_WSPLIT or get_wide_gemm() == "fp32" or not entries:
         return out_map
-    entries = [e[:5] for e in entries if e[3] % 8 == 0 and (e[4] > 64 or len(e) > 5)]
+    entries = [e[:5] for e in entries if e[3] % 8 == 0 and (e[4] > 64 or e[3] > 64 or len(e) > 5)]
     if not entries:
         return out_map
     total = sum(2 * K * N + 8 for _, _, _, K, N in entries)

@@ -1083,7 +1083,8 @@ def test_wide_gemm_stagings_agree_bitwise(ops, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(5120, 256, 128), (5120, 512, 256), (1280, 512, 512), (5120, 128, 256), (2600, 1024, 192),
-                                   (300, 512, 256), (130, 32, 128), (5000, 64, 160), (4099, 256, 100)])
+                                   (300, 512, 256), (130, 32, 128), (5000, 64, 160), (4099, 256, 100),
+                                   (20480, 128, 64), (8192, 256, 32), (3001, 128, 48)])       # (K > 64, N <= 64: 64 x 64 tiles instead of pgemm_kernel)
 def test_wide_gemm_tiles_agree_bitwise(ops, M, K, N):
     """The output tile of the LDS-DMA wide GEMM (rl_set_wgemm_tile: "auto" = 64 x 128 / 64 x 64 where 128 x 128 tiles leave most
     CUs without one - the deep levels' launches, round 6; "128" = one tile shape) does not change a product: Y is bitwise the
@@ -1100,7 +1101,7 @@ def test_wide_gemm_tiles_agree_bitwise(ops, M, K, N):
     ws = ops.split_weights([(W, 1, K, K, N), (Wt, N, 1, K, N)])
     bias, addend, old = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV), torch.randn(M, N, device=DEV)
     piv = torch.randn(N, device=DEV) * 0.1
-    h = N // 2 if N % 256 == 0 else (96 if N > 128 else 48)
+    h = N // 2 if (N % 256 == 0 or N <= 64) else (96 if N > 128 else 48)
 
     def run():
         res = []
@@ -1166,7 +1167,8 @@ def test_gemm_pair_equals_two_launches(ops, M, K, N1, N2, stats):
     assert len(ws) == 2
     nsl = H.row_blocks(2 * M, 128)
     try:
-        ops.set_wgemm_tile("128")                       # the pair runs on 128 x 128 tiles: the same slots and sums
+        ops.set_wgemm_tile("128")                       # the pair runs on 128 x 128 tiles: the same slots and sums ...
+        ops.set_gemm_ksplit(False)                      # ... in one pass over K ("128" alone restores round 5's K splits too)
         ref, st = [], []
         for W, N, piv in ((W1, N1, (p1, None)), (W2, N2, (p2, b2))):
             s = ops.new_stats(DEV, N) if stats else None
@@ -1174,6 +1176,7 @@ def test_gemm_pair_equals_two_launches(ops, M, K, N1, N2, stats):
             st.append(s)
     finally:
         ops.set_wgemm_tile("auto")
+        ops.set_gemm_ksplit(True)
     s1, s2 = (ops.new_stats(DEV, N1), ops.new_stats(DEV, N2)) if stats else (None, None)
     res = ops.gemm_pair(a, (W1, 1, K, N1, s1, (p1, None) if stats else None), (W2, 1, K, N2, s2, (p2, b2) if stats else None), ws)
     assert res is not None, "rl_gemm_pair refused a pair it should take"
@@ -1219,6 +1222,7 @@ def test_wide_gemm_dispatch_names_the_kernel_it_ran(ops):
                                            (20000, 40, 128, True, "dma", "wgemm_kernel"), (20000, 256, 128, False, "dma", "pgemm_kernel<8>"),
                                            (3000, 512, 256, True, "dma", "wgemm2_kernel"),        # (64 x 64 tiles: 188 of them, no K split)
                                            (300, 512, 256, True, "dma", "wgemm2_kernel"),         # (the LDS-DMA kernel never splits K)
+                                           (20000, 256, 64, True, "dma", "wgemm2_kernel"), (20000, 256, 64, False, "dma", "pgemm_kernel<4>"),
                                            (300, 512, 256, True, "registers", "wgemm_kernel+splitk"), (3000, 64, 64, False, "dma", "sgemm_kernel")]:
         A = torch.randn(M, K, device=DEV)
         W = torch.randn(N, K, device=DEV)
