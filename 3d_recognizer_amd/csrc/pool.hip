@@ -2665,6 +2665,9 @@ extern "C" int rl_pool_bwd(const rl_pool_desc* d, void* stream) {
     const int g = pool_grid(p.P, p.d, true, p.src > 0);
     RL_REQUIRE(d->slab_floats >= (int64_t)g * p.slab_stride, RL_ERR_ARGS, "rl_pool_bwd: slab too small");
     if (p.src > 0) {
+        // measurement switch (round 6, profiles/r06_xcd_bwd_pmc.md): the XCD-local point ranges of the forward for the backward too
+        static const bool xcd_bwd = getenv("RL_XCD_BWD") != nullptr;
+        if (xcd_bwd) p.xcd_chunk = xcd_chunk_for(p.P, g);
         RL_REQUIRE(p.sc1 && p.sh1 && (p.src < 2 || (p.sc2 && p.sh2)), RL_ERR_ARGS, "rl_pool_bwd: the virtual rpe branch needs its folded BatchNorm(s)");
         const int key = (pool_terms(p.d) == 0 ? 0 : d->rows_bf16 ? 200 : 100) + (p.d == 16 ? 10 : p.d == 32 ? 20 : 40) + (p.src == 2 ? 2 : 0) + (p.gu_accumulate ? 1 : 0);
 #define VBWD(K, DT, TERMS, SRC, NW, GB, ACC) \
