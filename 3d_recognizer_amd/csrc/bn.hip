@@ -258,6 +258,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_pair_kernel(const double*
     else bn_bwd_finalize_body(stats1, nslots, count, C, dgamma1, dbeta1, coef1, (int)blockIdx.x, red);
 }
 
+// several layers' backward finalizes in ONE launch (blockIdx.y = layer, blockIdx.x = channel): the virtual rpe stage whose sums its
+// pooling kernel left and the per-point layer whose reduce sweep ran right behind it are wanted at the same moment (round 6)
+constexpr int BNBF_MAX = 8;
+struct BnBwdFinBatch {
+    rl_bn_bwd_finalize_item it[BNBF_MAX];
+};
+__global__ __launch_bounds__(256) void bn_bwd_finalize_batch_kernel(const BnBwdFinBatch b) {
+    __shared__ double red[4][2];
+    const rl_bn_bwd_finalize_item& t = b.it[blockIdx.y];
+    if ((int)blockIdx.x >= t.C) return;
+    bn_bwd_finalize_body(t.stats, t.nslots, (double)t.count, t.C, t.dgamma, t.dbeta, t.coef, (int)blockIdx.x, red);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdParams p) {
     const int C = p.C;
     const int tpr = C < 256 ? C : 256;
@@ -729,6 +742,21 @@ extern "C" int rl_bn_finalize_batch(const rl_bn_finalize_item* items, int count,
         hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(maxc, n), dim3(256), 0, (hipStream_t)stream, b);
         RL_LAUNCH_CHECK("rl_bn_finalize_batch");
     }
+    return RL_OK;
+}
+
+extern "C" int rl_bn_bwd_finalize_batch(const rl_bn_bwd_finalize_item* items, int count, void* stream) {
+    RL_REQUIRE(items != nullptr && count > 0 && count <= BNBF_MAX, RL_ERR_ARGS, "rl_bn_bwd_finalize_batch: 1 .. %d items", BNBF_MAX);
+    BnBwdFinBatch b;
+    int maxc = 1;
+    for (int i = 0; i < count; ++i) {
+        const rl_bn_bwd_finalize_item& t = items[i];
+        RL_REQUIRE(t.stats && t.nslots > 0 && t.count > 0 && t.C > 0 && t.coef, RL_ERR_ARGS, "rl_bn_bwd_finalize_batch: item %d: bad arguments", i);
+        b.it[i] = t;
+        if (t.C > maxc) maxc = t.C;
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_batch_kernel, dim3(maxc, count), dim3(256), 0, (hipStream_t)stream, b);
+    RL_LAUNCH_CHECK("rl_bn_bwd_finalize_batch");
     return RL_OK;
 }
 

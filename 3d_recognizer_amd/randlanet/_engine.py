@@ -548,12 +548,17 @@ class Engine:
         ctx.bn_pre = {}           # raw tensor -> BatchNorm-backward partials its gradient's producer left (the fused head)
         ctx.bn_done = set()       # raw tensors whose BatchNorm backward already happened (fused at the residual junction)
         # weight-gradient slabs are summed by ONE launch after the last layer (they are only needed by the optimiser)
+        # backward finalizes of the virtual rpe stages wait for the next per-point layer's finalize launch and ride along with it
+        # (rl_bn_bwd_finalize_batch); the stage's weight-gradient kernel, which needs the result, follows that launch (_flush_rpe)
+        ctx.fin_queue, ctx.rpe_after = [], []
         ctx.pending = None if (ops.SIDE_STREAM_WGRAD or ops.NO_DEFERRED_WGRAD) else []
         # ... and the wide layers' weight-gradient KERNELS wait as well: one grouped launch for all of them at the end
         ctx.wbatch = [] if ctx.pending is not None else None
         for rec, lvl in zip(reversed(ctx.tape), reversed(ctx.tape.levels)):
             ops.LEVEL = lvl
             kind = rec[0]
+            if kind != "linear":
+                self._flush_rpe(ctx)
             if kind == "linear":
                 self._bwd_linear(ctx, grads, *rec[1:])
             elif kind == "pool":
@@ -619,6 +624,7 @@ class Engine:
                 ctx.grads[id(src.raw)] = [G, True]
             else:
                 raise AssertionError(kind)
+        self._flush_rpe(ctx)
         ops.LEVEL = -1
         self._main.wait_stream(self._side)
         if ctx.pending is not None:
@@ -641,12 +647,23 @@ class Engine:
         with torch.cuda.stream(self._side):
             fn()
 
+    def _flush_rpe(self, ctx: Context) -> None:
+        """Send out the queued backward finalizes of the virtual rpe stages (if no layer's finalize launch took them along) and
+        run what waited for them."""
+        if ctx.fin_queue:
+            first = ctx.fin_queue.pop(0)
+            ops._bn_bwd_finalize(*first, None, also=ctx.fin_queue)
+        for fn in ctx.rpe_after:
+            fn()
+        ctx.rpe_after.clear()
+
     def _bwd_linear(self, ctx, grads, a, out: Lazy, wname, bname, ks, ns, a_grad):
         G, init = self._gbuf(ctx, out)
         assert init, f"no gradient reached {wname}"
         if out.scale is not None and id(out.raw) not in ctx.bn_done:
             ops.bn_backward(G, out, grads[f"{out.bn}.weight"], grads[f"{out.bn}.bias"], True, sync=self.sync,
-                            stats=ctx.bn_pre.pop(id(out.raw), None))
+                            stats=ctx.bn_pre.pop(id(out.raw), None), also=ctx.fin_queue)
+            self._flush_rpe(ctx)
         n_out = out.C
         self._beside(ctx, lambda: ops.wgrad(a, G, out.bstride, n_out, grads[wname], ks, ns,
                                             grads[bname] if bname else None, pending=ctx.pending, batch=ctx.wbatch), G)
@@ -703,12 +720,22 @@ class Engine:
         # the stage's own backward: batch-statistics terms of its BatchNorm, then weight / bias (/ input) gradients
         layer = f"{e}.mlp_rpe{stage}"
         pending = ctx.pending if ctx.pending is not None else []
+        queue = ctx.fin_queue if (self.sync is None and ctx.pending is not None and not ops.NO_BN_BATCH) else None
         coef = ops.rpe_bn_backward(vr, stage, GU, grads[f"{layer}.batch_norm.weight"], grads[f"{layer}.batch_norm.bias"],
-                                   sync=self.sync, stats=bstats, nslots=nslots)
+                                   sync=self.sync, stats=bstats, nslots=nslots, queue=queue)
         GU1 = torch.empty_like(GU) if stage == 2 else None
-        ops.rpe_wgrad(vr, stage, GU, coef, grads[f"{layer}.conv.weight"], grads[f"{layer}.conv.bias"], pending, GU1)
-        if ctx.pending is None:
-            ops.wgrad_flush(pending)
+        lvl = ops.LEVEL
+
+        def finish():
+            keep, ops.LEVEL = ops.LEVEL, lvl
+            ops.rpe_wgrad(vr, stage, GU, coef, grads[f"{layer}.conv.weight"], grads[f"{layer}.conv.bias"], pending, GU1)
+            ops.LEVEL = keep
+            if ctx.pending is None:
+                ops.wgrad_flush(pending)
+        if queue is not None:
+            ctx.rpe_after.append(finish)        # behind the finalize launch that carries this stage's sums (_flush_rpe)
+        else:
+            finish()
         if stage == 2:
             ctx.grads[key] = [GU1, True]
 

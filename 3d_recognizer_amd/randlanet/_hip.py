@@ -171,6 +171,13 @@ class BnFinalizeItem(C.Structure):
     ]
 
 
+class BnBwdFinalizeItem(C.Structure):
+    _fields_ = [
+        ("stats", C.c_void_p), ("count", C.c_int64), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("coef", C.c_void_p),
+        ("nslots", C.c_int32), ("C", C.c_int32),
+    ]
+
+
 class SegsumDesc(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("lds", C.c_int64), ("src_bstride", C.c_int64),
@@ -228,6 +235,7 @@ _SIGNATURES = {
     "rl_wgrad_reduce_batch": (_i, [C.POINTER(WgradReduceItem), _i, _vp]),
     "rl_bn_finalize": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "rl_bn_finalize_batch": (_i, [C.POINTER(BnFinalizeItem), _i, _vp]),
+    "rl_bn_bwd_finalize_batch": (_i, [C.POINTER(BnBwdFinalizeItem), _i, _vp]),
     "rl_head_supported": (_i, [_i, _i]),
     "rl_head_grid": (_i, [_l]),
     "rl_head_fwd": (_i, [C.POINTER(HeadDesc), _vp, _vp]),

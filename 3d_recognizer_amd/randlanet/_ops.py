@@ -668,8 +668,23 @@ def _bn_bwd_desc(G: torch.Tensor, g_bstride: int, y: Lazy) -> H.BnBwdDesc:
     return d
 
 
-def _bn_bwd_finalize(stats, slots: int, rows: int, Cc: int, dgamma, dbeta, coef, sync: Optional[SyncGroup]) -> None:
-    """dgamma / dbeta = this rank's sums; coef = the means the apply pass subtracts - of the GLOBAL batch with `sync`."""
+def _bn_bwd_finalize(stats, slots: int, rows: int, Cc: int, dgamma, dbeta, coef, sync: Optional[SyncGroup],
+                     also: Optional[list] = None) -> None:
+    """dgamma / dbeta = this rank's sums; coef = the means the apply pass subtracts - of the GLOBAL batch with `sync`.
+    also: queued finalizes of OTHER layers, tuples (stats, slots, rows, C, dgamma, dbeta, coef) whose sums are complete - they
+    go out in this launch (rl_bn_bwd_finalize_batch) and the list is cleared."""
+    if also and sync is None and not NO_BN_BATCH:
+        todo = [(stats, slots, rows, Cc, dgamma, dbeta, coef)] + list(also)
+        arr = (H.BnBwdFinalizeItem * len(todo))()
+        for it, (s_, n_, r_, c_, dg_, db_, co_) in zip(arr, todo):
+            it.stats, it.count, it.dgamma, it.dbeta, it.coef, it.nslots, it.C = s_.data_ptr(), r_, H.ptr(dg_), H.ptr(db_), co_.data_ptr(), n_, c_
+        H.check(H.lib().rl_bn_bwd_finalize_batch(arr, len(todo), _st()), "rl_bn_bwd_finalize_batch")
+        also.clear()
+        return
+    if also:
+        for (s_, n_, r_, c_, dg_, db_, co_) in also:
+            _bn_bwd_finalize(s_, n_, r_, c_, dg_, db_, co_, sync)
+        also.clear()
     H.check(H.lib().rl_bn_bwd_finalize(stats.data_ptr(), slots, rows, Cc, H.ptr(dgamma), H.ptr(dbeta), coef.data_ptr(), _st()),
             "rl_bn_bwd_finalize")
     if sync is not None:
@@ -680,34 +695,37 @@ def _bn_bwd_finalize(stats, slots: int, rows: int, Cc: int, dgamma, dbeta, coef,
 
 
 def bn_backward(G: torch.Tensor, y: Lazy, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
-                training: bool, sync: Optional[SyncGroup] = None, stats: Optional[tuple] = None) -> None:
+                training: bool, sync: Optional[SyncGroup] = None, stats: Optional[tuple] = None, also: Optional[list] = None) -> bool:
     """In place: G (gradient w.r.t. the activated value of `y`) becomes the gradient w.r.t. y.raw.
-    stats: (partials, nslots) already left by the kernel that produced G (head_bwd) - no reduce sweep over G and Y here."""
+    stats: (partials, nslots) already left by the kernel that produced G (head_bwd) - no reduce sweep over G and Y here.
+    also: other layers' queued backward finalizes (see _bn_bwd_finalize) to send out with this layer's; returns True when they
+    went out (the list is then empty) - on the paths without a finalize launch of their own they stay queued."""
     d = _bn_bwd_desc(G, y.bstride, y)
     if stats is not None:
         assert training and y.mean is not None and sync is None
         coef = torch.empty(2 * y.C, dtype=F32, device=G.device)
-        _bn_bwd_finalize(stats[0], stats[1], y.rows, y.C, dgamma, dbeta, coef, None)
+        _bn_bwd_finalize(stats[0], stats[1], y.rows, y.C, dgamma, dbeta, coef, None, also=also)
         d.coef = coef.data_ptr()
         with _rec("bn_bwd_apply", (y.rows, y.C), 12 * y.rows * y.C, 0):
             H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
-        return
+        return not also
     if (training and y.mean is not None and sync is None and not NO_BN_SMALL and G.data_ptr() % 16 == 0 and y.raw.data_ptr() % 16 == 0
             and H.lib().rl_bn_bwd_fused_supported(y.rows, y.C, y.raw.shape[1])):
         # a small tensor: reduce, finalize and apply in one launch (a workgroup owns a channel quad and all its rows)
         with _rec("bn_bwd_fused", (y.rows, y.C), 12 * y.rows * y.C, 0):
             H.check(H.lib().rl_bn_bwd_fused(C.byref(d), y.rows, H.ptr(dgamma), H.ptr(dbeta), None, _st()), "rl_bn_bwd_fused")
-        return
+        return not also
     if training and y.mean is not None:
         stats = new_stats(G.device, y.C)
         coef = torch.empty(2 * y.C, dtype=F32, device=G.device)
         d.stats = stats.data_ptr()
         with _rec("bn_bwd_reduce", (y.rows, y.C), 8 * y.rows * y.C, 0):
             H.check(H.lib().rl_bn_bwd_reduce(C.byref(d), _st()), "rl_bn_bwd_reduce")
-        _bn_bwd_finalize(stats, H.lib().rl_bn_bwd_slots(y.rows), y.rows, y.C, dgamma, dbeta, coef, sync)
+        _bn_bwd_finalize(stats, H.lib().rl_bn_bwd_slots(y.rows), y.rows, y.C, dgamma, dbeta, coef, sync, also=also)
         d.coef = coef.data_ptr()
     with _rec("bn_bwd_apply", (y.rows, y.C), 12 * y.rows * y.C, 0):
         H.check(H.lib().rl_bn_bwd_apply(C.byref(d), _st()), "rl_bn_bwd_apply")
+    return not also
 
 
 def resid_bn_supported(y1: Lazy, y2: Lazy) -> bool:
@@ -949,7 +967,7 @@ def rpe_stats(v: VirtualRpe, stage: int):
 
 
 def rpe_bn_backward(v: VirtualRpe, stage: int, G: torch.Tensor, dgamma, dbeta, sync: Optional[SyncGroup] = None,
-                    stats: Optional[torch.Tensor] = None, nslots: int = 0) -> torch.Tensor:
+                    stats: Optional[torch.Tensor] = None, nslots: int = 0, queue: Optional[list] = None) -> torch.Tensor:
     """BatchNorm backward statistics of virtual stage `stage` from G (gradient w.r.t. its activated output): fills
     dgamma / dbeta and returns coef (2h floats) for rpe_wgrad.  `stats` / `nslots`: partials already produced by the
     pooling backward kernel that completed G (pool_bwd's bn_bwd_stats) - then no pass over G is made here."""
@@ -964,7 +982,10 @@ def rpe_bn_backward(v: VirtualRpe, stage: int, G: torch.Tensor, dgamma, dbeta, s
         with _rec("rpe_bn_reduce", (v.rows, v.h, stage), 4 * v.rows * v.h + 8 * v.rows, 0):
             H.check(H.lib().rl_rpe_bn_reduce(C.byref(pd), G.data_ptr(), stats.data_ptr(), _st()), "rl_rpe_bn_reduce")
     coef = torch.empty(2 * v.h, dtype=F32, device=G.device)
-    _bn_bwd_finalize(stats, nslots, v.rows, v.h, dgamma, dbeta, coef, sync)
+    if queue is not None and sync is None:
+        queue.append((stats, nslots, v.rows, v.h, dgamma, dbeta, coef))       # goes out with the next layer's finalize launch
+    else:
+        _bn_bwd_finalize(stats, nslots, v.rows, v.h, dgamma, dbeta, coef, sync)
     return coef
 
 

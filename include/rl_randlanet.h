@@ -395,6 +395,17 @@ int rl_bn_bwd_finalize(const double* stats, int nslots, int64_t count, int C, fl
 /* rl_bn_bwd_finalize for the two BatchNorms behind a residual junction (same row and channel counts) in one launch. */
 int rl_bn_bwd_finalize_pair(const double* stats0, const double* stats1, int nslots, int64_t count, int C, float* dgamma0,
                             float* dbeta0, float* coef0, float* dgamma1, float* dbeta1, float* coef1, void* stream);
+/* rl_bn_bwd_finalize for up to 8 unrelated layers in one launch (round 6): e.g. a virtual rpe stage (sums left by its pooling
+ * kernel) together with the per-point layer whose reduce sweep ran right behind it.  Same arithmetic per layer. */
+typedef struct rl_bn_bwd_finalize_item {
+    const double* stats;
+    int64_t count;
+    float* dgamma;
+    float* dbeta;
+    float* coef;
+    int32_t nslots, C;
+} rl_bn_bwd_finalize_item;
+int rl_bn_bwd_finalize_batch(const rl_bn_bwd_finalize_item* items, int count, void* stream);
 int rl_bn_bwd_apply(const rl_bn_bwd_desc* d, void* stream);
 /* The three steps in ONE launch for a small tensor (rows <= 2048, C % 4 == 0, ld % 4 == 0, 16-byte aligned; ask
  * rl_bn_bwd_fused_supported): a workgroup owns a channel quad and all its rows, so the batch sums never leave it.  G becomes
