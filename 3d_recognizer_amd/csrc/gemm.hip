@@ -142,6 +142,15 @@ struct GemmParams {
     long out2_bstride;
     int split_col;
     const __bf16* wsplit;      // wgemm: head plane [N][K] (k contiguous), tail plane follows at + N*K
+    // BatchNorm-BACKWARD sums as a by-product (sgemm_kernel only, round 6): this product IS the gradient G w.r.t. the activated output of
+    // a layer whose raw output Yl (same rows, same layout as Y) and folded BatchNorm are given - the epilogue leaves
+    // sum g' and sum g' xhat per column in `stats` (g' = G act'(Yl scale + shift), xhat = (Yl - mean) invstd): rl_bn_bwd_reduce's slots
+    const float* bnb_Y;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    float bnb_neg;             // act'(z) for z <= 0: 1 (none) / 0 (ReLU) / slope
     // rl_gemm_pair (wgemm2_kernel only): a SECOND product over the same A' in the same launch - the column blocks from pair_ny1
     // on belong to it: its own weight planes, columns, dense output, statistics and pivot
     int pair_ny1;              // 0: no second product
@@ -500,7 +509,7 @@ int fill_a(AOperand* a, const char* who, const float* A, long lda, long a_bstrid
 // are combined through LDS in a fixed order; every workgroup leaves one partial slab.
 // ===========================================================================================
 
-template <int KC, int NT>
+template <int KC, int NT, bool BNB = false>
 __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
     __shared__ double red[4][2][16 * NT];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
@@ -529,12 +538,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
     // configuration, the two-rank equivalence step - moved from 1e-4 to 0.5 - 3 % gradient differences: mean / variance come out of
     // sum and sum of squares by subtraction.  Reverted: nothing was gained.)
     float bias[NT], ssum[NT], ssq[NT], piv[NT];
+    float bsc[BNB ? NT : 1], bsh[BNB ? NT : 1], bmu[BNB ? NT : 1], bis[BNB ? NT : 1];      // BNB: the layer's folded BatchNorm per column
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) {
         const int n = nb * 16 + li;
         bias[nb] = (p.bias && n < N) ? p.bias[n] : 0.f;
         ssum[nb] = ssq[nb] = 0.f;
-        piv[nb] = stat_pivot(p, n);
+        piv[nb] = BNB ? 0.f : stat_pivot(p, n);
+        if constexpr (BNB) {
+            bsc[nb] = n < N ? p.bnb_scale[n] : 1.f; bsh[nb] = n < N ? p.bnb_shift[n] : 0.f;
+            bmu[nb] = n < N ? p.bnb_mean[n] : 0.f;  bis[nb] = n < N ? p.bnb_invstd[n] : 0.f;
+        }
     }
     const bool lazy = p.a.lazy.scale != nullptr;
     const float es = (!lazy || p.a.lazy.act == RL_ACT_NONE) ? 1.f : (p.a.lazy.act == RL_ACT_RELU ? 0.f : p.a.lazy.slope);
@@ -606,6 +620,23 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) v[nb] += o[nb];
                 }
+                if constexpr (BNB) {
+                    // this row of the layer's raw output (same offset as the gradient row): the terms rl_bn_bwd_reduce would sum
+                    const float* yl = p.bnb_Y + yoff + li;
+                    float t[NT];
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) t[nb] = (full || nb * 16 + li < N) ? yl[nb * 16] : 0.f;
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        if (full || nb * 16 + li < N) {
+                            y[nb * 16] = v[nb];
+                            const float z = t[nb] * bsc[nb] + bsh[nb];
+                            const float gp = v[nb] * (z > 0.f ? 1.f : p.bnb_neg);
+                            ssum[nb] += gp;
+                            ssq[nb] += gp * ((t[nb] - bmu[nb]) * bis[nb]);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb) {
                     if (full || nb * 16 + li < N) {
@@ -614,6 +645,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
                         ssum[nb] += dv;
                         ssq[nb] += dv * dv;
                     }
+                }
                 }
             }
         }
@@ -841,6 +873,12 @@ inline bool stream_wgrad_ok(int N, int K) { return (N <= 64 && K <= 64) || (K <=
 
 template <int KC>
 void launch_sgemm(int N, int gx, hipStream_t st, const GemmParams& p) {
+    if (p.bnb_Y) {       // with the BatchNorm-backward sums of the layer this product is the gradient of (N <= 64)
+        if (N <= 16)      hipLaunchKernelGGL((sgemm_kernel<KC, 1, true>), dim3(gx), dim3(256), 0, st, p);
+        else if (N <= 32) hipLaunchKernelGGL((sgemm_kernel<KC, 2, true>), dim3(gx), dim3(256), 0, st, p);
+        else              hipLaunchKernelGGL((sgemm_kernel<KC, 4, true>), dim3(gx), dim3(256), 0, st, p);
+        return;
+    }
     if (N <= 16)      hipLaunchKernelGGL((sgemm_kernel<KC, 1>), dim3(gx), dim3(256), 0, st, p);
     else if (N <= 32) hipLaunchKernelGGL((sgemm_kernel<KC, 2>), dim3(gx), dim3(256), 0, st, p);
     else if (N <= 64) hipLaunchKernelGGL((sgemm_kernel<KC, 4>), dim3(gx), dim3(256), 0, st, p);
@@ -2967,7 +3005,17 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
         RL_LAUNCH_CHECK("rl_gemm(split-scatter)");
         return RL_OK;
     }
-    if (d->a_mode == 0 && p.a.vec4p && ((d->K <= 64 && d->N <= 64) || (d->K <= 16 && d->N <= 128))) {
+    const bool streams = d->a_mode == 0 && p.a.vec4p && ((d->K <= 64 && d->N <= 64) || (d->K <= 16 && d->N <= 128));
+    if (d->bnb_Y) {
+        RL_REQUIRE(streams && d->N <= 64 && !split, RL_ERR_UNSUPPORTED,
+                   "rl_gemm: the BatchNorm-backward sums are a by-product of the streaming kernel only (K, N <= 64; ask rl_gemm_streams)");
+        RL_REQUIRE(d->stats && d->bnb_scale && d->bnb_shift && d->bnb_mean && d->bnb_invstd && !d->stats_pivot_mean, RL_ERR_ARGS,
+                   "rl_gemm: bnb_Y needs stats, the layer's scale / shift / mean / invstd and no pivot");
+        p.bnb_Y = d->bnb_Y; p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift; p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
+        p.bnb_neg = d->bnb_act == RL_ACT_RELU ? 0.f : (d->bnb_act == RL_ACT_LRELU ? d->bnb_slope : 1.f);
+        p.piv_mean = p.piv_bias = nullptr;
+    }
+    if (streams) {
         // every wavefront first loads the whole weight matrix into registers: with >= 2048 weights per
         // wavefront, fewer and longer-lived workgroups (two per CU) beat one 128-row tile per workgroup
         int sg = gx;
@@ -3030,6 +3078,13 @@ extern "C" int rl_gemm(const rl_gemm_desc* d, void* stream) {
     rl_note_kernel("gemm_kernel");
     RL_LAUNCH_CHECK("rl_gemm");
     return RL_OK;
+}
+
+// 1 if rl_gemm runs this product on the streaming kernel (the one that can leave BatchNorm-backward sums: rl_gemm_desc.bnb_Y)
+extern "C" int rl_gemm_streams(const rl_gemm_desc* d) {
+    if (!d || d->a_mode != 0 || d->addend || d->out2) return 0;
+    const bool vec4p = (d->lda % 4 == 0) && ((d->K + 3) / 4 * 4 <= d->lda) && (((uintptr_t)d->A & 15) == 0);
+    return (vec4p && d->K <= 64 && d->N <= 64) ? 1 : 0;
 }
 
 // ---- two products over ONE A' in one launch -------------------------------------------------------------------------------------

@@ -690,9 +690,17 @@ class Engine:
             if not ga[1]:
                 assert a.n == a.bstride and a.raw.shape[0] == a.B * a.n, "first writer must cover the tensor"
             gl = Lazy(G, out.B, out.n, out.bstride, n_out)
-            # dA = dY . W^T : the same kernel with the weight strides swapped
-            ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=ga[0], out_bstride=a.bstride, accumulate=ga[1],
-                     wsplit=getattr(ctx, "wsplit", None))
+            # dA = dY . W^T : the same kernel with the weight strides swapped.  Where this product COMPLETES the gradient of a
+            # BatchNorm layer's output - the layer has this one consumer (fc_end.0 -> fc_end.1, the last decoder step -> fc_end.0,
+            # pool2.mlp -> mlp2), or this is the second of its two (bn_start -> shortcut, then mlp1 of level 0) - and the streaming
+            # kernel takes it, the layer's BatchNorm-backward sums come out of the epilogue (no reduce sweep over G and Y later)
+            complete = (self.sync is None and a.scale is not None and a.mean is not None and a.rows == a.raw.shape[0] and
+                        ((not ga[1] and (wname in ("fc_end.1.conv.weight", "fc_end.0.conv.weight") or wname.endswith(".mlp2.conv.weight")))
+                         or (ga[1] and wname == "encoder.0.mlp1.conv.weight")))
+            res = ops.gemm(gl, self._w2(wname), ns, ks, a.C, None, out=ga[0], out_bstride=a.bstride, accumulate=ga[1],
+                           wsplit=getattr(ctx, "wsplit", None), bnb=a if complete else None)
+            if complete and res[1] is not None:
+                ctx.bn_pre[id(a.raw)] = res[1]
             ga[1] = True
 
     def _bwd_pool_virtual(self, ctx, grads, name, vr, g: Lazy, csr, idx, pooled: Lazy, n, d, stage):

@@ -47,6 +47,8 @@ class GemmDesc(C.Structure):
         ("split_col", C.c_int32),
         ("W_split", C.c_void_p),
         ("stats_pivot_mean", C.c_void_p), ("stats_pivot_bias", C.c_void_p),
+        ("bnb_Y", C.c_void_p), ("bnb_scale", C.c_void_p), ("bnb_shift", C.c_void_p), ("bnb_mean", C.c_void_p),
+        ("bnb_invstd", C.c_void_p), ("bnb_act", C.c_int32), ("bnb_slope", C.c_float),
     ]
 
 
@@ -215,6 +217,7 @@ _SIGNATURES = {
     "rl_knn_i32": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "rl_knn_multi_workspace_bytes": (_l, [C.POINTER(KnnTask), _i, _i]),
     "rl_knn_multi": (_i, [C.POINTER(KnnTask), _i, _i, _vp, _l, _vp]),
+    "rl_gemm_streams": (_i, [C.POINTER(GemmDesc)]),
     "rl_gemm_pair_supported": (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc)]),
     "rl_gemm_pair": (_i, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _vp]),
     "rl_gemm_kslab_floats": (_l, [_l, _i, _i]),

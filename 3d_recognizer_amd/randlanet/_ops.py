@@ -355,12 +355,15 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
          accumulate: bool = False, stats: Optional[torch.Tensor] = None,
          addend: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
          out2_index: Optional[torch.Tensor] = None, out2_bstride: int = 0, split_col: int = 0,
-         wsplit: Optional[dict] = None, pivot: Optional[tuple] = None) -> torch.Tensor:
+         wsplit: Optional[dict] = None, pivot: Optional[tuple] = None, bnb: Optional[Lazy] = None):
     """Y = A'.W (+ bias).  With `out2` (split epilogue, wide layers only): v = A'.W + addend; columns < split_col go to
     `out` (which then has split_col columns), the others to the dense (M, N - split_col) tensor `out2` (or, with
     `out2_index`, atomically to the rows it names) - the two halves of a concat's gradient in one pass.
     pivot (with stats): (running_mean, conv bias left out of this product or None) - the statistics are SHIFTED sums around
-    running_mean - bias (rl_gemm_desc.stats_pivot_*); the matching bn_finalize call must say pivoted=True."""
+    running_mean - bias (rl_gemm_desc.stats_pivot_*); the matching bn_finalize call must say pivoted=True.
+    bnb (a Lazy with batch statistics): this product is the complete gradient w.r.t. `bnb`'s ACTIVATED value and the streaming
+    kernel takes it - the BatchNorm-backward sums of `bnb`'s layer come out as a by-product (rl_gemm_desc.bnb_*): returns
+    (out, (partials, nslots)) with the pair bn_backward(stats=...) takes; (out, None) when the product does not qualify."""
     d = H.GemmDesc()
     M, K = _fill_a(d, a)
     assert isinstance(a, Rpe) or a.raw.dtype == F32, "rl_gemm reads fp32 rows"
@@ -400,15 +403,31 @@ def gemm(a, W: torch.Tensor, w_ks: int, w_ns: int, N: int, bias: Optional[torch.
                 assert out2.shape[0] >= (d.B - 1) * out2_bstride + 1
         d.addend, d.out2, d.out2_index = H.ptr(addend), H.ptr(out2), H.ptr(out2_index)
         d.out2_bstride, d.split_col = out2_bstride, split_col
+    bnb_pre = None
+    if bnb is not None:
+        if (stats is None and pivot is None and bnb.mean is not None and bnb.scale is not None and bnb.raw.dtype == F32
+                and bnb.raw.shape[1] == out.shape[1] and bnb.bstride == out_bstride and bnb.C == N and not NO_BNB_EPILOGUE
+                and 4 * M * N <= BNB_MAX_BYTES and H.lib().rl_gemm_streams(C.byref(d))):
+            _dev_check(bnb.raw, bnb.scale, bnb.shift, bnb.mean, bnb.invstd)
+            st_b = new_stats(W.device, N)
+            d.stats = st_b.data_ptr()
+            d.bnb_Y, d.bnb_scale, d.bnb_shift = bnb.raw.data_ptr(), bnb.scale.data_ptr(), bnb.shift.data_ptr()
+            d.bnb_mean, d.bnb_invstd, d.bnb_act, d.bnb_slope = bnb.mean.data_ptr(), bnb.invstd.data_ptr(), bnb.act, bnb.slope
+            bnb_pre = (st_b, gemm_stat_slots(M, N, K))
     kfloats = H.lib().rl_gemm_kslab_floats(M, N, K) if (N > 64 and not isinstance(a, Rpe) and out2 is None and addend is None) else 0
     if kfloats > 0:
         kslab = _slab(W.device, kfloats)
         d.kslab, d.kslab_floats = kslab.data_ptr(), kslab.numel()
     with _rec("gemm_rpe" if isinstance(a, Rpe) else "gemm", (M, K, N), 4 * (M * (K if not isinstance(a, Rpe) else 6) + M * N * (2 if accumulate else 1) + K * N), 2 * M * K * N):
         H.check(H.lib().rl_gemm(C.byref(d), _st()), "rl_gemm")
-    return out
+    return (out, bnb_pre) if bnb is not None else out
 
 
+# A/B: the BatchNorm-backward sums as a by-product of the streaming input-gradient GEMM (round 6); off = a reduce sweep per layer
+NO_BNB_EPILOGUE = bool(int(__import__("os").environ.get("RL_NO_BNB_EPILOGUE", "0")))
+# ... only for tensors up to this size: the epilogue reads the layer's output 4 bytes per lane, a reduce sweep 16 - on a large
+# tensor that costs more than the launch it saves (fc_end.0 at 8 clouds: 84 MB, +13 us per step; measured)
+BNB_MAX_BYTES = int(__import__("os").environ.get("RL_BNB_MAX_BYTES", str(32 << 20)))
 NO_GEMM_PAIR = bool(int(__import__("os").environ.get("RL_NO_GEMM_PAIR", "0")))      # A/B: mlp1 / shortcut as two launches
 
 

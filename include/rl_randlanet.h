@@ -190,6 +190,20 @@ typedef struct rl_gemm_desc {
      * told `pivoted`.  NULL = plain sums (pivot 0). */
     const float* stats_pivot_mean;
     const float* stats_pivot_bias;
+    /* optional (round 6), streaming kernel only (K, N <= 64: rl_gemm_streams(d) == 1): this product is the gradient G w.r.t. the
+     * ACTIVATED output of a BatchNorm layer - the input gradient of the layer behind it - and `stats` receives, instead of the
+     * forward sums, what rl_bn_bwd_reduce would leave for that layer: sum g' and sum g' xhat per column, g' = G act'(Yl scale +
+     * shift), xhat = (Yl - mean) invstd, with Yl = bnb_Y the layer's raw output (same rows and row layout as Y), bnb_scale /
+     * bnb_shift its folded BatchNorm, bnb_mean / bnb_invstd its saved batch statistics, bnb_act / bnb_slope its activation.
+     * rl_gemm_stat_slots(M, N, K) slots; then rl_bn_bwd_finalize + rl_bn_bwd_apply - no reduce sweep over G and Yl.
+     * Y must be complete after this call (the only or the last accumulating writer).  No pivot. */
+    const float* bnb_Y;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    int32_t bnb_act;
+    float bnb_slope;
 } rl_gemm_desc;
 
 /* TWO products over one A' in ONE launch of the LDS-DMA wide GEMM (round 6): Y1 = A'.W1, Y2 = A'.W2 - mlp1 and shortcut of an
@@ -200,6 +214,7 @@ typedef struct rl_gemm_desc {
  * statistics (with their pivots) for both or for none - each into its own buffer, rl_row_blocks(M, 128) slots; no bias, no
  * accumulate, no split epilogue.  Bitwise the results of two rl_gemm calls on 128 x 128 tiles.
  * rl_gemm_pair_supported: 1 if the pair can go out as one launch, else the caller issues two rl_gemm calls. */
+int rl_gemm_streams(const rl_gemm_desc* d);
 int rl_gemm_pair_supported(const rl_gemm_desc* a, const rl_gemm_desc* b);
 int rl_gemm_pair(const rl_gemm_desc* a, const rl_gemm_desc* b, void* stream);
 

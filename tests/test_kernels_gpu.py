@@ -1198,6 +1198,53 @@ def test_gemm_pair_equals_two_launches(ops, M, K, N1, N2, stats):
         assert torch.allclose(s1[:nsl, 1].sum(0), (d * d).sum(0), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,K,N,act,accumulate", [(5000, 32, 64, 1, False), (4099, 64, 8, 2, False), (3000, 8, 8, 2, True), (2600, 32, 16, 0, False)])
+def test_streaming_gemm_leaves_bn_backward_sums(ops, M, K, N, act, accumulate):
+    """rl_gemm_desc.bnb_* (round 6): an input-gradient product on the streaming kernel that completes the gradient of a BatchNorm
+    layer's output also leaves that layer's BatchNorm-backward sums - G bitwise what the plain product gives, the sums those of
+    rl_bn_bwd_reduce over the same G and Y, and the whole backward (dgamma, dbeta, dY) equal to the three-launch form."""
+    import ctypes
+    from randlanet import _hip as H
+    torch.manual_seed(M + K)
+    dY = torch.randn(M, K, device=DEV)
+    W = torch.randn(K, N, device=DEV) / K ** 0.5                      # (in, out) of the layer BEHIND: dA = dY . W, n contiguous
+    Yl = torch.randn(M, N, device=DEV)
+    mean, var = Yl.mean(0), Yl.var(0, unbiased=False)
+    gamma, beta = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV) * 0.2
+    invstd = torch.rsqrt(var + 1e-6)
+    scale = gamma * invstd
+    y = ops.Lazy(Yl, 1, M, M, N, scale, beta - mean * scale, act, 0.2 if act == 2 else 0.0, mean, invstd, "x")
+    old = torch.randn(M, N, device=DEV)
+    a = ops.plain(dY, 1, M)
+
+    def product(bnb):
+        out = old.clone() if accumulate else torch.empty(M, N, device=DEV)
+        return ops.gemm(a, W, N, 1, N, None, out=out, out_bstride=M, accumulate=accumulate, bnb=bnb)
+    G0 = product(None)
+    G1, pre = product(y)
+    assert pre is not None, "the streaming kernel should have taken this product"
+    assert H.lib().rl_last_kernel().decode() == "sgemm_kernel"
+    assert torch.equal(G0, G1)
+    # the sums of rl_bn_bwd_reduce over the same G and Y
+    st = ops.new_stats(DEV, N)
+    d = ops._bn_bwd_desc(G0, M, y)
+    d.stats = st.data_ptr()
+    H.check(H.lib().rl_bn_bwd_reduce(ctypes.byref(d), ops._st()), "rl_bn_bwd_reduce")
+    ref = st[:H.lib().rl_bn_bwd_slots(M)].sum(0)
+    got = pre[0][:pre[1]].sum(0)
+    scale_s = float(ref.abs().max()) + 1e-6
+    assert float((got - ref).abs().max()) < 2e-5 * scale_s + 1e-4, (got, ref)
+    # ... and the backward they drive
+    res = []
+    for stats in (None, pre):
+        G = G0.clone()
+        dg, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+        ops.bn_backward(G, y, dg, db, True, stats=stats)
+        res.append((G, dg, db))
+    for u, v in zip(*res):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5 * max(1.0, float(v.abs().max())))
+
+
 def test_gemm_pair_leaves_exact_fp32_products_alone(ops):
     """A product with K <= 64 and N <= 64 runs on the streaming kernel in exact fp32 products: rl_gemm_pair does not take it (its
     arithmetic would become bf16x3) - the caller issues two launches."""
