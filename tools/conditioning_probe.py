@@ -1,5 +1,12 @@
+#!/usr/bin/env python3
+"""How well conditioned is a train-step test point?  The same step with its BatchNorm partial sums merely RE-GROUPED (streaming GEMM
+on a third of its workgroups: bitwise the same products, other lanes add other rows) and with the sampling bands in cell order,
+against the run as drawn: worst gradient difference per tensor relative to the largest gradient entry.  Round 6 used it to find
+that `test_cell_order_...`'s test point moves by 1e-3 under ANY re-grouping (exact-product mode included) while the same net with
+other formula weights moves by 3e-7 - the bound of that test is now measured against the re-grouped run.
+usage: python tools/conditioning_probe.py [fp32|bf16x3] [N]"""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "3d_recognizer_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
 import numpy as np, torch
 from randlanet import _ops as ops
