@@ -38,6 +38,7 @@ FOLD_BIAS = not bool(int(__import__("os").environ.get("RL_NO_FOLD_BIAS", "0"))) 
 BN_PIVOT = not bool(int(__import__("os").environ.get("RL_NO_BN_PIVOT", "0")))
 # A/B: pivot on the running mean (round 5) instead of the engine's own pivot vectors (the previous batch's mean, round 6)
 BN_PIVOT_RUNNING = bool(int(__import__("os").environ.get("RL_BN_PIVOT_RUNNING", "0")))
+FC_START_GENERIC = bool(int(__import__("os").environ.get("RL_FC_START_GENERIC", "0")))      # A/B: fc_start on the unpadded rows
 # clouds below this size keep the permutation as drawn (a level-0 table of < 128 KB sits in L2 / L1 whatever the order)
 BAND_SORT_MIN_POINTS = 4096
 
@@ -443,7 +444,12 @@ class Engine:
         prep.csr_ready = None
 
         # fc_start + bn_start (modules.py:565-566)
-        x = self._linear(ctx, ops.plain(inp_p, B, N), "fc_start.weight", "fc_start.bias", 8, bn="bn_start.0",
+        # (coordinates only: the rows padded to 16 bytes - made for the virtual rpe branch - let fc_start's K = 3 product and its weight
+        # gradient run on the streaming kernels, 16-byte loads, instead of the generic gemm_kernel: 18 -> 6 us at 8 clouds)
+        a0 = ops.plain(inp_p, B, N)
+        if cin == 3 and prep.xyz4 is not None and not FC_START_GENERIC:
+            a0 = Lazy(prep.xyz4.view(B * N, 4), B, N, N, 3)
+        x = self._linear(ctx, a0, "fc_start.weight", "fc_start.bias", 8, bn="bn_start.0",
                          act=H.ACT_LRELU, slope=0.2, a_grad=False)
         # encoder (modules.py:582-589)
         skips: List[Lazy] = []
