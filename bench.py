@@ -262,7 +262,9 @@ def roofline_pass(stepper, eager_steps=3):
             if key in table:
                 roof["traffic"] = table[key]
                 roof["traffic_shape"] = roof["largest_shape"]["op"]
-                roof["traffic_over_algorithmic"] = round(table[key] / max(big["bytes"], 1), 3)
+                # (the PMC pass measured ONE launch form of the shape - for a GEMM the plain one, without the accumulating read of Y
+                # that some of the shape's launches in a step carry: its algorithmic bytes ride along in the table where they differ)
+                roof["traffic_over_algorithmic"] = round(table[key] / max(table.get(key + "|algorithmic", big["bytes"]), 1), 3)
             tot = table.get(f"{name}|*")
             if tot is not None:
                 roof["traffic_function_per_step"] = tot
