@@ -355,8 +355,16 @@ class Engine:
                 and all(a < b for a, b in zip(edges[:-1], edges[1:]))):
             prep.perm = ops.band_sort(inp, perm, edges)
         inp_p = torch.empty((B * N, cin), dtype=torch.float32, device=dev)
-        ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, index=prep.perm.view(-1),
-                      index_shared=prep.perm.dim() == 1)
+        # coordinates padded to 16 bytes for the kernels that gather them per neighbour (virtual rpe branch) and for fc_start
+        want4 = any(ops.virtual_rpe_supported(d, self.K, B * (N // dec ** l), N // dec ** l) for l, d in enumerate(self.layers))
+        xyz4 = torch.empty((B, N, 4), dtype=torch.float32, device=dev) if want4 else None
+        gather = dict(index=prep.perm.view(-1), index_shared=prep.perm.dim() == 1)
+        if want4 and cin == 3:
+            # (both from the permutation gather, one launch: the padded copy used to be a launch of its own behind the searches)
+            ops.copy_rows_pair(((inp.view(B * N, 3), (0, 3), N, inp_p, (0, 3), B * N, N), gather),
+                               ((inp.view(B * N, 3), (0, 3), N, xyz4.view(B * N, 4), (0, 3), B * N, N), gather))
+        else:
+            ops.copy_rows(inp.view(B * N, cin), (0, cin), N, inp_p, (0, cin), B * N, N, **gather)
         if cin == 3:
             xyz = inp_p.view(B, N, 3)
         else:
@@ -374,10 +382,7 @@ class Engine:
             tasks.append((N // ratio, dec * N // ratio, 1))
             ratio //= dec
         searches = ops.knn_multi(xyz, tasks)
-        # coordinates padded to 16 bytes for the kernels that gather them per neighbour (virtual rpe branch)
-        xyz4 = None
-        if any(ops.virtual_rpe_supported(d, self.K, B * (N // dec ** l), N // dec ** l) for l, d in enumerate(self.layers)):
-            xyz4 = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+        if want4 and cin != 3:
             ops.copy_rows(xyz.view(B * N, 3), (0, 3), N, xyz4.view(B * N, 4), (0, 3), B * N, N)
         prep.xyz4, prep.searches = xyz4, searches
         # training: the transpose of every neighbour graph ("who gathered from me"), so that the gathers' backward sums
