@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
 //   backward: dz from the finished totals (loss_bwd_kernel's formulas), G = (dz . W) * mask -> the gradient w.r.t. fc_end.1's
 //   ACTIVATED output, the two BatchNorm-backward sums of fc_end.1 (rl_bn_bwd_reduce's slots) and one partial slab of fc_end.3's
 //   weight / bias gradient per workgroup (rl_wgrad_reduce_batch's layout: dW[C][32], then db[C]).
-constexpr int HD_MAXC = 8;          // classes the fused head carries in registers (the metric: 2); more -> the un-fused path
+constexpr int HD_REGC = 8;          // classes head_fwd / head_bwd carry in registers; 9 .. HD_MAXC: headw_fwd / headw_bwd (MFMA + LDS)
+constexpr int HD_MAXC = 32;         // classes the fused head carries in registers (the metric: 2); more -> the un-fused path
 constexpr int HD_K = 32;            // input channels of fc_end.3 (modules.py:529)
 struct HeadParams {
     const float* X;                 // (rows, 32) raw output of fc_end.1
@@ -681,6 +682,376 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
     }
 }
 
+// ---- the fused head for 9 .. 32 classes (round 6: BASELINE configs S / Kt, 13 and 20 classes) -------------------------------------
+// head_fwd / head_bwd carry a class' weight row and its partial sums in registers: at 16 / 32 classes that is 256 VGPRs and slower
+// than the nine launches it replaces (measured: S 699 -> 678, Kt 351 -> 314 clouds/s).  Here the three small products of a trip of
+// 32 rows - logits = D.W^T (32 x 32 x MC), dD = dz.W (32 x MC x 32), dW += dz^T.D (MC x 32 x 32) - run on the matrix pipe in exact
+// fp32 (v_mfma_f32_16x16x4_f32, one 16 x 16 tile per wavefront), their operands staged in LDS: D (the row's Dropout output), W,
+// the logits, dz, dD.  What is per ROW (softmax, loss terms, counts, dz) stays with one lane per row, reading its row of logits
+// from LDS and adding its loss terms straight into its LDS row of doubles.  Same Dropout bits, same label fetch two / one trips
+// ahead, same records and slabs as the register kernels: the caller cannot tell which pair ran.
+//   MFMA 16x16x4 layouts (as in gemm.hip): A lane l -> A[row l & 15][k l >> 4], B lane l -> B[k l >> 4][col l & 15],
+//   D lane l, reg r -> row (l >> 4) * 4 + r, col l & 15.
+typedef float hw_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int HW_LD = 36;       // LDS row stride of the 32-float staging rows (16-byte aligned, conflict-free column reads)
+struct HeadWideConst {
+    float4 sc, sh;
+    bool lazy;
+    unsigned long long key;
+    __device__ __forceinline__ void load(const HeadParams& p, int l) {
+        lazy = p.lazy.scale != nullptr;
+        sc = make_float4(1.f, 1.f, 1.f, 1.f); sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lazy) {
+            sc = *reinterpret_cast<const float4*>(p.lazy.scale + 4 * l);
+            sh = *reinterpret_cast<const float4*>(p.lazy.shift + 4 * l);
+        }
+        key = p.drop ? (unsigned long long)p.key[0] : 0ull;
+    }
+    __device__ __forceinline__ float4 act(const HeadParams& p, const float4 x) const {
+        if (!lazy) return x;
+        return make_float4(rl_act(x.x * sc.x + sh.x, p.lazy.act, p.lazy.slope), rl_act(x.y * sc.y + sh.y, p.lazy.act, p.lazy.slope),
+                           rl_act(x.z * sc.z + sh.z, p.lazy.act, p.lazy.slope), rl_act(x.w * sc.w + sh.w, p.lazy.act, p.lazy.slope));
+    }
+};
+// logits of the trip's 32 rows: the wavefronts below NT = 2 * MC / 16 own one 16 x 16 tile each (rows rb, classes cb)
+template <int MC>
+__device__ __forceinline__ void headw_logits(const float (*Dl)[HW_LD], const float (&bw)[8], float bias, float (*lgs)[MC + 1],
+                                             int wave, int lane) {
+    constexpr int NT = 2 * (MC / 16);
+    if (wave < NT) {
+        const int rb = wave & 1, cb = wave >> 1;
+        hw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Dl[rb * 16 + (lane & 15)][4 * s + (lane >> 4)], bw[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgs[rb * 16 + (lane >> 4) * 4 + r][cb * 16 + (lane & 15)] = acc[r] + bias;
+    }
+}
+
+template <int MC>       // 16 or 32: the smallest that holds C
+__global__ __launch_bounds__(256) void headw_fwd_kernel(const HeadParams p) {
+    __shared__ __attribute__((aligned(16))) float Dl[32][HW_LD];
+    __shared__ float Wl[MC][HW_LD];
+    __shared__ float lgs[32][MC + 1];
+    __shared__ double accd[32][5 * MC + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 7;
+    const int C = p.C;
+    for (int e = tid; e < MC * 32; e += 256) Wl[e >> 5][e & 31] = (e >> 5) < C ? p.W[e] : 0.f;
+    if (tid < 32)
+        for (int e = 0; e < 5 * MC + 1; ++e) accd[tid][e] = 0.0;
+    __syncthreads();
+    constexpr int NT = 2 * (MC / 16);
+    float bw[8], bias = 0.f;
+    {
+        const int cb = wave < NT ? wave >> 1 : 0, cc = cb * 16 + (lane & 15);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bw[s] = Wl[cc][4 * s + (lane >> 4)];        // B[k][col] = W[col][k]
+        bias = cc < C ? p.bias[cc] : 0.f;
+    }
+    const long total = (long)p.B * p.N;
+    const long niter = (total + 31) / 32;
+    HeadWideConst hc;
+    hc.load(p, l);
+    long it = blockIdx.x;
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    int labn = 0;
+    HeadLab hn = {0u, 0};
+    if (it < niter) {
+        const long R0 = it * 32 + (tid >> 3);
+        xn = *reinterpret_cast<const float4*>(p.X + (R0 < total ? R0 : total - 1) * HD_K + 4 * l);
+        if (tid < 32) {
+            labn = head_label(p, head_perm(p, it * 32 + tid, total));
+            hn = head_perm(p, (it + gridDim.x < niter ? it + gridDim.x : it) * 32 + tid, total);
+        }
+    }
+    for (; it < niter; it += gridDim.x) {
+        const long R = it * 32 + (tid >> 3);
+        const bool valid = R < total;
+        const long Rc = valid ? R : total - 1;
+        const float4 x = xn;
+        const int lab = labn;
+        {
+            const long itn = it + gridDim.x < niter ? it + gridDim.x : it;
+            const long Rn = itn * 32 + (tid >> 3);
+            xn = *reinterpret_cast<const float4*>(p.X + (Rn < total ? Rn : total - 1) * HD_K + 4 * l);
+            if (tid < 32) {
+                labn = head_label(p, hn);
+                const long it2 = it + 2 * gridDim.x < niter ? it + 2 * gridDim.x : itn;
+                hn = head_perm(p, it2 * 32 + tid, total);
+            }
+        }
+        const float4 z = hc.act(p, x);
+        float4 d = z;
+        if (p.drop) {
+            unsigned bits = head_keep_bits(p, hc.key, Rc, l);
+            d = head_drop(z, bits, p.dscale);
+            if (p.mask) {
+                unsigned wbits = bits << (4 * l);
+                wbits |= __shfl_xor(wbits, 1, 64); wbits |= __shfl_xor(wbits, 2, 64); wbits |= __shfl_xor(wbits, 4, 64);
+                if (l == 0 && valid) p.mask[R] = wbits;
+            }
+        }
+        *reinterpret_cast<float4*>(&Dl[tid >> 3][4 * l]) = d;
+        head_lds_barrier();
+        headw_logits<MC>(Dl, bw, bias, lgs, wave, lane);
+        head_lds_barrier();
+        if (tid < 32) {
+            const long Rr = it * 32 + tid;
+            if (Rr < total) {
+                double* a = accd[tid];
+                float m = -INFINITY;
+                int pred = 0;
+                for (int c = 0; c < C; ++c) {
+                    const float v = lgs[tid][c];
+                    if (v > m) { m = v; pred = c; }
+                }
+                float den = 0.f;
+                for (int c = 0; c < C; ++c) den += expf(lgs[tid][c] - m);
+                const float inv = 1.f / den;
+                float lsum = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float zc = lgs[tid][c];
+                    const float pc = expf(zc - m) * inv;
+                    const float yc = (lab == c) ? 1.f : 0.f;
+                    a[0 * C + c] += (double)(yc * pc);
+                    a[1 * C + c] += (double)pc;
+                    if (p.kind == 0) {
+                        if (lab == c) lsum += (logf(den) + m) - zc;
+                    } else if (p.kind == 1) {
+                        const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
+                        const float pp = fminf(fmaxf(pc, LS_EPS), 1.f - LS_EPS);
+                        lsum += -yy * logf(pp) * powf(1.f - pp, p.gamma);
+                    }
+                }
+                if (pred == lab) a[2 * C + lab] += 1.0;
+                a[3 * C + lab] += 1.0;
+                a[4 * C + pred] += 1.0;
+                a[5 * C] += (double)lsum;
+            }
+        }
+        // (the next trip's Dl stores come behind the two barriers above; its first barrier orders them behind these LDS reads)
+    }
+    if (tid < 64) {
+        const int rs = rec_size(C);
+        for (int e = 0; e < rs; ++e) {
+            double v = tid < 32 ? accd[tid][e] : 0.0;
+            v = rl_wave_sum(v);
+            if (tid == 0) p.work[(long)blockIdx.x * rs + e] = v;
+        }
+    }
+}
+
+template <int MC>
+__global__ __launch_bounds__(256) void headw_bwd_kernel(const HeadParams p) {
+    __shared__ __attribute__((aligned(16))) float Dl[32][HW_LD];
+    __shared__ __attribute__((aligned(16))) float dDl[32][HW_LD];
+    __shared__ float Wl[MC][HW_LD];
+    __shared__ float lgs[32][MC + 1], dzs[32][MC + 1];
+    __shared__ float cu[MC], cw[MC];
+    __shared__ float red[4][8][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 7;
+    const int C = p.C;
+    const int rs = rec_size(C);
+    const double* totals = p.work + (long)RL_MAX_SLOTS * rs;
+    for (int e = tid; e < MC * 32; e += 256) Wl[e >> 5][e & 31] = (e >> 5) < C ? p.W[e] : 0.f;
+    if (tid < MC) {
+        float u = 0.f, w = 0.f;
+        const int c = tid;
+        const int c0 = p.neglect ? 1 : 0;
+        if (p.kind == 2 && c < C && c >= c0) {
+            const double tp = totals[c], sp = totals[C + c], sy = totals[3 * C + c];
+            const double D = tp + (double)p.alpha * (sy - tp) + (1.0 - (double)p.alpha) * (sp - tp) + (double)LS_EPS;
+            const double ti = (tp + (double)LS_EPS) / D;
+            const double base = 1.0 - ti;
+            const double dl = -((double)p.gamma / (double)(C - c0)) *
+                              ((p.gamma == 1.f) ? 1.0 : pow(base > 0.0 ? base : 0.0, (double)p.gamma - 1.0));
+            u = (float)(dl / D);
+            w = (float)(-dl * (tp + (double)LS_EPS) * (1.0 - (double)p.alpha) / (D * D));
+        }
+        cu[c] = u;
+        cw[c] = w;
+    }
+    __syncthreads();
+    const float invn = 1.f / (float)p.norm_points;
+    constexpr int NT = 2 * (MC / 16);       // logits tiles, and dW tiles (MC / 16 class blocks x 2 k blocks)
+    // loop-invariant MFMA operands of this wavefront's tiles, in registers
+    float bw[8], bias = 0.f;                // logits: B[k][class] = W[class][k]
+    float bd[MC / 4];                       // dD:     B[class][k]  = W[class][k]      (tile rows rb2, k block kb2)
+    {
+        const int cb = wave < NT ? wave >> 1 : 0, cc = cb * 16 + (lane & 15);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bw[s] = Wl[cc][4 * s + (lane >> 4)];
+        bias = cc < C ? p.bias[cc] : 0.f;
+        const int kb2 = wave >> 1;
+#pragma unroll
+        for (int s = 0; s < MC / 4; ++s) bd[s] = Wl[4 * s + (lane >> 4)][kb2 * 16 + (lane & 15)];
+    }
+    hw_f32x4 accw = {0.f, 0.f, 0.f, 0.f};   // this wavefront's 16 x 16 tile of dW (class block wave & (MC / 16 - 1), k block wave / (MC / 16))
+    float ab = 0.f;                         // db[tid] (tid < MC)
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sx = sg;
+    float4 mu = sg, is = sg;
+    if (p.bstats) {
+        mu = *reinterpret_cast<const float4*>(p.mean + 4 * l);
+        is = *reinterpret_cast<const float4*>(p.invstd + 4 * l);
+    }
+    HeadWideConst hc;
+    hc.load(p, l);
+    const float4 bsc = hc.sc, bsh = hc.sh;
+    const long total = (long)p.B * p.N;
+    const long niter = (total + 31) / 32;
+    long it = blockIdx.x;
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned mwn = 0xFFFFFFFFu;
+    int labn = 0;
+    HeadLab hn = {0u, 0};
+    const bool use_mask = p.drop && p.mask;
+    if (it < niter) {
+        const long R0 = it * 32 + (tid >> 3), Rq = R0 < total ? R0 : total - 1;
+        xn = *reinterpret_cast<const float4*>(p.X + Rq * HD_K + 4 * l);
+        if (use_mask) mwn = p.mask[Rq];
+        if (tid < 32) {
+            labn = head_label(p, head_perm(p, it * 32 + tid, total));
+            hn = head_perm(p, (it + gridDim.x < niter ? it + gridDim.x : it) * 32 + tid, total);
+        }
+    }
+    for (; it < niter; it += gridDim.x) {
+        const long R = it * 32 + (tid >> 3);
+        const bool valid = R < total;
+        const long Rc = valid ? R : total - 1;
+        const float4 x = xn;
+        const unsigned mw = mwn;
+        const int lab = labn;
+        {
+            const long itn = it + gridDim.x < niter ? it + gridDim.x : it;
+            const long Rn = itn * 32 + (tid >> 3), Rq = Rn < total ? Rn : total - 1;
+            xn = *reinterpret_cast<const float4*>(p.X + Rq * HD_K + 4 * l);
+            if (use_mask) mwn = p.mask[Rq];
+            if (tid < 32) {
+                labn = head_label(p, hn);
+                const long it2 = it + 2 * gridDim.x < niter ? it + 2 * gridDim.x : itn;
+                hn = head_perm(p, it2 * 32 + tid, total);
+            }
+        }
+        const float4 z = hc.act(p, x);
+        unsigned bits = 15u;
+        if (p.drop) bits = use_mask ? (mw >> (4 * l)) & 15u : head_keep_bits(p, hc.key, Rc, l);
+        const float4 d = p.drop ? head_drop(z, bits, p.dscale) : z;
+        *reinterpret_cast<float4*>(&Dl[tid >> 3][4 * l]) = d;
+        head_lds_barrier();
+        headw_logits<MC>(Dl, bw, bias, lgs, wave, lane);
+        head_lds_barrier();
+        if (tid < 32) {         // per ROW: softmax and the loss derivative (loss_bwd_kernel's formulas), dz of every class to LDS
+            const long Rr = it * 32 + tid;
+            for (int c = C; c < MC; ++c) dzs[tid][c] = 0.f;
+            if (Rr < total) {
+                float m = -INFINITY;
+                for (int c = 0; c < C; ++c) m = fmaxf(m, lgs[tid][c]);
+                float den = 0.f;
+                for (int c = 0; c < C; ++c) den += expf(lgs[tid][c] - m);
+                const float inv = 1.f / den;
+                if (p.kind == 0) {
+                    for (int c = 0; c < C; ++c)
+                        dzs[tid][c] = (expf(lgs[tid][c] - m) * inv - (lab == c ? 1.f : 0.f)) * invn * p.grad_scale;
+                } else {
+                    float dot = 0.f;
+                    for (int c = 0; c < C; ++c) {
+                        const float pc = expf(lgs[tid][c] - m) * inv;
+                        const float yc = (lab == c) ? 1.f : 0.f;
+                        float dp;
+                        if (p.kind == 2) dp = cu[c] * yc + cw[c];
+                        else {
+                            const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
+                            dp = 0.f;
+                            if (pc >= LS_EPS && pc <= 1.f - LS_EPS)
+                                dp = -yy * (powf(1.f - pc, p.gamma) / pc - p.gamma * logf(pc) * powf(1.f - pc, p.gamma - 1.f)) * invn;
+                        }
+                        dzs[tid][c] = dp;           // (dp for now; turned into dz below once the row's dot product is known)
+                        dot += pc * dp;
+                    }
+                    for (int c = 0; c < C; ++c) {
+                        const float pc = expf(lgs[tid][c] - m) * inv;
+                        dzs[tid][c] = pc * (dzs[tid][c] - dot) * p.grad_scale;
+                    }
+                }
+            } else {
+                for (int c = 0; c < C; ++c) dzs[tid][c] = 0.f;
+            }
+        }
+        head_lds_barrier();
+        {
+            // dD[row][k] = sum_c dz[row][c] W[c][k]: four 16 x 16 tiles (rows wave & 1, k block wave >> 1), MC / 4 steps
+            const int rb2 = wave & 1, kb2 = wave >> 1;
+            hw_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < MC / 4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dzs[rb2 * 16 + (lane & 15)][4 * s + (lane >> 4)], bd[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dDl[rb2 * 16 + (lane >> 4) * 4 + r][kb2 * 16 + (lane & 15)] = acc[r];
+            // dW[c][k] += sum_rows dz[row][c] D[row][k]: NT tiles, 8 steps over the trip's 32 rows
+            if (wave < NT) {
+                const int cbw = wave & (MC / 16 - 1), kbw = wave / (MC / 16);
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    accw = __builtin_amdgcn_mfma_f32_16x16x4f32(dzs[4 * s + (lane >> 4)][cbw * 16 + (lane & 15)],
+                                                               Dl[4 * s + (lane >> 4)][kbw * 16 + (lane & 15)], accw, 0, 0, 0);
+            }
+            if (tid < MC) {
+                float t = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) t += dzs[r][tid];
+                ab += t;
+            }
+        }
+        head_lds_barrier();
+        const float4 dd = *reinterpret_cast<const float4*>(&dDl[tid >> 3][4 * l]);
+        const float4 g = p.drop ? head_drop(dd, bits, p.dscale) : dd;
+        if (valid) {
+            *reinterpret_cast<float4*>(p.G + R * HD_K + 4 * l) = g;
+            if (p.bstats) {
+                const float g0 = g.x * rl_act_grad(x.x * bsc.x + bsh.x, p.lazy.act, p.lazy.slope);
+                const float g1 = g.y * rl_act_grad(x.y * bsc.y + bsh.y, p.lazy.act, p.lazy.slope);
+                const float g2 = g.z * rl_act_grad(x.z * bsc.z + bsh.z, p.lazy.act, p.lazy.slope);
+                const float g3 = g.w * rl_act_grad(x.w * bsc.w + bsh.w, p.lazy.act, p.lazy.slope);
+                sg.x += g0; sg.y += g1; sg.z += g2; sg.w += g3;
+                sx.x += g0 * ((x.x - mu.x) * is.x); sx.y += g1 * ((x.y - mu.y) * is.y);
+                sx.z += g2 * ((x.z - mu.z) * is.z); sx.w += g3 * ((x.w - mu.w) * is.w);
+            }
+        }
+        // (the next trip's first barrier orders its Dl / dzs / dDl stores behind the LDS reads above)
+    }
+    // this workgroup's slab: dW[C][32] from the tile accumulators, db[C]; the BatchNorm-backward sums as in head_bwd_kernel
+    float* slab = p.slab + (long)blockIdx.x * (C * HD_K + C);
+    if (wave < NT) {
+        const int cbw = wave & (MC / 16 - 1), kbw = wave / (MC / 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = cbw * 16 + (lane >> 4) * 4 + r;
+            if (c < C) slab[c * HD_K + kbw * 16 + (lane & 15)] = accw[r];
+        }
+    }
+    if (tid < C) slab[C * HD_K + tid] = ab;
+    if (p.bstats) {
+        float v[8] = {sg.x, sg.y, sg.z, sg.w, sx.x, sx.y, sx.z, sx.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = v[j];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            if (lane < 8) red[wave][lane][j] = t;
+        }
+        __syncthreads();
+        if (tid < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double a0 = ((double)red[0][tid][j] + (double)red[1][tid][j]) + ((double)red[2][tid][j] + (double)red[3][tid][j]);
+                const double a1 = ((double)red[0][tid][4 + j] + (double)red[1][tid][4 + j]) + ((double)red[2][tid][4 + j] + (double)red[3][tid][4 + j]);
+                p.bstats[((long)blockIdx.x * 2 + 0) * HD_K + 4 * tid + j] = a0;
+                p.bstats[((long)blockIdx.x * 2 + 1) * HD_K + 4 * tid + j] = a1;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, const float* __restrict__ lr, float b1,
                                                    float b2, float eps, float gscale, const int64_t* __restrict__ step) {
@@ -860,7 +1231,9 @@ extern "C" int rl_head_fwd(const rl_head_desc* d, double* out, void* stream) {
     const int g = head_grid((long)d->B * d->N);
     if (d->C <= 2) hipLaunchKernelGGL(head_fwd_kernel<2>, dim3(g), dim3(256), 0, st, p);
     else if (d->C <= 4) hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(g), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(g), dim3(256), 0, st, p);
+    else if (d->C <= 8) hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(g), dim3(256), 0, st, p);
+    else if (d->C <= 16) hipLaunchKernelGGL(headw_fwd_kernel<16>, dim3(g), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(headw_fwd_kernel<32>, dim3(g), dim3(256), 0, st, p);
     rl_note_kernel("head_fwd_kernel");
     RL_LAUNCH_CHECK("rl_head_fwd");
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, d->work, g, (double)d->B * (double)d->N, d->C, d->loss_kind,
@@ -876,7 +1249,9 @@ extern "C" int rl_head_bwd(const rl_head_desc* d, void* stream) {
     const int g = head_grid((long)d->B * d->N);
     if (d->C <= 2) hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
     else if (d->C <= 4) hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    else if (d->C <= 8) hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    else if (d->C <= 16) hipLaunchKernelGGL(headw_bwd_kernel<16>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(headw_bwd_kernel<32>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
     rl_note_kernel("head_bwd_kernel");
     RL_LAUNCH_CHECK("rl_head_bwd");
     return RL_OK;

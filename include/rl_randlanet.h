@@ -738,7 +738,9 @@ int rl_batch_draw(const rl_cloud_job* jobs_dev, int B, int n, uint64_t seed, int
  *     bn_bwd_stats (optional): [rl_head_grid(rows)][2][32] doubles, the partials rl_bn_bwd_reduce would leave for fc_end.1
  *     (needs mean / invstd); slab: rl_head_grid(rows) partial records of C*32 + C floats (dW[C][32], then db[C]) for
  *     rl_wgrad_reduce_batch (nsplit = rl_head_grid(rows), N = C, K = 32).
- * rl_head_supported(C, K): 1 for K == 32 and 1 <= C <= 8; otherwise the caller runs the separate entry points. */
+ * rl_head_supported(C, K): 1 for K == 32 and 1 <= C <= 32 (up to 8 classes: a class' weights and sums in registers; 9 .. 32,
+ * round 6: the three 32-row products of a trip on exact-fp32 MFMA with their operands in LDS); otherwise the caller runs the
+ * separate entry points. */
 typedef struct rl_head_desc {
     const float* X;
     const float* scale;
