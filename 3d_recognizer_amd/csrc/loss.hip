@@ -734,13 +734,21 @@ __global__ __launch_bounds__(256) void headw_fwd_kernel(const HeadParams p) {
     __shared__ __attribute__((aligned(16))) float Dl[32][HW_LD];
     __shared__ float Wl[MC][HW_LD];
     __shared__ float lgs[32][MC + 1];
-    __shared__ double accd[32][5 * MC + 1];
+    __shared__ int labl[32];
+    constexpr int J = MC / 8;               // classes per lane of a row's octet: lane l owns classes l, l + 8, ...
+    __shared__ double part[4][8][5 * J + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 7;
     const int C = p.C;
     for (int e = tid; e < MC * 32; e += 256) Wl[e >> 5][e & 31] = (e >> 5) < C ? p.W[e] : 0.f;
-    if (tid < 32)
-        for (int e = 0; e < 5 * MC + 1; ++e) accd[tid][e] = 0.0;
     __syncthreads();
+    // what is per ROW runs on the row's OCTET (lane l: classes l, l + 8, ...; maximum / sums by a 3-step butterfly) - with one lane
+    // per row, 32 lanes did all of it while 224 waited.  Sums in fp32 per lane, moved into doubles every HW_FLUSH trips.
+    constexpr int HW_FLUSH = 64;
+    float acc[5 * J + 1];
+    double accd[5 * J + 1];
+#pragma unroll
+    for (int e = 0; e < 5 * J + 1; ++e) { acc[e] = 0.f; accd[e] = 0.0; }
+    int trips = 0;
     constexpr int NT = 2 * (MC / 16);
     float bw[8], bias = 0.f;
     {
@@ -793,52 +801,86 @@ __global__ __launch_bounds__(256) void headw_fwd_kernel(const HeadParams p) {
             }
         }
         *reinterpret_cast<float4*>(&Dl[tid >> 3][4 * l]) = d;
+        if (tid < 32) labl[tid] = lab;
         head_lds_barrier();
         headw_logits<MC>(Dl, bw, bias, lgs, wave, lane);
         head_lds_barrier();
-        if (tid < 32) {
-            const long Rr = it * 32 + tid;
-            if (Rr < total) {
-                double* a = accd[tid];
-                float m = -INFINITY;
-                int pred = 0;
-                for (int c = 0; c < C; ++c) {
-                    const float v = lgs[tid][c];
-                    if (v > m) { m = v; pred = c; }
-                }
-                float den = 0.f;
-                for (int c = 0; c < C; ++c) den += expf(lgs[tid][c] - m);
-                const float inv = 1.f / den;
-                float lsum = 0.f;
-                for (int c = 0; c < C; ++c) {
-                    const float zc = lgs[tid][c];
-                    const float pc = expf(zc - m) * inv;
-                    const float yc = (lab == c) ? 1.f : 0.f;
-                    a[0 * C + c] += (double)(yc * pc);
-                    a[1 * C + c] += (double)pc;
-                    if (p.kind == 0) {
-                        if (lab == c) lsum += (logf(den) + m) - zc;
-                    } else if (p.kind == 1) {
-                        const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
-                        const float pp = fminf(fmaxf(pc, LS_EPS), 1.f - LS_EPS);
-                        lsum += -yy * logf(pp) * powf(1.f - pp, p.gamma);
+        {
+            const int row = tid >> 3;
+            const int labr = labl[row];
+            float lg[J];
+            float m = -INFINITY;
+            int pred = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int c = l + 8 * j;
+                lg[j] = c < C ? lgs[row][c] : -INFINITY;
+                if (lg[j] > m) { m = lg[j]; pred = c; }           // (ascending classes: the lowest index among equals, like the row loop)
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const float mo = __shfl_xor(m, o, 64);
+                const int po = __shfl_xor(pred, o, 64);
+                if (mo > m || (mo == m && po < pred)) { m = mo; pred = po; }
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (l + 8 * j < C) den += expf(lg[j] - m);
+            den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64); den += __shfl_xor(den, 4, 64);
+            const float inv = 1.f / den;
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int c = l + 8 * j;
+                    if (c < C) {
+                        const float pc = expf(lg[j] - m) * inv;
+                        const float yc = (labr == c) ? 1.f : 0.f;
+                        acc[0 * J + j] += yc * pc;
+                        acc[1 * J + j] += pc;
+                        acc[2 * J + j] += (pred == c && labr == c) ? 1.f : 0.f;
+                        acc[3 * J + j] += (labr == c) ? 1.f : 0.f;
+                        acc[4 * J + j] += (pred == c) ? 1.f : 0.f;
+                        if (p.kind == 0) {
+                            if (labr == c) acc[5 * J] += (logf(den) + m) - lg[j];
+                        } else if (p.kind == 1) {
+                            const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
+                            const float pp = fminf(fmaxf(pc, LS_EPS), 1.f - LS_EPS);
+                            acc[5 * J] += -yy * logf(pp) * powf(1.f - pp, p.gamma);
+                        }
                     }
                 }
-                if (pred == lab) a[2 * C + lab] += 1.0;
-                a[3 * C + lab] += 1.0;
-                a[4 * C + pred] += 1.0;
-                a[5 * C] += (double)lsum;
+            }
+            if (++trips == HW_FLUSH) {
+                trips = 0;
+#pragma unroll
+                for (int e = 0; e < 5 * J + 1; ++e) { accd[e] += (double)acc[e]; acc[e] = 0.f; }
             }
         }
-        // (the next trip's Dl stores come behind the two barriers above; its first barrier orders them behind these LDS reads)
+        // (the next trip's Dl / labl stores come behind the two barriers above; its first barrier orders them behind these LDS reads)
     }
-    if (tid < 64) {
+    // the octets of a wavefront (lanes l, l + 8, ...) by a fixed butterfly, the four wavefronts through LDS in order; then lane l
+    // writes its classes' entries of the workgroup's record, the loss term summed over the eight lanes
+#pragma unroll
+    for (int e = 0; e < 5 * J + 1; ++e) {
+        double v = accd[e] + (double)acc[e];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lane < 8) part[wave][lane][e] = v;
+    }
+    __syncthreads();
+    if (tid < 8) {
         const int rs = rec_size(C);
-        for (int e = 0; e < rs; ++e) {
-            double v = tid < 32 ? accd[tid][e] : 0.0;
-            v = rl_wave_sum(v);
-            if (tid == 0) p.work[(long)blockIdx.x * rs + e] = v;
-        }
+        double* w = p.work + (long)blockIdx.x * rs;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int c = tid + 8 * j;
+                if (c < C) w[k * C + c] = (part[0][tid][k * J + j] + part[1][tid][k * J + j]) + (part[2][tid][k * J + j] + part[3][tid][k * J + j]);
+            }
+        double ls = (part[0][tid][5 * J] + part[1][tid][5 * J]) + (part[2][tid][5 * J] + part[3][tid][5 * J]);
+        ls += __shfl_xor(ls, 1, 64); ls += __shfl_xor(ls, 2, 64); ls += __shfl_xor(ls, 4, 64);
+        if (tid == 0) w[5 * C] = ls;
     }
 }
 
@@ -850,6 +892,8 @@ __global__ __launch_bounds__(256) void headw_bwd_kernel(const HeadParams p) {
     __shared__ float lgs[32][MC + 1], dzs[32][MC + 1];
     __shared__ float cu[MC], cw[MC];
     __shared__ float red[4][8][8];
+    __shared__ int labl[32];
+    constexpr int J = MC / 8;               // classes per lane of a row's octet (see headw_fwd_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 7;
     const int C = p.C;
     const int rs = rec_size(C);
@@ -938,44 +982,54 @@ __global__ __launch_bounds__(256) void headw_bwd_kernel(const HeadParams p) {
         if (p.drop) bits = use_mask ? (mw >> (4 * l)) & 15u : head_keep_bits(p, hc.key, Rc, l);
         const float4 d = p.drop ? head_drop(z, bits, p.dscale) : z;
         *reinterpret_cast<float4*>(&Dl[tid >> 3][4 * l]) = d;
+        if (tid < 32) labl[tid] = lab;
         head_lds_barrier();
         headw_logits<MC>(Dl, bw, bias, lgs, wave, lane);
         head_lds_barrier();
-        if (tid < 32) {         // per ROW: softmax and the loss derivative (loss_bwd_kernel's formulas), dz of every class to LDS
-            const long Rr = it * 32 + tid;
-            for (int c = C; c < MC; ++c) dzs[tid][c] = 0.f;
-            if (Rr < total) {
-                float m = -INFINITY;
-                for (int c = 0; c < C; ++c) m = fmaxf(m, lgs[tid][c]);
-                float den = 0.f;
-                for (int c = 0; c < C; ++c) den += expf(lgs[tid][c] - m);
-                const float inv = 1.f / den;
-                if (p.kind == 0) {
-                    for (int c = 0; c < C; ++c)
-                        dzs[tid][c] = (expf(lgs[tid][c] - m) * inv - (lab == c ? 1.f : 0.f)) * invn * p.grad_scale;
-                } else {
-                    float dot = 0.f;
-                    for (int c = 0; c < C; ++c) {
-                        const float pc = expf(lgs[tid][c] - m) * inv;
-                        const float yc = (lab == c) ? 1.f : 0.f;
-                        float dp;
-                        if (p.kind == 2) dp = cu[c] * yc + cw[c];
-                        else {
-                            const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
-                            dp = 0.f;
-                            if (pc >= LS_EPS && pc <= 1.f - LS_EPS)
-                                dp = -yy * (powf(1.f - pc, p.gamma) / pc - p.gamma * logf(pc) * powf(1.f - pc, p.gamma - 1.f)) * invn;
-                        }
-                        dzs[tid][c] = dp;           // (dp for now; turned into dz below once the row's dot product is known)
-                        dot += pc * dp;
+        {       // per ROW, on the row's octet: softmax and the loss derivative (loss_bwd_kernel's formulas), dz of every class to LDS
+            const int row = tid >> 3;
+            const int labr = labl[row];
+            float lg[J], pc[J], dp[J];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                lg[j] = l + 8 * j < C ? lgs[row][l + 8 * j] : -INFINITY;
+                m = fmaxf(m, lg[j]);
+            }
+            m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                pc[j] = l + 8 * j < C ? expf(lg[j] - m) : 0.f;
+                den += pc[j];
+            }
+            den += __shfl_xor(den, 1, 64); den += __shfl_xor(den, 2, 64); den += __shfl_xor(den, 4, 64);
+            const float inv = 1.f / den;
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int c = l + 8 * j;
+                pc[j] *= inv;
+                dp[j] = 0.f;
+                if (c < C) {
+                    const float yc = (labr == c) ? 1.f : 0.f;
+                    if (p.kind == 0) dp[j] = (pc[j] - yc) * invn;          // (dz itself for cross entropy)
+                    else if (p.kind == 2) dp[j] = cu[c] * yc + cw[c];
+                    else {
+                        const float yy = fminf(fmaxf(yc, LS_EPS), 1.f - LS_EPS);
+                        if (pc[j] >= LS_EPS && pc[j] <= 1.f - LS_EPS)
+                            dp[j] = -yy * (powf(1.f - pc[j], p.gamma) / pc[j] - p.gamma * logf(pc[j]) * powf(1.f - pc[j], p.gamma - 1.f)) * invn;
                     }
-                    for (int c = 0; c < C; ++c) {
-                        const float pc = expf(lgs[tid][c] - m) * inv;
-                        dzs[tid][c] = pc * (dzs[tid][c] - dot) * p.grad_scale;
-                    }
+                    dot += pc[j] * dp[j];
                 }
-            } else {
-                for (int c = 0; c < C; ++c) dzs[tid][c] = 0.f;
+            }
+            dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 4, 64);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int c = l + 8 * j;
+                float dz = 0.f;
+                if (valid && c < C) dz = (p.kind == 0 ? dp[j] : pc[j] * (dp[j] - dot)) * p.grad_scale;
+                dzs[row][c] = dz;           // (c < MC always: the classes past C and the rows past the end hold zeros)
             }
         }
         head_lds_barrier();
