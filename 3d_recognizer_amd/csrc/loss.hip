@@ -1283,6 +1283,7 @@ extern "C" int rl_head_fwd(const rl_head_desc* d, double* out, void* stream) {
     RL_REQUIRE(out, RL_ERR_ARGS, "rl_head_fwd: null out");
     hipStream_t st = (hipStream_t)stream;
     const int g = head_grid((long)d->B * d->N);
+    // (the MFMA kernels at 2 classes, measured: 6.353 -> 6.374 ms per step - up to 8 classes the register kernels stay)
     if (d->C <= 2) hipLaunchKernelGGL(head_fwd_kernel<2>, dim3(g), dim3(256), 0, st, p);
     else if (d->C <= 4) hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(g), dim3(256), 0, st, p);
     else if (d->C <= 8) hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(g), dim3(256), 0, st, p);
