@@ -23,6 +23,8 @@ Usage:  python tests/golden/bisect_probe.py --variant base --seeds 0:256 [--proc
 Results: tests/golden/bisect/<variant>.npz (seeds, histories (S, 6, 4): loss, mIoU, val_loss, val_mIoU); the fixtures of
 tests/test_model_gpu.py::test_denoised_training_matches_denoised_reference: --export (256 seeds, two draws of `base`) and
 --variant fcstart --seeds 0:4096 --fixture train_seeds_denoised_fc4096.npz (one draw; ~25 minutes on 8 cores).
+Round 6 added seeds 4096:10240 and 10240:16384 the same way (train_seeds_denoised_fc10240.npz / _fc16384.npz, --procs 7: 64 seeds
+per minute) for the 16384-seed comparison of profiles/r06_denoised_16384.txt (tools/denoised_compare.py).
 """
 import argparse
 import os

@@ -256,7 +256,10 @@ def test_denoised_training_matches_denoised_reference(golden_dir, monkeypatch, f
       1024 seeds here (RL_DENOISED_SEEDS: up to the fixture's 4096; 2048 until round 5 - the suite then took 604 s of its 900 s
       limit) against train_seeds_denoised_fc4096.npz.
       Round 5, all 4096 seeds (profiles/r05_denoised_hip_4096.npz): default bf16x3 arithmetic -0.09 +- 0.09 / -0.03 +- 0.06 /
-      -0.04 +- 0.06 points; exact fp32 products -0.01 +- 0.08 / +0.03 +- 0.06 / +0.06 +- 0.06."""
+      -0.04 +- 0.06 points; exact fp32 products -0.01 +- 0.08 / +0.03 +- 0.06 / +0.06 +- 0.06.
+      Round 6, 16384 seeds on both sides (profiles/r06_denoised_16384.txt; the reference's extra seeds are
+      train_seeds_denoised_fc10240.npz / _fc16384.npz, compared by tools/denoised_compare.py, not by this test): -0.042 +- 0.042 /
+      -0.021 +- 0.031 / -0.058 +- 0.030 points in the default arithmetic, -0.029 / -0.005 / -0.071 with exact fp32 products."""
     fc = frozen.endswith("fc_start_bias")
     _freeze_zero_gradient_biases(monkeypatch, fc_start=fc)
     if fc:
